@@ -1,0 +1,84 @@
+"""ctypes binding of libe2e_asr_hip.so (the C ABI declared in include/e2e_asr_hip.h).
+
+There is NO fallback: if the shared library is missing or a symbol is absent this
+module raises, and every op in e2e_asr_amd.ops raises with it.  Build it with
+``python -c "import __graft_entry__ as g; g.build()"`` or ``e2e_asr_amd/csrc/build.sh``.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libe2e_asr_hip.so")
+
+c_fp = C.POINTER(C.c_float)
+c_ip = C.POINTER(C.c_int)
+vp = C.c_void_p
+
+
+class DecWeights(C.Structure):
+    _fields_ = [(n, vp) for n in (
+        "embedding", "attn_enc_w", "attn_v", "attn_w", "attn_b", "lm_kernel", "lm_bias",
+        "dec_kernel", "dec_bias", "inp_w", "inp_b", "ap_w", "ap_b", "out_w", "out_b",
+        "simple_w", "simple_b")]
+
+
+class DecDims(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("B", "Te", "D", "A", "H", "lmH", "E", "V", "T_out")]
+
+
+class DecWs(C.Structure):
+    _fields_ = [(n, vp) for n in (
+        "hf", "tok", "lm_gates", "lm_c", "lm_h", "lm_hd", "sp", "x", "dec_gates", "dec_c",
+        "dec_h", "alpha", "ctx", "p", "zeros")]
+
+
+class DecGrads(C.Structure):
+    _fields_ = [(n, vp) for n in (
+        "embedding", "attn_enc_w", "attn_v", "attn_w", "attn_b", "lm_kernel", "lm_bias",
+        "dec_kernel", "dec_bias", "inp_w", "inp_b", "ap_w", "ap_b", "out_w", "out_b",
+        "simple_w", "simple_b")]
+
+
+# name -> (restype, argtypes); every symbol include/e2e_asr_hip.h declares
+SIGNATURES = {
+    "asr_gemm_f32": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp,
+                               C.c_int, vp, C.c_int, vp, C.c_int]),
+    "asr_lstm_ws_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "asr_lstm_layer_fwd": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int,
+                                     vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_size_t, vp,
+                                     C.c_float, C.c_uint]),
+    "asr_linear_fwd": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, vp, C.c_int, vp,
+                                 vp, C.c_int, C.c_int, C.c_int, vp, C.c_int]),
+    "asr_lstm_cell_fwd": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int,
+                                    vp, vp, vp, vp, C.c_float, C.c_uint, C.c_uint]),
+    "asr_attention_lds_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "asr_attention_fwd": (C.c_int, [vp, vp, C.c_int] + [vp] * 8 + [C.c_int] * 5),
+    "asr_masked_ce_fwd": (C.c_int, [vp] * 7 + [C.c_int] * 3),
+    "asr_masked_ce_bwd": (C.c_int, [vp] * 7 + [C.c_int] * 3),
+    "asr_next_token": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_uint, C.c_uint]),
+    "asr_attn_decoder_fwd": (C.c_int, [vp, C.POINTER(DecWeights), C.POINTER(DecDims), C.POINTER(DecWs),
+                                       vp, vp, vp, C.c_int, c_fp, C.c_float, C.c_float, C.c_uint, vp]),
+}
+
+
+def load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "e2e_asr_amd: HIP library not built (%s missing). Run __graft_entry__.build(). "
+            "There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so is stale
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = load()
+    return _lib

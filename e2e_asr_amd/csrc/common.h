@@ -1,0 +1,71 @@
+// Shared device/host helpers for the e2e_asr gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define ASR_OK 0
+#define ASR_EINVAL (-1)
+#define ASR_ELAUNCH (-2)
+#define ASR_EUNSUPPORTED (-3)
+
+#define ASR_CHECK_LAUNCH()                                  \
+    do {                                                    \
+        hipError_t e__ = hipGetLastError();                 \
+        if (e__ != hipSuccess) return ASR_ELAUNCH;          \
+    } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned long long u64;
+
+namespace asr {
+
+// ---- math: v_exp_f32 / v_rcp_f32 based, ~1-2 ulp; saturate cleanly at +-inf ----
+__device__ __forceinline__ float fast_sigmoid(float x) {
+    return __frcp_rn(1.0f + __expf(-x));
+}
+__device__ __forceinline__ float fast_tanh(float x) {
+    // tanh(x) = 1 - 2/(exp(2x)+1); exp->inf gives 1, exp->0 gives -1.
+    return 1.0f - 2.0f * __frcp_rn(__expf(2.0f * x) + 1.0f);
+}
+
+// ---- DPP butterflies inside a row of 16 lanes (no LDS) ----
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+// All 16 lanes of each DPP row end up holding the row's sum.
+__device__ __forceinline__ float row16_allreduce_sum(float v) {
+    v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]  (xor 1)
+    v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]  (xor 2)
+    v += dpp_mov<0x141>(v);   // row_half_mirror      (joins the two quads of each 8)
+    v += dpp_mov<0x140>(v);   // row_mirror           (joins the two halves of the 16)
+    return v;
+}
+__device__ __forceinline__ float wave_allreduce_sum(float v) {
+    v = row16_allreduce_sum(v);
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+__device__ __forceinline__ float wave_allreduce_max(float v) {
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v = fmaxf(v, __shfl_xor(v, m));
+    return v;
+}
+
+// ---- counter-based uniform [0,1) for dropout (same value in fwd and bwd) ----
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ float uniform01(uint32_t seed, uint32_t a, uint32_t b) {
+    uint32_t h = mix32(seed ^ mix32(a * 0x9E3779B9U + 0x85EBCA6BU) ^ mix32(b + 0xC2B2AE35U));
+    return (float)(h >> 8) * (1.0f / 16777216.0f);
+}
+// DropoutWrapper(output_keep_prob): 0 or 1/keep.
+__device__ __forceinline__ float keep_scale(uint32_t seed, uint32_t a, uint32_t b, float keep) {
+    return (keep >= 1.0f) ? 1.0f : (uniform01(seed, a, b) < keep ? __frcp_rn(keep) : 0.0f);
+}
+
+}  // namespace asr

@@ -1,0 +1,79 @@
+// Attention decoder, whole-sequence forward: the raw_rnn loop of attn_decoder.py:37-172
+// unrolled on the host into stream-ordered launches of the step kernels (skinny.hip,
+// attention.hip, loss.hip).  No allocation, no synchronisation: the caller can capture the
+// whole call in a hipGraph.
+//
+// Step structure (see oracle/asr_oracle.py::attn_decoder for the restated semantics):
+//   i = 0..T_out-1:
+//     lm cell on emb[tok[i]]                 (:148)   -> lm_c[i], lm_h[i]
+//     [SimpleProjection]                     (:149-151)
+//     x[i] = [lm_out, ctx[i-1]].W_inp + b    (:157-158)
+//     outer cell on x[i]                     (:166)   -> dec_c[i], dec_h[i]
+//     attention(q = dec_c[i])                (:114, decoder.py:79-80) -> alpha[i], ctx[i]
+//     p[i] = [q, ctx[i]].W_ap + b            (:116-118)
+//     logits[i] = p[i].W_out + b             (:124-125), zero rows once i >= seq_len[b]
+//     tok[i+1] = teacher / argmax / sample   (:128-145)
+// raw_rnn's state copy-through for finished rows is not materialised: a finished row's
+// emit is zero and its loss weight is zero, so its state is unobservable.
+#include "common.h"
+#include "../../include/e2e_asr_hip.h"
+
+extern "C" int asr_attn_decoder_fwd(void* stream, const asr_dec_weights* w, const asr_dec_dims* d,
+                                    const asr_dec_ws* ws, const float* enc, const int* enc_len,
+                                    const int* seq_len, int mode, const float* coin_host, float samp_prob,
+                                    float keep_lm, unsigned seed, float* logits) {
+    if (!w || !d || !ws || !enc || !enc_len || !seq_len || !logits) return ASR_EINVAL;
+    if (mode < 0 || mode > 2 || (mode == 2 && !coin_host)) return ASR_EINVAL;
+    const int B = d->B, Te = d->Te, D = d->D, A = d->A, H = d->H, lmH = d->lmH, E = d->E, V = d->V, T = d->T_out;
+    if (B <= 0 || T <= 0) return ASR_EINVAL;
+    if (keep_lm < 1.0f && !ws->lm_hd) return ASR_EINVAL;
+    if (w->simple_w && !ws->sp) return ASR_EINVAL;
+    int rc;
+    // hf = enc . AttnW   (attn_decoder.py:70-73)
+    if ((rc = asr_gemm_f32(stream, 0, 0, B * Te, A, D, enc, D, w->attn_enc_w, A, ws->hf, A, nullptr, 0))) return rc;
+    const int P = w->simple_w ? H : lmH;
+    for (int i = 0; i < T; ++i) {
+        const size_t o = (size_t)i * B;
+        const float* lm_hp = i ? ws->lm_h + (o - B) * lmH : ws->zeros;
+        const float* lm_cp = i ? ws->lm_c + (o - B) * lmH : nullptr;
+        if ((rc = asr_lstm_cell_fwd(stream, w->embedding, E, E, ws->tok + o, lm_hp, lm_cp, w->lm_kernel,
+                                    w->lm_bias, lmH, B, ws->lm_c + o * lmH, ws->lm_h + o * lmH,
+                                    keep_lm < 1.0f ? ws->lm_hd + o * lmH : nullptr,
+                                    ws->lm_gates ? ws->lm_gates + o * 4 * lmH : nullptr, keep_lm, seed, (unsigned)i)))
+            return rc;
+        const float* lm_out = keep_lm < 1.0f ? ws->lm_hd + o * lmH : ws->lm_h + o * lmH;
+        if (w->simple_w) {
+            if ((rc = asr_linear_fwd(stream, lm_out, lmH, lmH, nullptr, nullptr, 0, 0, w->simple_w, H,
+                                     w->simple_b, ws->sp + o * H, H, B, H, nullptr, 0)))
+                return rc;
+            lm_out = ws->sp + o * H;
+        }
+        const float* ctx_prev = i ? ws->ctx + (o - B) * D : ws->zeros;
+        if ((rc = asr_linear_fwd(stream, lm_out, P, P, nullptr, ctx_prev, D, D, w->inp_w, E, w->inp_b,
+                                 ws->x + o * E, E, B, E, nullptr, 0)))
+            return rc;
+        const float* dh = i ? ws->dec_h + (o - B) * H : ws->zeros;
+        const float* dc = i ? ws->dec_c + (o - B) * H : nullptr;
+        if ((rc = asr_lstm_cell_fwd(stream, ws->x + o * E, E, E, nullptr, dh, dc, w->dec_kernel, w->dec_bias, H, B,
+                                    ws->dec_c + o * H, ws->dec_h + o * H, nullptr,
+                                    ws->dec_gates ? ws->dec_gates + o * 4 * H : nullptr, 1.0f, 0, 0)))
+            return rc;
+        if ((rc = asr_attention_fwd(stream, ws->dec_c + o * H, H, w->attn_w, w->attn_b, w->attn_v, ws->hf, enc,
+                                    enc_len, ws->alpha + o * Te, ws->ctx + o * D, B, Te, H, A, D)))
+            return rc;
+        if ((rc = asr_linear_fwd(stream, ws->dec_c + o * H, H, H, nullptr, ws->ctx + o * D, D, D, w->ap_w, H,
+                                 w->ap_b, ws->p + o * H, H, B, H, nullptr, 0)))
+            return rc;
+        if ((rc = asr_linear_fwd(stream, ws->p + o * H, H, H, nullptr, nullptr, 0, 0, w->out_w, V, w->out_b,
+                                 logits + o * V, V, B, V, seq_len, i)))
+            return rc;
+        if (i + 1 < T) {
+            const bool sample = mode == 2 && samp_prob > 0.f && !(coin_host[i] < 1.0f - samp_prob);
+            if (mode == 1 || sample)
+                if ((rc = asr_next_token(stream, logits + o * V, B, V, V, ws->tok + o + B, sample ? 1 : 0, seed,
+                                         (unsigned)i)))
+                    return rc;
+        }
+    }
+    return ASR_OK;
+}

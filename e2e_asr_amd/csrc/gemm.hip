@@ -1,0 +1,181 @@
+// fp32 GEMM on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32: exact f32 fmaf chain).
+//
+//   C[M,N] (+)= op(A) . op(B) + bias[N]
+//
+// Used for every non-recurrent dense contraction on the hot path: the all-timestep
+// LSTM input projection X.K_x (encoder.py:78-81 hoisted out of the while_loop), the
+// attention precompute enc.AttnW (attn_decoder.py:70-73), and in training the data
+// and weight gradient products.
+//
+// Tiling (wave64, not warp32): 128x128 block tile, BK=16, 4 waves as 2x2, each wave a
+// 64x64 sub-tile = 2x2 MFMA 32x32 tiles (4 x 16 accumulator registers).  LDS holds both
+// operands k-major ([k][m] / [k][n]) so that an MFMA operand read is one conflict-free
+// ds_read_b32 per lane (lanes 0-31: consecutive m at k, lanes 32-63: at k+1).  Global ->
+// register prefetch of tile t+1 is issued before the MFMAs of tile t.
+#include "common.h"
+
+namespace asr {
+
+constexpr int BM = 128, BN = 128, BK = 16, LDT = 132;  // LDT: padded k-row (16-B aligned)
+
+struct GemmArgs {
+    const float* A; const float* B; float* C; const float* bias;
+    int M, N, K, lda, ldb, ldc;
+    int accumulate;   // C += result
+    int vecA, vecB;   // 16-B vector loads legal for this operand
+};
+
+// Load 4 consecutive floats p[0..3] where element i is valid iff i < nvalid.
+__device__ __forceinline__ float4 ld4(const float* p, int nvalid, bool vec) {
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (nvalid >= 4 && vec) return *reinterpret_cast<const float4*>(p);
+    if (nvalid > 0) r.x = p[0];
+    if (nvalid > 1) r.y = p[1];
+    if (nvalid > 2) r.z = p[2];
+    if (nvalid > 3) r.w = p[3];
+    return r;
+}
+
+// Operand staging.  "KM" = operand stored [k][m] in memory (contiguous along m/n):
+// thread -> (k = tid>>4, mq = tid&15), two float4 at m = mq*4 and mq*4+64.
+// "MK" = operand stored [m][k] (contiguous along k): thread -> (m = tid>>1, kh = tid&1),
+// two float4 at k = kh*8, kh*8+4, transposed on the LDS store.
+template <bool KMAJOR>
+struct Stager {
+    float4 r0, r1;
+    __device__ __forceinline__ void load(const float* P, int ld, int m0, int k0, int Mdim, int Kdim,
+                                         bool vec, int tid) {
+        if (KMAJOR) {
+            int k = k0 + (tid >> 4), m = m0 + (tid & 15) * 4;
+            if (k < Kdim) {
+                const float* p = P + (size_t)k * ld + m;
+                r0 = ld4(p, Mdim - m, vec);
+                r1 = ld4(p + 64, Mdim - m - 64, vec);
+            } else {
+                r0 = r1 = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        } else {
+            int m = m0 + (tid >> 1), k = k0 + (tid & 1) * 8;
+            if (m < Mdim) {
+                const float* p = P + (size_t)m * ld + k;
+                r0 = ld4(p, Kdim - k, vec);
+                r1 = ld4(p + 4, Kdim - k - 4, vec);
+            } else {
+                r0 = r1 = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    }
+    __device__ __forceinline__ void store(float* S, int tid) const {
+        if (KMAJOR) {
+            float* s = S + (tid >> 4) * LDT + (tid & 15) * 4;
+            *reinterpret_cast<float4*>(s) = r0;
+            *reinterpret_cast<float4*>(s + 64) = r1;
+        } else {
+            float* s = S + ((tid & 1) * 8) * LDT + (tid >> 1);
+            s[0] = r0.x; s[LDT] = r0.y; s[2 * LDT] = r0.z; s[3 * LDT] = r0.w;
+            s[4 * LDT] = r1.x; s[5 * LDT] = r1.y; s[6 * LDT] = r1.z; s[7 * LDT] = r1.w;
+        }
+    }
+};
+
+// TA: A is given transposed ([K,M] row-major).  TB: B is given transposed ([N,K] row-major).
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
+    __shared__ __attribute__((aligned(16))) float As[BK * LDT];
+    __shared__ __attribute__((aligned(16))) float Bs[BK * LDT];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1;
+
+    // XCD-aware tile order: blocks b and b+8 share an L2, so give each XCD label a
+    // contiguous run of row-tiles that re-use the same B panel / neighbouring A panels.
+    const int ntn = (a.N + BN - 1) / BN, ntm = (a.M + BM - 1) / BM;
+    const int nwg = ntn * ntm;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+    }
+    const int m0 = (bid / ntn) * BM, n0 = (bid % ntn) * BN;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    Stager<TA> sa;    // A natural [M,K] is m-major => KMAJOR = TA
+    Stager<!TB> sb;   // B natural [K,N] is k-major => KMAJOR = !TB
+    const int nk = (a.K + BK - 1) / BK;
+    sa.load(a.A, a.lda, m0, 0, a.M, a.K, a.vecA, tid);
+    sb.load(a.B, a.ldb, n0, 0, a.N, a.K, a.vecB, tid);
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();               // previous tile's reads are done
+        sa.store(As, tid);
+        sb.store(Bs, tid);
+        __syncthreads();
+        if (kt + 1 < nk) {             // prefetch next tile under this tile's MFMAs
+            sa.load(a.A, a.lda, m0, (kt + 1) * BK, a.M, a.K, a.vecA, tid);
+            sb.load(a.B, a.ldb, n0, (kt + 1) * BK, a.N, a.K, a.vecB, tid);
+        }
+        const float* ap = As + (lane >> 5) * LDT + wr * 64 + (lane & 31);
+        const float* bp = Bs + (lane >> 5) * LDT + wc * 64 + (lane & 31);
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            float a0 = ap[kk * LDT], a1 = ap[kk * LDT + 32];
+            float b0 = bp[kk * LDT], b1 = bp[kk * LDT + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+    // Epilogue.  C/D map of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int n = n0 + wc * 64 + ni * 32 + (lane & 31);
+            if (n >= a.N) continue;
+            const float bv = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m < a.M) {
+                    float* cp = a.C + (size_t)m * a.ldc + n;
+                    float v = acc[mi][ni][r] + bv;
+                    if (a.accumulate) v += *cp;
+                    *cp = v;
+                }
+            }
+        }
+}
+
+}  // namespace asr
+
+// ---------------------------------------------------------------------------------
+// C ABI (declared in include/e2e_asr_hip.h)
+// ---------------------------------------------------------------------------------
+extern "C" int asr_gemm_f32(void* stream, int transA, int transB, int M, int N, int K,
+                            const float* A, int lda, const float* B, int ldb,
+                            float* C, int ldc, const float* bias, int accumulate) {
+    using namespace asr;
+    if (M < 0 || N < 0 || K < 0 || !C || (K > 0 && (!A || !B))) return ASR_EINVAL;
+    if (M == 0 || N == 0) return ASR_OK;
+    if (lda < (transA ? M : K) || ldb < (transB ? K : N) || ldc < N) return ASR_EINVAL;
+    GemmArgs g;
+    g.A = A; g.B = B; g.C = C; g.bias = bias;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.accumulate = accumulate;
+    g.vecA = ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && (lda % 4 == 0);
+    g.vecB = ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && (ldb % 4 == 0);
+    const int nwg = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (transA && transB)       hipLaunchKernelGGL((gemm_f32_kernel<true, true>), dim3(nwg), dim3(256), 0, s, g);
+    else if (transA)            hipLaunchKernelGGL((gemm_f32_kernel<true, false>), dim3(nwg), dim3(256), 0, s, g);
+    else if (transB)            hipLaunchKernelGGL((gemm_f32_kernel<false, true>), dim3(nwg), dim3(256), 0, s, g);
+    else                        hipLaunchKernelGGL((gemm_f32_kernel<false, false>), dim3(nwg), dim3(256), 0, s, g);
+    ASR_CHECK_LAUNCH();
+    return ASR_OK;
+}

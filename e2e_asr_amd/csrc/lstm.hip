@@ -1,0 +1,295 @@
+// Persistent (Bi)LSTM layer, forward -- the 1,500-step serial chain of the encoder.
+//
+// Reference semantics (encoder.py:55-91): tf.nn.bidirectional_dynamic_rnn /
+// tf.nn.dynamic_rnn over BasicLSTMCell (arithmetic restated at basic_lstm.py:14-23:
+// [x,h].K + b -> i,j,f,o; c' = c*sigmoid(f+1) + sigmoid(i)*tanh(j); h' = sigmoid(o)*tanh(c')),
+// sequence_length masking (t >= len[b]: output 0, state copied through), backward
+// direction = reverse_sequence o rnn o reverse_sequence (the cell walks t = len[b]-1 .. 0).
+//
+// MI355X design.  The input half of the contraction, X.K_x + b for ALL timesteps, is
+// one MFMA GEMM per direction (gemm.hip) written to `gates` [B,T,ND,4H].  What is left
+// per step is h_{t-1}.K_h (H x 4H) + the cell -- a dependent chain, so what matters is
+// step LATENCY, not FLOPs.  Decomposition:
+//   * utterances are independent => the batch is cut into groups of R rows; groups
+//     never synchronise with each other (no grid barrier anywhere);
+//   * inside a group, K_h is cut column-wise over G = H/HS workgroups, each owning HS
+//     hidden units with all 4 of their gates.  Its K_h slice (H x 4HS fp32 = 128 KB at
+//     H=256) lives in REGISTERS for the whole sequence (KPT*4 per thread); c stays in
+//     registers too; h_{t-1} (R x H) is staged through LDS each step;
+//   * the only inter-workgroup traffic is the all-gather of h_t inside a group: R*H
+//     8-byte {tag = step+1, value} granules, each written by ONE write-through (sc1)
+//     store and polled with sc1 loads -- the data is its own flag, one L2 round trip
+//     per step, correct for any workgroup->XCD placement (guide: Guideline 16, R2).
+//     Group members are placed on one XCD label (blockIdx % 8) for speed only.
+//   * both directions and all groups run concurrently: ND * ceil(B/R) * G workgroups
+//     (= 256 = one per CU at B=32, R=2, H=256).
+// Thread map (16*HS = 512 threads): lane = 16*cgl + kq; unit u = 4*wave + cgl; the 16
+// lanes of a DPP row hold the 16 K-chunks of one unit, so the K reduction is 4 DPP
+// butterflies with no LDS, and lanes kq < R of each row run the cell for batch row kq.
+#include "common.h"
+
+namespace asr {
+
+struct LstmRecArgs {
+    float* gates;          // [B][T][ND][4H] in: x.Kx+b   out (save): activated i,j,f,o
+    const float* kh[2];    // per direction: recurrent rows of the TF kernel, [H][4H]
+    const int* len;        // [B]
+    float* out;            // [B][Tout][ND*H]
+    float* csave;          // [B][T][ND][H] or nullptr
+    u64* hx;               // exchange granules [ND*NG][2][R][H]
+    int* err;              // set to 1 on poll timeout
+    int B, T, Tout, ND;
+    float keep; uint32_t seed;
+};
+
+__device__ __forceinline__ bool poll_granule(const u64* g, uint32_t epoch, float& val, int* err) {
+    long long t0 = 0;
+    for (uint32_t spins = 0;; ++spins) {
+        u64 x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((uint32_t)(x >> 32) == epoch) { val = __uint_as_float((uint32_t)x); return true; }
+        if ((spins & 1023) == 1023) {              // bounded spin: ~2 s of wall clock
+            long long now = wall_clock64();
+            if (t0 == 0) t0 = now;
+            else if (now - t0 > 200000000LL) { *err = 1; val = 0.f; return false; }
+            if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { val = 0.f; return false; }
+        }
+    }
+}
+
+template <int H, int HS, int R>
+__global__ __launch_bounds__(16 * HS) void lstm_rec_fwd_kernel(LstmRecArgs a) {
+    constexpr int KPT = H / 16;        // K values per lane
+    constexpr int CS = KPT + 4;        // padded LDS chunk stride (conflict-free b128 reads)
+    constexpr int G = H / HS;          // workgroups per group
+    constexpr int NT = 16 * HS;
+    __shared__ __attribute__((aligned(16))) float hl[R * 16 * CS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kq = lane & 15, cgl = lane >> 4;
+    const int NG = (a.B + R - 1) / R;
+    const int ngroups = a.ND * NG;
+    int grp, mem;
+    if ((ngroups & 7) == 0) {          // members of a group share blockIdx % 8 (one XCD label)
+        mem = (blockIdx.x >> 3) % G;
+        grp = (blockIdx.x & 7) + 8 * (blockIdx.x / (8 * G));
+    } else {
+        grp = blockIdx.x / G; mem = blockIdx.x % G;
+    }
+    const int dir = grp / NG, bg = grp % NG;
+    const int r0 = bg * R;
+    const int u = wave * 4 + cgl;
+    const int j = mem * HS + u;        // hidden unit owned by this DPP row
+    const int H4 = 4 * H;
+
+    // recurrent weights -> registers (once)
+    float w[KPT][4];
+    {
+        const float* kh = a.kh[dir];
+#pragma unroll
+        for (int i = 0; i < KPT; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) w[i][g] = kh[(size_t)(kq * KPT + i) * H4 + g * H + j];
+    }
+
+    int lenr[R];
+    int S = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        lenr[r] = (r0 + r < a.B) ? min(a.len[r0 + r], a.T) : 0;
+        S = max(S, lenr[r]);
+    }
+    const int my_r = kq;                          // cell lane: batch row kq of the group (kq < R)
+    const bool cell_lane = kq < R;
+    int my_len = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) if (kq == r) my_len = lenr[r];
+    const int my_b = r0 + my_r;
+
+    float c = 0.f, h = 0.f;
+    u64* hxg = a.hx + (size_t)grp * 2 * R * H;
+
+    for (int s = 0; s < S; ++s) {
+        // (1) prefetch this step's input projection for the cell lanes (independent of h)
+        const bool live = cell_lane && s < my_len;
+        const int t = dir ? (my_len - 1 - s) : s;
+        float gx[4] = {0.f, 0.f, 0.f, 0.f};
+        float* gp = nullptr;
+        if (live) {
+            gp = a.gates + (((size_t)my_b * a.T + t) * a.ND + dir) * H4 + j;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) gx[g] = gp[g * H];
+        }
+        // (2) gather h_{s-1} of the group's rows (all H units) from the exchange buffer
+        float acc[R][4];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[r][g] = 0.f;
+        if (s > 0) {
+            const u64* src = hxg + (size_t)((s - 1) & 1) * R * H;
+            for (int idx = tid; idx < R * H; idx += NT) {
+                const int r = idx / H, k = idx % H;
+                float v = 0.f;
+                if (r0 + r < a.B) poll_granule(src + idx, (uint32_t)s, v, a.err);
+                hl[(r * 16 + k / KPT) * CS + (k % KPT)] = v;
+            }
+            __syncthreads();
+            // (3) h.K_h for this lane's K chunk
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const float4* hp = reinterpret_cast<const float4*>(hl + (r * 16 + kq) * CS);
+#pragma unroll
+                for (int i4 = 0; i4 < KPT / 4; ++i4) {
+                    const float4 hv = hp[i4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        acc[r][g] = fmaf(hv.x, w[4 * i4 + 0][g], acc[r][g]);
+                        acc[r][g] = fmaf(hv.y, w[4 * i4 + 1][g], acc[r][g]);
+                        acc[r][g] = fmaf(hv.z, w[4 * i4 + 2][g], acc[r][g]);
+                        acc[r][g] = fmaf(hv.w, w[4 * i4 + 3][g], acc[r][g]);
+                    }
+                }
+            }
+            // (4) reduce over the 16 K chunks (DPP row), every lane of the row gets the sum
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[r][g] = row16_allreduce_sum(acc[r][g]);
+            __syncthreads();   // hl may be overwritten next step
+        }
+        // (5) the cell, in lanes kq < R (row kq of the group, unit j)
+        if (cell_lane) {
+            float pre[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (kq == r) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) pre[g] = acc[r][g];
+                }
+            if (live) {
+                const float gi = fast_sigmoid(pre[0] + gx[0]);
+                const float gj = fast_tanh(pre[1] + gx[1]);
+                const float gf = fast_sigmoid(pre[2] + gx[2] + 1.0f);   // forget bias
+                const float go = fast_sigmoid(pre[3] + gx[3]);
+                c = c * gf + gi * gj;
+                h = go * fast_tanh(c);
+                float o = h;
+                if (a.keep < 1.0f)
+                    o *= keep_scale(a.seed, (uint32_t)(my_b * a.Tout + t), (uint32_t)(dir * H + j), a.keep);
+                a.out[((size_t)my_b * a.Tout + t) * (a.ND * H) + dir * H + j] = o;
+                if (a.csave) {
+                    gp[0] = gi; gp[H] = gj; gp[2 * H] = gf; gp[3 * H] = go;
+                    a.csave[(((size_t)my_b * a.T + t) * a.ND + dir) * H + j] = c;
+                }
+            }
+            // publish h_s (unchanged for rows past their length): ONE 8-byte sc1 store
+            if (my_b < a.B && s + 1 < S) {
+                u64* dst = hxg + ((size_t)(s & 1) * R + my_r) * H + j;
+                __hip_atomic_store(dst, ((u64)(uint32_t)(s + 1) << 32) | __float_as_uint(h),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+    // zero output past each row's length (dynamic_rnn zero-fill; also the pyramid pad frame)
+    for (int r = 0; r < R; ++r) {
+        if (r0 + r >= a.B) break;
+        const int nz = a.Tout - lenr[r];
+        for (int idx = tid; idx < nz * HS; idx += NT) {
+            const int t = lenr[r] + idx / HS, uu = idx % HS;
+            a.out[((size_t)(r0 + r) * a.Tout + t) * (a.ND * H) + dir * H + mem * HS + uu] = 0.f;
+        }
+    }
+}
+
+template <int H, int R>
+static int launch_rec(hipStream_t s, const LstmRecArgs& a) {
+    constexpr int HS = 32;
+    const int NG = (a.B + R - 1) / R;
+    const int grid = a.ND * NG * (H / HS);
+    hipLaunchKernelGGL((lstm_rec_fwd_kernel<H, HS, R>), dim3(grid), dim3(16 * HS), 0, s, a);
+    return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
+}
+
+template <int H>
+static int launch_rec_h(hipStream_t s, const LstmRecArgs& a, int R) {
+    switch (R) {
+        case 1: return launch_rec<H, 1>(s, a);
+        case 2: return launch_rec<H, 2>(s, a);
+        case 4: return launch_rec<H, 4>(s, a);
+        case 8: return launch_rec<H, 8>(s, a);
+    }
+    return ASR_EINVAL;
+}
+
+}  // namespace asr
+
+extern "C" int asr_gemm_f32(void*, int, int, int, int, int, const float*, int, const float*, int,
+                            float*, int, const float*, int);
+
+// rows per group: smallest R whose grid fits one workgroup per CU (256 CUs); override for tuning
+static int pick_rows(int B, int ND, int G) {
+    if (const char* e = getenv("ASR_LSTM_R")) { int r = atoi(e); if (r == 1 || r == 2 || r == 4 || r == 8) return r; }
+    for (int R : {1, 2, 4, 8})
+        if (ND * ((B + R - 1) / R) * G <= 256) return R;
+    return 8;
+}
+
+extern "C" size_t asr_lstm_ws_bytes(int B, int H, int ndir) {
+    // worst case R=1: ND * B groups * 2 parities * H granules; R>1 never needs more
+    return (size_t)ndir * (size_t)((B + 7) / 8 * 8) * 2 * H * sizeof(u64);
+}
+
+extern "C" int asr_lstm_layer_fwd(void* stream, const float* x, int B, int T, int in_dim, int ldx,
+                                  const int* len, int H, int ndir,
+                                  const float* kernel_fw, const float* bias_fw,
+                                  const float* kernel_bw, const float* bias_bw,
+                                  float* out, int Tout, float* gates, float* csave,
+                                  void* hx_ws, size_t hx_bytes, int* err_flag,
+                                  float keep_prob, unsigned seed) {
+    using namespace asr;
+    if (!x || !len || !kernel_fw || !bias_fw || !out || !gates || !hx_ws || !err_flag) return ASR_EINVAL;
+    if (ndir != 1 && ndir != 2) return ASR_EINVAL;
+    if (ndir == 2 && (!kernel_bw || !bias_bw)) return ASR_EINVAL;
+    if (B <= 0 || T <= 0 || in_dim <= 0 || Tout < T || ldx < in_dim) return ASR_EINVAL;
+    if (H != 64 && H != 128 && H != 256 && H != 512) return ASR_EUNSUPPORTED;
+    if (hx_bytes < asr_lstm_ws_bytes(B, H, ndir)) return ASR_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int H4 = 4 * H;
+    // input projection for all timesteps: gates[b,t,dir,:] = x[b,t,:] . K_x + bias
+    for (int d = 0; d < ndir; ++d) {
+        int rc = asr_gemm_f32(stream, 0, 0, B * T, H4, in_dim, x, ldx, d ? kernel_bw : kernel_fw, H4,
+                              gates + (size_t)d * H4, ndir * H4, d ? bias_bw : bias_fw, 0);
+        if (rc) return rc;
+    }
+    if (hipMemsetAsync(hx_ws, 0, asr_lstm_ws_bytes(B, H, ndir), s) != hipSuccess) return ASR_ELAUNCH;
+    LstmRecArgs a;
+    a.gates = gates;
+    a.kh[0] = kernel_fw + (size_t)in_dim * H4;
+    a.kh[1] = ndir == 2 ? kernel_bw + (size_t)in_dim * H4 : nullptr;
+    a.len = len; a.out = out; a.csave = csave; a.hx = static_cast<u64*>(hx_ws); a.err = err_flag;
+    a.B = B; a.T = T; a.Tout = Tout; a.ND = ndir; a.keep = keep_prob; a.seed = seed;
+    const int R = pick_rows(B, ndir, H / 32);
+    // batches too large for one resident grid run as consecutive launches over row ranges
+    const int max_groups = 256 / (H / 32) / ndir;
+    const int rows_per_launch = max_groups > 0 ? max_groups * R : R;
+    for (int b0 = 0; b0 < B; b0 += rows_per_launch) {
+        LstmRecArgs c = a;
+        const int nb = (B - b0 < rows_per_launch) ? (B - b0) : rows_per_launch;
+        c.B = nb;
+        c.gates = a.gates + (size_t)b0 * T * ndir * H4;
+        c.len = len + b0;
+        c.out = out + (size_t)b0 * Tout * ndir * H;
+        c.csave = csave ? csave + (size_t)b0 * T * ndir * H : nullptr;
+        int rc;
+        switch (H) {
+            case 64: rc = launch_rec_h<64>(s, c, R); break;
+            case 128: rc = launch_rec_h<128>(s, c, R); break;
+            case 256: rc = launch_rec_h<256>(s, c, R); break;
+            default: rc = launch_rec_h<512>(s, c, R); break;
+        }
+        if (rc) return rc;
+        if (b0 + rows_per_launch < B &&
+            hipMemsetAsync(hx_ws, 0, asr_lstm_ws_bytes(B, H, ndir), s) != hipSuccess) return ASR_ELAUNCH;
+    }
+    return ASR_OK;
+}

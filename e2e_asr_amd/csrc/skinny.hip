@@ -1,0 +1,155 @@
+// Skinny (M = batch <= a few 16-row tiles) dense layers of the attention-decoder step.
+//
+// Reference ops (attn_decoder.py): `_linear([a,b], n, True)` = concat(a,b).W + bias at
+// :117 (AttnProjection), :122/125 (OutputProjection), :151 (SimpleProjection), :158
+// (InputProjection); and the two BasicLSTMCell calls per step (:148 lm cell, :166 outer
+// cell through raw_rnn) whose arithmetic is basic_lstm.py:14-23.
+//
+// One workgroup = one 16(columns) x 16(batch rows) output tile on v_mfma_f32_16x16x4_f32
+// (exact f32).  W is streamed ONCE straight from global/L2 into the MFMA A-operand
+// registers (no LDS: it is not shared between waves -- each of the 4 waves owns a quarter
+// of K); X rows are read as 16-byte vectors.  The 4 K-partials meet in LDS and wave 0
+// runs the epilogue.  The concat of the reference is never materialised: the K loop
+// switches source pointer at K1.  In LSTM mode the 16 tile columns are 4 hidden units x
+// their 4 gates (column n_local = 4*unit + gate -> TF column gate*H + j), so that the
+// MFMA result layout (row = 4*(lane>>4) + reg) hands each lane the i,j,f,o of ONE unit for
+// ONE batch row and the cell runs in registers.
+#include "common.h"
+
+namespace asr {
+
+struct SkinnyArgs {
+    const float* x1; int ld1; int K1; const int* gather1;   // row b of X1 = x1 + (gather1? gather1[b] : b)*ld1
+    const float* x2; int ld2; int K2;
+    const float* W; int ldw; const float* bias;
+    int M, N;
+    // linear mode
+    float* out; int ldo;
+    const int* zero_from; int zero_t;     // rows with zero_t >= zero_from[b] are written as zeros (raw_rnn emit)
+    // LSTM mode (H > 0)
+    int H; const float* c_prev; float* c_out; float* h_out; float* hdrop_out; float* gates_out;
+    float keep; uint32_t seed; uint32_t step;
+};
+
+template <bool LSTM>
+__global__ __launch_bounds__(256) void skinny_kernel(SkinnyArgs a) {
+    __shared__ float red[3][4][64];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int nl = lane & 15, g4 = lane >> 4;
+    const int K = a.K1 + a.K2;
+    // column of W feeding output row nl of the MFMA tile
+    int colW; bool colok;
+    if (LSTM) { const int j = blockIdx.x * 4 + (nl >> 2); colW = (nl & 3) * a.H + j; colok = j < a.H; }
+    else      { colW = blockIdx.x * 16 + nl; colok = colW < a.N; }
+    const int brow = blockIdx.y * 16 + nl;      // batch row this lane supplies as MFMA B operand
+    const bool rowok = brow < a.M;
+    const float* xr1 = nullptr; const float* xr2 = nullptr;
+    if (rowok) {
+        xr1 = a.x1 + (size_t)(a.gather1 ? a.gather1[brow] : brow) * a.ld1;
+        if (a.K2 > 0) xr2 = a.x2 + (size_t)brow * a.ld2;
+    }
+    const int chunk = ((K + 63) / 64) * 16;
+    const int kbeg = w * chunk, kend = min(K, kbeg + chunk);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int kb = kbeg; kb < kend; kb += 16) {
+        const int k = kb + 4 * g4;
+        float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+        float wv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (k < K) {
+            if (rowok) xv = (k < a.K1) ? *reinterpret_cast<const float4*>(xr1 + k)
+                                       : *reinterpret_cast<const float4*>(xr2 + (k - a.K1));
+            if (colok) {
+                const float* wp = a.W + (size_t)k * a.ldw + colW;
+                wv[0] = wp[0]; wv[1] = wp[a.ldw]; wv[2] = wp[2 * (size_t)a.ldw]; wv[3] = wp[3 * (size_t)a.ldw];
+            }
+        }
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[0], xv.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[1], xv.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[2], xv.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[3], xv.w, acc, 0, 0, 0);
+    }
+    if (w > 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[w - 1][r][lane] = acc[r];
+    }
+    __syncthreads();
+    if (w != 0) return;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] += red[0][r][lane] + red[1][r][lane] + red[2][r][lane];
+    // lane holds D[n_local = 4*g4 + r][batch = nl]
+    const int b = blockIdx.y * 16 + nl;
+    if (b >= a.M) return;
+    if (LSTM) {
+        const int j = blockIdx.x * 4 + g4;
+        if (j >= a.H) return;
+        const int H = a.H;
+        const float gi = fast_sigmoid(acc[0] + a.bias[j]);
+        const float gj = fast_tanh(acc[1] + a.bias[H + j]);
+        const float gf = fast_sigmoid(acc[2] + a.bias[2 * H + j] + 1.0f);
+        const float go = fast_sigmoid(acc[3] + a.bias[3 * H + j]);
+        const float cp = a.c_prev ? a.c_prev[(size_t)b * H + j] : 0.f;
+        const float c = cp * gf + gi * gj;
+        const float h = go * fast_tanh(c);
+        a.c_out[(size_t)b * H + j] = c;
+        a.h_out[(size_t)b * H + j] = h;
+        if (a.hdrop_out)
+            a.hdrop_out[(size_t)b * H + j] = h * keep_scale(a.seed, a.step * (uint32_t)a.M + (uint32_t)b, (uint32_t)j, a.keep);
+        if (a.gates_out) {
+            float* gp = a.gates_out + (size_t)b * 4 * H + j;
+            gp[0] = gi; gp[H] = gj; gp[2 * H] = gf; gp[3 * H] = go;
+        }
+    } else {
+        const int n = blockIdx.x * 16 + 4 * g4;
+        const bool z = a.zero_from && a.zero_t >= a.zero_from[b];
+        float* op = a.out + (size_t)b * a.ldo + n;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (n + r < a.N) op[r] = z ? 0.f : acc[r] + (a.bias ? a.bias[n + r] : 0.f);
+    }
+}
+
+}  // namespace asr
+
+static int skinny_check(const asr::SkinnyArgs& a) {
+    if (!a.x1 || !a.W || a.M <= 0 || a.K1 <= 0 || a.K2 < 0) return ASR_EINVAL;
+    if ((a.K1 & 3) || (a.K2 & 3) || (a.ld1 & 3) || (a.K2 > 0 && (!a.x2 || (a.ld2 & 3)))) return ASR_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(a.x1) & 15) || (a.x2 && (reinterpret_cast<uintptr_t>(a.x2) & 15))) return ASR_EINVAL;
+    return ASR_OK;
+}
+
+// out[M,N] = [X1 | X2] . W + bias   (rows b with zero_t >= zero_from[b] are emitted as 0)
+extern "C" int asr_linear_fwd(void* stream, const float* x1, int ld1, int K1, const int* gather1,
+                              const float* x2, int ld2, int K2, const float* W, int ldw,
+                              const float* bias, float* out, int ldo, int M, int N,
+                              const int* zero_from, int zero_t) {
+    asr::SkinnyArgs a{};
+    a.x1 = x1; a.ld1 = ld1; a.K1 = K1; a.gather1 = gather1; a.x2 = x2; a.ld2 = ld2; a.K2 = K2;
+    a.W = W; a.ldw = ldw; a.bias = bias; a.M = M; a.N = N; a.out = out; a.ldo = ldo;
+    a.zero_from = zero_from; a.zero_t = zero_t;
+    if (int rc = skinny_check(a)) return rc;
+    if (!out || N <= 0 || ldw < N || ldo < N) return ASR_EINVAL;
+    dim3 grid((N + 15) / 16, (M + 15) / 16);
+    hipLaunchKernelGGL((asr::skinny_kernel<false>), grid, dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    ASR_CHECK_LAUNCH();
+    return ASR_OK;
+}
+
+// BasicLSTMCell step: (c,h) = cell([X1 | h_prev], c_prev) with TF kernel [K1+H, 4H], gates i,j,f,o.
+extern "C" int asr_lstm_cell_fwd(void* stream, const float* x1, int ld1, int K1, const int* gather1,
+                                 const float* h_prev, const float* c_prev, const float* kernel,
+                                 const float* bias, int H, int M, float* c_out, float* h_out,
+                                 float* hdrop_out, float* gates_out, float keep, unsigned seed,
+                                 unsigned step) {
+    asr::SkinnyArgs a{};
+    a.x1 = x1; a.ld1 = ld1; a.K1 = K1; a.gather1 = gather1; a.x2 = h_prev; a.ld2 = H; a.K2 = H;
+    a.W = kernel; a.ldw = 4 * H; a.bias = bias; a.M = M; a.N = 4 * H; a.H = H;
+    a.c_prev = c_prev; a.c_out = c_out; a.h_out = h_out; a.hdrop_out = hdrop_out; a.gates_out = gates_out;
+    a.keep = keep; a.seed = seed; a.step = step;
+    if (int rc = skinny_check(a)) return rc;
+    if (!h_prev || !bias || !c_out || !h_out || H <= 0 || (H & 3)) return ASR_EINVAL;
+    dim3 grid((H + 3) / 4, (M + 15) / 16);
+    hipLaunchKernelGGL((asr::skinny_kernel<true>), grid, dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    ASR_CHECK_LAUNCH();
+    return ASR_OK;
+}

@@ -1,0 +1,263 @@
+"""Thin torch-tensor wrappers over the C ABI (include/e2e_asr_hip.h).
+
+torch is plumbing here: it owns device memory and the stream.  Every function
+below launches hand-written gfx950 kernels through ctypes; none has a fallback.
+Errors follow the reference's Python-exception convention: invalid arguments raise
+ValueError, launch failures RuntimeError.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+_ERR = {-1: (ValueError, "invalid argument"), -2: (RuntimeError, "kernel launch failed"),
+        -3: (ValueError, "unsupported shape")}
+
+
+def _check(rc, what):
+    if rc != 0:
+        exc, msg = _ERR.get(rc, (RuntimeError, "error %d" % rc))
+        raise exc("%s: %s" % (what, msg))
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32(t, name):
+    if t is None:
+        return None
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise ValueError("%s must be a contiguous float32 CUDA tensor" % name)
+    return t
+
+
+def _i32(t, name):
+    if not (t.is_cuda and t.dtype == torch.int32 and t.is_contiguous()):
+        raise ValueError("%s must be a contiguous int32 CUDA tensor" % name)
+    return t
+
+
+def gemm(a, b, bias=None, trans_a=False, trans_b=False, out=None, accumulate=False):
+    """out[M,N] (+)= op(a) @ op(b) + bias.  2-D float32 CUDA tensors (row stride = size(1))."""
+    _f32(a, "a"); _f32(b, "b"); _f32(bias, "bias")
+    M, K = (a.shape[1], a.shape[0]) if trans_a else a.shape
+    Kb, N = (b.shape[1], b.shape[0]) if trans_b else b.shape
+    if K != Kb:
+        raise ValueError("gemm: inner dimensions differ (%d vs %d)" % (K, Kb))
+    if out is None:
+        out = torch.empty((M, N), device=a.device, dtype=torch.float32)
+    _f32(out, "out")
+    rc = _lib.lib().asr_gemm_f32(_stream(), int(trans_a), int(trans_b), M, N, K, _p(a), a.shape[1],
+                                 _p(b), b.shape[1], _p(out), out.shape[1], _p(bias), int(accumulate))
+    _check(rc, "asr_gemm_f32")
+    return out
+
+
+class _Flag:
+    """Device int that kernels set when an inter-workgroup wait times out."""
+    _t = {}
+
+    @classmethod
+    def get(cls, dev):
+        if dev not in cls._t:
+            cls._t[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
+        return cls._t[dev]
+
+
+def check_device_flag(dev):
+    """Raise if any persistent kernel on `dev` reported a timeout (synchronises)."""
+    f = _Flag.get(dev)
+    if int(f.item()) != 0:
+        f.zero_()
+        raise RuntimeError("e2e_asr_amd: persistent LSTM kernel timed out waiting for a peer workgroup")
+
+
+_hx_cache = {}
+
+
+def lstm_layer_fwd(x, seq_len, kernel_fw, bias_fw, kernel_bw=None, bias_bw=None, t_out=None,
+                   save=False, keep_prob=1.0, seed=0):
+    """One (Bi)LSTM layer (encoder.py:55-91).  x [B,T,in] batch-major, seq_len int32 [B].
+
+    Returns out [B,t_out,ndir*H] (zeros past each length) and, when save=True, the
+    activated gates [B,T,ndir,4H] and cell states [B,T,ndir,H] for the backward pass.
+    """
+    _f32(x, "x"); _i32(seq_len, "seq_len")
+    B, T, IN = x.shape
+    H = kernel_fw.shape[1] // 4
+    ndir = 1 if kernel_bw is None else 2
+    if kernel_fw.shape[0] != IN + H:
+        raise ValueError("lstm kernel rows %d != in+H = %d" % (kernel_fw.shape[0], IN + H))
+    t_out = T if t_out is None else t_out
+    dev = x.device
+    out = torch.empty((B, t_out, ndir * H), device=dev, dtype=torch.float32)
+    gates = torch.empty((B, T, ndir, 4 * H), device=dev, dtype=torch.float32)
+    csave = torch.empty((B, T, ndir, H), device=dev, dtype=torch.float32) if save else None
+    L = _lib.lib()
+    nbytes = L.asr_lstm_ws_bytes(B, H, ndir)
+    key = (dev, nbytes)
+    if key not in _hx_cache:
+        _hx_cache[key] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    hx = _hx_cache[key]
+    rc = L.asr_lstm_layer_fwd(_stream(), _p(x), B, T, IN, IN, _p(seq_len), H, ndir,
+                              _p(_f32(kernel_fw, "kernel_fw")), _p(_f32(bias_fw, "bias_fw")),
+                              _p(_f32(kernel_bw, "kernel_bw")), _p(_f32(bias_bw, "bias_bw")),
+                              _p(out), t_out, _p(gates), _p(csave), _p(hx), nbytes,
+                              _p(_Flag.get(dev)), float(keep_prob), int(seed) & 0xFFFFFFFF)
+    _check(rc, "asr_lstm_layer_fwd")
+    return (out, gates, csave) if save else out
+
+
+def linear(x1, w, bias=None, x2=None, gather=None, zero_from=None, zero_t=0, out=None):
+    """[x1 | x2] @ w + bias for a skinny batch (attn_decoder.py `_linear` call sites)."""
+    _f32(x1, "x1"); _f32(w, "w")
+    M = x1.shape[0] if gather is None else gather.shape[0]
+    K1 = x1.shape[1]
+    K2 = 0 if x2 is None else x2.shape[1]
+    N = w.shape[1]
+    if w.shape[0] != K1 + K2:
+        raise ValueError("linear: weight rows %d != %d" % (w.shape[0], K1 + K2))
+    if out is None:
+        out = torch.empty((M, N), device=x1.device, dtype=torch.float32)
+    rc = _lib.lib().asr_linear_fwd(_stream(), _p(x1), x1.shape[1], K1, _p(gather), _p(_f32(x2, "x2")),
+                                   K2, K2, _p(w), N, _p(_f32(bias, "bias")), _p(out), out.shape[1], M, N,
+                                   _p(zero_from), int(zero_t))
+    _check(rc, "asr_linear_fwd")
+    return out
+
+
+def lstm_cell(x, h_prev, c_prev, kernel, bias, gather=None, keep_prob=1.0, seed=0, step=0,
+              save_gates=False):
+    """One BasicLSTMCell step (basic_lstm.py:14-23) -> (c, h[, h_dropped][, gates])."""
+    _f32(x, "x"); _f32(h_prev, "h_prev"); _f32(kernel, "kernel"); _f32(bias, "bias")
+    H = kernel.shape[1] // 4
+    M = x.shape[0] if gather is None else gather.shape[0]
+    dev = x.device
+    c = torch.empty((M, H), device=dev, dtype=torch.float32)
+    h = torch.empty_like(c)
+    hd = torch.empty_like(c) if keep_prob < 1.0 else None
+    g = torch.empty((M, 4 * H), device=dev, dtype=torch.float32) if save_gates else None
+    rc = _lib.lib().asr_lstm_cell_fwd(_stream(), _p(x), x.shape[1], x.shape[1], _p(gather), _p(h_prev),
+                                      _p(_f32(c_prev, "c_prev")), _p(kernel), _p(bias), H, M, _p(c), _p(h),
+                                      _p(hd), _p(g), float(keep_prob), int(seed) & 0xFFFFFFFF, int(step))
+    _check(rc, "asr_lstm_cell_fwd")
+    res = (c, h)
+    if hd is not None:
+        res += (hd,)
+    if g is not None:
+        res += (g,)
+    return res
+
+
+def attention(q, w_att, b_att, v, hf, enc, enc_len):
+    """Fused Bahdanau attention (attn_decoder.py:77-93) -> (ctx [B,D], alpha [B,Te])."""
+    for n, t in (("q", q), ("w_att", w_att), ("b_att", b_att), ("v", v), ("hf", hf), ("enc", enc)):
+        _f32(t, n)
+    _i32(enc_len, "enc_len")
+    B, Te, D = enc.shape
+    H, A = w_att.shape
+    alpha = torch.empty((B, Te), device=q.device, dtype=torch.float32)
+    ctx = torch.empty((B, D), device=q.device, dtype=torch.float32)
+    rc = _lib.lib().asr_attention_fwd(_stream(), _p(q), q.shape[1], _p(w_att), _p(b_att), _p(v), _p(hf),
+                                      _p(enc), _p(enc_len), _p(alpha), _p(ctx), B, Te, H, A, D)
+    _check(rc, "asr_attention_fwd")
+    return ctx, alpha
+
+
+def masked_ce(logits, targets, seq_len):
+    """losses.py:7-35 forward -> (loss scalar tensor, lse workspace)."""
+    _f32(logits, "logits"); _i32(targets, "targets"); _i32(seq_len, "seq_len")
+    T, B = targets.shape
+    V = logits.shape[1]
+    dev = logits.device
+    nll = torch.empty(T * B, device=dev, dtype=torch.float32)
+    lse = torch.empty(T * B, device=dev, dtype=torch.float32)
+    loss = torch.empty(1, device=dev, dtype=torch.float32)
+    rc = _lib.lib().asr_masked_ce_fwd(_stream(), _p(logits), _p(targets), _p(seq_len), _p(nll), _p(lse),
+                                      _p(loss), T, B, V)
+    _check(rc, "asr_masked_ce_fwd")
+    return loss, lse
+
+
+def masked_ce_bwd(logits, targets, lse, seq_len, grad_scale):
+    T, B = targets.shape
+    V = logits.shape[1]
+    d = torch.empty_like(logits)
+    rc = _lib.lib().asr_masked_ce_bwd(_stream(), _p(logits), _p(targets), _p(lse), _p(seq_len),
+                                      _p(_f32(grad_scale, "grad_scale")), _p(d), T, B, V)
+    _check(rc, "asr_masked_ce_bwd")
+    return d
+
+
+def next_token(logits, sample=False, seed=0, step=0):
+    B, V = logits.shape
+    tok = torch.empty(B, device=logits.device, dtype=torch.int32)
+    rc = _lib.lib().asr_next_token(_stream(), _p(_f32(logits, "logits")), B, V, V, _p(tok), int(sample),
+                                   int(seed) & 0xFFFFFFFF, int(step))
+    _check(rc, "asr_next_token")
+    return tok
+
+
+DEC_WEIGHT_LEAVES = {   # struct field -> variable leaf under model/rnn_decoder_<task>/
+    "embedding": "decoder/embedding", "attn_enc_w": "AttnW", "attn_v": "AttnV",
+    "attn_w": "rnn/Attention/kernel", "attn_b": "rnn/Attention/bias",
+    "lm_kernel": "rnn/basic_lstm_cell/kernel", "lm_bias": "rnn/basic_lstm_cell/bias",
+    "dec_kernel": "rnn/basic_lstm_cell_1/kernel", "dec_bias": "rnn/basic_lstm_cell_1/bias",
+    "inp_w": "rnn/InputProjection/kernel", "inp_b": "rnn/InputProjection/bias",
+    "ap_w": "rnn/AttnProjection/kernel", "ap_b": "rnn/AttnProjection/bias",
+    "out_w": "rnn/OutputProjection/kernel", "out_b": "rnn/OutputProjection/bias",
+    "simple_w": "rnn/SimpleProjection/kernel", "simple_b": "rnn/SimpleProjection/bias",
+}
+
+
+def _dec_struct(cls, tensors):
+    s = cls()
+    for f, _ in cls._fields_:
+        t = tensors.get(f)
+        setattr(s, f, None if t is None else t.data_ptr())
+    return s
+
+
+def attn_decoder_fwd(wt, dec_inp, seq_len, enc, enc_len, mode=0, coin=None, samp_prob=0.0,
+                     keep_lm=1.0, seed=0, t_out=None):
+    """Whole attention decoder forward (attn_decoder.py:37-172).
+
+    wt: dict struct-field -> float32 CUDA tensor (see DEC_WEIGHT_LEAVES).
+    dec_inp int32 [T_dec,B]; seq_len int32 [B] (device) ; enc [B,Te,D]; enc_len int32 [B].
+    Returns logits [(T_out*B),V] and the activation dict consumed by the backward.
+    """
+    B, Te, D = enc.shape
+    V, E = wt["embedding"].shape
+    H = wt["dec_kernel"].shape[1] // 4
+    lmH = wt["lm_kernel"].shape[1] // 4
+    A = wt["attn_w"].shape[1]
+    if t_out is None:
+        t_out = int(seq_len.max().item())
+    T = t_out
+    dev = enc.device
+    f = lambda *s: torch.empty(s, device=dev, dtype=torch.float32)
+    ws = dict(hf=f(B, Te, A), tok=dec_inp[:T].contiguous().clone(), lm_gates=f(T, B, 4 * lmH),
+              lm_c=f(T, B, lmH), lm_h=f(T, B, lmH), lm_hd=f(T, B, lmH) if keep_lm < 1.0 else None,
+              sp=f(T, B, H) if wt.get("simple_w") is not None else None, x=f(T, B, E),
+              dec_gates=f(T, B, 4 * H), dec_c=f(T, B, H), dec_h=f(T, B, H), alpha=f(T, B, Te),
+              ctx=f(T, B, D), p=f(T, B, H),
+              zeros=torch.zeros(B * max(H, lmH, D), device=dev, dtype=torch.float32))
+    logits = f(T * B, V)
+    cw = _dec_struct(_lib.DecWeights, wt)
+    cd = _lib.DecDims(B, Te, D, A, H, lmH, E, V, T)
+    cws = _dec_struct(_lib.DecWs, ws)
+    coin_arr = None
+    if coin is not None:
+        coin_arr = (C.c_float * len(coin))(*[float(c) for c in coin])
+    rc = _lib.lib().asr_attn_decoder_fwd(_stream(), C.byref(cw), C.byref(cd), C.byref(cws), _p(enc),
+                                         _p(_i32(enc_len, "enc_len")), _p(_i32(seq_len, "seq_len")),
+                                         int(mode), coin_arr, float(samp_prob), float(keep_lm),
+                                         int(seed) & 0xFFFFFFFF, _p(logits))
+    _check(rc, "asr_attn_decoder_fwd")
+    return logits, ws

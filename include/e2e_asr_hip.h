@@ -1,0 +1,130 @@
+/* e2e_asr_hip.h -- C ABI of the MI355X (gfx950) hot-path library libe2e_asr_hip.so.
+ *
+ * The reference (shtoshni/e2e_asr) is pure Python/TensorFlow-1.x and has NO native
+ * interface to mirror; what each entry point replaces is the TensorFlow op sequence the
+ * cited reference lines execute inside sess.run (train.py:297-299).  The Python package
+ * e2e_asr_amd binds these with ctypes (e2e_asr_amd/_lib.py); INTEGRATION.md shows the stub.
+ *
+ * Conventions: plain C, no torch types.  Every pointer is a DEVICE pointer unless the
+ * parameter is documented as host.  `stream` is a hipStream_t passed as void*.  All calls
+ * are asynchronous on `stream`, allocate nothing, never synchronise (graph-capturable);
+ * the caller owns every buffer including workspaces.  Return: 0 ok, -1 invalid argument,
+ * -2 launch failure, -3 unsupported shape.  float = IEEE binary32, row-major, weights in
+ * the TensorFlow layout the reference checkpoints use (LSTM kernel [in+H, 4H], gate
+ * order i,j,f,o, forget bias +1 added at run time -- basic_lstm.py:14-23).
+ */
+#ifndef E2E_ASR_HIP_H
+#define E2E_ASR_HIP_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* C[M,N] (+)= op(A).op(B) + bias[N]; fp32 MFMA.  transA: A is [K,M]; transB: B is [N,K].
+ * Replaces tf.matmul / conv2d-1x1 call sites: encoder.py:78-81 (input half of the LSTM
+ * kernel, hoisted over all timesteps), attn_decoder.py:73 (AttnW). */
+int asr_gemm_f32(void* stream, int transA, int transB, int M, int N, int K,
+                 const float* A, int lda, const float* B, int ldb,
+                 float* C, int ldc, const float* bias, int accumulate);
+
+/* One (Bi)LSTM encoder layer over a whole padded batch -- encoder.py:55-91
+ * (bidirectional_dynamic_rnn / dynamic_rnn over BasicLSTMCell with sequence_length).
+ * x [B,T,in] batch-major (row stride ldx); out [B,Tout,ndir*H] with fw in [:H], bw in
+ * [H:]; rows t >= len[b] (and the pad frames T..Tout-1 of the pyramid, encoder.py:104-110)
+ * are written as exact zeros.  gates [B,T,ndir,4H] is workspace; with csave != NULL it
+ * leaves the activated gates and csave [B,T,ndir,H] the cell states for the backward pass.
+ * keep_prob < 1 applies DropoutWrapper(output_keep_prob) (encoder.py:49-52) to `out`.
+ * err_flag: device int, set non-zero if an inter-workgroup wait timed out. H in {64,128,256,512}. */
+size_t asr_lstm_ws_bytes(int B, int H, int ndir);
+int asr_lstm_layer_fwd(void* stream, const float* x, int B, int T, int in_dim, int ldx,
+                       const int* len, int H, int ndir,
+                       const float* kernel_fw, const float* bias_fw,
+                       const float* kernel_bw, const float* bias_bw,
+                       float* out, int Tout, float* gates, float* csave,
+                       void* hx_ws, size_t hx_bytes, int* err_flag,
+                       float keep_prob, unsigned seed);
+
+/* out[M,N] = [X1 | X2].W + bias -- `_linear` of attn_decoder.py:117,122,125,151,158.
+ * gather1 != NULL: row b of X1 is x1[gather1[b]] (embedding_lookup, decoder.py:101).
+ * zero_from != NULL: rows with zero_t >= zero_from[b] are emitted as zeros (raw_rnn). */
+int asr_linear_fwd(void* stream, const float* x1, int ld1, int K1, const int* gather1,
+                   const float* x2, int ld2, int K2, const float* W, int ldw,
+                   const float* bias, float* out, int ldo, int M, int N,
+                   const int* zero_from, int zero_t);
+
+/* One BasicLSTMCell step for M rows -- basic_lstm.py:14-23 / attn_decoder.py:148,166. */
+int asr_lstm_cell_fwd(void* stream, const float* x1, int ld1, int K1, const int* gather1,
+                      const float* h_prev, const float* c_prev, const float* kernel,
+                      const float* bias, int H, int M, float* c_out, float* h_out,
+                      float* hdrop_out, float* gates_out, float keep, unsigned seed, unsigned step);
+
+/* Fused attention: query projection + score + masked softmax + context --
+ * attn_decoder.py:77-93, beam_search.py:150-159. */
+size_t asr_attention_lds_bytes(int Te, int H, int A);
+int asr_attention_fwd(void* stream, const float* q, int ldq, const float* w_att,
+                      const float* b_att, const float* v, const float* hf,
+                      const float* enc, const int* enc_len, float* alpha, float* ctx,
+                      int B, int Te, int H, int A, int D);
+
+/* losses.py:7-35.  logits [T*B,V] time-major; targets [T,B]; nll_ws,lse_ws [T*B]. */
+int asr_masked_ce_fwd(void* stream, const float* logits, const int* targets, const int* len,
+                      float* nll_ws, float* lse_ws, float* loss, int T, int B, int V);
+int asr_masked_ce_bwd(void* stream, const float* logits, const int* targets, const float* lse_ws,
+                      const int* len, const float* grad_scale, float* dlogits, int T, int B, int V);
+
+/* decoder.py:149-150 (argmax feedback) / :176-177 (multinomial feedback, Gumbel-max). */
+int asr_next_token(void* stream, const float* logits, int B, int V, int ldl, int* tok_out,
+                   int sample, unsigned seed, unsigned step);
+
+/* ---- whole attention-decoder forward (attn_decoder.py:37-172 under tf.nn.raw_rnn) ---- */
+typedef struct {
+    const float* embedding;   /* [V,E]        model/rnn_decoder_<task>/decoder/embedding */
+    const float* attn_enc_w;  /* [D,A]        .../AttnW (squeezed) */
+    const float* attn_v;      /* [A]          .../AttnV */
+    const float* attn_w;      /* [H,A]        .../rnn/Attention/kernel */
+    const float* attn_b;      /* [A] */
+    const float* lm_kernel;   /* [E+lmH,4lmH] .../rnn/basic_lstm_cell/kernel */
+    const float* lm_bias;
+    const float* dec_kernel;  /* [E+H,4H]     .../rnn/basic_lstm_cell_1/kernel */
+    const float* dec_bias;
+    const float* inp_w;       /* [P+D,E]      .../rnn/InputProjection/kernel, P = H if simple else lmH */
+    const float* inp_b;
+    const float* ap_w;        /* [H+D,H]      .../rnn/AttnProjection/kernel */
+    const float* ap_b;
+    const float* out_w;       /* [H,V]        .../rnn/OutputProjection/kernel */
+    const float* out_b;
+    const float* simple_w;    /* [lmH,H] or NULL  .../rnn/SimpleProjection/kernel */
+    const float* simple_b;
+} asr_dec_weights;
+
+typedef struct { int B, Te, D, A, H, lmH, E, V, T_out; } asr_dec_dims;
+
+typedef struct {              /* activations: outputs of the forward, inputs of the backward */
+    float* hf;                /* [B,Te,A] */
+    int*   tok;               /* [T_out,B] token fed at each step; caller pre-fills with dec_inp[:T_out] */
+    float* lm_gates;          /* [T_out,B,4lmH] */
+    float* lm_c;              /* [T_out,B,lmH] */
+    float* lm_h;              /* [T_out,B,lmH] */
+    float* lm_hd;             /* [T_out,B,lmH] dropped lm output (NULL when keep_lm >= 1) */
+    float* sp;                /* [T_out,B,H] SimpleProjection output (NULL unless simple_w) */
+    float* x;                 /* [T_out,B,E] */
+    float* dec_gates;         /* [T_out,B,4H] */
+    float* dec_c;             /* [T_out,B,H]  (= attention query, decoder.py:79-80) */
+    float* dec_h;             /* [T_out,B,H] */
+    float* alpha;             /* [T_out,B,Te] */
+    float* ctx;               /* [T_out,B,D] */
+    float* p;                 /* [T_out,B,H] */
+    float* zeros;             /* [B*max(H,lmH,D)] zeros */
+} asr_dec_ws;
+
+/* mode 0: teacher forcing; 1: greedy (eval, decoder.py:139-154); 2: scheduled sampling
+ * with host coins coin[t] (attn_decoder.py:131-139).  logits [T_out*B,V] time-major. */
+int asr_attn_decoder_fwd(void* stream, const asr_dec_weights* w, const asr_dec_dims* d,
+                         const asr_dec_ws* ws, const float* enc, const int* enc_len,
+                         const int* seq_len, int mode, const float* coin_host, float samp_prob,
+                         float keep_lm, unsigned seed, float* logits);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
