@@ -1,0 +1,79 @@
+"""Attention decoder -- host-side mirror of the reference's attn_decoder.py (18-186).
+
+__call__ keeps the reference signature and output convention (time-major flattened logits
+[(T_out*B), V], zero rows for finished utterances); the loop body runs as the HIP step
+kernels orchestrated by csrc/decoder.hip.
+"""
+import numpy as np
+import torch
+
+from . import ops
+from .decoder import Decoder
+from .weights import dec_name
+
+
+class AttnDecoder(Decoder):
+    @classmethod
+    def class_params(cls):
+        params = super(AttnDecoder, cls).class_params()       # attn_decoder.py:21-28
+        params["attention_vec_size"] = 128
+        params["lm_hidden_size"] = 256
+        params["ind_softmax"] = False
+        return params
+
+    def __init__(self, isTraining, params=None, scope=None, variables=None):
+        super(AttnDecoder, self).__init__(isTraining=isTraining, params=params)
+        self.scope = scope
+        self.variables = variables
+        self.cell = self.get_cell()
+        self.saved = None
+        self.rng_seed = 0
+        self.coin_rng = np.random.default_rng(0)
+
+    def weight_tensors(self):
+        """struct field -> tensor, by TF variable name (beam_search.py:56-98)."""
+        v, task = self.variables, self.scope
+        out = {}
+        for field, leaf in ops.DEC_WEIGHT_LEAVES.items():
+            if self.params.ind_softmax and leaf.startswith("rnn/OutputProjection"):
+                leaf = leaf.replace("OutputProjection", "OutputProjection2")   # attn_decoder.py:119-122
+            t = v.get(dec_name(task, leaf))
+            if t is not None and field == "attn_enc_w":
+                t = t.reshape(t.shape[-2], t.shape[-1])
+            out[field] = t
+        return out
+
+    def __call__(self, decoder_inp, seq_len, encoder_hidden_states, seq_len_inp):
+        """decoder_inp [T_dec,B] int; seq_len [B] target lengths (host); encoder_hidden_states
+        [B,Te,D]; seq_len_inp [B] (host).  Returns logits [(T_out*B),V] -- attn_decoder.py:37-172."""
+        p = self.params
+        dev = encoder_hidden_states.device
+        seq_len = np.asarray(seq_len).astype(np.int64)
+        t_out = int(seq_len.max())
+        if t_out > decoder_inp.shape[0]:
+            raise ValueError("decoder input has %d steps, need %d" % (decoder_inp.shape[0], t_out))
+        if p.lm_hidden_size != p.hidden_size_dec and dec_name(self.scope, "rnn/SimpleProjection/kernel") not in self.variables:
+            raise ValueError("Could not find SimpleProjection weights for lm_hidden_size != hidden_size_dec")
+        feedback = self.prepare_decoder_input(decoder_inp, None)
+        mode = {"teacher": 0, "argmax": 1, "sample": 2}[feedback]
+        coin = None
+        if mode == 2:   # one uniform scalar per step for the whole batch (attn_decoder.py:132)
+            coin = self.coin_rng.random(t_out)
+        keep_lm = p.out_prob_dec if self.isTraining else 1.0
+        tok = decoder_inp if decoder_inp.dtype == torch.int32 else decoder_inp.to(torch.int32)
+        logits, ws = ops.attn_decoder_fwd(
+            self.weight_tensors(), tok.to(dev), torch.from_numpy(seq_len.astype(np.int32)).to(dev),
+            encoder_hidden_states.contiguous(), torch.from_numpy(np.asarray(seq_len_inp).astype(np.int32)).to(dev),
+            mode=mode, coin=coin, samp_prob=p.samp_prob, keep_lm=keep_lm, seed=self.rng_seed, t_out=t_out)
+        self.saved = dict(ws=ws, seq_len=seq_len, t_out=t_out, keep_lm=keep_lm, seed=self.rng_seed,
+                          enc=encoder_hidden_states, enc_len=np.asarray(seq_len_inp))
+        return logits
+
+    @classmethod
+    def add_parse_options(cls, parser):
+        super(AttnDecoder, cls).add_parse_options(parser)     # attn_decoder.py:174-186
+        parser.add_argument("-samp_prob", "--samp_prob", default=0.1, type=float, help="Scheduled sampling probability")
+        parser.add_argument("-attn_vec_size", "--attention_vec_size", default=128, type=int, help="Attention vector size")
+        parser.add_argument("-lm_hsize", "--lm_hidden_size", default=256, type=int, help="Hidden Size of LM layer")
+        parser.add_argument("-ind_softmax", "--ind_softmax", default=False, action="store_true",
+                            help="Independent (from LM) softmax params")

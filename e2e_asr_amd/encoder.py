@@ -1,0 +1,119 @@
+"""Encoder of the seq2seq model -- host-side mirror of the reference's encoder.py.
+
+Same constructor, __call__ signature, defaults and flags as reference encoder.py:15-200;
+the computation is the HIP path: per layer one MFMA GEMM per direction for the input
+projection and one persistent recurrent kernel (csrc/lstm.hip).  Layout decision: every
+tensor stays batch-major [B,T,feat] end to end.  The reference's two transposes per layer
+(encoder.py:158,164), the fw/bw concat (:83) and the pyramid reshape (:112-115) all
+disappear: the kernel writes fw|bw halves in place and [B,T,2H] -> [B,T/2,4H] is a view.
+"""
+import numpy as np
+import torch
+
+from . import ops
+from .base_params import BaseParams, Bunch
+from .weights import enc_name
+
+
+class Encoder(BaseParams):
+    """Encodes a padded batch of filterbank frames with a pyramidal (Bi)LSTM stack."""
+
+    @classmethod
+    def class_params(cls):
+        # encoder.py:18-31 (note: use_lstm defaults False here but the CLI flag below is
+        # store_true with default=True, so LSTM is what every reference run uses)
+        return Bunch(bi_dir=True, hidden_size=256, out_prob=0.9, skip_step=2, initial_res_fac=1,
+                     use_lstm=False, stack_cons=1, max_scaling_down=8)
+
+    def __init__(self, params=None, isTraining=True, variables=None):
+        self.params = params if params is not None else self.class_params()
+        self.isTraining = isTraining
+        self.variables = variables
+        self.saved = None          # per-layer activations for the backward pass
+        self.dropout_seed = 0
+
+    def get_cell(self):
+        """encoder.py:42-53.  The cell is realised inside csrc/lstm.hip; only LSTM exists
+        (the GRU branch is unreachable from the reference CLI, encoder.py:187)."""
+        if not self.params.use_lstm:
+            raise NotImplementedError("GRUCell encoder: not on the hot path (reference CLI always sets use_lstm)")
+        return "BasicLSTMCell(%d)" % self.params.hidden_size
+
+    def _layer_weights(self, depth):
+        v = self.variables
+        if self.params.bi_dir:
+            return (v[enc_name(depth, "fw", "kernel")], v[enc_name(depth, "fw", "bias")],
+                    v[enc_name(depth, "bw", "kernel")], v[enc_name(depth, "bw", "bias")])
+        return (v[enc_name(depth, "", "kernel", False)], v[enc_name(depth, "", "bias", False)], None, None)
+
+    def _pyramid_plan(self, T, seq_len_host):
+        """encoder.py:94-119: pad (skip - max_len % skip) frames when max_len % skip != 0, then
+        reshape; tf.reshape fails when the padded T is not divisible -- same error here."""
+        skip = self.params.skip_step
+        rem = int(seq_len_host.max()) % skip
+        t_out = T + (skip - rem if rem else 0)
+        if t_out % skip:
+            raise ValueError("pyramid: padded length %d not divisible by skip_step %d" % (t_out, skip))
+        return t_out
+
+    def __call__(self, encoder_input, seq_len, num_layers):
+        """encoder_input [B,T,F] float32 CUDA; seq_len [B] (host array or tensor);
+        num_layers {task: depth}.  Returns (attention_states{depth: [B,T_d,D]},
+        time_major_states{depth}, seq_len_inps{depth: host int64 array}) -- encoder.py:122-180."""
+        params = self.params
+        self.get_cell()
+        attention_states, time_major_states, seq_len_inps = {}, {}, {}
+        max_depth = 0
+        for task, nl in num_layers.items():
+            (time_major_states if task == "state" else attention_states)[nl] = None
+            max_depth = max(max_depth, nl)
+        lens = np.asarray(seq_len.cpu() if torch.is_tensor(seq_len) else seq_len).astype(np.int64)
+        x = encoder_input
+        res = params.initial_res_fac
+        if res > 1:                                               # encoder.py:150-153
+            x = x[:, ::res, :].contiguous()
+            lens = np.ceil(lens / float(res)).astype(np.int64)
+        keep = params.out_prob if self.isTraining else 1.0
+        save = self.isTraining
+        self.saved = []
+        for i in range(max_depth):
+            d = i + 1
+            B, T, _ = x.shape
+            reduce_after = params.skip_step > 1 and i != max_depth - 1 and res < params.max_scaling_down
+            t_out = self._pyramid_plan(T, lens) if reduce_after else T
+            lens_dev = torch.from_numpy(lens.astype(np.int32)).to(x.device)
+            kf, bf, kb, bb = self._layer_weights(d)
+            seed = (self.dropout_seed * 1000003 + d * 7919) & 0x7FFFFFFF
+            r = ops.lstm_layer_fwd(x, lens_dev, kf, bf, kb, bb, t_out=t_out, save=save,
+                                   keep_prob=keep, seed=seed)
+            out = r[0] if save else r
+            if save:
+                self.saved.append(dict(x=x, lens=lens, lens_dev=lens_dev, gates=r[1], c=r[2], out=out,
+                                       T=T, t_out=t_out, keep=keep, seed=seed, depth=d))
+            view = out[:, :T] if t_out != T else out
+            if d in time_major_states:
+                time_major_states[d] = view.transpose(0, 1)
+            if d in attention_states:
+                attention_states[d] = view
+            seq_len_inps[d] = lens
+            if reduce_after:                                       # encoder.py:172-176
+                x = out.view(B, t_out // params.skip_step, out.shape[2] * params.skip_step)
+                lens = np.ceil(lens / float(params.skip_step)).astype(np.int64)
+                res *= params.skip_step
+            else:
+                x = out
+        return attention_states, time_major_states, seq_len_inps
+
+    @classmethod
+    def add_parse_options(cls, parser):
+        # encoder.py:182-200 -- same flags, same defaults
+        for flags, kw in (
+            (("-out_prob", "--out_prob"), dict(default=0.9, type=float, help="Output keep probability for dropout")),
+            (("-use_lstm", "--use_lstm"), dict(default=True, action="store_true", help="LSTM cell (always on)")),
+            (("-hsize", "--hidden_size"), dict(default=256, type=int, help="Hidden layer size")),
+            (("-skip_step", "--skip_step"), dict(default=2, type=int, help="Frame skipping factor up the stack")),
+            (("-init_res_fac", "--initial_res_fac"), dict(default=1, type=int, help="Initial resolution factor")),
+            (("-stack_cons",), dict(default=1, type=int, help="Stacking consecutive frames in input")),
+            (("-max_scaling_down",), dict(default=8, type=int, help="Maximum reduction in resolution")),
+        ):
+            parser.add_argument(*flags, **kw)

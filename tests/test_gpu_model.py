@@ -1,0 +1,198 @@
+"""GPU parity at model level: the host-side mirror classes (Encoder, AttnDecoder,
+Seq2SeqModel, LossUtils) driving the HIP path, against the CPU oracle in float64 on the
+same float32 weights/inputs.  Tolerance for logits: 1e-3 (BASELINE.json north_star),
+in practice ~1e-5."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import asr_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _f64(w):
+    return {k: np.asarray(v, np.float64) for k, v in w.items()}
+
+
+def _model(params_update=None, enc_update=None, dec_update=None, tasks=("char",), num_layers=None,
+           feat=20, training=True, vocab=None, seed=3):
+    from e2e_asr_amd.seq2seq_model import Seq2SeqModel
+    from e2e_asr_amd.attn_decoder import AttnDecoder
+    p = Seq2SeqModel.class_params()
+    p.tasks = list(tasks)
+    p.num_layers = num_layers or {"char": 4}
+    p.max_output = {"char": 12, "phone": 14}
+    p.encoder_params.use_lstm = True
+    p.encoder_params.out_prob = 1.0
+    for k, v in (enc_update or {}).items():
+        p.encoder_params[k] = v
+    p.decoder_params = {}
+    for t in tasks:
+        dp = AttnDecoder.class_params()
+        dp.out_prob_dec = 1.0
+        dp.samp_prob = 0.0
+        dp.vocab_size = (vocab or {"char": 50, "phone": 20})[t]
+        for k, v in (dec_update or {}).items():
+            dp[k] = v
+        p.decoder_params[t] = dp
+    for k, v in (params_update or {}).items():
+        p[k] = v
+    return Seq2SeqModel(None, isTraining=training, params=p, device=DEV, feat_length=feat, seed=seed)
+
+
+def _batch(rng, B, T, F, tdec, vocab, lens=None, tasks=("char",)):
+    from e2e_asr_amd.weights import synthetic_batch
+    b = synthetic_batch(B=B, T=T, F=F, t_dec=tdec, vocab=vocab, variable_len=True, seed=int(rng.integers(1 << 30)),
+                        tasks=tasks)
+    if lens is not None:
+        b["logmel_len"] = np.asarray(lens, np.int64)
+    return b
+
+
+def test_encoder_pyramid_odd_lengths_vs_oracle():
+    """4-layer pyramidal BiLSTM, T=37 (odd -> zero pad frame at every reduction), ragged
+    lengths incl. 1; taps at depth 3 (phone) and 4 (char) -- encoder.py:122-180."""
+    rng = np.random.default_rng(0)
+    m = _model(enc_update=dict(hidden_size=64), tasks=("char", "phone"), num_layers={"char": 4, "phone": 3},
+               dec_update=dict(hidden_size_dec=64, lm_hidden_size=64, emb_size=32, attention_vec_size=16))
+    B, T, F = 6, 37, 20
+    x = rng.standard_normal((B, T, F)).astype(np.float32)
+    lens = np.array([37, 36, 1, 2, 19, 8])
+    for b in range(B):
+        x[b, lens[b]:] = 0
+    att, _, sl = m.encoder(torch.from_numpy(x).to(DEV), lens, {"char": 4, "phone": 3})
+    w = _f64(m.variables.to_arrays())
+    ratt, _, rsl = O.encoder(x.astype(np.float64), lens, w, {"char": 4, "phone": 3})
+    for d in (3, 4):
+        np.testing.assert_array_equal(sl[d], rsl[d])
+        got = att[d].cpu().numpy()
+        assert got.shape == ratt[d].shape
+        np.testing.assert_allclose(got, ratt[d], rtol=0, atol=5e-5)
+        for b in range(B):
+            assert not got[b, rsl[d][b]:].any()      # padding frames are exact zeros
+
+
+def test_config1_uni_lstm_greedy_vs_oracle():
+    """BASELINE config 1: 1-layer uni-LSTM(128) encoder + greedy decoder, batch 4x100x40."""
+    rng = np.random.default_rng(1)
+    m = _model(enc_update=dict(hidden_size=128, bi_dir=False), num_layers={"char": 1}, feat=40, training=False,
+               dec_update=dict(hidden_size_dec=128, lm_hidden_size=128, emb_size=64), vocab={"char": 100})
+    b = _batch(rng, 4, 100, 40, 13, 100, lens=[100, 73, 40, 100])
+    out = m.forward(b)["char"].cpu().numpy()
+    w = _f64(m.variables.to_arrays())
+    b64 = dict(b); b64["logmel"] = b["logmel"].astype(np.float64)
+    ref = O.seq2seq_forward(b64, w, num_layers={"char": 1}, bi_dir=False, is_training=False,
+                            max_output={"char": 12})["outputs"]["char"]
+    assert out.shape == ref.shape == (12 * 4, 100)
+    np.testing.assert_allclose(out, ref, rtol=0, atol=1e-3)
+    np.testing.assert_array_equal(m.greedy_ids().cpu().numpy(), O.greedy_decode_ids(ref, 4))
+
+
+@pytest.mark.parametrize("simple", [False, True])
+def test_decoder_teacher_forced_vs_oracle(simple):
+    """attn_decoder.py:37-172 in training mode (no sampling, no dropout), ragged targets:
+    finished rows emit zeros; optional SimpleProjection (lm_hidden_size != hidden_size_dec)."""
+    rng = np.random.default_rng(2 + simple)
+    m = _model(enc_update=dict(hidden_size=64), num_layers={"char": 2},
+               dec_update=dict(hidden_size_dec=32, lm_hidden_size=20 if simple else 32, emb_size=24,
+                               attention_vec_size=16))
+    b = _batch(rng, 5, 16, 20, 13, 50)
+    m.forward(b)
+    out = m.outputs["char"].cpu().numpy()
+    w = _f64(m.variables.to_arrays())
+    b64 = dict(b); b64["logmel"] = b["logmel"].astype(np.float64)
+    r = O.seq2seq_forward(b64, w, num_layers={"char": 2}, is_training=True)
+    np.testing.assert_allclose(out, r["outputs"]["char"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(m.losses["char"].item(), r["losses"]["char"], rtol=1e-5)
+    T_out = int(b["char_len"].max())
+    o3 = out.reshape(T_out, 5, -1)
+    for bb in range(5):
+        assert not o3[b["char_len"][bb]:, bb].any()
+
+
+@pytest.mark.parametrize("variant", ["plain", "simple"])
+def test_decoder_reference_greedy_chain_golden(golden_dir, variant):
+    """Eval-mode decoder on the golden weights must emit the token chain that the REFERENCE's
+    get_top_k (beam_search.py:178-219) produced with argmax feedback."""
+    from e2e_asr_amd import ops
+    g = np.load(os.path.join(golden_dir, "decoder_step_%s.npz" % variant))
+    pre = "w_dec/model/rnn_decoder_char/"
+    wt = {}
+    for field, leaf in ops.DEC_WEIGHT_LEAVES.items():
+        k = pre + leaf
+        if k in g.files:
+            a = g[k]
+            if field == "attn_enc_w":
+                a = a.reshape(a.shape[-2], a.shape[-1])
+            wt[field] = torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+        else:
+            wt[field] = None
+    toks = g["greedy_lm0_tokens"]
+    n = len(toks)
+    enc = torch.from_numpy(g["enc_T100"][None]).to(DEV)
+    dec_inp = torch.ones((n + 1, 1), dtype=torch.int32, device=DEV)
+    ln = torch.tensor([n], dtype=torch.int32, device=DEV)
+    logits, ws = ops.attn_decoder_fwd(wt, dec_inp, ln, enc, torch.tensor([100], dtype=torch.int32, device=DEV),
+                                      mode=1, t_out=n)
+    ids = logits.argmax(1).cpu().numpy()
+    np.testing.assert_array_equal(ids, toks)
+    lp = torch.log_softmax(logits.double(), 1).cpu().numpy()
+    np.testing.assert_allclose(lp[np.arange(n), toks], g["greedy_lm0_scores"], rtol=0, atol=1e-4)
+
+
+def test_config2_architecture_short_T_vs_oracle():
+    """BASELINE config-2 architecture (4-layer pyramidal BiLSTM(256) + attn decoder(256),
+    V=1000, F=80) at T=64, B=8 so the float64 oracle finishes in seconds; logits within the
+    north-star tolerance 1e-3."""
+    rng = np.random.default_rng(4)
+    m = _model(feat=80, vocab={"char": 1000}, params_update=dict(max_output={"char": 20}))
+    b = _batch(rng, 8, 64, 80, 21, 1000)
+    m.forward(b)
+    out = m.outputs["char"].cpu().numpy()
+    w = _f64(m.variables.to_arrays())
+    b64 = dict(b); b64["logmel"] = b["logmel"].astype(np.float64)
+    r = O.seq2seq_forward(b64, w, is_training=True)
+    err = np.abs(out - r["outputs"]["char"]).max()
+    assert err < 1e-3, err
+    np.testing.assert_allclose(m.total_loss.item(), r["total_loss"], rtol=1e-5)
+    print("config-2 arch logits max|diff| = %.3g" % err)
+
+
+def test_multitask_phone_decoder_on_lower_layer():
+    """BASELINE config 4: aux phone decoder on a lower encoder layer, losses averaged
+    (seq2seq_model.py:140-144)."""
+    rng = np.random.default_rng(5)
+    m = _model(enc_update=dict(hidden_size=64), tasks=("char", "phone"), num_layers={"char": 4, "phone": 2},
+               dec_update=dict(hidden_size_dec=32, lm_hidden_size=32, emb_size=24, attention_vec_size=16))
+    b = _batch(rng, 4, 32, 20, 9, 20, tasks=("char", "phone"))
+    m.forward(b)
+    w = _f64(m.variables.to_arrays())
+    b64 = dict(b); b64["logmel"] = b["logmel"].astype(np.float64)
+    r = O.seq2seq_forward(b64, w, tasks=("char", "phone"), num_layers={"char": 4, "phone": 2}, is_training=True)
+    for t in ("char", "phone"):
+        np.testing.assert_allclose(m.outputs[t].cpu().numpy(), r["outputs"][t], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(m.total_loss.item(), r["total_loss"], rtol=1e-5)
+
+
+def test_encoder_dropout_is_output_only():
+    """DropoutWrapper(output_keep_prob) (encoder.py:49-52): emitted h is 0 or h/keep; the
+    recurrent state is untouched, so the kept entries equal the no-dropout run / keep."""
+    from e2e_asr_amd import ops
+    rng = np.random.default_rng(6)
+    B, T, IN, H = 8, 40, 16, 64
+    x = torch.from_numpy(rng.standard_normal((B, T, IN)).astype(np.float32)).to(DEV)
+    k = torch.from_numpy(rng.uniform(-0.2, 0.2, (IN + H, 4 * H)).astype(np.float32)).to(DEV)
+    bz = torch.zeros(4 * H, device=DEV)
+    ln = torch.full((B,), T, dtype=torch.int32, device=DEV)
+    base = ops.lstm_layer_fwd(x, ln, k, bz, k, bz)
+    drop = ops.lstm_layer_fwd(x, ln, k, bz, k, bz, keep_prob=0.9, seed=123)
+    kept = drop != 0
+    frac = kept.float().mean().item()
+    assert 0.88 < frac < 0.92, frac
+    np.testing.assert_allclose(drop[kept].cpu().numpy(), (base[kept] / 0.9).cpu().numpy(), rtol=1e-6)
+    drop2 = ops.lstm_layer_fwd(x, ln, k, bz, k, bz, keep_prob=0.9, seed=123)
+    assert torch.equal(drop, drop2)                      # counter-based mask: reproducible
