@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py -- encoder+decoder frames/sec at batch 32 x 800 frames x 80 mel (BASELINE.json).
+
+  python bench.py --gpus N --steps K --warmup W      (N>1: launched by torch.distributed.run)
+
+One "step" = one pass of the hot path over one synthetic batch already resident in HBM:
+  --mode train : forward (teacher forcing + scheduled sampling + dropout) + backward +
+                 [RCCL all-reduce] + global-norm clip + Adam     (train.py:297-299)
+  --mode fwd   : forward only (training-mode graph, loss included)
+Workload = BASELINE config 2: 4-layer pyramidal BiLSTM(256) + attention decoder(256), V=1000,
+B=32 per GPU, T=800, F=80, fp32, synthetic data, random-init weights.  Weak scaling: per-GPU
+batch fixed, `value` = N * B * T / max-over-ranks step time.
+Adds `roofline` (dominant kernel, HIP-event timed on its launch stream) and `cpu_baseline`
+(the CPU oracle timed on this host's cores on a bounded sample, rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+B, T, F, TDEC, V = 32, 800, 80, 121, 1000
+H = 256
+# algorithmic FLOPs (SURVEY.md 8d / BASELINE.md section 2)
+ENC_LAYER_T = [800, 400, 200, 100]
+ENC_LAYER_IN = [80, 1024, 1024, 1024]
+REC_FLOP_FWD = sum(2 * H * 4 * H * 2 * t * B for t in ENC_LAYER_T)                  # 50.33 GFLOP
+PROJ_FLOP_FWD = sum(2 * i * 4 * H * 2 * t * B for t, i in zip(ENC_LAYER_T, ENC_LAYER_IN))  # 102.34 GFLOP
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: matrix/vector FP32 peak
+PEAK_HBM_GBS = 8000.0
+
+
+def build_model(dev, training=True):
+    from e2e_asr_amd.seq2seq_model import Seq2SeqModel
+    p = Seq2SeqModel.class_params()
+    p.encoder_params.use_lstm = True          # the reference CLI always sets it (encoder.py:187)
+    return Seq2SeqModel(None, isTraining=training, params=p, device=dev, feat_length=F, seed=10)
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """The CPU oracle (oracle/asr_oracle.py, 'port' of the reference graph: per-timestep
+    BasicLSTMCell loop with masking, float32) on a bounded sample of the SAME workload:
+    the first `bs` utterances of the synthetic batch, forward pass.  NumPy's BLAS uses the
+    host cores it is given; cores = threads actually used."""
+    from e2e_asr_amd.weights import init_weights, synthetic_batch
+    from oracle import asr_oracle as O
+    try:
+        import threadpoolctl
+        nthreads = max(i["num_threads"] for i in threadpoolctl.threadpool_info() if i.get("user_api") == "blas")
+    except Exception:
+        nthreads = os.cpu_count()
+    w = init_weights(seed=10)
+    bs = 4
+    batch = synthetic_batch(B=B, T=T, F=F, t_dec=TDEC, vocab=V)
+    sub = {k: (v[:bs] if hasattr(v, "__len__") else v) for k, v in batch.items()}
+    sub["char"] = sub["char"][:, :int(sub["char_len"].max()) + 1]     # T_dec - 1 == max(len) (tf_utils.py:4-12)
+    t0 = time.time()
+    O.seq2seq_forward(sub, w, is_training=True)
+    dt = time.time() - t0
+    reps = 1
+    if dt < seconds_budget / 3:
+        n = min(3, int(seconds_budget / 3 / max(dt, 1e-3)))
+        t0 = time.time()
+        for _ in range(n):
+            O.seq2seq_forward(sub, w, is_training=True)
+        dt = (time.time() - t0) / n
+        reps = n
+    return dict(value=bs * T / dt, unit="frames/s", cores=int(nthreads), kind="port",
+                sample="forward pass (encoder+decoder+loss, float32 NumPy oracle) of %d of the %d utterances "
+                       "x %d frames, %d rep(s), %.1f s each; forward only (the oracle has no backward)" % (bs, B, T, reps, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--mode", default="auto", choices=["auto", "train", "fwd"])
+    ap.add_argument("--variable-len", action="store_true", help="lengths U[400,800] (masking run)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from e2e_asr_amd import ops
+    from e2e_asr_amd.weights import synthetic_batch
+    model = build_model(dev, training=True)
+    has_train = hasattr(model, "step")
+    mode = args.mode if args.mode != "auto" else ("train" if has_train else "fwd")
+    if world > 1:
+        from e2e_asr_amd.parallel import DataParallel
+        DataParallel(model)                       # broadcast weights, hook the grad all-reduce
+    batch = synthetic_batch(B=B, T=T, F=F, t_dec=TDEC, vocab=V, variable_len=args.variable_len, seed=1234 + rank)
+    # inputs resident in HBM before the timed region
+    batch = {k: (torch.as_tensor(v).to(dev) if k == "logmel" else v) for k, v in batch.items()}
+
+    def one_step():
+        if mode == "train":
+            model.step(batch)
+        else:
+            model.forward(batch)
+
+    for _ in range(args.warmup):
+        one_step()
+    torch.cuda.synchronize()
+    ops.check_device_flag(dev)
+    ops.prof_enable(True)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ops.check_device_flag(dev)
+    rec_ms, rec_n = ops.prof_read("lstm_rec_fwd")
+    recb_ms, recb_n = ops.prof_read("lstm_rec_bwd")
+    decf_ms, decf_n = ops.prof_read("decoder_fwd")
+    ops.prof_enable(False)
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    ms_step = dt / args.steps * 1e3
+    frames = world * B * T
+    value = frames / (dt / args.steps)
+    flop_per_frame = (REC_FLOP_FWD + PROJ_FLOP_FWD + 14.25e9) / (B * T) * (3 if mode == "train" else 1)
+    # dominant kernel: the persistent recurrent LSTM kernel (4 launches/step: T=800/400/200/100)
+    rec_per_step_ms = rec_ms / args.steps
+    achieved = REC_FLOP_FWD / (rec_per_step_ms * 1e-3) / 1e12 if rec_ms > 0 else None
+    traffic = None
+    tp = os.path.join(ROOT, "profiles", "traffic_r01.json")
+    if os.path.exists(tp):
+        try:
+            traffic = json.load(open(tp)).get("lstm_rec_fwd_bytes_per_launch")
+        except Exception:
+            traffic = None
+    out = {
+        "metric": "encoder+decoder frames/sec at batch32x800frx80mel", "value": value, "unit": "frames/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "config2: 4-layer pyramidal BiLSTM(256)+attn decoder(256), V=1000, per-GPU batch "
+                               "32x800x80, %s step%s" % (
+                                   "full train (fwd+bwd+clip+Adam%s)" % ("+RCCL all-reduce" if world > 1 else "")
+                                   if mode == "train" else "forward-only (training graph incl. loss)",
+                                   ", variable lengths" if args.variable_len else ", all lengths 800"),
+                   "mode": mode, "global_batch": world * B, "frames_per_utt": T, "parallelism": "dp%d" % world},
+        "model_tflops": value * flop_per_frame / 1e12,
+        "roofline": {"bound": "mfma", "kernel": "lstm_rec_fwd_kernel<256,32,2> (persistent recurrent LSTM, 4 launches/step)",
+                     "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                     "frac": (achieved / PEAK_F32_MFMA_TFLOPS) if achieved else None, "traffic": traffic,
+                     "avg_launch_ms": rec_ms / max(rec_n, 1), "launches": rec_n,
+                     "serial_chain_steps": sum(ENC_LAYER_T), "us_per_recurrent_step": rec_per_step_ms * 1e3 / sum(ENC_LAYER_T)},
+        "phases_ms_per_step": {"lstm_rec_fwd": rec_per_step_ms, "lstm_rec_bwd": recb_ms / args.steps,
+                               "decoder_fwd": decf_ms / args.steps},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

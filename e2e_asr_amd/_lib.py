@@ -56,6 +56,8 @@ SIGNATURES = {
     "asr_masked_ce_fwd": (C.c_int, [vp] * 7 + [C.c_int] * 3),
     "asr_masked_ce_bwd": (C.c_int, [vp] * 7 + [C.c_int] * 3),
     "asr_next_token": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_uint, C.c_uint]),
+    "asr_prof_enable": (C.c_int, [C.c_int]),
+    "asr_prof_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "asr_attn_decoder_fwd": (C.c_int, [vp, C.POINTER(DecWeights), C.POINTER(DecDims), C.POINTER(DecWs),
                                        vp, vp, vp, C.c_int, c_fp, C.c_float, C.c_float, C.c_uint, vp]),
 }

@@ -3,4 +3,4 @@
 set -e
 cd "$(dirname "$0")"
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -o libe2e_asr_hip.so \
-    gemm.hip lstm.hip skinny.hip attention.hip loss.hip decoder.hip $EXTRA_SRCS
+    *.hip $EXTRA_SRCS

@@ -18,7 +18,18 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned long long u64;
 
+#define ASR_PROF_TAGS 8
+#define ASR_PROF_LSTM_REC_FWD 0
+#define ASR_PROF_LSTM_REC_BWD 1
+#define ASR_PROF_GEMM 2
+#define ASR_PROF_DECODER_FWD 3
+#define ASR_PROF_DECODER_BWD 4
+#define ASR_PROF_OPTIM 5
+
 namespace asr {
+
+void prof_begin(int tag, hipStream_t s);   // prof.hip
+void prof_end(int tag, hipStream_t s);
 
 // ---- math: v_exp_f32 / v_rcp_f32 based, ~1-2 ulp; saturate cleanly at +-inf ----
 __device__ __forceinline__ float fast_sigmoid(float x) {

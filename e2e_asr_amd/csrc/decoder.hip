@@ -32,6 +32,7 @@ extern "C" int asr_attn_decoder_fwd(void* stream, const asr_dec_weights* w, cons
     // hf = enc . AttnW   (attn_decoder.py:70-73)
     if ((rc = asr_gemm_f32(stream, 0, 0, B * Te, A, D, enc, D, w->attn_enc_w, A, ws->hf, A, nullptr, 0))) return rc;
     const int P = w->simple_w ? H : lmH;
+    asr::prof_begin(ASR_PROF_DECODER_FWD, static_cast<hipStream_t>(stream));
     for (int i = 0; i < T; ++i) {
         const size_t o = (size_t)i * B;
         const float* lm_hp = i ? ws->lm_h + (o - B) * lmH : ws->zeros;
@@ -75,5 +76,6 @@ extern "C" int asr_attn_decoder_fwd(void* stream, const asr_dec_weights* w, cons
                     return rc;
         }
     }
+    asr::prof_end(ASR_PROF_DECODER_FWD, static_cast<hipStream_t>(stream));
     return ASR_OK;
 }

@@ -281,12 +281,14 @@ extern "C" int asr_lstm_layer_fwd(void* stream, const float* x, int B, int T, in
         c.out = out + (size_t)b0 * Tout * ndir * H;
         c.csave = csave ? csave + (size_t)b0 * T * ndir * H : nullptr;
         int rc;
+        prof_begin(ASR_PROF_LSTM_REC_FWD, s);
         switch (H) {
             case 64: rc = launch_rec_h<64>(s, c, R); break;
             case 128: rc = launch_rec_h<128>(s, c, R); break;
             case 256: rc = launch_rec_h<256>(s, c, R); break;
             default: rc = launch_rec_h<512>(s, c, R); break;
         }
+        prof_end(ASR_PROF_LSTM_REC_FWD, s);
         if (rc) return rc;
         if (b0 + rows_per_launch < B &&
             hipMemsetAsync(hx_ws, 0, asr_lstm_ws_bytes(B, H, ndir), s) != hipSuccess) return ASR_ELAUNCH;

@@ -24,14 +24,16 @@ struct SkinnyArgs {
     const float* W; int ldw; const float* bias;
     int M, N;
     // linear mode
-    float* out; int ldo;
+    float* out; int ldo; int accumulate;
     const int* zero_from; int zero_t;     // rows with zero_t >= zero_from[b] are written as zeros (raw_rnn emit)
     // LSTM mode (H > 0)
     int H; const float* c_prev; float* c_out; float* h_out; float* hdrop_out; float* gates_out;
     float keep; uint32_t seed; uint32_t step;
 };
 
-template <bool LSTM>
+// WT: the weight is given transposed, W[n][k] (row stride ldw along n) -- the data-gradient
+// products dY.W^T of the backward pass; the lane then reads 4 consecutive k as one float4.
+template <bool LSTM, bool WT>
 __global__ __launch_bounds__(256) void skinny_kernel(SkinnyArgs a) {
     __shared__ float red[3][4][64];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -51,23 +53,36 @@ __global__ __launch_bounds__(256) void skinny_kernel(SkinnyArgs a) {
     const int chunk = ((K + 63) / 64) * 16;
     const int kbeg = w * chunk, kend = min(K, kbeg + chunk);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-    for (int kb = kbeg; kb < kend; kb += 16) {
-        const int k = kb + 4 * g4;
-        float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
-        float wv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (k < K) {
-            if (rowok) xv = (k < a.K1) ? *reinterpret_cast<const float4*>(xr1 + k)
-                                       : *reinterpret_cast<const float4*>(xr2 + (k - a.K1));
-            if (colok) {
-                const float* wp = a.W + (size_t)k * a.ldw + colW;
-                wv[0] = wp[0]; wv[1] = wp[a.ldw]; wv[2] = wp[2 * (size_t)a.ldw]; wv[3] = wp[3 * (size_t)a.ldw];
+    // All loads of a group of IT k-steps are issued before the first MFMA consumes one, so
+    // a wave pays ~one memory round trip per group instead of one per k-step.
+    constexpr int IT = 12;
+    for (int kb0 = kbeg; kb0 < kend; kb0 += 16 * IT) {
+        float4 xv[IT]; float4 wv[IT];
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int k = kb0 + 16 * it + 4 * g4;
+            xv[it] = make_float4(0.f, 0.f, 0.f, 0.f); wv[it] = xv[it];
+            if (k < kend) {
+                if (rowok) xv[it] = (k < a.K1) ? *reinterpret_cast<const float4*>(xr1 + k)
+                                               : *reinterpret_cast<const float4*>(xr2 + (k - a.K1));
+                if (colok) {
+                    if (WT) {
+                        wv[it] = *reinterpret_cast<const float4*>(a.W + (size_t)colW * a.ldw + k);
+                    } else {
+                        const float* wp = a.W + (size_t)k * a.ldw + colW;
+                        wv[it].x = wp[0]; wv[it].y = wp[a.ldw];
+                        wv[it].z = wp[2 * (size_t)a.ldw]; wv[it].w = wp[3 * (size_t)a.ldw];
+                    }
+                }
             }
         }
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[0], xv.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[1], xv.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[2], xv.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[3], xv.w, acc, 0, 0, 0);
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[it].x, xv[it].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[it].y, xv[it].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[it].z, xv[it].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[it].w, xv[it].w, acc, 0, 0, 0);
+        }
     }
     if (w > 0) {
 #pragma unroll
@@ -105,7 +120,11 @@ __global__ __launch_bounds__(256) void skinny_kernel(SkinnyArgs a) {
         float* op = a.out + (size_t)b * a.ldo + n;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            if (n + r < a.N) op[r] = z ? 0.f : acc[r] + (a.bias ? a.bias[n + r] : 0.f);
+            if (n + r < a.N) {
+                float v = z ? 0.f : acc[r] + (a.bias ? a.bias[n + r] : 0.f);
+                if (a.accumulate) v += op[r];
+                op[r] = v;
+            }
     }
 }
 
@@ -130,7 +149,7 @@ extern "C" int asr_linear_fwd(void* stream, const float* x1, int ld1, int K1, co
     if (int rc = skinny_check(a)) return rc;
     if (!out || N <= 0 || ldw < N || ldo < N) return ASR_EINVAL;
     dim3 grid((N + 15) / 16, (M + 15) / 16);
-    hipLaunchKernelGGL((asr::skinny_kernel<false>), grid, dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    hipLaunchKernelGGL((asr::skinny_kernel<false, false>), grid, dim3(256), 0, static_cast<hipStream_t>(stream), a);
     ASR_CHECK_LAUNCH();
     return ASR_OK;
 }
@@ -149,7 +168,22 @@ extern "C" int asr_lstm_cell_fwd(void* stream, const float* x1, int ld1, int K1,
     if (int rc = skinny_check(a)) return rc;
     if (!h_prev || !bias || !c_out || !h_out || H <= 0 || (H & 3)) return ASR_EINVAL;
     dim3 grid((H + 3) / 4, (M + 15) / 16);
-    hipLaunchKernelGGL((asr::skinny_kernel<true>), grid, dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    hipLaunchKernelGGL((asr::skinny_kernel<true, false>), grid, dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    ASR_CHECK_LAUNCH();
+    return ASR_OK;
+}
+
+// out[M,N] (+)= X[M,K] . Wt^T + bias, Wt given as [N,K] (row stride ldw): the data-gradient
+// products of the backward pass, e.g. [dx | dh_prev] = dGates . K^T with K the TF kernel [in+H, 4H].
+extern "C" int asr_linear_wt_fwd(void* stream, const float* x, int ldx, int K, const float* Wt, int ldw,
+                                 float* out, int ldo, int M, int N, int accumulate) {
+    asr::SkinnyArgs a{};
+    a.x1 = x; a.ld1 = ldx; a.K1 = K; a.W = Wt; a.ldw = ldw; a.M = M; a.N = N; a.out = out; a.ldo = ldo;
+    a.accumulate = accumulate;
+    if (int rc = skinny_check(a)) return rc;
+    if (!out || N <= 0 || ldw < K || ldo < N || (ldw & 3) || (reinterpret_cast<uintptr_t>(Wt) & 15)) return ASR_EINVAL;
+    dim3 grid((N + 15) / 16, (M + 15) / 16);
+    hipLaunchKernelGGL((asr::skinny_kernel<false, true>), grid, dim3(256), 0, static_cast<hipStream_t>(stream), a);
     ASR_CHECK_LAUNCH();
     return ASR_OK;
 }

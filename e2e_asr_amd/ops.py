@@ -261,3 +261,17 @@ def attn_decoder_fwd(wt, dec_inp, seq_len, enc, enc_len, mode=0, coin=None, samp
                                          int(seed) & 0xFFFFFFFF, _p(logits))
     _check(rc, "asr_attn_decoder_fwd")
     return logits, ws
+
+
+PROF_TAGS = {"lstm_rec_fwd": 0, "lstm_rec_bwd": 1, "gemm": 2, "decoder_fwd": 3, "decoder_bwd": 4, "optim": 5}
+
+
+def prof_enable(on=True):
+    _lib.lib().asr_prof_enable(int(on))
+
+
+def prof_read(tag):
+    """(total_ms, launches) of a profiled kernel family since prof_enable (synchronises)."""
+    ms, n = C.c_double(0), C.c_int(0)
+    _check(_lib.lib().asr_prof_read(PROF_TAGS[tag], C.byref(ms), C.byref(n)), "asr_prof_read")
+    return ms.value, n.value

@@ -124,6 +124,12 @@ int asr_attn_decoder_fwd(void* stream, const asr_dec_weights* w, const asr_dec_d
                          const int* seq_len, int mode, const float* coin_host, float samp_prob,
                          float keep_lm, unsigned seed, float* logits);
 
+/* Optional per-kernel HIP-event timing on the launch stream (bench.py roofline leg).
+ * tag: 0 lstm recurrent fwd, 1 lstm recurrent bwd, 2 gemm, 3 decoder fwd, 4 decoder bwd, 5 optimizer.
+ * asr_prof_read is a HOST call that synchronises on the recorded events. */
+int asr_prof_enable(int on);
+int asr_prof_read(int tag, double* total_ms, int* launches);
+
 #ifdef __cplusplus
 }
 #endif

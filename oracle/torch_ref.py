@@ -1,0 +1,182 @@
+"""Torch (CPU, autograd) restatement of the reference TF graph -- TEST INFRASTRUCTURE.
+
+Same op-for-op structure as oracle/asr_oracle.py (which is the primary oracle and is
+pinned by the reference's golden vectors); this twin exists because the product path needs
+GRADIENT parity (tf.gradients, seq2seq_model.py:148) and a CPU train-step baseline, and
+NumPy has no autograd.  tests/test_oracle_torch_ref.py checks its forward against
+asr_oracle on the same inputs, so the gradients it yields are gradients of the pinned
+forward.  Per-timestep BasicLSTMCell loops exactly as dynamic_rnn / raw_rnn execute them
+(no fused/oneDNN RNN primitive).  Only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg may import this.
+"""
+import numpy as np
+import torch
+
+from . import asr_oracle as O
+
+
+def lstm_cell(x, c, h, w, b):
+    """basic_lstm.py:14-23."""
+    z = torch.cat((x, h), -1) @ w + b
+    i, j, f, o = z.chunk(4, -1)
+    nc = c * torch.sigmoid(f + 1) + torch.sigmoid(i) * torch.tanh(j)
+    return nc, torch.sigmoid(o) * torch.tanh(nc)
+
+
+def lstm_layer(x_tm, seq_len, w, b, reverse=False, keep_mask=None):
+    """encoder.py:55-91, one direction (see asr_oracle.lstm_layer)."""
+    T, B, _ = x_tm.shape
+    H = w.shape[1] // 4
+    seq_len = torch.as_tensor(np.asarray(seq_len), dtype=torch.long)
+    c = x_tm.new_zeros(B, H); h = x_tm.new_zeros(B, H)
+    ar = torch.arange(B)
+    outs = [None] * T if not reverse else None
+    if reverse:
+        out = x_tm.new_zeros(T, B, H)
+    for s in range(int(seq_len.max())):
+        live = (s < seq_len)
+        t_idx = (seq_len - 1 - s) if reverse else torch.full((B,), s, dtype=torch.long)
+        t_safe = torch.where(live, t_idx, torch.zeros_like(t_idx))
+        nc, nh = lstm_cell(x_tm[t_safe, ar], c, h, w, b)
+        lv = live[:, None]
+        c = torch.where(lv, nc, c); h = torch.where(lv, nh, h)
+        if reverse:
+            out = out.index_put((t_safe[live], ar[live]), nh[live])
+        else:
+            outs[s] = torch.where(lv, nh, torch.zeros_like(nh))
+    if not reverse:
+        z = x_tm.new_zeros(B, H)
+        out = torch.stack([o if o is not None else z for o in outs], 0)
+    if keep_mask is not None:
+        out = out * keep_mask
+    return out
+
+
+def encoder(x_bm, seq_len, W, num_layers, bi_dir=True, skip_step=2, max_scaling_down=8, keep_masks=None):
+    """encoder.py:122-180."""
+    att, lens = {}, {}
+    max_depth = max(num_layers.values())
+    seq_len = np.asarray(seq_len).astype(np.int64)
+    res, enc_in = 1, x_bm
+    for i in range(max_depth):
+        d = i + 1
+        x_tm = enc_in.transpose(0, 1)
+        km = keep_masks.get(d) if keep_masks else (None, None)
+        if bi_dir:
+            fw = lstm_layer(x_tm, seq_len, W[O.enc_var(d, "fw", "kernel")], W[O.enc_var(d, "fw", "bias")], False, km[0])
+            bw = lstm_layer(x_tm, seq_len, W[O.enc_var(d, "bw", "kernel")], W[O.enc_var(d, "bw", "bias")], True, km[1])
+            out = torch.cat((fw, bw), 2)
+        else:
+            out = lstm_layer(x_tm, seq_len, W[O.enc_var(d, "", "kernel", False)], W[O.enc_var(d, "", "bias", False)],
+                             False, km[0])
+        out_bm = out.transpose(0, 1)
+        if d in num_layers.values():
+            att[d] = out_bm
+        lens[d] = seq_len
+        if skip_step > 1 and i != max_depth - 1 and res < max_scaling_down:
+            B, T, Fd = out_bm.shape
+            rem = int(seq_len.max()) % skip_step
+            if rem:
+                out_bm = torch.cat((out_bm, out_bm.new_zeros(B, skip_step - rem, Fd)), 1)
+            enc_in = out_bm.reshape(B, out_bm.shape[1] // skip_step, Fd * skip_step)
+            seq_len = np.ceil(seq_len / float(skip_step)).astype(np.int64)
+            res *= skip_step
+        else:
+            enc_in = out_bm
+    return att, lens
+
+
+def attn_decoder(dec_inp, seq_len, enc, seq_len_inp, W, task="char", lm_keep_masks=None, tokens=None):
+    """attn_decoder.py:37-172 in training mode.  `tokens` [T_out,B]: the token actually fed
+    at each step (teacher or sampled, taken from the product path so both follow one path)."""
+    g = lambda leaf: W[O.dec_var(task, leaf)]
+    opt = lambda leaf: W.get(O.dec_var(task, leaf))
+    emb = g("decoder/embedding")
+    seq_len = np.asarray(seq_len).astype(np.int64)
+    B, Te, D = enc.shape
+    H = g("rnn/basic_lstm_cell_1/kernel").shape[1] // 4
+    lmH = g("rnn/basic_lstm_cell/kernel").shape[1] // 4
+    T_out = int(seq_len.max())
+    mask = (torch.arange(Te)[None] < torch.as_tensor(np.asarray(seq_len_inp))[:, None]).to(enc.dtype)
+    aw = g("AttnW"); aw = aw.reshape(aw.shape[-2], aw.shape[-1])
+    hf = enc @ aw
+    z = lambda n: enc.new_zeros(B, n)
+    c, h, lc, lh, ctx = z(H), z(H), z(lmH), z(lmH), z(D)
+    dec_inp = torch.as_tensor(np.asarray(dec_inp), dtype=torch.long)
+    toks = dec_inp if tokens is None else torch.as_tensor(np.asarray(tokens), dtype=torch.long)
+    outs = []
+    fin = torch.as_tensor(0 >= seq_len)
+    for t in range(T_out):
+        lc, lh = lstm_cell(emb[toks[t]], lc, lh, g("rnn/basic_lstm_cell/kernel"), g("rnn/basic_lstm_cell/bias"))
+        lo = lh if lm_keep_masks is None else lh * lm_keep_masks[t]
+        if opt("rnn/SimpleProjection/kernel") is not None:
+            lo = lo @ g("rnn/SimpleProjection/kernel") + g("rnn/SimpleProjection/bias")
+        x = torch.cat((lo, ctx), 1) @ g("rnn/InputProjection/kernel") + g("rnn/InputProjection/bias")
+        nc, nh = lstm_cell(x, c, h, g("rnn/basic_lstm_cell_1/kernel"), g("rnn/basic_lstm_cell_1/bias"))
+        q = nc
+        y = q @ g("rnn/Attention/kernel") + g("rnn/Attention/bias")
+        s = (g("AttnV") * torch.tanh(hf + y[:, None, :])).sum(2)
+        a = torch.softmax(s, 1) * mask
+        a = a / a.sum(1, keepdim=True)
+        ctx = (a[:, :, None] * enc).sum(1)
+        p = torch.cat((q, ctx), 1) @ g("rnn/AttnProjection/kernel") + g("rnn/AttnProjection/bias")
+        logits = p @ g("rnn/OutputProjection/kernel") + g("rnn/OutputProjection/bias")
+        fb = fin[:, None]
+        outs.append(torch.where(fb, torch.zeros_like(logits), logits))
+        c = torch.where(fb, c, nc); h = torch.where(fb, h, nh)
+        fin = fin | torch.as_tensor((t + 1) >= seq_len)
+    return torch.cat(outs, 0)
+
+
+def cross_entropy_loss(logits, targets, seq_len):
+    """losses.py:7-35."""
+    T, B = targets.shape
+    ln = torch.as_tensor(np.asarray(seq_len))
+    ce = torch.nn.functional.cross_entropy(logits, torch.as_tensor(np.asarray(targets), dtype=torch.long).reshape(-1),
+                                           reduction="none").reshape(T, B)
+    m = (torch.arange(T)[:, None] < ln[None]).to(logits.dtype)
+    return ((ce * m).sum(0) / ln.to(logits.dtype)).mean()
+
+
+def seq2seq_loss(batch, W, tasks=("char",), num_layers=None, bi_dir=True, avg=True, tokens=None,
+                 enc_keep_masks=None, lm_keep_masks=None):
+    """seq2seq_model.py:88-144 in training mode -> (total_loss, {task: loss}, {task: logits})."""
+    num_layers = num_layers or {"char": 4}
+    x = torch.as_tensor(batch["logmel"])
+    att, lens = encoder(x, batch["logmel_len"], W, {t: num_layers[t] for t in tasks}, bi_dir=bi_dir,
+                        keep_masks=enc_keep_masks)
+    losses, outs = {}, {}
+    for task in tasks:
+        dec_inp = np.transpose(np.asarray(batch[task]))
+        dlen = np.asarray(batch[task + "_len"])
+        d = num_layers[task]
+        outs[task] = attn_decoder(dec_inp, dlen, att[d], lens[d], W, task,
+                                  lm_keep_masks=None if lm_keep_masks is None else lm_keep_masks[task],
+                                  tokens=None if tokens is None else tokens[task])
+        T_out = int(dlen.max())
+        losses[task] = cross_entropy_loss(outs[task], dec_inp[1:1 + T_out], dlen)
+    total = sum(losses.values())
+    if avg:
+        total = total / float(len(tasks))
+    return total, losses, outs
+
+
+def weights_to_torch(weights, dtype=torch.float64, requires_grad=True):
+    return {k: torch.tensor(np.asarray(v), dtype=dtype, requires_grad=requires_grad) for k, v in weights.items()}
+
+
+def train_step_reference(batch, weights, adam_state, step, lr=1e-3, clip=5.0, **kw):
+    """One reference optimizer step (seq2seq_model.py:137-155): tf.gradients ->
+    clip_by_global_norm(5.0) -> Adam.  Returns (new_weights, new_state, loss, grads, gnorm)."""
+    W = weights_to_torch(weights)
+    total, _, _ = seq2seq_loss(batch, W, **kw)
+    total.backward()
+    names = list(weights.keys())
+    grads = [W[n].grad.numpy() if W[n].grad is not None else np.zeros_like(weights[n], np.float64) for n in names]
+    clipped, gn = O.clip_by_global_norm(grads, clip)
+    new_w, new_s = {}, {}
+    for n, g in zip(names, clipped):
+        m, v = adam_state.get(n, (np.zeros_like(g), np.zeros_like(g)))
+        nw, m, v = O.adam_step(np.asarray(weights[n], np.float64), m, v, g, step, lr)
+        new_w[n] = nw; new_s[n] = (m, v)
+    return new_w, new_s, float(total.item()), dict(zip(names, grads)), gn

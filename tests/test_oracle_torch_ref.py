@@ -1,0 +1,95 @@
+"""CPU: the torch-autograd twin (oracle/torch_ref.py) must reproduce the pinned NumPy oracle's
+forward, so its gradients are gradients of the pinned function.  Also encoder property tests
+that pin the restated TF semantics."""
+import numpy as np
+import pytest
+import torch
+
+from e2e_asr_amd.weights import init_weights, synthetic_batch
+from oracle import asr_oracle as O
+from oracle import torch_ref as R
+
+
+def _small(tasks=("char",), bi_dir=True, depth=3, lm_hidden=12):
+    w = init_weights(feat=10, hidden=8, bi_dir=bi_dir, depth=depth, tasks=tasks, vocab={"char": 17, "phone": 9},
+                     emb=12, hidden_dec=12, lm_hidden=lm_hidden, attn_vec=8, seed=1)
+    for k in w:      # non-zero biases so bias paths are exercised
+        if k.endswith("bias"):
+            w[k] = np.random.default_rng(len(k)).uniform(-0.2, 0.2, w[k].shape).astype(np.float32)
+    return {k: v.astype(np.float64) for k, v in w.items()}
+
+
+@pytest.mark.parametrize("tasks,bi,lmh", [(("char",), True, 12), (("char", "phone"), True, 12), (("char",), False, 7)])
+def test_torch_ref_matches_numpy_oracle(tasks, bi, lmh):
+    w = _small(tasks, bi, lm_hidden=lmh)
+    b = synthetic_batch(B=3, T=13, F=10, t_dec=7, vocab=9, variable_len=True, seed=3, tasks=tasks)
+    b["logmel"] = b["logmel"].astype(np.float64)
+    nl = {"char": 3, "phone": 2}
+    ref = O.seq2seq_forward(b, w, tasks=tasks, num_layers=nl, bi_dir=bi, is_training=True)
+    W = R.weights_to_torch(w)
+    total, losses, outs = R.seq2seq_loss(b, W, tasks=tasks, num_layers=nl, bi_dir=bi)
+    for t in tasks:
+        np.testing.assert_allclose(outs[t].detach().numpy(), ref["outputs"][t], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(total.item(), ref["total_loss"], rtol=1e-12)
+    total.backward()
+    assert all(W[k].grad is not None and torch.isfinite(W[k].grad).all() for k in W)
+
+
+def test_all_equal_length_equals_unmasked():
+    """dynamic_rnn with len == T must equal the plain recurrence (no masking effects)."""
+    rng = np.random.default_rng(0)
+    T, B, I, H = 9, 3, 5, 4
+    x = rng.standard_normal((T, B, I)); w = rng.uniform(-0.5, 0.5, (I + H, 4 * H)); b = rng.uniform(-0.5, 0.5, 4 * H)
+    out, _ = O.lstm_layer(x, [T] * B, w, b)
+    c = np.zeros((B, H)); h = np.zeros((B, H))
+    for t in range(T):
+        c, h = O.lstm_cell(x[t], c, h, w, b)
+        np.testing.assert_array_equal(out[t], h)
+
+
+def test_backward_direction_is_reverse_sequence():
+    """bw(x) == reverse_sequence(fw(reverse_sequence(x))) per utterance, zeros past the length."""
+    rng = np.random.default_rng(1)
+    T, B, I, H = 11, 4, 3, 5
+    x = rng.standard_normal((T, B, I)); w = rng.uniform(-0.5, 0.5, (I + H, 4 * H)); b = rng.uniform(-0.5, 0.5, 4 * H)
+    lens = np.array([11, 4, 1, 7])
+    bw, _ = O.lstm_layer(x, lens, w, b, reverse=True)
+    xr = np.zeros_like(x)
+    for i, L in enumerate(lens):
+        xr[:L, i] = x[:L, i][::-1]
+    fw, _ = O.lstm_layer(xr, lens, w, b)
+    for i, L in enumerate(lens):
+        np.testing.assert_array_equal(bw[:L, i], fw[:L, i][::-1])
+        assert not bw[L:, i].any()
+
+
+def test_pyramid_odd_even_and_lengths():
+    x = np.arange(2 * 5 * 3, dtype=np.float64).reshape(2, 5, 3)
+    out, ln = O.pyramid(x, [5, 2])
+    assert out.shape == (2, 3, 6) and list(ln) == [3, 1]
+    np.testing.assert_array_equal(out[0, 2], np.concatenate((x[0, 4], np.zeros(3))))    # [h_last, 0]
+    out, ln = O.pyramid(x[:, :4], [4, 3])
+    assert out.shape == (2, 2, 6) and list(ln) == [2, 2]
+    with pytest.raises(ValueError):
+        O.pyramid(x, [4, 2])          # max_len even but T odd: tf.reshape would fail
+
+
+def test_loss_matches_torch_composition():
+    rng = np.random.default_rng(2)
+    T, B, V = 6, 4, 11
+    lg = rng.standard_normal((T * B, V)); tg = rng.integers(0, V, (T, B)); ln = np.array([6, 1, 3, 5])
+    ref = O.cross_entropy_loss(lg, tg, ln)
+    got = R.cross_entropy_loss(torch.tensor(lg), tg, ln).item()
+    np.testing.assert_allclose(got, ref, rtol=1e-12)
+
+
+def test_adam_and_clip_tf_semantics():
+    g = [np.array([3.0, 4.0]), np.array([12.0])]            # global norm 13
+    cl, gn = O.clip_by_global_norm(g, 5.0)
+    assert abs(gn - 13.0) < 1e-12
+    np.testing.assert_allclose(np.concatenate(cl), np.array([3.0, 4.0, 12.0]) * 5.0 / 13.0)
+    cl, _ = O.clip_by_global_norm(g, 20.0)                  # below the threshold: untouched
+    np.testing.assert_allclose(np.concatenate(cl), [3.0, 4.0, 12.0])
+    var, m, v = O.adam_step(np.array([1.0]), np.zeros(1), np.zeros(1), np.array([0.5]), 1, 1e-3)
+    # step 1: m = 0.05, v = 2.5e-4, lr_t = 1e-3*sqrt(1e-3)/0.1 -> update = lr_t*m/(sqrt(v)+eps) ~= 1e-3
+    np.testing.assert_allclose(var, 1.0 - 1e-3 * np.sqrt(1e-3) / 0.1 * 0.05 / (np.sqrt(2.5e-4) + 1e-8))
