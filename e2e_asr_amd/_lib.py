@@ -45,8 +45,18 @@ SIGNATURES = {
                                C.c_int, vp, C.c_int, vp, C.c_int]),
     "asr_lstm_ws_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "asr_lstm_layer_fwd": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int,
-                                     vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_size_t, vp,
+                                     vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, C.c_size_t, vp,
                                      C.c_float, C.c_uint]),
+    "asr_lstm_bwd_ws_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "asr_lstm_layer_bwd": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int,
+                                     vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp,
+                                     vp, C.c_size_t, vp, C.c_float, C.c_uint]),
+    "asr_linear_wt_fwd": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "asr_colsum_f32": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int]),
+    "asr_gather_rows": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int]),
+    "asr_scatter_add_rows": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int]),
+    "asr_sumsq_f32": (C.c_int, [vp, vp, C.c_size_t, vp, vp]),
+    "asr_clip_adam_f32": (C.c_int, [vp, vp, vp, vp, vp, C.c_size_t, vp] + [C.c_float] * 6),
     "asr_linear_fwd": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, vp, C.c_int, vp,
                                  vp, C.c_int, C.c_int, C.c_int, vp, C.c_int]),
     "asr_lstm_cell_fwd": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int,

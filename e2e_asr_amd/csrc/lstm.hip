@@ -36,9 +36,10 @@ struct LstmRecArgs {
     const int* len;        // [B]
     float* out;            // [B][Tout][ND*H]
     float* csave;          // [B][T][ND][H] or nullptr
+    float* hprev;          // [B][T][ND][H] or nullptr: h_{t-1} (undropped) for dK_h = Hprev^T.dG
     u64* hx;               // exchange granules [ND*NG][2][R][H]
     int* err;              // set to 1 on poll timeout
-    int B, T, Tout, ND;
+    int B, T, Tout, ND, boff;
     float keep; uint32_t seed;
 };
 
@@ -171,11 +172,12 @@ __global__ __launch_bounds__(16 * HS) void lstm_rec_fwd_kernel(LstmRecArgs a) {
                 const float gj = fast_tanh(pre[1] + gx[1]);
                 const float gf = fast_sigmoid(pre[2] + gx[2] + 1.0f);   // forget bias
                 const float go = fast_sigmoid(pre[3] + gx[3]);
+                if (a.hprev) a.hprev[(((size_t)my_b * a.T + t) * a.ND + dir) * H + j] = h;
                 c = c * gf + gi * gj;
                 h = go * fast_tanh(c);
                 float o = h;
                 if (a.keep < 1.0f)
-                    o *= keep_scale(a.seed, (uint32_t)(my_b * a.Tout + t), (uint32_t)(dir * H + j), a.keep);
+                    o *= keep_scale(a.seed, (uint32_t)((a.boff + my_b) * a.Tout + t), (uint32_t)(dir * H + j), a.keep);
                 a.out[((size_t)my_b * a.Tout + t) * (a.ND * H) + dir * H + j] = o;
                 if (a.csave) {
                     gp[0] = gi; gp[H] = gj; gp[2 * H] = gf; gp[3 * H] = go;
@@ -227,7 +229,7 @@ extern "C" int asr_gemm_f32(void*, int, int, int, int, int, const float*, int, c
                             float*, int, const float*, int);
 
 // rows per group: smallest R whose grid fits one workgroup per CU (256 CUs); override for tuning
-static int pick_rows(int B, int ND, int G) {
+int asr_lstm_pick_rows(int B, int ND, int G) {
     if (const char* e = getenv("ASR_LSTM_R")) { int r = atoi(e); if (r == 1 || r == 2 || r == 4 || r == 8) return r; }
     for (int R : {1, 2, 4, 8})
         if (ND * ((B + R - 1) / R) * G <= 256) return R;
@@ -243,7 +245,7 @@ extern "C" int asr_lstm_layer_fwd(void* stream, const float* x, int B, int T, in
                                   const int* len, int H, int ndir,
                                   const float* kernel_fw, const float* bias_fw,
                                   const float* kernel_bw, const float* bias_bw,
-                                  float* out, int Tout, float* gates, float* csave,
+                                  float* out, int Tout, float* gates, float* csave, float* hprev,
                                   void* hx_ws, size_t hx_bytes, int* err_flag,
                                   float keep_prob, unsigned seed) {
     using namespace asr;
@@ -266,9 +268,9 @@ extern "C" int asr_lstm_layer_fwd(void* stream, const float* x, int B, int T, in
     a.gates = gates;
     a.kh[0] = kernel_fw + (size_t)in_dim * H4;
     a.kh[1] = ndir == 2 ? kernel_bw + (size_t)in_dim * H4 : nullptr;
-    a.len = len; a.out = out; a.csave = csave; a.hx = static_cast<u64*>(hx_ws); a.err = err_flag;
+    a.len = len; a.out = out; a.csave = csave; a.hprev = hprev; a.boff = 0; a.hx = static_cast<u64*>(hx_ws); a.err = err_flag;
     a.B = B; a.T = T; a.Tout = Tout; a.ND = ndir; a.keep = keep_prob; a.seed = seed;
-    const int R = pick_rows(B, ndir, H / 32);
+    const int R = asr_lstm_pick_rows(B, ndir, H / 32);
     // batches too large for one resident grid run as consecutive launches over row ranges
     const int max_groups = 256 / (H / 32) / ndir;
     const int rows_per_launch = max_groups > 0 ? max_groups * R : R;
@@ -280,6 +282,8 @@ extern "C" int asr_lstm_layer_fwd(void* stream, const float* x, int B, int T, in
         c.len = len + b0;
         c.out = out + (size_t)b0 * Tout * ndir * H;
         c.csave = csave ? csave + (size_t)b0 * T * ndir * H : nullptr;
+        c.hprev = hprev ? hprev + (size_t)b0 * T * ndir * H : nullptr;
+        c.boff = b0;
         int rc;
         prof_begin(ASR_PROF_LSTM_REC_FWD, s);
         switch (H) {

@@ -1,0 +1,286 @@
+// Persistent (Bi)LSTM layer, backward through time -- the gradient of csrc/lstm.hip.
+//
+// Reference: tf.gradients through bidirectional_dynamic_rnn/BasicLSTMCell
+// (seq2seq_model.py:148 over encoder.py:55-91).  With saved activations i,j,f,o (sigmoid /
+// tanh already applied), c_t, and c_{t-1}:
+//   tc = tanh(c_t); do = dh*tc; dc_tot = dc_carry + dh*o*(1-tc^2)
+//   di = dc_tot*j; dj = dc_tot*i; df = dc_tot*c_{t-1}; dc_carry' = dc_tot*f
+//   dG = [di*i(1-i), dj*(1-j^2), df*f(1-f), do*o(1-o)]           (pre-activation grads)
+//   dh_{t-1} (recurrent part) = dG . K_h^T
+// dG overwrites the saved gates in place ([B,T,ND,4H]); the input/weight gradients are then
+// three MFMA GEMMs per direction (dX = dG.K_x^T, dK_x = X^T.dG, dK_h = Hprev^T.dG).
+//
+// Same decomposition as the forward: groups of R batch rows x G = H/32 workgroups, each
+// owning 32 hidden units (all 4 gates) with its K_h column slice in registers.  A workgroup
+// can only form the PARTIAL of dh_{t-1} over its own 128 gate columns, for all H units, so
+// the per-step exchange is a reduce-scatter instead of an all-gather: each workgroup
+// publishes R*H partial values as {tag, value} granules addressed to the owner of each unit
+// and every cell thread sums the G partials of its (row, unit) in fixed order (bitwise
+// reproducible).  Same granule count per step as the forward (R*H).
+// Thread map: lane = 16*kgl + nc; the DPP row's 16 lanes hold the 16 column chunks (8 gate
+// columns = 2 units x 4 gates) and each lane KG = H/32 output rows k, so the reduction over
+// columns is again 4 DPP butterflies.
+#include "common.h"
+
+namespace asr {
+
+struct LstmBwdArgs {
+    float* gates;          // [B][T][ND][4H]  in: activated gates   out: dG (zero past len)
+    const float* csave;    // [B][T][ND][H]
+    const float* dout;     // [B][Tout][ND*H] gradient w.r.t. the layer output
+    const float* kh[2];
+    const int* len;
+    u64* hx;               // [groups][2][G dst][G src][R][32] granules
+    int* err;
+    int B, T, Tout, ND, boff;
+    float keep; uint32_t seed;
+};
+
+__device__ __forceinline__ bool poll_sum(const u64* g, int stride, int n, uint32_t epoch, float& sum, int* err) {
+    // n granules at g[i*stride]; all loads in flight, re-poll the late ones; sum in index order
+    float v[16]; bool ok[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { v[i] = 0.f; ok[i] = i >= n; }
+    long long t0 = 0;
+    for (uint32_t spins = 0;; ++spins) {
+        bool all = true;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if (!ok[i]) {
+                const u64 x = __hip_atomic_load(g + (size_t)i * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((uint32_t)(x >> 32) == epoch) { v[i] = __uint_as_float((uint32_t)x); ok[i] = true; }
+                else all = false;
+            }
+        }
+        if (all) break;
+        if ((spins & 1023) == 1023) {
+            const long long now = wall_clock64();
+            if (t0 == 0) t0 = now;
+            else if (now - t0 > 200000000LL) { *err = 1; sum = 0.f; return false; }
+            if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { sum = 0.f; return false; }
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += v[i];
+    sum = s;
+    return true;
+}
+
+template <int H, int R>
+__global__ __launch_bounds__(512) void lstm_rec_bwd_kernel(LstmBwdArgs a) {
+    constexpr int HS = 32, NT = 512;
+    constexpr int G = H / HS;          // workgroups per group (<= 16)
+    constexpr int KG = H / 32;         // output rows k per lane
+    constexpr int CS = 12;             // padded LDS chunk stride (8 values + 4)
+    __shared__ __attribute__((aligned(16))) float dgl[R * 16 * CS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nc = lane & 15, kg = wave * 4 + (lane >> 4);
+    const int NG = (a.B + R - 1) / R;
+    const int ngroups = a.ND * NG;
+    int grp, mem;
+    if ((ngroups & 7) == 0) { mem = (blockIdx.x >> 3) % G; grp = (blockIdx.x & 7) + 8 * (blockIdx.x / (8 * G)); }
+    else { grp = blockIdx.x / G; mem = blockIdx.x % G; }
+    const int dir = grp / NG, bg = grp % NG;
+    const int r0 = bg * R;
+    const int H4 = 4 * H;
+    const int j0 = mem * HS;
+
+    // K_h slice -> registers: w[i][jn] = K_h[kg*KG + i][col(8*nc + jn)], local column n = 4*unit + gate
+    float w[KG][8];
+    {
+        const float* kh = a.kh[dir];
+#pragma unroll
+        for (int i = 0; i < KG; ++i)
+#pragma unroll
+            for (int jn = 0; jn < 8; ++jn) {
+                const int n = 8 * nc + jn;
+                w[i][jn] = kh[(size_t)(kg * KG + i) * H4 + (n & 3) * H + j0 + (n >> 2)];
+            }
+    }
+    int S = 0;
+    for (int r = 0; r < R; ++r) {
+        const int l = (r0 + r < a.B) ? min(a.len[r0 + r], a.T) : 0;
+        S = max(S, l);
+    }
+    // cell threads: tid < R*HS -> (row r = tid % R, unit u = tid / R)
+    const bool cell = tid < R * HS;
+    const int cr = tid % R, cu = tid / R;
+    const int cb = r0 + cr;
+    const int clen = (cell && cb < a.B) ? min(a.len[cb], a.T) : 0;
+    const int cj = j0 + cu;
+    float dc = 0.f;
+    u64* hxg = a.hx + (size_t)grp * 2 * G * G * R * HS;
+
+    for (int s = 0; s < S; ++s) {
+        const bool live = cell && s < clen;
+        const int t = dir ? s : (clen - 1 - s);          // reverse of the forward walk
+        float gi = 0.f, gj = 0.f, gf = 0.f, go = 0.f, cc = 0.f, cp = 0.f, dh = 0.f;
+        float* gp = nullptr;
+        if (live) {      // operands that do not depend on the exchange: issue first
+            gp = a.gates + (((size_t)cb * a.T + t) * a.ND + dir) * H4 + cj;
+            gi = gp[0]; gj = gp[H]; gf = gp[2 * H]; go = gp[3 * H];
+            const float* cs = a.csave + (((size_t)cb * a.T + t) * a.ND + dir) * H + cj;
+            cc = cs[0];
+            const int tp = dir ? t + 1 : t - 1;           // time index of the forward's previous step
+            cp = (tp >= 0 && tp < clen) ? cs[(ptrdiff_t)(tp - t) * a.ND * H] : 0.f;
+            dh = a.dout[((size_t)cb * a.Tout + t) * (a.ND * H) + dir * H + cj];
+            if (a.keep < 1.0f)
+                dh *= keep_scale(a.seed, (uint32_t)((a.boff + cb) * a.Tout + t), (uint32_t)(dir * H + cj), a.keep);
+        }
+        if (live && s > 0) {     // recurrent part: sum of the G partials addressed to (row, unit)
+            float rec;
+            const u64* src = hxg + ((size_t)((s - 1) & 1) * G + mem) * G * R * HS + (size_t)cr * HS + cu;
+            poll_sum(src, R * HS, G, (uint32_t)s, rec, a.err);
+            dh += rec;
+        }
+        float4 dg = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live) {
+            const float tc = fast_tanh(cc);
+            const float dct = dc + dh * go * (1.f - tc * tc);
+            dg.x = dct * gj * gi * (1.f - gi);
+            dg.y = dct * gi * (1.f - gj * gj);
+            dg.z = dct * cp * gf * (1.f - gf);
+            dg.w = dh * tc * go * (1.f - go);
+            dc = dct * gf;
+            gp[0] = dg.x; gp[H] = dg.y; gp[2 * H] = dg.z; gp[3 * H] = dg.w;
+        }
+        if (cell) {   // local column n = 4*cu + gate -> chunk cu/2, offset 4*(cu&1)
+            *reinterpret_cast<float4*>(dgl + (cr * 16 + (cu >> 1)) * CS + 4 * (cu & 1)) = dg;
+        }
+        __syncthreads();
+        if (s + 1 < S) {
+            // partial dh_{prev}[r][k] over this workgroup's 128 gate columns
+            float acc[R][KG];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const float4 d0 = *reinterpret_cast<const float4*>(dgl + (r * 16 + nc) * CS);
+                const float4 d1 = *reinterpret_cast<const float4*>(dgl + (r * 16 + nc) * CS + 4);
+#pragma unroll
+                for (int i = 0; i < KG; ++i) {
+                    float x = d0.x * w[i][0];
+                    x = fmaf(d0.y, w[i][1], x); x = fmaf(d0.z, w[i][2], x); x = fmaf(d0.w, w[i][3], x);
+                    x = fmaf(d1.x, w[i][4], x); x = fmaf(d1.y, w[i][5], x);
+                    x = fmaf(d1.z, w[i][6], x); x = fmaf(d1.w, w[i][7], x);
+                    acc[r][i] = row16_allreduce_sum(x);
+                }
+            }
+            // publish: lane nc sends value(s) vi = nc, nc+16, ... of the row's R*KG results
+            u64* dstb = hxg + (size_t)(s & 1) * G * G * R * HS;
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int i = 0; i < KG; ++i) {
+                    if (((r * KG + i) & 15) == nc && r0 + r < a.B) {
+                        const int k = kg * KG + i;
+                        u64* dst = dstb + ((size_t)(k / HS) * G + mem) * R * HS + (size_t)r * HS + (k % HS);
+                        __hip_atomic_store(dst, ((u64)(uint32_t)(s + 1) << 32) | __float_as_uint(acc[r][i]),
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+        }
+        __syncthreads();     // dgl is rewritten next step
+    }
+    // dG = 0 past each row's length (the weight/input GEMMs read every row)
+    for (int r = 0; r < R; ++r) {
+        if (r0 + r >= a.B) break;
+        const int l = min(a.len[r0 + r], a.T);
+        const int nz = a.T - l;
+        for (int idx = tid; idx < nz * 4 * HS; idx += NT) {
+            const int t = l + idx / (4 * HS), q = idx % (4 * HS);
+            a.gates[(((size_t)(r0 + r) * a.T + t) * a.ND + dir) * H4 + (q / HS) * H + j0 + (q % HS)] = 0.f;
+        }
+    }
+}
+
+template <int H>
+static int launch_bwd_h(hipStream_t s, const LstmBwdArgs& a, int R) {
+    const int grid = a.ND * ((a.B + R - 1) / R) * (H / 32);
+    switch (R) {
+        case 1: hipLaunchKernelGGL((lstm_rec_bwd_kernel<H, 1>), dim3(grid), dim3(512), 0, s, a); break;
+        case 2: hipLaunchKernelGGL((lstm_rec_bwd_kernel<H, 2>), dim3(grid), dim3(512), 0, s, a); break;
+        case 4: hipLaunchKernelGGL((lstm_rec_bwd_kernel<H, 4>), dim3(grid), dim3(512), 0, s, a); break;
+        case 8: hipLaunchKernelGGL((lstm_rec_bwd_kernel<H, 8>), dim3(grid), dim3(512), 0, s, a); break;
+        default: return ASR_EINVAL;
+    }
+    return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
+}
+
+}  // namespace asr
+
+extern "C" int asr_gemm_f32(void*, int, int, int, int, int, const float*, int, const float*, int,
+                            float*, int, const float*, int);
+extern "C" int asr_colsum_f32(void* stream, const float* x, int ldx, int M, int N, float* out, int accumulate);
+int asr_lstm_pick_rows(int B, int ND, int G);
+
+extern "C" size_t asr_lstm_bwd_ws_bytes(int B, int H, int ndir) {
+    const size_t G = H / 32;
+    return (size_t)ndir * (size_t)((B + 7) / 8 * 8) * 2 * G * H * sizeof(u64);
+}
+
+// Backward of asr_lstm_layer_fwd.  gates/csave/hprev are the forward's saved tensors; gates is
+// overwritten with dG.  dx [B,T,in] (may be NULL for the first layer) receives the input
+// gradient; dkernel_*/dbias_* are ACCUMULATED into (TF layout [in+H,4H] / [4H]).
+extern "C" int asr_lstm_layer_bwd(void* stream, const float* x, int B, int T, int in_dim, int ldx,
+                                  const int* len, int H, int ndir,
+                                  const float* kernel_fw, const float* kernel_bw,
+                                  const float* dout, int Tout, float* gates, const float* csave,
+                                  const float* hprev, float* dx,
+                                  float* dkernel_fw, float* dbias_fw, float* dkernel_bw, float* dbias_bw,
+                                  void* hx_ws, size_t hx_bytes, int* err_flag, float keep_prob, unsigned seed) {
+    using namespace asr;
+    if (!x || !len || !kernel_fw || !dout || !gates || !csave || !hprev || !dkernel_fw || !dbias_fw || !hx_ws || !err_flag)
+        return ASR_EINVAL;
+    if (ndir != 1 && ndir != 2) return ASR_EINVAL;
+    if (ndir == 2 && (!kernel_bw || !dkernel_bw || !dbias_bw)) return ASR_EINVAL;
+    if (H != 64 && H != 128 && H != 256 && H != 512) return ASR_EUNSUPPORTED;
+    if (hx_bytes < asr_lstm_bwd_ws_bytes(B, H, ndir)) return ASR_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int H4 = 4 * H, G = H / 32;
+    LstmBwdArgs a;
+    a.gates = gates; a.csave = csave; a.dout = dout;
+    a.kh[0] = kernel_fw + (size_t)in_dim * H4;
+    a.kh[1] = ndir == 2 ? kernel_bw + (size_t)in_dim * H4 : nullptr;
+    a.len = len; a.hx = static_cast<u64*>(hx_ws); a.err = err_flag;
+    a.B = B; a.T = T; a.Tout = Tout; a.ND = ndir; a.boff = 0; a.keep = keep_prob; a.seed = seed;
+    const int R = asr_lstm_pick_rows(B, ndir, G);
+    const int max_groups = 256 / G / ndir;
+    const int rows_per_launch = max_groups > 0 ? max_groups * R : R;
+    for (int b0 = 0; b0 < B; b0 += rows_per_launch) {
+        if (hipMemsetAsync(hx_ws, 0, asr_lstm_bwd_ws_bytes(B, H, ndir), s) != hipSuccess) return ASR_ELAUNCH;
+        LstmBwdArgs c = a;
+        c.B = (B - b0 < rows_per_launch) ? (B - b0) : rows_per_launch;
+        c.boff = b0;
+        c.gates = gates + (size_t)b0 * T * ndir * H4;
+        c.csave = csave + (size_t)b0 * T * ndir * H;
+        c.dout = dout + (size_t)b0 * Tout * ndir * H;
+        c.len = len + b0;
+        int rc;
+        prof_begin(ASR_PROF_LSTM_REC_BWD, s);
+        switch (H) {
+            case 64: rc = launch_bwd_h<64>(s, c, R); break;
+            case 128: rc = launch_bwd_h<128>(s, c, R); break;
+            case 256: rc = launch_bwd_h<256>(s, c, R); break;
+            default: rc = launch_bwd_h<512>(s, c, R); break;
+        }
+        prof_end(ASR_PROF_LSTM_REC_BWD, s);
+        if (rc) return rc;
+    }
+    // input / weight gradients: three GEMMs + a column sum per direction
+    const int M = B * T;
+    for (int d = 0; d < ndir; ++d) {
+        const float* dG = gates + (size_t)d * H4;
+        const int ldg = ndir * H4;
+        const float* K = d ? kernel_bw : kernel_fw;
+        float* dK = d ? dkernel_bw : dkernel_fw;
+        float* dB = d ? dbias_bw : dbias_fw;
+        int rc;
+        if (dx && (rc = asr_gemm_f32(stream, 0, 1, M, in_dim, H4, dG, ldg, K, H4, dx, in_dim, nullptr, d > 0))) return rc;
+        if ((rc = asr_gemm_f32(stream, 1, 0, in_dim, H4, M, x, ldx, dG, ldg, dK, H4, nullptr, 1))) return rc;
+        if ((rc = asr_gemm_f32(stream, 1, 0, H, H4, M, hprev + (size_t)d * H, ndir * H, dG, ldg,
+                               dK + (size_t)in_dim * H4, H4, nullptr, 1))) return rc;
+        if ((rc = asr_colsum_f32(stream, dG, ldg, M, H4, dB, 1))) return rc;
+    }
+    return ASR_OK;
+}

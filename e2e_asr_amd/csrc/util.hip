@@ -1,0 +1,141 @@
+// Small bandwidth-bound helpers: bias-gradient column sums, embedding gather / scatter-add,
+// and the fused global-norm clip + Adam update over the flat parameter buffer.
+#include "common.h"
+#include <algorithm>
+
+namespace asr {
+
+// out[n] (+)= sum_m x[m][n].  Block = 64 columns x 4 row-strips; fixed order -> reproducible.
+__global__ __launch_bounds__(256) void colsum_kernel(const float* x, int ldx, int M, int N, float* out, int accumulate) {
+    __shared__ float part[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), strip = threadIdx.x >> 6;
+    float s = 0.f;
+    if (c < N) {
+        const int rows = (M + 3) / 4;
+        const int m0 = strip * rows, m1 = min(M, m0 + rows);
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int m = m0;
+        for (; m + 3 < m1; m += 4) {
+            s0 += x[(size_t)m * ldx + c]; s1 += x[(size_t)(m + 1) * ldx + c];
+            s2 += x[(size_t)(m + 2) * ldx + c]; s3 += x[(size_t)(m + 3) * ldx + c];
+        }
+        for (; m < m1; ++m) s0 += x[(size_t)m * ldx + c];
+        s = (s0 + s1) + (s2 + s3);
+    }
+    part[strip][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (strip == 0 && c < N) {
+        const float t = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+        out[c] = accumulate ? out[c] + t : t;
+    }
+}
+
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* table, const int* idx, float* out, int rows, int width) {
+    const int w4 = width >> 2;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)rows * w4; i += (size_t)gridDim.x * 256) {
+        const int r = (int)(i / w4), c = (int)(i % w4);
+        reinterpret_cast<float4*>(out)[i] = reinterpret_cast<const float4*>(table + (size_t)idx[r] * width)[c];
+    }
+}
+
+__global__ __launch_bounds__(256) void scatter_add_rows_kernel(float* tg, const int* idx, const float* g, int rows, int width) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)rows * width; i += (size_t)gridDim.x * 256) {
+        const int r = (int)(i / width), c = (int)(i % width);
+        atomicAdd(tg + (size_t)idx[r] * width + c, g[i]);
+    }
+}
+
+// stage 1: up to 1024 block partials of sum(x^2); stage 2: one block sums them in order.
+__global__ __launch_bounds__(256) void sumsq_stage1(const float* x, size_t n, float* ws) {
+    __shared__ float red[256];
+    float s = 0.f;
+    const size_t n4 = n >> 2;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    if (blockIdx.x == 0) for (size_t i = (n4 << 2) + threadIdx.x; i < n; i += 256) s += x[i] * x[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) ws[blockIdx.x] = red[0];
+}
+__global__ __launch_bounds__(256) void sumsq_stage2(const float* ws, int nb, float* out) {
+    __shared__ float red[256];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nb; i += 256) s += ws[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) out[0] = red[0];
+}
+
+__global__ __launch_bounds__(256) void clip_adam_kernel(float* p, float* m, float* v, const float* g, size_t n,
+                                                        const float* sumsq, float gscale, float clip, float lr_t,
+                                                        float b1, float b2, float eps) {
+    // tf.clip_by_global_norm: scale = clip * min(1/norm, 1/clip) = clip / max(norm, clip)
+    const float norm = sqrtf(sumsq[0]) * gscale;
+    const float sc = gscale * (norm > 0.f ? clip / fmaxf(norm, clip) : 1.f);
+    const size_t n4 = n >> 2;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        float4 gg = reinterpret_cast<const float4*>(g)[i];
+        float4 mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i], pp = reinterpret_cast<float4*>(p)[i];
+#define ASR_ADAM1(c) { const float gx = gg.c * sc; mm.c = b1 * mm.c + (1.f - b1) * gx; vv.c = b2 * vv.c + (1.f - b2) * gx * gx; \
+                       pp.c -= lr_t * mm.c / (sqrtf(vv.c) + eps); }
+        ASR_ADAM1(x) ASR_ADAM1(y) ASR_ADAM1(z) ASR_ADAM1(w)
+#undef ASR_ADAM1
+        reinterpret_cast<float4*>(m)[i] = mm; reinterpret_cast<float4*>(v)[i] = vv; reinterpret_cast<float4*>(p)[i] = pp;
+    }
+    if (blockIdx.x == 0)
+        for (size_t i = (n4 << 2) + threadIdx.x; i < n; i += 256) {
+            const float gx = g[i] * sc;
+            m[i] = b1 * m[i] + (1.f - b1) * gx; v[i] = b2 * v[i] + (1.f - b2) * gx * gx;
+            p[i] -= lr_t * m[i] / (sqrtf(v[i]) + eps);
+        }
+}
+
+}  // namespace asr
+
+extern "C" int asr_colsum_f32(void* stream, const float* x, int ldx, int M, int N, float* out, int accumulate) {
+    if (!x || !out || M < 0 || N <= 0 || ldx < N) return ASR_EINVAL;
+    hipLaunchKernelGGL(asr::colsum_kernel, dim3((N + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream), x, ldx, M, N, out, accumulate);
+    ASR_CHECK_LAUNCH();
+    return ASR_OK;
+}
+extern "C" int asr_gather_rows(void* stream, const float* table, const int* idx, float* out, int rows, int width) {
+    if (!table || !idx || !out || rows <= 0 || width <= 0 || (width & 3)) return ASR_EINVAL;
+    const int grid = (int)std::min<size_t>(2048, ((size_t)rows * (width >> 2) + 255) / 256);
+    hipLaunchKernelGGL(asr::gather_rows_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), table, idx, out, rows, width);
+    ASR_CHECK_LAUNCH();
+    return ASR_OK;
+}
+extern "C" int asr_scatter_add_rows(void* stream, float* tg, const int* idx, const float* g, int rows, int width) {
+    if (!tg || !idx || !g || rows <= 0 || width <= 0) return ASR_EINVAL;
+    const int grid = (int)std::min<size_t>(2048, ((size_t)rows * width + 255) / 256);
+    hipLaunchKernelGGL(asr::scatter_add_rows_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), tg, idx, g, rows, width);
+    ASR_CHECK_LAUNCH();
+    return ASR_OK;
+}
+extern "C" int asr_sumsq_f32(void* stream, const float* x, size_t n, float* ws, float* out) {
+    if (!x || !ws || !out || n == 0 || (reinterpret_cast<uintptr_t>(x) & 15)) return ASR_EINVAL;
+    const int nb = (int)std::min<size_t>(1024, (n / 4 + 255) / 256 + 1);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(asr::sumsq_stage1, dim3(nb), dim3(256), 0, s, x, n, ws);
+    hipLaunchKernelGGL(asr::sumsq_stage2, dim3(1), dim3(256), 0, s, ws, nb, out);
+    ASR_CHECK_LAUNCH();
+    return ASR_OK;
+}
+extern "C" int asr_clip_adam_f32(void* stream, float* p, float* m, float* v, const float* g, size_t n,
+                                 const float* sumsq, float grad_scale, float clip_norm, float lr_t,
+                                 float beta1, float beta2, float eps) {
+    if (!p || !m || !v || !g || !sumsq || n == 0) return ASR_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v) |
+         reinterpret_cast<uintptr_t>(g)) & 15) return ASR_EINVAL;
+    const int nb = (int)std::min<size_t>(2048, (n / 4 + 255) / 256 + 1);
+    asr::prof_begin(ASR_PROF_OPTIM, static_cast<hipStream_t>(stream));
+    hipLaunchKernelGGL(asr::clip_adam_kernel, dim3(nb), dim3(256), 0, static_cast<hipStream_t>(stream), p, m, v, g, n,
+                       sumsq, grad_scale, clip_norm, lr_t, beta1, beta2, eps);
+    asr::prof_end(ASR_PROF_OPTIM, static_cast<hipStream_t>(stream));
+    ASR_CHECK_LAUNCH();
+    return ASR_OK;
+}

@@ -88,7 +88,7 @@ class Encoder(BaseParams):
                                    keep_prob=keep, seed=seed)
             out = r[0] if save else r
             if save:
-                self.saved.append(dict(x=x, lens=lens, lens_dev=lens_dev, gates=r[1], c=r[2], out=out,
+                self.saved.append(dict(x=x, lens=lens, lens_dev=lens_dev, gates=r[1], c=r[2], hprev=r[3], out=out,
                                        T=T, t_out=t_out, keep=keep, seed=seed, depth=d))
             view = out[:, :T] if t_out != T else out
             if d in time_major_states:

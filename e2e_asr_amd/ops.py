@@ -99,19 +99,93 @@ def lstm_layer_fwd(x, seq_len, kernel_fw, bias_fw, kernel_bw=None, bias_bw=None,
     out = torch.empty((B, t_out, ndir * H), device=dev, dtype=torch.float32)
     gates = torch.empty((B, T, ndir, 4 * H), device=dev, dtype=torch.float32)
     csave = torch.empty((B, T, ndir, H), device=dev, dtype=torch.float32) if save else None
+    hprev = torch.empty((B, T, ndir, H), device=dev, dtype=torch.float32) if save else None
     L = _lib.lib()
     nbytes = L.asr_lstm_ws_bytes(B, H, ndir)
-    key = (dev, nbytes)
-    if key not in _hx_cache:
-        _hx_cache[key] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    hx = _hx_cache[key]
+    hx = _hx(dev, nbytes)
     rc = L.asr_lstm_layer_fwd(_stream(), _p(x), B, T, IN, IN, _p(seq_len), H, ndir,
                               _p(_f32(kernel_fw, "kernel_fw")), _p(_f32(bias_fw, "bias_fw")),
                               _p(_f32(kernel_bw, "kernel_bw")), _p(_f32(bias_bw, "bias_bw")),
-                              _p(out), t_out, _p(gates), _p(csave), _p(hx), nbytes,
+                              _p(out), t_out, _p(gates), _p(csave), _p(hprev), _p(hx), nbytes,
                               _p(_Flag.get(dev)), float(keep_prob), int(seed) & 0xFFFFFFFF)
     _check(rc, "asr_lstm_layer_fwd")
-    return (out, gates, csave) if save else out
+    return (out, gates, csave, hprev) if save else out
+
+
+def _hx(dev, nbytes):
+    key = (dev, nbytes)
+    if key not in _hx_cache:
+        _hx_cache[key] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    return _hx_cache[key]
+
+
+def lstm_layer_bwd(x, seq_len, kernel_fw, kernel_bw, dout, gates, csave, hprev, dk_fw, db_fw, dk_bw=None,
+                   db_bw=None, need_dx=True, keep_prob=1.0, seed=0):
+    """Backward of lstm_layer_fwd.  `gates` is overwritten with dG; weight/bias gradients are
+    ACCUMULATED into dk_*/db_* (views of the flat gradient buffer).  Returns dx [B,T,in] or None."""
+    B, T, IN = x.shape
+    H = kernel_fw.shape[1] // 4
+    ndir = 1 if kernel_bw is None else 2
+    dev = x.device
+    dx = torch.empty_like(x) if need_dx else None
+    L = _lib.lib()
+    nbytes = L.asr_lstm_bwd_ws_bytes(B, H, ndir)
+    rc = L.asr_lstm_layer_bwd(_stream(), _p(x), B, T, IN, IN, _p(seq_len), H, ndir, _p(kernel_fw), _p(kernel_bw),
+                              _p(_f32(dout, "dout")), dout.shape[1], _p(gates), _p(csave), _p(hprev), _p(dx),
+                              _p(dk_fw), _p(db_fw), _p(dk_bw), _p(db_bw), _p(_hx(dev, nbytes)), nbytes,
+                              _p(_Flag.get(dev)), float(keep_prob), int(seed) & 0xFFFFFFFF)
+    _check(rc, "asr_lstm_layer_bwd")
+    return dx
+
+
+def linear_wt(x, wt, out=None, accumulate=False, n=None, k=None, ldw=None):
+    """out[M,N] (+)= x[M,K] @ wt[N,K]^T -- data-gradient products (wt = rows of a TF kernel)."""
+    M = x.shape[0]
+    K = x.shape[1] if k is None else k
+    N = wt.shape[0] if n is None else n
+    ldw = wt.shape[1] if ldw is None else ldw
+    if out is None:
+        out = torch.empty((M, N), device=x.device, dtype=torch.float32)
+    rc = _lib.lib().asr_linear_wt_fwd(_stream(), _p(x), x.shape[1], K, _p(wt), ldw, _p(out), out.shape[1], M, N,
+                                      int(accumulate))
+    _check(rc, "asr_linear_wt_fwd")
+    return out
+
+
+def colsum(x, out, accumulate=True):
+    M, N = x.shape
+    _check(_lib.lib().asr_colsum_f32(_stream(), _p(x), x.stride(0), M, N, _p(out), int(accumulate)), "asr_colsum_f32")
+    return out
+
+
+def gather_rows(table, idx):
+    out = torch.empty((idx.numel(), table.shape[1]), device=table.device, dtype=torch.float32)
+    _check(_lib.lib().asr_gather_rows(_stream(), _p(table), _p(idx), _p(out), idx.numel(), table.shape[1]), "asr_gather_rows")
+    return out
+
+
+def scatter_add_rows(table_grad, idx, g):
+    _check(_lib.lib().asr_scatter_add_rows(_stream(), _p(table_grad), _p(idx), _p(g), idx.numel(), table_grad.shape[1]),
+           "asr_scatter_add_rows")
+
+
+_sumsq_ws = {}
+
+
+def sumsq(x, out=None):
+    dev = x.device
+    if dev not in _sumsq_ws:
+        _sumsq_ws[dev] = torch.empty(1024, device=dev, dtype=torch.float32)
+    if out is None:
+        out = torch.empty(1, device=dev, dtype=torch.float32)
+    _check(_lib.lib().asr_sumsq_f32(_stream(), _p(x), x.numel(), _p(_sumsq_ws[dev]), _p(out)), "asr_sumsq_f32")
+    return out
+
+
+def clip_adam(p, m, v, g, sumsq_t, grad_scale, clip_norm, lr_t, beta1=0.9, beta2=0.999, eps=1e-8):
+    _check(_lib.lib().asr_clip_adam_f32(_stream(), _p(p), _p(m), _p(v), _p(g), p.numel(), _p(sumsq_t),
+                                        float(grad_scale), float(clip_norm), float(lr_t), float(beta1),
+                                        float(beta2), float(eps)), "asr_clip_adam_f32")
 
 
 def linear(x1, w, bias=None, x2=None, gather=None, zero_from=None, zero_t=0, out=None):

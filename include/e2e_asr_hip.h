@@ -32,7 +32,8 @@ int asr_gemm_f32(void* stream, int transA, int transB, int M, int N, int K,
  * x [B,T,in] batch-major (row stride ldx); out [B,Tout,ndir*H] with fw in [:H], bw in
  * [H:]; rows t >= len[b] (and the pad frames T..Tout-1 of the pyramid, encoder.py:104-110)
  * are written as exact zeros.  gates [B,T,ndir,4H] is workspace; with csave != NULL it
- * leaves the activated gates and csave [B,T,ndir,H] the cell states for the backward pass.
+ * leaves the activated gates, csave [B,T,ndir,H] the cell states and hprev [B,T,ndir,H] the
+ * (undropped) previous hidden states for the backward pass.
  * keep_prob < 1 applies DropoutWrapper(output_keep_prob) (encoder.py:49-52) to `out`.
  * err_flag: device int, set non-zero if an inter-workgroup wait timed out. H in {64,128,256,512}. */
 size_t asr_lstm_ws_bytes(int B, int H, int ndir);
@@ -40,9 +41,40 @@ int asr_lstm_layer_fwd(void* stream, const float* x, int B, int T, int in_dim, i
                        const int* len, int H, int ndir,
                        const float* kernel_fw, const float* bias_fw,
                        const float* kernel_bw, const float* bias_bw,
-                       float* out, int Tout, float* gates, float* csave,
+                       float* out, int Tout, float* gates, float* csave, float* hprev,
                        void* hx_ws, size_t hx_bytes, int* err_flag,
                        float keep_prob, unsigned seed);
+
+/* Backward of asr_lstm_layer_fwd (tf.gradients through encoder.py:55-91): persistent BPTT
+ * kernel (dG overwrites `gates`), then dX = dG.K_x^T, dK_x = X^T.dG, dK_h = Hprev^T.dG and
+ * dbias = colsum(dG).  dkernel and dbias arguments are ACCUMULATED into; dx may be NULL. */
+size_t asr_lstm_bwd_ws_bytes(int B, int H, int ndir);
+int asr_lstm_layer_bwd(void* stream, const float* x, int B, int T, int in_dim, int ldx,
+                       const int* len, int H, int ndir,
+                       const float* kernel_fw, const float* kernel_bw,
+                       const float* dout, int Tout, float* gates, const float* csave,
+                       const float* hprev, float* dx,
+                       float* dkernel_fw, float* dbias_fw, float* dkernel_bw, float* dbias_bw,
+                       void* hx_ws, size_t hx_bytes, int* err_flag, float keep_prob, unsigned seed);
+
+/* out[M,N] (+)= X.Wt^T with Wt given [N,K]: data-gradient products of the decoder backward. */
+int asr_linear_wt_fwd(void* stream, const float* x, int ldx, int K, const float* Wt, int ldw,
+                      float* out, int ldo, int M, int N, int accumulate);
+
+/* out[N] (+)= column sums of x[M,N] (bias gradients); fixed-order, reproducible. */
+int asr_colsum_f32(void* stream, const float* x, int ldx, int M, int N, float* out, int accumulate);
+/* out[r,:] = table[idx[r],:] (embedding_lookup) and table_grad[idx[r],:] += g[r,:] (its gradient). */
+int asr_gather_rows(void* stream, const float* table, const int* idx, float* out, int rows, int width);
+int asr_scatter_add_rows(void* stream, float* table_grad, const int* idx, const float* g, int rows, int width);
+
+/* tf.clip_by_global_norm + tf.train.AdamOptimizer over flat buffers (seq2seq_model.py:137-155).
+ * asr_sumsq: out[0] = sum(x^2) (two-stage, fixed order; ws >= 1024 floats).
+ * asr_clip_adam: g' = g * grad_scale * clip/max(sqrt(sumsq*grad_scale^2), clip);
+ *   m,v EMA; p -= lr_t * m/(sqrt(v)+eps), lr_t = lr*sqrt(1-b2^t)/(1-b1^t) computed by the caller. */
+int asr_sumsq_f32(void* stream, const float* x, size_t n, float* ws, float* out);
+int asr_clip_adam_f32(void* stream, float* p, float* m, float* v, const float* g, size_t n,
+                      const float* sumsq, float grad_scale, float clip_norm, float lr_t,
+                      float beta1, float beta2, float eps);
 
 /* out[M,N] = [X1 | X2].W + bias -- `_linear` of attn_decoder.py:117,122,125,151,158.
  * gather1 != NULL: row b of X1 is x1[gather1[b]] (embedding_lookup, decoder.py:101).

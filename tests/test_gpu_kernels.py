@@ -74,7 +74,7 @@ def test_lstm_layer_fwd(dev, B, Tn, IN, H, bi, lens, tout):
     args = [T(x, dev), T(lens, dev, torch.int32), T(fw[0], dev), T(fw[1], dev)]
     if bi:
         args += [T(bw[0], dev), T(bw[1], dev)]
-    out, gates, cs = ops.lstm_layer_fwd(*args, t_out=tout, save=True)
+    out, gates, cs, hp = ops.lstm_layer_fwd(*args, t_out=tout, save=True)
     ops.check_device_flag(dev)
     out = out.cpu().numpy()
     np.testing.assert_allclose(out[:, :Tn], ref, rtol=0, atol=2e-5)
@@ -227,3 +227,83 @@ def test_next_token_argmax_first_max(dev):
     x[1, 999] = 1; x[2, 0] = 1; x[3, 511] = 2; x[3, 512] = 2
     tok = ops.next_token(T(x, dev)).cpu().numpy()
     np.testing.assert_array_equal(tok, np.argmax(x, 1))
+
+
+# ------------------------------------------------------------------ LSTM layer backward
+@pytest.mark.parametrize("B,Tn,IN,H,bi,lens,keep", [
+    (4, 30, 40, 128, False, [30, 21, 1, 9], 1.0),
+    (5, 17, 24, 64, True, [17, 16, 1, 2, 9], 1.0),
+    (32, 24, 80, 256, True, None, 1.0),
+    (6, 12, 16, 64, True, [12, 5, 12, 3, 8, 1], 0.9),        # with output dropout
+    (70, 6, 16, 256, True, None, 1.0),                        # multi-launch batch split
+])
+def test_lstm_layer_bwd_vs_autograd(dev, B, Tn, IN, H, bi, lens, keep):
+    """BPTT kernel + dX/dK/db GEMMs against torch autograd (float64) on the oracle twin."""
+    from e2e_asr_amd import ops
+    from oracle import torch_ref as R
+    rng = np.random.default_rng(B * 31 + Tn)
+    if lens is None:
+        lens = rng.integers(1, Tn + 1, B); lens[0] = Tn
+    x, lens, fw, bw = _lstm_case(rng, B, Tn, IN, H, bi, lens)
+    dout = rng.standard_normal((B, Tn, H * (2 if bi else 1))).astype(np.float32)
+    nd = 2 if bi else 1
+    ld = T(lens, dev, torch.int32)
+    xt = T(x, dev)
+    w = [T(fw[0], dev), T(fw[1], dev)] + ([T(bw[0], dev), T(bw[1], dev)] if bi else [None, None])
+    out, gates, cs, hp = ops.lstm_layer_fwd(xt, ld, w[0], w[1], w[2], w[3], save=True, keep_prob=keep, seed=77)
+    dk = [torch.zeros_like(w[0]), torch.zeros_like(w[1])] + ([torch.zeros_like(w[2]), torch.zeros_like(w[3])] if bi else [None, None])
+    dx = ops.lstm_layer_bwd(xt, ld, w[0], w[2], T(dout, dev), gates, cs, hp, dk[0], dk[1], dk[2], dk[3],
+                            keep_prob=keep, seed=77)
+    ops.check_device_flag(dev)
+    # reference: autograd through the torch twin, with the kernel's own dropout mask
+    o = out.cpu().numpy()
+    km = (None, None)
+    if keep < 1.0:
+        base = ops.lstm_layer_fwd(xt, ld, w[0], w[1], w[2], w[3]).cpu().numpy()
+        mask = np.where(base != 0, o / np.where(base != 0, base, 1), 0.0)      # 0 or 1/keep
+        mt = torch.tensor(np.transpose(mask, (1, 0, 2)), dtype=torch.float64)
+        km = (mt[:, :, :H], mt[:, :, H:] if bi else None)
+    x64 = torch.tensor(np.transpose(x, (1, 0, 2)), dtype=torch.float64, requires_grad=True)
+    p64 = [torch.tensor(a, dtype=torch.float64, requires_grad=True) for a in (fw + (bw if bi else ()))]
+    o_fw = R.lstm_layer(x64, lens, p64[0], p64[1], False, km[0])
+    ref = torch.cat((o_fw, R.lstm_layer(x64, lens, p64[2], p64[3], True, km[1])), 2) if bi else o_fw
+    (ref * torch.tensor(np.transpose(dout, (1, 0, 2)), dtype=torch.float64)).sum().backward()
+    sc = lambda a: max(1.0, float(np.abs(a).max()))
+    gx = np.transpose(x64.grad.numpy(), (1, 0, 2))
+    np.testing.assert_allclose(dx.cpu().numpy(), gx, rtol=0, atol=2e-4 * sc(gx))
+    for got, want in zip([d for d in dk if d is not None], p64):
+        g = want.grad.numpy()
+        np.testing.assert_allclose(got.cpu().numpy(), g, rtol=0, atol=3e-4 * sc(g))
+
+
+def test_colsum_gather_scatter_optimizer(dev):
+    from e2e_asr_amd import ops
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((1000, 130)).astype(np.float32)
+    out = torch.ones(130, device=dev)
+    ops.colsum(T(x, dev), out, accumulate=True)
+    np.testing.assert_allclose(out.cpu().numpy(), 1 + x.astype(np.float64).sum(0), rtol=0, atol=2e-4)
+    tab = rng.standard_normal((50, 24)).astype(np.float32)
+    idx = rng.integers(0, 50, 77)
+    g = ops.gather_rows(T(tab, dev), T(idx, dev, torch.int32))
+    np.testing.assert_array_equal(g.cpu().numpy(), tab[idx])
+    tg = torch.zeros(50, 24, device=dev)
+    ops.scatter_add_rows(tg, T(idx, dev, torch.int32), g)
+    ref = np.zeros((50, 24)); np.add.at(ref, idx, tab[idx])
+    np.testing.assert_allclose(tg.cpu().numpy(), ref, rtol=0, atol=1e-5)
+    # clip + Adam vs the oracle (TF semantics), two consecutive steps, both clip regimes
+    n = 10007
+    p0 = rng.standard_normal(n).astype(np.float32)
+    for gmag in (0.001, 3.0):
+        p = T(p0, dev).clone(); m = torch.zeros_like(p); v = torch.zeros_like(p)
+        rp, rm, rv = p0.astype(np.float64), np.zeros(n), np.zeros(n)
+        for step in (1, 2):
+            gg = (rng.standard_normal(n) * gmag).astype(np.float32)
+            gd = T(gg, dev)
+            ss = ops.sumsq(gd)
+            lr_t = 1e-3 * np.sqrt(1 - 0.999 ** step) / (1 - 0.9 ** step)
+            ops.clip_adam(p, m, v, gd, ss, 1.0, 5.0, lr_t)
+            (cg,), gn = O.clip_by_global_norm([gg.astype(np.float64)], 5.0)
+            np.testing.assert_allclose(np.sqrt(ss.item()), gn, rtol=1e-5)
+            rp, rm, rv = O.adam_step(rp, rm, rv, cg, step, 1e-3)
+        np.testing.assert_allclose(p.cpu().numpy(), rp, rtol=0, atol=2e-6)
