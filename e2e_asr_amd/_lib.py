@@ -32,6 +32,11 @@ class DecWs(C.Structure):
         "dec_h", "alpha", "ctx", "p", "zeros")]
 
 
+class DecBwdWs(C.Structure):
+    _fields_ = [(n, vp) for n in ("dP", "dQC", "dY", "dXH", "dLC", "dlm", "dEH", "dc_dec", "dc_lm", "dhf",
+                                  "dv_part", "emb_all")]
+
+
 class DecGrads(C.Structure):
     _fields_ = [(n, vp) for n in (
         "embedding", "attn_enc_w", "attn_v", "attn_w", "attn_b", "lm_kernel", "lm_bias",
@@ -66,6 +71,9 @@ SIGNATURES = {
     "asr_masked_ce_fwd": (C.c_int, [vp] * 7 + [C.c_int] * 3),
     "asr_masked_ce_bwd": (C.c_int, [vp] * 7 + [C.c_int] * 3),
     "asr_next_token": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_uint, C.c_uint]),
+    "asr_attn_decoder_bwd": (C.c_int, [vp, C.POINTER(DecWeights), C.POINTER(DecWeights), C.POINTER(DecDims),
+                                       C.POINTER(DecWs), C.POINTER(DecBwdWs), vp, vp, vp, vp, C.c_float, C.c_uint]),
+    "asr_scatter_add_rows_ld": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int]),
     "asr_prof_enable": (C.c_int, [C.c_int]),
     "asr_prof_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "asr_attn_decoder_fwd": (C.c_int, [vp, C.POINTER(DecWeights), C.POINTER(DecDims), C.POINTER(DecWs),

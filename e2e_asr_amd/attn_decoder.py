@@ -61,13 +61,35 @@ class AttnDecoder(Decoder):
             coin = self.coin_rng.random(t_out)
         keep_lm = p.out_prob_dec if self.isTraining else 1.0
         tok = decoder_inp if decoder_inp.dtype == torch.int32 else decoder_inp.to(torch.int32)
+        enc = encoder_hidden_states.contiguous()
+        enc_len_dev = torch.from_numpy(np.asarray(seq_len_inp).astype(np.int32)).to(dev)
         logits, ws = ops.attn_decoder_fwd(
             self.weight_tensors(), tok.to(dev), torch.from_numpy(seq_len.astype(np.int32)).to(dev),
-            encoder_hidden_states.contiguous(), torch.from_numpy(np.asarray(seq_len_inp).astype(np.int32)).to(dev),
-            mode=mode, coin=coin, samp_prob=p.samp_prob, keep_lm=keep_lm, seed=self.rng_seed, t_out=t_out)
+            enc, enc_len_dev, mode=mode, coin=coin, samp_prob=p.samp_prob, keep_lm=keep_lm,
+            seed=self.rng_seed, t_out=t_out)
         self.saved = dict(ws=ws, seq_len=seq_len, t_out=t_out, keep_lm=keep_lm, seed=self.rng_seed,
-                          enc=encoder_hidden_states, enc_len=np.asarray(seq_len_inp))
+                          enc=enc, enc_len=np.asarray(seq_len_inp), enc_len_dev=enc_len_dev)
         return logits
+
+    def grad_tensors(self):
+        """Views of the flat gradient buffer, by the same struct fields as weight_tensors()."""
+        v, task = self.variables, self.scope
+        v.ensure_grad()
+        out = {}
+        for field, leaf in ops.DEC_WEIGHT_LEAVES.items():
+            if self.params.ind_softmax and leaf.startswith("rnn/OutputProjection"):
+                leaf = leaf.replace("OutputProjection", "OutputProjection2")
+            name = dec_name(task, leaf)
+            out[field] = v.grad_of(name) if name in v else None
+        return out
+
+    def backward(self, dlogits, denc):
+        """Gradient of __call__: accumulates weight gradients into the flat buffer and the
+        encoder-state gradient into denc [B,Te,D]."""
+        sv = self.saved
+        ops.attn_decoder_bwd(self.weight_tensors(), self.grad_tensors(), sv["ws"], sv["enc"], sv["enc_len_dev"],
+                             dlogits, denc, keep_lm=sv["keep_lm"], seed=sv["seed"])
+        self.saved = None
 
     @classmethod
     def add_parse_options(cls, parser):

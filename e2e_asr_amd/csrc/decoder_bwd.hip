@@ -1,0 +1,341 @@
+// Attention decoder, backward (tf.gradients through attn_decoder.py:37-172 / raw_rnn).
+//
+// Everything that does not sit on the reverse-time dependency chain is hoisted out of the
+// loop into MFMA GEMMs over all T_out*B rows at once:
+//   before the loop:  dP   = dLogits . W_out^T            dQC = dP . W_ap^T  (= [dq | dctx])
+//   after the loop:   every weight gradient (X^T . dY), bias gradients (column sums), the
+//                     embedding scatter-add, dAttnW = enc^T . dhf and denc += dhf . AttnW^T.
+// The loop itself (i = T_out-1 .. 0) carries d(dec c,h), d(lm c,h), dctx and runs per step:
+//   K1  per-utterance fused kernel: attention backward (dalpha, softmax bwd, tanh bwd,
+//       dhf/denc accumulation, dy) + dq = dy.W_att^T + outer-cell pointwise backward -> dG_dec
+//   S1  [dx | dh_prev]      = dG_dec . K_dec^T      (skinny MFMA, transposed weight)
+//   S2  [dlm_out | dctx_prev] = dx . W_inp^T
+//   (S2b dlm = dlm_out . W_simple^T when SimpleProjection exists)
+//   K2  lm-cell pointwise backward (dropout mask re-derived from the counter hash) -> dG_lm
+//   S3  [demb | dlm_h_prev] = dG_lm . K_lm^T
+// A finished row (t >= seq_len[b]) has dLogits = 0 and zero loss weight, so its state carries
+// no gradient; raw_rnn's copy-through therefore needs no special case (see decoder.hip).
+#include "common.h"
+#include <algorithm>
+#include "../../include/e2e_asr_hip.h"
+
+namespace asr {
+
+struct DecBwdStepArgs {
+    // attention operands
+    const float* q; const float* w_att; const float* b_att; const float* v;
+    const float* hf; const float* enc; const int* enc_len; const float* alpha;
+    const float* dqc;          // [B][H+D]: dq_ap | dctx_ap for this step
+    const float* dctx_carry; int ld_carry;   // dLC[i+1][:, P:] or nullptr
+    float* dhf; float* denc;   // accumulators [B][Te][A], [B][Te][D]
+    float* dy;                 // [B][A] this step
+    float* dv_part;            // [B][A] accumulated over steps
+    // outer cell operands
+    float* gates;              // [B][4H] in: activated gates, out: dG
+    const float* c_prev;       // [B][H] or nullptr
+    const float* dh_carry; int ld_dh;        // dXH[i+1][:, E:] or nullptr
+    float* dc_carry;           // [B][H] in/out
+    int B, Te, H, A, D;
+};
+
+// dynamic LDS: dctx[D] | al[Te] (alpha, then de) | ys[A] | qs[H] | dys[A] | part[256*4]
+__global__ __launch_bounds__(256) void dec_attn_cell_bwd_kernel(DecBwdStepArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int NT = 256;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x;
+    const int A = a.A, H = a.H, D = a.D, Te = a.Te;
+    float* dctx = smem;
+    float* al = dctx + ((D + 3) & ~3);
+    float* ys = al + ((Te + 3) & ~3);
+    float* qs = ys + ((A + 3) & ~3);
+    float* dys = qs + ((H + 3) & ~3);
+    float* part = dys + ((A + 3) & ~3);
+    __shared__ float wred[4];
+    const int L = min(max(a.enc_len[b], 0), Te);
+
+    for (int d = tid; d < D; d += NT) {
+        float x = a.dqc[(size_t)b * (H + D) + H + d];
+        if (a.dctx_carry) x += a.dctx_carry[(size_t)b * a.ld_carry + d];
+        dctx[d] = x;
+    }
+    for (int t = tid; t < Te; t += NT) al[t] = a.alpha[(size_t)b * Te + t];
+    for (int k = tid; k < H; k += NT) qs[k] = a.q[(size_t)b * H + k];
+    __syncthreads();
+    // ---- dalpha[tau] = dctx . enc[tau];  denc[tau] += alpha[tau] * dctx   (one DPP row per tau)
+    const int kq = lane & 15, rr = tid >> 4;
+    float sdot = 0.f;      // sum_tau alpha*dalpha (lanes kq==0 only)
+    for (int tau = rr; tau < L; tau += NT / 16) {
+        const float* ep = a.enc + ((size_t)b * Te + tau) * D;
+        float* gp = a.denc + ((size_t)b * Te + tau) * D;
+        const float at = al[tau];
+        float s = 0.f;
+        for (int d4 = kq; d4 < (D >> 2); d4 += 16) {
+            const float4 ev = *reinterpret_cast<const float4*>(ep + 4 * d4);
+            const float4 dv = *reinterpret_cast<const float4*>(dctx + 4 * d4);
+            float4 gv = *reinterpret_cast<float4*>(gp + 4 * d4);
+            s = fmaf(ev.x, dv.x, s); s = fmaf(ev.y, dv.y, s); s = fmaf(ev.z, dv.z, s); s = fmaf(ev.w, dv.w, s);
+            gv.x = fmaf(at, dv.x, gv.x); gv.y = fmaf(at, dv.y, gv.y); gv.z = fmaf(at, dv.z, gv.z); gv.w = fmaf(at, dv.w, gv.w);
+            *reinterpret_cast<float4*>(gp + 4 * d4) = gv;
+        }
+        s = row16_allreduce_sum(s);
+        if (kq == 0) { part[tau] = s; sdot += at * s; }      // part[0..Te) holds dalpha for now
+    }
+    // block sum of sdot in fixed order: lanes -> waves
+    sdot = wave_allreduce_sum(kq == 0 ? sdot : 0.f);
+    if (lane == 0) wred[wave] = sdot;
+    __syncthreads();
+    const float S = (wred[0] + wred[1]) + (wred[2] + wred[3]);
+    for (int t = tid; t < L; t += NT) al[t] = al[t] * (part[t] - S);     // de[tau]
+    __syncthreads();
+    // ---- y = q.W_att + b_att (recomputed; same decomposition as the forward kernel)
+    {
+        const int na4 = A >> 2;
+        const int kparts = max(1, NT / na4);
+        const int a4 = tid % na4, kp = tid / na4;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (kp < kparts) {
+            const int kc = (H + kparts - 1) / kparts;
+            const int k0 = kp * kc, k1 = min(H, k0 + kc);
+#pragma unroll 8
+            for (int k = k0; k < k1; ++k) {
+                const float4 wv = *reinterpret_cast<const float4*>(a.w_att + (size_t)k * A + 4 * a4);
+                const float qk = qs[k];
+                s.x = fmaf(qk, wv.x, s.x); s.y = fmaf(qk, wv.y, s.y); s.z = fmaf(qk, wv.z, s.z); s.w = fmaf(qk, wv.w, s.w);
+            }
+        }
+        *reinterpret_cast<float4*>(part + 4 * tid) = s;
+        __syncthreads();
+        for (int aa = tid; aa < A; aa += NT) {
+            float acc = a.b_att[aa];
+            for (int p = 0; p < kparts; ++p) acc += part[4 * (p * na4 + (aa >> 2)) + (aa & 3)];
+            ys[aa] = acc;
+        }
+        __syncthreads();
+    }
+    // ---- tanh backward: ds = de*v*(1-th^2); dhf += ds; dy[a] = sum_tau ds; dv[a] += sum_tau de*th
+    // lane kq owns float4 chunks a4 = kq, kq+16, ... (<= 4 chunks => A <= 256)
+    {
+        float4 dyl[4], dvl[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { dyl[c] = make_float4(0.f, 0.f, 0.f, 0.f); dvl[c] = dyl[c]; }
+        for (int tau = rr; tau < L; tau += NT / 16) {
+            const float de = al[tau];
+            const float* hp = a.hf + ((size_t)b * Te + tau) * A;
+            float* gp = a.dhf + ((size_t)b * Te + tau) * A;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int a4 = kq + 16 * c;
+                if (a4 < (A >> 2)) {
+                    const float4 hv = *reinterpret_cast<const float4*>(hp + 4 * a4);
+                    const float4 yv = *reinterpret_cast<const float4*>(ys + 4 * a4);
+                    const float4 vv = *reinterpret_cast<const float4*>(a.v + 4 * a4);
+                    float4 gv = *reinterpret_cast<float4*>(gp + 4 * a4);
+                    float th, ds;
+#define ASR_TB(f) th = fast_tanh(hv.f + yv.f); ds = de * vv.f * (1.f - th * th); gv.f += ds; dyl[c].f += ds; dvl[c].f = fmaf(de, th, dvl[c].f);
+                    ASR_TB(x) ASR_TB(y) ASR_TB(z) ASR_TB(w)
+#undef ASR_TB
+                    *reinterpret_cast<float4*>(gp + 4 * a4) = gv;
+                }
+            }
+        }
+        // reduce the 16 DPP rows of the block: through LDS, fixed order
+        __syncthreads();
+        float* pdy = part;                 // [16 rows][A]
+        float* pdv = part + 16 * A;        // needs 32*A floats <= 256*4 + slack (A <= 256 checked by the host)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int a4 = kq + 16 * c;
+            if (a4 < (A >> 2)) {
+                *reinterpret_cast<float4*>(pdy + rr * A + 4 * a4) = dyl[c];
+                *reinterpret_cast<float4*>(pdv + rr * A + 4 * a4) = dvl[c];
+            }
+        }
+        __syncthreads();
+        for (int aa = tid; aa < A; aa += NT) {
+            float sy = 0.f, sv = 0.f;
+            for (int r = 0; r < 16; ++r) { sy += pdy[r * A + aa]; sv += pdv[r * A + aa]; }
+            dys[aa] = sy;
+            a.dy[(size_t)b * A + aa] = sy;
+            a.dv_part[(size_t)b * A + aa] += sv;
+        }
+        __syncthreads();
+    }
+    // ---- dq = dq_ap + dy.W_att^T + dc_carry, then the outer cell's pointwise backward
+    for (int k = tid; k < H; k += NT) {
+        const float* wr = a.w_att + (size_t)k * A;
+        float s0 = 0.f, s1 = 0.f;
+        for (int a4 = 0; a4 < (A >> 2); a4 += 2) {
+            const float4 w0 = *reinterpret_cast<const float4*>(wr + 4 * a4);
+            const float4 y0 = *reinterpret_cast<const float4*>(dys + 4 * a4);
+            s0 = fmaf(w0.x, y0.x, s0); s0 = fmaf(w0.y, y0.y, s0); s0 = fmaf(w0.z, y0.z, s0); s0 = fmaf(w0.w, y0.w, s0);
+            if (a4 + 1 < (A >> 2)) {
+                const float4 w1 = *reinterpret_cast<const float4*>(wr + 4 * a4 + 4);
+                const float4 y1 = *reinterpret_cast<const float4*>(dys + 4 * a4 + 4);
+                s1 = fmaf(w1.x, y1.x, s1); s1 = fmaf(w1.y, y1.y, s1); s1 = fmaf(w1.z, y1.z, s1); s1 = fmaf(w1.w, y1.w, s1);
+            }
+        }
+        const float dq = a.dqc[(size_t)b * (H + D) + k] + (s0 + s1) + a.dc_carry[(size_t)b * H + k];
+        const float dh = a.dh_carry ? a.dh_carry[(size_t)b * a.ld_dh + k] : 0.f;
+        float* gp = a.gates + (size_t)b * 4 * H + k;
+        const float gi = gp[0], gj = gp[H], gf = gp[2 * H], go = gp[3 * H];
+        const float cp = a.c_prev ? a.c_prev[(size_t)b * H + k] : 0.f;
+        const float tc = fast_tanh(qs[k]);
+        const float dct = dq + dh * go * (1.f - tc * tc);
+        gp[0] = dct * gj * gi * (1.f - gi);
+        gp[H] = dct * gi * (1.f - gj * gj);
+        gp[2 * H] = dct * cp * gf * (1.f - gf);
+        gp[3 * H] = dh * tc * go * (1.f - go);
+        a.dc_carry[(size_t)b * H + k] = dct * gf;
+    }
+}
+
+struct LmBwdArgs {
+    float* gates; const float* c; const float* c_prev;      // [B][4H] (in: gates, out: dG), [B][H], [B][H]|null
+    const float* dlo; int ld_dlo;                            // grad w.r.t. the (dropped) lm output
+    const float* dh_carry; int ld_dh;                        // dEH[i+1][:, E:] or nullptr
+    float* dc_carry;                                         // [B][H] in/out
+    int B, H; float keep; uint32_t seed; uint32_t step;
+};
+
+__global__ __launch_bounds__(256) void lm_cell_bwd_kernel(LmBwdArgs a) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= a.B * a.H) return;
+    const int b = idx / a.H, k = idx % a.H, H = a.H;
+    float dh = a.dlo[(size_t)b * a.ld_dlo + k] * keep_scale(a.seed, a.step * (uint32_t)a.B + (uint32_t)b, (uint32_t)k, a.keep);
+    if (a.dh_carry) dh += a.dh_carry[(size_t)b * a.ld_dh + k];
+    float* gp = a.gates + (size_t)b * 4 * H + k;
+    const float gi = gp[0], gj = gp[H], gf = gp[2 * H], go = gp[3 * H];
+    const float cp = a.c_prev ? a.c_prev[(size_t)b * H + k] : 0.f;
+    const float tc = fast_tanh(a.c[(size_t)b * H + k]);
+    const float dct = a.dc_carry[(size_t)b * H + k] + dh * go * (1.f - tc * tc);
+    gp[0] = dct * gj * gi * (1.f - gi);
+    gp[H] = dct * gi * (1.f - gj * gj);
+    gp[2 * H] = dct * cp * gf * (1.f - gf);
+    gp[3 * H] = dh * tc * go * (1.f - go);
+    a.dc_carry[(size_t)b * H + k] = dct * gf;
+}
+
+}  // namespace asr
+
+extern "C" int asr_colsum_f32(void*, const float*, int, int, int, float*, int);
+extern "C" int asr_gather_rows(void*, const float*, const int*, float*, int, int);
+extern "C" int asr_scatter_add_rows_ld(void*, float*, const int*, const float*, int, int, int);
+
+static size_t dec_bwd_lds(int Te, int H, int A, int D) {
+    auto r4 = [](int x) { return (size_t)((x + 3) & ~3); };
+    const size_t part = std::max<size_t>(256 * 4, std::max<size_t>(32 * (size_t)A, r4(Te)));
+    return sizeof(float) * (r4(D) + r4(Te) + 2 * r4(A) + r4(H) + part);
+}
+
+// Gradients are ACCUMULATED into `g` (same field layout as the weights) and into denc
+// [B,Te,D]; dec_gates / lm_gates in `ws` are overwritten with the pre-activation gradients.
+extern "C" int asr_attn_decoder_bwd(void* stream, const asr_dec_weights* w, const asr_dec_weights* g,
+                                    const asr_dec_dims* d, const asr_dec_ws* ws, const asr_dec_bwd_ws* bw,
+                                    const float* enc, const int* enc_len, const float* dlogits,
+                                    float* denc, float keep_lm, unsigned seed) {
+    using namespace asr;
+    if (!w || !g || !d || !ws || !bw || !enc || !enc_len || !dlogits || !denc) return ASR_EINVAL;
+    const int B = d->B, Te = d->Te, D = d->D, A = d->A, H = d->H, lmH = d->lmH, E = d->E, V = d->V, T = d->T_out;
+    if ((A & 3) || (D & 3) || A > 256) return ASR_EUNSUPPORTED;
+    const size_t lds = dec_bwd_lds(Te, H, A, D);
+    if (lds > 150 * 1024) return ASR_EUNSUPPORTED;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int TB = T * B;
+    const int P = w->simple_w ? H : lmH;
+    int rc;
+    prof_begin(ASR_PROF_DECODER_BWD, s);
+    // ---- hoisted data gradients: dP = dLogits.W_out^T ; dQC = dP.W_ap^T
+    if ((rc = asr_gemm_f32(stream, 0, 1, TB, H, V, dlogits, V, w->out_w, V, bw->dP, H, nullptr, 0))) return rc;
+    if ((rc = asr_gemm_f32(stream, 0, 1, TB, H + D, H, bw->dP, H, w->ap_w, H, bw->dQC, H + D, nullptr, 0))) return rc;
+    if (hipMemsetAsync(bw->dc_dec, 0, sizeof(float) * B * H, s) != hipSuccess) return ASR_ELAUNCH;
+    if (hipMemsetAsync(bw->dc_lm, 0, sizeof(float) * B * lmH, s) != hipSuccess) return ASR_ELAUNCH;
+    if (hipMemsetAsync(bw->dhf, 0, sizeof(float) * (size_t)B * Te * A, s) != hipSuccess) return ASR_ELAUNCH;
+    if (hipMemsetAsync(bw->dv_part, 0, sizeof(float) * B * A, s) != hipSuccess) return ASR_ELAUNCH;
+    const int ldXH = E + H, ldLC = P + D, ldEH = E + lmH;
+    for (int i = T - 1; i >= 0; --i) {
+        const size_t o = (size_t)i * B;
+        const bool last = i == T - 1;
+        DecBwdStepArgs a;
+        a.q = ws->dec_c + o * H; a.w_att = w->attn_w; a.b_att = w->attn_b; a.v = w->attn_v;
+        a.hf = ws->hf; a.enc = enc; a.enc_len = enc_len; a.alpha = ws->alpha + o * Te;
+        a.dqc = bw->dQC + o * (H + D);
+        a.dctx_carry = last ? nullptr : bw->dLC + (o + B) * ldLC + P; a.ld_carry = ldLC;
+        a.dhf = bw->dhf; a.denc = denc; a.dy = bw->dY + o * A; a.dv_part = bw->dv_part;
+        a.gates = ws->dec_gates + o * 4 * H;
+        a.c_prev = i ? ws->dec_c + (o - B) * H : nullptr;
+        a.dh_carry = last ? nullptr : bw->dXH + (o + B) * ldXH + E; a.ld_dh = ldXH;
+        a.dc_carry = bw->dc_dec;
+        a.B = B; a.Te = Te; a.H = H; a.A = A; a.D = D;
+        hipLaunchKernelGGL(dec_attn_cell_bwd_kernel, dim3(B), dim3(256), lds, s, a);
+        // [dx | dh_prev] = dG_dec . K_dec^T
+        if ((rc = asr_linear_wt_fwd(stream, ws->dec_gates + o * 4 * H, 4 * H, 4 * H, w->dec_kernel, 4 * H,
+                                    bw->dXH + o * ldXH, ldXH, B, E + H, 0))) return rc;
+        // [dlm_out | dctx_prev] = dx . W_inp^T
+        if ((rc = asr_linear_wt_fwd(stream, bw->dXH + o * ldXH, ldXH, E, w->inp_w, E, bw->dLC + o * ldLC, ldLC, B, P + D, 0)))
+            return rc;
+        const float* dlo = bw->dLC + o * ldLC; int ld_dlo = ldLC;
+        if (w->simple_w) {
+            if ((rc = asr_linear_wt_fwd(stream, bw->dLC + o * ldLC, ldLC, H, w->simple_w, H, bw->dlm + o * lmH, lmH, B, lmH, 0)))
+                return rc;
+            dlo = bw->dlm + o * lmH; ld_dlo = lmH;
+        }
+        LmBwdArgs l;
+        l.gates = ws->lm_gates + o * 4 * lmH; l.c = ws->lm_c + o * lmH; l.c_prev = i ? ws->lm_c + (o - B) * lmH : nullptr;
+        l.dlo = dlo; l.ld_dlo = ld_dlo;
+        l.dh_carry = last ? nullptr : bw->dEH + (o + B) * ldEH + E; l.ld_dh = ldEH;
+        l.dc_carry = bw->dc_lm; l.B = B; l.H = lmH; l.keep = keep_lm; l.seed = seed; l.step = (uint32_t)i;
+        hipLaunchKernelGGL(lm_cell_bwd_kernel, dim3((B * lmH + 255) / 256), dim3(256), 0, s, l);
+        // [demb | dlm_h_prev] = dG_lm . K_lm^T
+        if ((rc = asr_linear_wt_fwd(stream, ws->lm_gates + o * 4 * lmH, 4 * lmH, 4 * lmH, w->lm_kernel, 4 * lmH,
+                                    bw->dEH + o * ldEH, ldEH, B, E + lmH, 0))) return rc;
+    }
+    if (hipGetLastError() != hipSuccess) return ASR_ELAUNCH;
+    // ---- weight gradients: X^T . dY over all steps (accumulate into g)
+    auto wgrad = [&](int M, int N, int K, const float* Ap, int lda, const float* Bp, int ldb, float* C) {
+        return asr_gemm_f32(stream, 1, 0, M, N, K, Ap, lda, Bp, ldb, C, N, nullptr, 1);
+    };
+    float* gw = nullptr;
+    // OutputProjection
+    gw = const_cast<float*>(g->out_w);
+    if ((rc = wgrad(H, V, TB, ws->p, H, dlogits, V, gw))) return rc;
+    if ((rc = asr_colsum_f32(stream, dlogits, V, TB, V, const_cast<float*>(g->out_b), 1))) return rc;
+    // AttnProjection: rows [q | ctx]
+    gw = const_cast<float*>(g->ap_w);
+    if ((rc = wgrad(H, H, TB, ws->dec_c, H, bw->dP, H, gw))) return rc;
+    if ((rc = wgrad(D, H, TB, ws->ctx, D, bw->dP, H, gw + (size_t)H * H))) return rc;
+    if ((rc = asr_colsum_f32(stream, bw->dP, H, TB, H, const_cast<float*>(g->ap_b), 1))) return rc;
+    // Attention query projection, AttnV
+    if ((rc = wgrad(H, A, TB, ws->dec_c, H, bw->dY, A, const_cast<float*>(g->attn_w)))) return rc;
+    if ((rc = asr_colsum_f32(stream, bw->dY, A, TB, A, const_cast<float*>(g->attn_b), 1))) return rc;
+    if ((rc = asr_colsum_f32(stream, bw->dv_part, A, B, A, const_cast<float*>(g->attn_v), 1))) return rc;
+    // outer cell kernel: rows [x | h_prev]
+    gw = const_cast<float*>(g->dec_kernel);
+    if ((rc = wgrad(E, 4 * H, TB, ws->x, E, ws->dec_gates, 4 * H, gw))) return rc;
+    if (T > 1 && (rc = wgrad(H, 4 * H, TB - B, ws->dec_h, H, ws->dec_gates + (size_t)B * 4 * H, 4 * H, gw + (size_t)E * 4 * H))) return rc;
+    if ((rc = asr_colsum_f32(stream, ws->dec_gates, 4 * H, TB, 4 * H, const_cast<float*>(g->dec_bias), 1))) return rc;
+    // InputProjection: rows [lm_out' | ctx_prev]
+    const float* lo = w->simple_w ? ws->sp : (keep_lm < 1.0f ? ws->lm_hd : ws->lm_h);
+    gw = const_cast<float*>(g->inp_w);
+    if ((rc = wgrad(P, E, TB, lo, P, bw->dXH, ldXH, gw))) return rc;
+    if (T > 1 && (rc = wgrad(D, E, TB - B, ws->ctx, D, bw->dXH + (size_t)B * ldXH, ldXH, gw + (size_t)P * E))) return rc;
+    if ((rc = asr_colsum_f32(stream, bw->dXH, ldXH, TB, E, const_cast<float*>(g->inp_b), 1))) return rc;
+    if (w->simple_w) {
+        const float* lmo = keep_lm < 1.0f ? ws->lm_hd : ws->lm_h;
+        if ((rc = wgrad(lmH, H, TB, lmo, lmH, bw->dLC, ldLC, const_cast<float*>(g->simple_w)))) return rc;
+        if ((rc = asr_colsum_f32(stream, bw->dLC, ldLC, TB, H, const_cast<float*>(g->simple_b), 1))) return rc;
+    }
+    // lm cell kernel: rows [emb[tok] | lm_h_prev]; embedding gradient
+    if ((rc = asr_gather_rows(stream, w->embedding, ws->tok, bw->emb_all, TB, E))) return rc;
+    gw = const_cast<float*>(g->lm_kernel);
+    if ((rc = wgrad(E, 4 * lmH, TB, bw->emb_all, E, ws->lm_gates, 4 * lmH, gw))) return rc;
+    if (T > 1 && (rc = wgrad(lmH, 4 * lmH, TB - B, ws->lm_h, lmH, ws->lm_gates + (size_t)B * 4 * lmH, 4 * lmH,
+                             gw + (size_t)E * 4 * lmH))) return rc;
+    if ((rc = asr_colsum_f32(stream, ws->lm_gates, 4 * lmH, TB, 4 * lmH, const_cast<float*>(g->lm_bias), 1))) return rc;
+    if ((rc = asr_scatter_add_rows_ld(stream, const_cast<float*>(g->embedding), ws->tok, bw->dEH, TB, E, ldEH))) return rc;
+    // AttnW and the encoder-state gradient through hf = enc.AttnW
+    if ((rc = wgrad(D, A, B * Te, enc, D, bw->dhf, A, const_cast<float*>(g->attn_enc_w)))) return rc;
+    if ((rc = asr_gemm_f32(stream, 0, 1, B * Te, D, A, bw->dhf, A, w->attn_enc_w, A, denc, D, nullptr, 1))) return rc;
+    prof_end(ASR_PROF_DECODER_BWD, s);
+    return ASR_OK;
+}

@@ -38,10 +38,10 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* table, co
     }
 }
 
-__global__ __launch_bounds__(256) void scatter_add_rows_kernel(float* tg, const int* idx, const float* g, int rows, int width) {
+__global__ __launch_bounds__(256) void scatter_add_rows_kernel(float* tg, const int* idx, const float* g, int rows, int width, int ldg) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)rows * width; i += (size_t)gridDim.x * 256) {
         const int r = (int)(i / width), c = (int)(i % width);
-        atomicAdd(tg + (size_t)idx[r] * width + c, g[i]);
+        atomicAdd(tg + (size_t)idx[r] * width + c, g[(size_t)r * ldg + c]);
     }
 }
 
@@ -109,10 +109,14 @@ extern "C" int asr_gather_rows(void* stream, const float* table, const int* idx,
     ASR_CHECK_LAUNCH();
     return ASR_OK;
 }
+extern "C" int asr_scatter_add_rows_ld(void* stream, float* tg, const int* idx, const float* g, int rows, int width, int ldg);
 extern "C" int asr_scatter_add_rows(void* stream, float* tg, const int* idx, const float* g, int rows, int width) {
-    if (!tg || !idx || !g || rows <= 0 || width <= 0) return ASR_EINVAL;
+    return asr_scatter_add_rows_ld(stream, tg, idx, g, rows, width, width);
+}
+extern "C" int asr_scatter_add_rows_ld(void* stream, float* tg, const int* idx, const float* g, int rows, int width, int ldg) {
+    if (!tg || !idx || !g || rows <= 0 || width <= 0 || ldg < width) return ASR_EINVAL;
     const int grid = (int)std::min<size_t>(2048, ((size_t)rows * width + 255) / 256);
-    hipLaunchKernelGGL(asr::scatter_add_rows_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), tg, idx, g, rows, width);
+    hipLaunchKernelGGL(asr::scatter_add_rows_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), tg, idx, g, rows, width, ldg);
     ASR_CHECK_LAUNCH();
     return ASR_OK;
 }

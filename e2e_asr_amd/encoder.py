@@ -104,6 +104,40 @@ class Encoder(BaseParams):
                 x = out
         return attention_states, time_major_states, seq_len_inps
 
+    def backward(self, d_states, variables=None):
+        """Gradient of __call__ (tf.gradients through encoder.py:122-180).  d_states: {depth:
+        gradient w.r.t. attention_states[depth], [B,T_d,D]}.  Weight gradients are accumulated
+        into the flat gradient buffer; the pyramid reshape is again only a view: the input
+        gradient of layer d+1 [B,T/2,4H] IS the output gradient of layer d [B,T,2H]."""
+        v = self.variables if variables is None else variables
+        v.ensure_grad()
+        dx = None
+        for sv in reversed(self.saved):
+            d = sv["depth"]
+            out = sv["out"]
+            if dx is not None:
+                dout = dx.view(out.shape)
+                if d in d_states and d_states[d] is not None:
+                    dout[:, :sv["T"]].add_(d_states[d])
+            else:
+                dout = d_states[d]
+                if dout.shape[1] != sv["t_out"]:
+                    pad = dout.new_zeros(dout.shape[0], sv["t_out"], dout.shape[2])
+                    pad[:, :dout.shape[1]] = dout
+                    dout = pad
+            if self.params.bi_dir:
+                names = [enc_name(d, "fw", "kernel"), enc_name(d, "fw", "bias"), enc_name(d, "bw", "kernel"), enc_name(d, "bw", "bias")]
+                kf, kb = v[names[0]], v[names[2]]
+                g = [v.grad_of(n) for n in names]
+            else:
+                names = [enc_name(d, "", "kernel", False), enc_name(d, "", "bias", False)]
+                kf, kb = v[names[0]], None
+                g = [v.grad_of(n) for n in names] + [None, None]
+            dx = ops.lstm_layer_bwd(sv["x"], sv["lens_dev"], kf, kb, dout.contiguous(), sv["gates"], sv["c"], sv["hprev"],
+                                    g[0], g[1], g[2], g[3], need_dx=d > 1, keep_prob=sv["keep"], seed=sv["seed"])
+        self.saved = None
+        return dx
+
     @classmethod
     def add_parse_options(cls, parser):
         # encoder.py:182-200 -- same flags, same defaults

@@ -334,7 +334,31 @@ def attn_decoder_fwd(wt, dec_inp, seq_len, enc, enc_len, mode=0, coin=None, samp
                                          int(mode), coin_arr, float(samp_prob), float(keep_lm),
                                          int(seed) & 0xFFFFFFFF, _p(logits))
     _check(rc, "asr_attn_decoder_fwd")
+    ws["_dims"] = (B, Te, D, A, H, lmH, E, V, T)
     return logits, ws
+
+
+def attn_decoder_bwd(wt, gt, ws, enc, enc_len, dlogits, denc, keep_lm=1.0, seed=0):
+    """Backward of attn_decoder_fwd.  wt/gt: weight and gradient tensors by struct field (gradients
+    are accumulated into gt, which are views of the flat gradient buffer); denc [B,Te,D] is
+    accumulated into."""
+    B, Te, D, A, H, lmH, E, V, T = ws["_dims"]
+    dev = enc.device
+    f = lambda *s: torch.empty(s, device=dev, dtype=torch.float32)
+    P = H if wt.get("simple_w") is not None else lmH
+    bw = dict(dP=f(T, B, H), dQC=f(T, B, H + D), dY=f(T, B, A), dXH=f(T, B, E + H), dLC=f(T, B, P + D),
+              dlm=f(T, B, lmH) if wt.get("simple_w") is not None else None, dEH=f(T, B, E + lmH),
+              dc_dec=f(B, H), dc_lm=f(B, lmH), dhf=f(B, Te, A), dv_part=f(B, A), emb_all=f(T, B, E))
+    cw = _dec_struct(_lib.DecWeights, wt)
+    cg = _dec_struct(_lib.DecWeights, gt)
+    cd = _lib.DecDims(B, Te, D, A, H, lmH, E, V, T)
+    cws = _dec_struct(_lib.DecWs, {k: v for k, v in ws.items() if k != "_dims"})
+    cbw = _dec_struct(_lib.DecBwdWs, bw)
+    rc = _lib.lib().asr_attn_decoder_bwd(_stream(), C.byref(cw), C.byref(cg), C.byref(cd), C.byref(cws),
+                                         C.byref(cbw), _p(enc), _p(enc_len), _p(_f32(dlogits, "dlogits")),
+                                         _p(_f32(denc, "denc")), float(keep_lm), int(seed) & 0xFFFFFFFF)
+    _check(rc, "asr_attn_decoder_bwd")
+    return bw
 
 
 PROF_TAGS = {"lstm_rec_fwd": 0, "lstm_rec_bwd": 1, "gemm": 2, "decoder_fwd": 3, "decoder_bwd": 4, "optim": 5}

@@ -152,6 +152,50 @@ class Seq2SeqModel(BaseParams):
             self.total_loss = total
         return self.outputs
 
+    # ------------------------------------------------------------------ backward + update
+    def backward(self):
+        """tf.gradients(total_loss, trainable_vars) (seq2seq_model.py:148) into variables.grad."""
+        params = self.params
+        v = self.variables
+        v.ensure_grad()
+        v.grad.zero_()
+        gscale = torch.full((1,), 1.0 / len(params.tasks) if params.avg else 1.0, device=self.device)
+        d_states = {}
+        for task in params.tasks:
+            lw = self._loss_ws[task]
+            dlogits = ops.masked_ce_bwd(self.outputs[task], lw["targets"], lw["lse"], lw["len"], gscale)
+            d = params.num_layers[task]
+            if d not in d_states:
+                d_states[d] = torch.zeros_like(self.decoder[task].saved["enc"])
+            self.decoder[task].backward(dlogits, d_states[d])
+        self.encoder.backward(d_states)
+
+    def apply_gradients(self, slot="Adam", lr=None):
+        """[data-parallel all-reduce ->] tf.clip_by_global_norm -> AdamOptimizer.apply_gradients
+        (seq2seq_model.py:137,150-155).  The all-reduce sums shard gradients; the 1/N is folded
+        into the clip+Adam kernel, so clipping sees the global-batch gradient."""
+        v = self.variables
+        n = 1
+        if self.dist is not None:
+            n = self.dist.all_reduce_grads(v.grad)
+        m, vv = v.ensure_adam(slot)
+        self._gnorm_sq = ops.sumsq(v.grad)
+        self.global_step += 1
+        t = self.global_step
+        lr = self.learning_rate if lr is None else lr
+        lr_t = lr * np.sqrt(1.0 - 0.999 ** t) / (1.0 - 0.9 ** t)
+        ops.clip_adam(v.flat, m, vv, v.grad, self._gnorm_sq, 1.0 / n, self.params.max_gradient_norm, lr_t)
+
+    def step(self, batch=None):
+        """One sess.run([model.updates, model.losses]) (train.py:297-299).  Returns the losses
+        dict (device scalars; no host synchronisation inside the step)."""
+        if not self.isTraining:
+            raise ValueError("step() needs a model built with isTraining=True")
+        self.forward(batch)
+        self.backward()
+        self.apply_gradients()
+        return self.losses
+
     # greedy hypotheses of the eval graph (eval_model.py:84-87)
     def greedy_ids(self, task="char"):
         logits = self.outputs[task]

@@ -156,6 +156,30 @@ int asr_attn_decoder_fwd(void* stream, const asr_dec_weights* w, const asr_dec_d
                          const int* seq_len, int mode, const float* coin_host, float samp_prob,
                          float keep_lm, unsigned seed, float* logits);
 
+typedef struct {              /* backward scratch (device), sized by the caller */
+    float* dP;                /* [T_out,B,H]      dLogits . W_out^T */
+    float* dQC;               /* [T_out,B,H+D]    dP . W_ap^T = [dq | dctx] */
+    float* dY;                /* [T_out,B,A]      grad of the attention query projection */
+    float* dXH;               /* [T_out,B,E+H]    [dx | dh_prev] of the outer cell */
+    float* dLC;               /* [T_out,B,P+D]    [dlm_out | dctx_prev] */
+    float* dlm;               /* [T_out,B,lmH]    (SimpleProjection only, else NULL) */
+    float* dEH;               /* [T_out,B,E+lmH]  [demb | dlm_h_prev] */
+    float* dc_dec;            /* [B,H]  carry */
+    float* dc_lm;             /* [B,lmH] carry */
+    float* dhf;               /* [B,Te,A] */
+    float* dv_part;           /* [B,A] */
+    float* emb_all;           /* [T_out,B,E] gathered embeddings */
+} asr_dec_bwd_ws;
+
+/* Backward of asr_attn_decoder_fwd.  Weight gradients are ACCUMULATED into `g` (same field
+ * layout as the weights, pointing into the flat gradient buffer); denc [B,Te,D] is
+ * accumulated into; ws->dec_gates / ws->lm_gates are overwritten. */
+int asr_attn_decoder_bwd(void* stream, const asr_dec_weights* w, const asr_dec_weights* g,
+                         const asr_dec_dims* d, const asr_dec_ws* ws, const asr_dec_bwd_ws* bw,
+                         const float* enc, const int* enc_len, const float* dlogits,
+                         float* denc, float keep_lm, unsigned seed);
+int asr_scatter_add_rows_ld(void* stream, float* table_grad, const int* idx, const float* g, int rows, int width, int ldg);
+
 /* Optional per-kernel HIP-event timing on the launch stream (bench.py roofline leg).
  * tag: 0 lstm recurrent fwd, 1 lstm recurrent bwd, 2 gemm, 3 decoder fwd, 4 decoder bwd, 5 optimizer.
  * asr_prof_read is a HOST call that synchronises on the recorded events. */

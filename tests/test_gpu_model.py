@@ -196,3 +196,98 @@ def test_encoder_dropout_is_output_only():
     np.testing.assert_allclose(drop[kept].cpu().numpy(), (base[kept] / 0.9).cpu().numpy(), rtol=1e-6)
     drop2 = ops.lstm_layer_fwd(x, ln, k, bz, k, bz, keep_prob=0.9, seed=123)
     assert torch.equal(drop, drop2)                      # counter-based mask: reproducible
+
+
+# ------------------------------------------------------------------ gradients / train step
+def _np_keep_scale(seed, a, b, keep):
+    """NumPy replica of csrc/common.h keep_scale (counter-based dropout mask)."""
+    def mix(x):
+        x = x.astype(np.uint64)
+        x ^= x >> 16; x = (x * 0x7feb352d) & 0xFFFFFFFF; x ^= x >> 15; x = (x * 0x846ca68b) & 0xFFFFFFFF; x ^= x >> 16
+        return x
+    a = np.asarray(a, np.uint64); b = np.asarray(b, np.uint64)
+    h = mix(np.uint64(seed) ^ mix((a * 0x9E3779B9 + 0x85EBCA6B) & 0xFFFFFFFF) ^ mix((b + 0xC2B2AE35) & 0xFFFFFFFF))
+    u = (h >> 8).astype(np.float32) * np.float32(1.0 / 16777216.0)
+    return np.where(u < np.float32(keep), np.float32(1.0) / np.float32(keep), np.float32(0.0)).astype(np.float64)
+
+
+@pytest.mark.parametrize("case", ["plain", "multitask_simple", "uni", "dropout"])
+def test_full_model_gradients_vs_autograd(case):
+    """tf.gradients parity: every trainable variable's gradient from the HIP backward against
+    torch autograd (float64) through the oracle twin, on the same batch/tokens/masks."""
+    from oracle import torch_ref as R
+    rng = np.random.default_rng(7)
+    kw = dict(enc_update=dict(hidden_size=64), dec_update=dict(hidden_size_dec=32, lm_hidden_size=32, emb_size=24,
+                                                               attention_vec_size=16), num_layers={"char": 3})
+    tasks, bi = ("char",), True
+    if case == "multitask_simple":
+        tasks = ("char", "phone")
+        kw["dec_update"]["lm_hidden_size"] = 20
+        kw["num_layers"] = {"char": 3, "phone": 2}
+    if case == "uni":
+        kw["enc_update"]["bi_dir"] = False; bi = False
+    if case == "dropout":
+        kw["enc_update"]["out_prob"] = 0.8
+        kw["dec_update"]["out_prob_dec"] = 0.8
+    m = _model(tasks=tasks, **kw)
+    B, Tn = 5, 21
+    b = _batch(rng, B, Tn, 20, 9, 20, tasks=tasks)
+    m.global_step = 3
+    m.forward(b)
+    enc_masks, lm_masks = None, None
+    if case == "dropout":
+        enc_masks = {}
+        for sv in m.encoder.saved:
+            Bq, To, W = sv["out"].shape
+            bb, tt, jj = np.meshgrid(np.arange(Bq), np.arange(To), np.arange(W), indexing="ij")
+            mk = _np_keep_scale(sv["seed"], bb * To + tt, jj, 0.8)[:, :sv["T"]]
+            mk = torch.tensor(np.transpose(mk, (1, 0, 2)))
+            enc_masks[sv["depth"]] = (mk[:, :, :64], mk[:, :, 64:])
+        lm_masks = {}
+        for t in tasks:
+            sv = m.decoder[t].saved
+            T_out = sv["t_out"]
+            ii, bb, jj = np.meshgrid(np.arange(T_out), np.arange(B), np.arange(32), indexing="ij")
+            lm_masks[t] = torch.tensor(_np_keep_scale(sv["seed"], ii * B + bb, jj, 0.8))
+    loss_gpu = m.total_loss.item()
+    m.backward()
+    from e2e_asr_amd import ops
+    ops.check_device_flag(torch.device(DEV))
+    w = _f64(m.variables.to_arrays())
+    W = R.weights_to_torch(w)
+    b64 = dict(b); b64["logmel"] = b["logmel"].astype(np.float64)
+    total, _, _ = R.seq2seq_loss(b64, W, tasks=tasks, num_layers=kw["num_layers"], bi_dir=bi,
+                                 enc_keep_masks=enc_masks, lm_keep_masks=lm_masks)
+    np.testing.assert_allclose(loss_gpu, total.item(), rtol=2e-5)
+    total.backward()
+    worst = 0.0
+    for name in m.variables.names():
+        got = m.variables.grad_of(name).cpu().numpy()
+        ref = W[name].grad.numpy()
+        scale = max(1e-3, float(np.abs(ref).max()))
+        err = float(np.abs(got - ref).max()) / scale
+        worst = max(worst, err)
+        assert err < 2e-3, (name, err, scale)
+    print("%s: worst relative gradient error %.2e over %d variables" % (case, worst, len(m.variables.names())))
+
+
+def test_train_steps_match_reference_optimizer():
+    """Three optimizer steps (forward, backward, clip_by_global_norm(5), Adam) of the HIP path
+    against the float64 reference step (seq2seq_model.py:137-155): losses and weights agree."""
+    from oracle import torch_ref as R
+    rng = np.random.default_rng(8)
+    m = _model(enc_update=dict(hidden_size=64), dec_update=dict(hidden_size_dec=32, lm_hidden_size=32, emb_size=24,
+                                                                attention_vec_size=16), num_layers={"char": 2})
+    w = _f64(m.variables.to_arrays())
+    state = {}
+    for step in (1, 2, 3):
+        b = _batch(rng, 4, 16, 20, 8, 20)
+        losses = m.step(b)
+        b64 = dict(b); b64["logmel"] = b["logmel"].astype(np.float64)
+        w, state, ref_loss, _, gn = R.train_step_reference(b64, w, state, step, lr=1e-3, clip=5.0, num_layers={"char": 2})
+        np.testing.assert_allclose(losses["char"].item(), ref_loss, rtol=5e-5)
+        np.testing.assert_allclose(np.sqrt(m._gnorm_sq.item()), gn, rtol=1e-3)
+    got = m.variables.to_arrays()
+    for name in got:
+        np.testing.assert_allclose(got[name], w[name], rtol=0, atol=2e-5)
+    assert m.global_step == 3
