@@ -13,6 +13,8 @@
 // ds_read_b32 per lane (lanes 0-31: consecutive m at k, lanes 32-63: at k+1).  Global ->
 // register prefetch of tile t+1 is issued before the MFMAs of tile t.
 #include "common.h"
+#include <algorithm>
+#include <cstdlib>
 
 namespace asr {
 
@@ -22,6 +24,7 @@ struct GemmArgs {
     const float* A; const float* B; float* C; const float* bias;
     int M, N, K, lda, ldb, ldc;
     int accumulate;   // C += result
+    int splits;       // K split over blockIdx.y; >1 => atomicAdd epilogue into a pre-zeroed / accumulated C
     int vecA, vecB;   // 16-B vector loads legal for this operand
 };
 
@@ -107,10 +110,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
 
     Stager<TA> sa;    // A natural [M,K] is m-major => KMAJOR = TA
     Stager<!TB> sb;   // B natural [K,N] is k-major => KMAJOR = !TB
-    const int nk = (a.K + BK - 1) / BK;
-    sa.load(a.A, a.lda, m0, 0, a.M, a.K, a.vecA, tid);
-    sb.load(a.B, a.ldb, n0, 0, a.N, a.K, a.vecB, tid);
-    for (int kt = 0; kt < nk; ++kt) {
+    // split-K: this block owns k-tiles [kt0, kt1)
+    const int nk_all = (a.K + BK - 1) / BK;
+    const int per = (nk_all + a.splits - 1) / a.splits;
+    const int kt0 = blockIdx.y * per, kt1 = min(nk_all, kt0 + per);
+    if (kt0 >= kt1) return;
+    sa.load(a.A, a.lda, m0, kt0 * BK, a.M, a.K, a.vecA, tid);
+    sb.load(a.B, a.ldb, n0, kt0 * BK, a.N, a.K, a.vecB, tid);
+    const int nk = kt1;
+    for (int kt = kt0; kt < nk; ++kt) {
         __syncthreads();               // previous tile's reads are done
         sa.store(As, tid);
         sb.store(Bs, tid);
@@ -138,15 +146,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
         for (int ni = 0; ni < 2; ++ni) {
             const int n = n0 + wc * 64 + ni * 32 + (lane & 31);
             if (n >= a.N) continue;
-            const float bv = a.bias ? a.bias[n] : 0.f;
+            const float bv = (a.bias && blockIdx.y == 0) ? a.bias[n] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (m < a.M) {
                     float* cp = a.C + (size_t)m * a.ldc + n;
                     float v = acc[mi][ni][r] + bv;
-                    if (a.accumulate) v += *cp;
-                    *cp = v;
+                    if (a.splits > 1) { atomicAdd(cp, v); }      // 32 lanes x 4 B = one 128-B segment per row
+                    else { if (a.accumulate) v += *cp; *cp = v; }
                 }
             }
         }
@@ -172,10 +180,23 @@ extern "C" int asr_gemm_f32(void* stream, int transA, int transB, int M, int N, 
     g.vecB = ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && (ldb % 4 == 0);
     const int nwg = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (transA && transB)       hipLaunchKernelGGL((gemm_f32_kernel<true, true>), dim3(nwg), dim3(256), 0, s, g);
-    else if (transA)            hipLaunchKernelGGL((gemm_f32_kernel<true, false>), dim3(nwg), dim3(256), 0, s, g);
-    else if (transB)            hipLaunchKernelGGL((gemm_f32_kernel<false, true>), dim3(nwg), dim3(256), 0, s, g);
-    else                        hipLaunchKernelGGL((gemm_f32_kernel<false, false>), dim3(nwg), dim3(256), 0, s, g);
+    // Few output tiles but a long K (weight gradients X^T.dY with K = B*T): split K over
+    // blockIdx.y so the chip is filled; partial tiles meet in C through float atomics
+    // (summation order, hence the last bits, may differ from run to run).
+    int splits = 1;
+    const int nk = (K + BK - 1) / BK;
+    if (transA && nwg < 192 && nk >= 64) {     // weight-gradient form only: forward products stay bit-reproducible
+        splits = std::min((768 + nwg - 1) / nwg, nk / 16);
+        if (const char* e = getenv("ASR_GEMM_SPLITK")) splits = std::max(1, atoi(e));
+    }
+    g.splits = splits;
+    if (splits > 1 && !accumulate) {
+        if (hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, s) != hipSuccess) return ASR_ELAUNCH;
+    }
+    if (transA && transB)       hipLaunchKernelGGL((gemm_f32_kernel<true, true>), dim3(nwg, splits), dim3(256), 0, s, g);
+    else if (transA)            hipLaunchKernelGGL((gemm_f32_kernel<true, false>), dim3(nwg, splits), dim3(256), 0, s, g);
+    else if (transB)            hipLaunchKernelGGL((gemm_f32_kernel<false, true>), dim3(nwg, splits), dim3(256), 0, s, g);
+    else                        hipLaunchKernelGGL((gemm_f32_kernel<false, false>), dim3(nwg, splits), dim3(256), 0, s, g);
     ASR_CHECK_LAUNCH();
     return ASR_OK;
 }

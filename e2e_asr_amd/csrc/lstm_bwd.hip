@@ -36,23 +36,27 @@ struct LstmBwdArgs {
     float keep; uint32_t seed;
 };
 
-__device__ __forceinline__ bool poll_sum(const u64* g, int stride, int n, uint32_t epoch, float& sum, int* err) {
-    // n granules at g[i*stride]; all loads in flight, re-poll the late ones; sum in index order
-    float v[16]; bool ok[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { v[i] = 0.f; ok[i] = i >= n; }
+// Sum of N granules at g[i*stride], all carrying tag `epoch`.  Every pass re-loads ALL N
+// unconditionally (one memory round trip with N loads in flight -- a per-granule "if not yet
+// ok" makes hipcc serialise the loads into N dependent round trips); fixed summation order.
+template <int N>
+__device__ __forceinline__ bool poll_sum(const u64* g, int stride, uint32_t epoch, float& sum, int* err) {
     long long t0 = 0;
     for (uint32_t spins = 0;; ++spins) {
+        u64 x[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            x[i] = __hip_atomic_load(g + (size_t)i * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         bool all = true;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            if (!ok[i]) {
-                const u64 x = __hip_atomic_load(g + (size_t)i * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((uint32_t)(x >> 32) == epoch) { v[i] = __uint_as_float((uint32_t)x); ok[i] = true; }
-                else all = false;
-            }
+        for (int i = 0; i < N; ++i) all &= (uint32_t)(x[i] >> 32) == epoch;
+        if (all) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < N; ++i) s += __uint_as_float((uint32_t)x[i]);
+            sum = s;
+            return true;
         }
-        if (all) break;
         if ((spins & 1023) == 1023) {
             const long long now = wall_clock64();
             if (t0 == 0) t0 = now;
@@ -60,11 +64,6 @@ __device__ __forceinline__ bool poll_sum(const u64* g, int stride, int n, uint32
             if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { sum = 0.f; return false; }
         }
     }
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) s += v[i];
-    sum = s;
-    return true;
 }
 
 template <int H, int R>
@@ -132,7 +131,7 @@ __global__ __launch_bounds__(512) void lstm_rec_bwd_kernel(LstmBwdArgs a) {
         if (live && s > 0) {     // recurrent part: sum of the G partials addressed to (row, unit)
             float rec;
             const u64* src = hxg + ((size_t)((s - 1) & 1) * G + mem) * G * R * HS + (size_t)cr * HS + cu;
-            poll_sum(src, R * HS, G, (uint32_t)s, rec, a.err);
+            poll_sum<G>(src, R * HS, (uint32_t)s, rec, a.err);
             dh += rec;
         }
         float4 dg = make_float4(0.f, 0.f, 0.f, 0.f);

@@ -5,28 +5,30 @@
 
 namespace asr {
 
-// out[n] (+)= sum_m x[m][n].  Block = 64 columns x 4 row-strips; fixed order -> reproducible.
-__global__ __launch_bounds__(256) void colsum_kernel(const float* x, int ldx, int M, int N, float* out, int accumulate) {
+// out[n] += sum_m x[m][n].  Block = 64 columns x 4 row-strips of its blockIdx.y slab; slabs
+// meet through one float atomic per column (out is pre-zeroed by the host when not accumulating).
+__global__ __launch_bounds__(256) void colsum_kernel(const float* x, int ldx, int M, int N, float* out, int rows_per_slab) {
     __shared__ float part[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), strip = threadIdx.x >> 6;
+    const int s0 = blockIdx.y * rows_per_slab, s1 = min(M, s0 + rows_per_slab);
     float s = 0.f;
     if (c < N) {
-        const int rows = (M + 3) / 4;
-        const int m0 = strip * rows, m1 = min(M, m0 + rows);
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        const int rows = (s1 - s0 + 3) / 4;
+        const int m0 = s0 + strip * rows, m1 = min(s1, m0 + rows);
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
         int m = m0;
         for (; m + 3 < m1; m += 4) {
-            s0 += x[(size_t)m * ldx + c]; s1 += x[(size_t)(m + 1) * ldx + c];
-            s2 += x[(size_t)(m + 2) * ldx + c]; s3 += x[(size_t)(m + 3) * ldx + c];
+            a0 += x[(size_t)m * ldx + c]; a1 += x[(size_t)(m + 1) * ldx + c];
+            a2 += x[(size_t)(m + 2) * ldx + c]; a3 += x[(size_t)(m + 3) * ldx + c];
         }
-        for (; m < m1; ++m) s0 += x[(size_t)m * ldx + c];
-        s = (s0 + s1) + (s2 + s3);
+        for (; m < m1; ++m) a0 += x[(size_t)m * ldx + c];
+        s = (a0 + a1) + (a2 + a3);
     }
     part[strip][threadIdx.x & 63] = s;
     __syncthreads();
     if (strip == 0 && c < N) {
         const float t = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
-        out[c] = accumulate ? out[c] + t : t;
+        if (gridDim.y == 1) out[c] += t; else atomicAdd(out + c, t);
     }
 }
 
@@ -98,7 +100,14 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(float* p, float* m, floa
 
 extern "C" int asr_colsum_f32(void* stream, const float* x, int ldx, int M, int N, float* out, int accumulate) {
     if (!x || !out || M < 0 || N <= 0 || ldx < N) return ASR_EINVAL;
-    hipLaunchKernelGGL(asr::colsum_kernel, dim3((N + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream), x, ldx, M, N, out, accumulate);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (!accumulate && hipMemsetAsync(out, 0, sizeof(float) * N, s) != hipSuccess) return ASR_ELAUNCH;
+    const int nx = (N + 63) / 64;
+    int slabs = std::max(1, std::min(M / 256, (512 + nx - 1) / nx));
+    const int rows_per_slab = (M + slabs - 1) / slabs;
+    slabs = (M + rows_per_slab - 1) / rows_per_slab;
+    if (M == 0) return ASR_OK;
+    hipLaunchKernelGGL(asr::colsum_kernel, dim3(nx, slabs), dim3(256), 0, s, x, ldx, M, N, out, rows_per_slab);
     ASR_CHECK_LAUNCH();
     return ASR_OK;
 }

@@ -104,7 +104,7 @@ class Encoder(BaseParams):
                 x = out
         return attention_states, time_major_states, seq_len_inps
 
-    def backward(self, d_states, variables=None):
+    def backward(self, d_states, variables=None, on_layer_done=None):
         """Gradient of __call__ (tf.gradients through encoder.py:122-180).  d_states: {depth:
         gradient w.r.t. attention_states[depth], [B,T_d,D]}.  Weight gradients are accumulated
         into the flat gradient buffer; the pyramid reshape is again only a view: the input
@@ -135,6 +135,8 @@ class Encoder(BaseParams):
                 g = [v.grad_of(n) for n in names] + [None, None]
             dx = ops.lstm_layer_bwd(sv["x"], sv["lens_dev"], kf, kb, dout.contiguous(), sv["gates"], sv["c"], sv["hprev"],
                                     g[0], g[1], g[2], g[3], need_dx=d > 1, keep_prob=sv["keep"], seed=sv["seed"])
+            if on_layer_done is not None:
+                on_layer_done(d)
         self.saved = None
         return dx
 

@@ -1,0 +1,90 @@
+"""Data-parallel training over the GPUs of one node: one process per GPU, RCCL over xGMI.
+
+The reference has no distributed code at all; this is the MI355X-native
+addition.  Utterances are independent, so the global batch is sharded by utterance with an
+equal shard per rank and a full replica of the 10.6 M parameters per GPU.  The only exchange
+is the gradient all-reduce(sum), placed between tf.gradients and clip_by_global_norm in the
+seq2seq_model.py:148-155 sequence so that the clip sees the global-batch gradient; 1/N is
+folded into the fused clip+Adam kernel.  Because loss = mean over utterances of a
+length-normalised cost (losses.py:32-35), equal shards make mean-of-means exact.
+
+xGMI is point-to-point (7 links x ~153 GB/s per GPU): a ring all-reduce is bound by ONE link,
+so fewer, larger messages win.  The flat fp32 gradient buffer (42.5 MB) is reduced in at most
+five contiguous buckets -- decoders, then encoder layers top-down -- each launched
+asynchronously as soon as its gradients are final, so the exchange hides under the encoder's
+backward-through-time.
+"""
+import torch
+import torch.distributed as dist
+
+
+class DataParallel(object):
+    def __init__(self, model, process_group=None, overlap=True):
+        if not dist.is_initialized():
+            raise RuntimeError("DataParallel needs torch.distributed.init_process_group() first")
+        self.group = process_group
+        self.world = dist.get_world_size(process_group)
+        self.rank = dist.get_rank(process_group)
+        self.overlap = overlap
+        self._pending = []
+        self._covered = 0
+        self._n = model.variables.flat.numel()
+        # identical initial weights everywhere (rank 0's), like a restored checkpoint
+        dist.broadcast(model.variables.flat, src=0, group=process_group)
+        self.buckets = self.bucket_ranges(model.variables)
+        model.dist = self
+
+    @staticmethod
+    def bucket_ranges(variables):
+        """Contiguous [lo, hi) ranges of the flat buffer in the order their gradients become
+        final during backward: all decoders first, then encoder layers from the top."""
+        specs = variables._specs
+        groups = {}
+        for name, _, off, n in specs:
+            if "/encoder/RNNLayer" in name:
+                key = int(name.split("RNNLayer")[1].split("/")[0])
+            else:
+                key = 0                       # decoders (and anything else): first bucket
+            lo, hi = groups.get(key, (off, off))
+            groups[key] = (min(lo, off), max(hi, off + (n + 3) // 4 * 4))
+        order = [0] + sorted((k for k in groups if k > 0), reverse=True)
+        return [(k, groups[k]) for k in order if k in groups]
+
+    def grad_ready(self, key, flat_grad):
+        """Called by the model's backward when bucket `key` is final: launch its all-reduce."""
+        if not self.overlap or self.world == 1:
+            return
+        for k, (lo, hi) in self.buckets:
+            if k == key:
+                self._pending.append(dist.all_reduce(flat_grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group,
+                                                     async_op=True))
+                self._covered += hi - lo
+
+    def all_reduce_grads(self, flat_grad):
+        """Finish the exchange; returns N so the caller scales by 1/N."""
+        if self.world > 1:
+            if self._pending:
+                for w in self._pending:
+                    w.wait()
+                if self._covered != sum(hi - lo for _, (lo, hi) in self.buckets):
+                    raise RuntimeError("gradient buckets incomplete: %d of %d elements reduced" % (self._covered, self._n))
+            else:
+                dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+        self._pending, self._covered = [], 0
+        return self.world
+
+    def all_reduce_scalar_mean(self, t):
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            t /= self.world
+        return t
+
+
+def shard_batch(batch, rank, world):
+    """Equal utterance shards (train.py bucket batches are 128/64/32: all divisible by 8)."""
+    B = len(batch["logmel_len"])
+    if B % world:
+        raise ValueError("global batch %d is not divisible by world size %d" % (B, world))
+    per = B // world
+    sl = slice(rank * per, (rank + 1) * per)
+    return {k: (v[sl] if hasattr(v, "__len__") and len(v) == B else v) for k, v in batch.items()}
