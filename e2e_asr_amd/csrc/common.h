@@ -32,12 +32,14 @@ void prof_begin(int tag, hipStream_t s);   // prof.hip
 void prof_end(int tag, hipStream_t s);
 
 // ---- math: v_exp_f32 / v_rcp_f32 based, ~1-2 ulp; saturate cleanly at +-inf ----
+// (__frcp_rn would expand to the ~10-instruction IEEE divide; v_rcp_f32 is 1 ulp and one instruction)
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float fast_sigmoid(float x) {
-    return __frcp_rn(1.0f + __expf(-x));
+    return fast_rcp(1.0f + __expf(-x));
 }
 __device__ __forceinline__ float fast_tanh(float x) {
     // tanh(x) = 1 - 2/(exp(2x)+1); exp->inf gives 1, exp->0 gives -1.
-    return 1.0f - 2.0f * __frcp_rn(__expf(2.0f * x) + 1.0f);
+    return 1.0f - 2.0f * fast_rcp(__expf(2.0f * x) + 1.0f);
 }
 
 // ---- DPP butterflies inside a row of 16 lanes (no LDS) ----
@@ -76,7 +78,7 @@ __device__ __forceinline__ float uniform01(uint32_t seed, uint32_t a, uint32_t b
 }
 // DropoutWrapper(output_keep_prob): 0 or 1/keep.
 __device__ __forceinline__ float keep_scale(uint32_t seed, uint32_t a, uint32_t b, float keep) {
-    return (keep >= 1.0f) ? 1.0f : (uniform01(seed, a, b) < keep ? __frcp_rn(keep) : 0.0f);
+    return (keep >= 1.0f) ? 1.0f : (uniform01(seed, a, b) < keep ? 1.0f / keep : 0.0f);
 }
 
 }  // namespace asr

@@ -31,11 +31,12 @@
 namespace asr {
 
 struct LstmRecArgs {
-    float* gates;          // [B][T][ND][4H] in: x.Kx+b   out (save): activated i,j,f,o
+    const float* __restrict__ gates;   // [B][T][ND][4H]  x.Kx+b (read only here)
+    float* __restrict__ act;           // [B][T][ND][H][8] saved {i,j,f,o | c, c_prev, -, -} or nullptr
     const float* kh[2];    // per direction: recurrent rows of the TF kernel, [H][4H]
     const int* len;        // [B]
     float* out;            // [B][Tout][ND*H]
-    float* csave;          // [B][T][ND][H] or nullptr
+    unsigned long long* dbg;  // diagnostic stamps (STAMP build) or nullptr
     float* hprev;          // [B][T][ND][H] or nullptr: h_{t-1} (undropped) for dK_h = Hprev^T.dG
     u64* hx;               // exchange granules [ND*NG][2][R][H]
     int* err;              // set to 1 on poll timeout
@@ -57,13 +58,41 @@ __device__ __forceinline__ bool poll_granule(const u64* g, uint32_t epoch, float
     }
 }
 
-template <int H, int HS, int R>
+// STAMP: diagnostic build only (ASR_LSTM_STAMP=1): per-phase s_memtime totals of workgroup 0
+// go to a debug buffer that no other code reads; never used for timing claims.
+#define ASR_STAMP(i) if (STAMP) { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); stamp[i] += t__ - tlast; tlast = t__; }
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bool poll_granule2(const u64* g, uint32_t epoch, float& v0, float& v1, int* err) {
+    long long t0 = 0;
+    const u32x4* p = reinterpret_cast<const u32x4*>(g);
+    for (uint32_t spins = 0;; ++spins) {
+        // 16-byte load with sc1 (system-coherent, bypasses the per-CU L1)
+        u32x4 x;
+        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(x) : "v"(p) : "memory");
+        if (x.y == epoch && x.w == epoch) { v0 = __uint_as_float(x.x); v1 = __uint_as_float(x.z); return true; }
+        if ((spins & 1023) == 1023) {
+            long long now = wall_clock64();
+            if (t0 == 0) t0 = now;
+            else if (now - t0 > 200000000LL) { *err = 1; v0 = v1 = 0.f; return false; }
+            if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { v0 = v1 = 0.f; return false; }
+        }
+    }
+}
+
+template <int H, int HS, int R, bool STAMP = false>
 __global__ __launch_bounds__(16 * HS) void lstm_rec_fwd_kernel(LstmRecArgs a) {
     constexpr int KPT = H / 16;        // K values per lane
     constexpr int CS = KPT + 4;        // padded LDS chunk stride (conflict-free b128 reads)
     constexpr int G = H / HS;          // workgroups per group
     constexpr int NT = 16 * HS;
+    constexpr int NCELL = R * HS;      // cell threads: the first NCELL threads
+    constexpr int NCW = (NCELL + 63) / 64 * 64;   // ... rounded up to whole waves: those waves never poll
+    static_assert(NCW < NT, "need at least one polling wave");
+    constexpr int NPOLL = NT - NCW;    // the other waves poll; the cell waves own every store
     __shared__ __attribute__((aligned(16))) float hl[R * 16 * CS];
+    __shared__ __attribute__((aligned(16))) float sums[HS * R * 4];
+    unsigned long long stamp[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long tlast = STAMP ? __builtin_amdgcn_s_memtime() : 0;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kq = lane & 15, cgl = lane >> 4;
@@ -78,8 +107,8 @@ __global__ __launch_bounds__(16 * HS) void lstm_rec_fwd_kernel(LstmRecArgs a) {
     }
     const int dir = grp / NG, bg = grp % NG;
     const int r0 = bg * R;
-    const int u = wave * 4 + cgl;
-    const int j = mem * HS + u;        // hidden unit owned by this DPP row
+    const int u = wave * 4 + cgl;      // matvec role: unit of this DPP row
+    const int j = mem * HS + u;
     const int H4 = 4 * H;
 
     // recurrent weights -> registers (once)
@@ -91,51 +120,63 @@ __global__ __launch_bounds__(16 * HS) void lstm_rec_fwd_kernel(LstmRecArgs a) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) w[i][g] = kh[(size_t)(kq * KPT + i) * H4 + g * H + j];
     }
-
-    int lenr[R];
     int S = 0;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        lenr[r] = (r0 + r < a.B) ? min(a.len[r0 + r], a.T) : 0;
-        S = max(S, lenr[r]);
-    }
-    const int my_r = kq;                          // cell lane: batch row kq of the group (kq < R)
-    const bool cell_lane = kq < R;
-    int my_len = 0;
-#pragma unroll
-    for (int r = 0; r < R; ++r) if (kq == r) my_len = lenr[r];
-    const int my_b = r0 + my_r;
+    for (int r = 0; r < R; ++r) S = max(S, (r0 + r < a.B) ? min(a.len[r0 + r], a.T) : 0);
 
+    // cell role (threads < NCELL): row cr of the group, unit cu -> 32 consecutive units per row,
+    // so every store of the step is a coalesced 128-byte (or 1 KiB for the records) segment
+    const bool cell = tid < NCELL;
+    // wave-uniform role flag through readfirstlane: a SCALAR branch, so the cell path carries no
+    // exec-masked register initialisation (which costs a vmcnt(0) -- i.e. a drain of the
+    // previous step's stores -- at every loop head)
+    const bool cell_wave = __builtin_amdgcn_readfirstlane(tid) < NCW;
+    const int cr = min(tid / HS, R - 1), cu = tid % HS;
+    const int cb = r0 + cr;
+    const int cj = mem * HS + cu;
+    const int clen = (cell && cb < a.B) ? min(a.len[cb], a.T) : 0;
+    const int cb_safe = min(cb, a.B - 1);
     float c = 0.f, h = 0.f;
     u64* hxg = a.hx + (size_t)grp * 2 * R * H;
+    // x.Kx+b of the NEXT step is loaded at the end of each cell phase (software pipelining): the
+    // registers are loop-carried, never re-initialised, so the loop head needs no vmcnt wait and the
+    // load latency hides under the next step's exchange.
+    float gx0 = 0.f, gx1 = 0.f, gx2 = 0.f, gx3 = 0.f;
+    auto prefetch = [&](int s) {
+        const int t = dir ? (clen - 1 - s) : s;
+        const int ts = min(max(t, 0), a.T - 1);
+        const float* gp = a.gates + (((size_t)cb_safe * a.T + ts) * a.ND + dir) * H4 + cj;
+        gx0 = gp[0]; gx1 = gp[H]; gx2 = gp[2 * H]; gx3 = gp[3 * H];
+    };
+    if (cell_wave) prefetch(0);
 
     for (int s = 0; s < S; ++s) {
-        // (1) prefetch this step's input projection for the cell lanes (independent of h)
-        const bool live = cell_lane && s < my_len;
-        const int t = dir ? (my_len - 1 - s) : s;
-        float gx[4] = {0.f, 0.f, 0.f, 0.f};
-        float* gp = nullptr;
-        if (live) {
-            gp = a.gates + (((size_t)my_b * a.T + t) * a.ND + dir) * H4 + j;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) gx[g] = gp[g * H];
-        }
-        // (2) gather h_{s-1} of the group's rows (all H units) from the exchange buffer
+        const bool live = cell && s < clen;
+        const int t = dir ? (clen - 1 - s) : s;
+        ASR_STAMP(0)
         float acc[R][4];
 #pragma unroll
         for (int r = 0; r < R; ++r)
 #pragma unroll
             for (int g = 0; g < 4; ++g) acc[r][g] = 0.f;
         if (s > 0) {
-            const u64* src = hxg + (size_t)((s - 1) & 1) * R * H;
-            for (int idx = tid; idx < R * H; idx += NT) {
-                const int r = idx / H, k = idx % H;
-                float v = 0.f;
-                if (r0 + r < a.B) poll_granule(src + idx, (uint32_t)s, v, a.err);
-                hl[(r * 16 + k / KPT) * CS + (k % KPT)] = v;
+            // (2) polling waves gather h_{s-1} (R x H granules) into LDS; they issue no stores, so
+            //     their vmcnt(0) waits only for the poll itself
+            if (!cell_wave) {
+                // one 16-byte sc1 load = two adjacent granules (each 8-byte half is written by one
+                // store and arrives untorn); R*H/2 pairs over the polling threads
+                const u64* src = hxg + (size_t)((s - 1) & 1) * R * H;
+                for (int pidx = tid - NCW; pidx < R * H / 2; pidx += NPOLL) {
+                    const int idx = 2 * pidx;
+                    const int r = idx / H, k = idx % H;
+                    float v0 = 0.f, v1 = 0.f;
+                    if (r0 + r < a.B) poll_granule2(src + idx, (uint32_t)s, v0, v1, a.err);
+                    *reinterpret_cast<float2*>(hl + (r * 16 + k / KPT) * CS + (k % KPT)) = make_float2(v0, v1);
+                }
             }
+            ASR_STAMP(1)
             __syncthreads();
-            // (3) h.K_h for this lane's K chunk
+            ASR_STAMP(2)
+            // (3) h.K_h for this lane's K chunk, (4) DPP-row reduction over the 16 chunks
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const float4* hp = reinterpret_cast<const float4*>(hl + (r * 16 + kq) * CS);
@@ -151,63 +192,86 @@ __global__ __launch_bounds__(16 * HS) void lstm_rec_fwd_kernel(LstmRecArgs a) {
                     }
                 }
             }
-            // (4) reduce over the 16 K chunks (DPP row), every lane of the row gets the sum
 #pragma unroll
             for (int r = 0; r < R; ++r)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) acc[r][g] = row16_allreduce_sum(acc[r][g]);
-            __syncthreads();   // hl may be overwritten next step
+            if (kq == 0) {
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    *reinterpret_cast<float4*>(sums + (r * HS + u) * 4) = make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
+            }
+            ASR_STAMP(3)
+            __syncthreads();   // sums complete; hl free for the next step's pollers
+            ASR_STAMP(4)
         }
-        // (5) the cell, in lanes kq < R (row kq of the group, unit j)
-        if (cell_lane) {
-            float pre[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-                if (kq == r) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) pre[g] = acc[r][g];
-                }
+        // (5) the cell, on the cell waves only
+        if (cell_wave && cell) {
+            float4 pre = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (s > 0) pre = *reinterpret_cast<const float4*>(sums + (cr * HS + cu) * 4);
+            float gi = 0.f, gj = 0.f, gf = 0.f, go = 0.f, h_old = h, c_old = c;
             if (live) {
-                const float gi = fast_sigmoid(pre[0] + gx[0]);
-                const float gj = fast_tanh(pre[1] + gx[1]);
-                const float gf = fast_sigmoid(pre[2] + gx[2] + 1.0f);   // forget bias
-                const float go = fast_sigmoid(pre[3] + gx[3]);
-                if (a.hprev) a.hprev[(((size_t)my_b * a.T + t) * a.ND + dir) * H + j] = h;
+                gi = fast_sigmoid(pre.x + gx0);
+                gj = fast_tanh(pre.y + gx1);
+                gf = fast_sigmoid(pre.z + gx2 + 1.0f);   // forget bias
+                go = fast_sigmoid(pre.w + gx3);
                 c = c * gf + gi * gj;
                 h = go * fast_tanh(c);
-                float o = h;
-                if (a.keep < 1.0f)
-                    o *= keep_scale(a.seed, (uint32_t)((a.boff + my_b) * a.Tout + t), (uint32_t)(dir * H + j), a.keep);
-                a.out[((size_t)my_b * a.Tout + t) * (a.ND * H) + dir * H + j] = o;
-                if (a.csave) {
-                    gp[0] = gi; gp[H] = gj; gp[2 * H] = gf; gp[3 * H] = go;
-                    a.csave[(((size_t)my_b * a.T + t) * a.ND + dir) * H + j] = c;
-                }
             }
-            // publish h_s (unchanged for rows past their length): ONE 8-byte sc1 store
-            if (my_b < a.B && s + 1 < S) {
-                u64* dst = hxg + ((size_t)(s & 1) * R + my_r) * H + j;
+            // publish h_s FIRST (unchanged for rows past their length): it is the critical path of
+            // every other workgroup of the group.  ONE 8-byte sc1 store.
+            if (cb < a.B && s + 1 < S) {
+                u64* dst = hxg + ((size_t)(s & 1) * R + cr) * H + cj;
                 __hip_atomic_store(dst, ((u64)(uint32_t)(s + 1) << 32) | __float_as_uint(h),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+            if (live) {       // bookkeeping stores, off the critical path
+                const size_t ridx = (((size_t)cb * a.T + t) * a.ND + dir) * H + cj;
+                float o = h;
+                if (a.keep < 1.0f)
+                    o *= keep_scale(a.seed, (uint32_t)((a.boff + cb) * a.Tout + t), (uint32_t)(dir * H + cj), a.keep);
+                a.out[((size_t)cb * a.Tout + t) * (a.ND * H) + dir * H + cj] = o;
+                if (a.hprev) a.hprev[ridx] = h_old;
+                if (a.act) {      // one 32-byte record per (b,t,dir,unit): two 16-byte stores
+                    float4* rp = reinterpret_cast<float4*>(a.act + ridx * 8);
+                    rp[0] = make_float4(gi, gj, gf, go);
+                    rp[1] = make_float4(c, c_old, 0.f, 0.f);
+                }
+            }
+            if (s + 1 < S) prefetch(s + 1);
         }
+        ASR_STAMP(5)
+    }
+    if (STAMP && a.dbg && blockIdx.x == 0 && (tid == 0 || tid == NT - 1)) {
+        unsigned long long* d = a.dbg + (tid == 0 ? 0 : 8);
+        for (int i = 0; i < 6; ++i) d[i] = stamp[i];
+        d[6] = (unsigned long long)S;
     }
     // zero output past each row's length (dynamic_rnn zero-fill; also the pyramid pad frame)
     for (int r = 0; r < R; ++r) {
         if (r0 + r >= a.B) break;
-        const int nz = a.Tout - lenr[r];
+        const int l = min(a.len[r0 + r], a.T);
+        const int nz = a.Tout - l;
         for (int idx = tid; idx < nz * HS; idx += NT) {
-            const int t = lenr[r] + idx / HS, uu = idx % HS;
+            const int t = l + idx / HS, uu = idx % HS;
             a.out[((size_t)(r0 + r) * a.Tout + t) * (a.ND * H) + dir * H + mem * HS + uu] = 0.f;
         }
     }
 }
 
+static unsigned long long* g_lstm_dbg = nullptr;
+extern "C" int asr_debug_set_buffer(void* p) { g_lstm_dbg = static_cast<unsigned long long*>(p); return ASR_OK; }
+
 template <int H, int R>
-static int launch_rec(hipStream_t s, const LstmRecArgs& a) {
+static int launch_rec(hipStream_t s, const LstmRecArgs& a0) {
     constexpr int HS = 32;
+    LstmRecArgs a = a0;
+    a.dbg = g_lstm_dbg;
     const int NG = (a.B + R - 1) / R;
     const int grid = a.ND * NG * (H / HS);
+    if (H == 256 && R == 2 && g_lstm_dbg && getenv("ASR_LSTM_STAMP"))
+        hipLaunchKernelGGL((lstm_rec_fwd_kernel<256, HS, 2, true>), dim3(grid), dim3(16 * HS), 0, s, a);
+    else
     hipLaunchKernelGGL((lstm_rec_fwd_kernel<H, HS, R>), dim3(grid), dim3(16 * HS), 0, s, a);
     return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
 }
@@ -245,7 +309,7 @@ extern "C" int asr_lstm_layer_fwd(void* stream, const float* x, int B, int T, in
                                   const int* len, int H, int ndir,
                                   const float* kernel_fw, const float* bias_fw,
                                   const float* kernel_bw, const float* bias_bw,
-                                  float* out, int Tout, float* gates, float* csave, float* hprev,
+                                  float* out, int Tout, float* gates, float* act, float* hprev,
                                   void* hx_ws, size_t hx_bytes, int* err_flag,
                                   float keep_prob, unsigned seed) {
     using namespace asr;
@@ -268,7 +332,7 @@ extern "C" int asr_lstm_layer_fwd(void* stream, const float* x, int B, int T, in
     a.gates = gates;
     a.kh[0] = kernel_fw + (size_t)in_dim * H4;
     a.kh[1] = ndir == 2 ? kernel_bw + (size_t)in_dim * H4 : nullptr;
-    a.len = len; a.out = out; a.csave = csave; a.hprev = hprev; a.boff = 0; a.hx = static_cast<u64*>(hx_ws); a.err = err_flag;
+    a.len = len; a.out = out; a.act = act; a.hprev = hprev; a.boff = 0; a.hx = static_cast<u64*>(hx_ws); a.err = err_flag;
     a.B = B; a.T = T; a.Tout = Tout; a.ND = ndir; a.keep = keep_prob; a.seed = seed;
     const int R = asr_lstm_pick_rows(B, ndir, H / 32);
     // batches too large for one resident grid run as consecutive launches over row ranges
@@ -281,7 +345,7 @@ extern "C" int asr_lstm_layer_fwd(void* stream, const float* x, int B, int T, in
         c.gates = a.gates + (size_t)b0 * T * ndir * H4;
         c.len = len + b0;
         c.out = out + (size_t)b0 * Tout * ndir * H;
-        c.csave = csave ? csave + (size_t)b0 * T * ndir * H : nullptr;
+        c.act = act ? act + (size_t)b0 * T * ndir * H * 8 : nullptr;
         c.hprev = hprev ? hprev + (size_t)b0 * T * ndir * H : nullptr;
         c.boff = b0;
         int rc;

@@ -25,9 +25,9 @@
 namespace asr {
 
 struct LstmBwdArgs {
-    float* gates;          // [B][T][ND][4H]  in: activated gates   out: dG (zero past len)
-    const float* csave;    // [B][T][ND][H]
-    const float* dout;     // [B][Tout][ND*H] gradient w.r.t. the layer output
+    float* __restrict__ gates;         // [B][T][ND][4H]  out: dG (zero past len)
+    const float* __restrict__ act;     // [B][T][ND][H][8] forward records {i,j,f,o | c, c_prev, -, -}
+    const float* __restrict__ dout;    // [B][Tout][ND*H] gradient w.r.t. the layer output
     const float* kh[2];
     const int* len;
     u64* hx;               // [groups][2][G dst][G src][R][32] granules
@@ -36,43 +36,41 @@ struct LstmBwdArgs {
     float keep; uint32_t seed;
 };
 
-// Sum of N granules at g[i*stride], all carrying tag `epoch`.  Every pass re-loads ALL N
-// unconditionally (one memory round trip with N loads in flight -- a per-granule "if not yet
-// ok" makes hipcc serialise the loads into N dependent round trips); fixed summation order.
-template <int N>
-__device__ __forceinline__ bool poll_sum(const u64* g, int stride, uint32_t epoch, float& sum, int* err) {
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// Two adjacent granules with one 16-byte sc1 load (each 8-byte half is written by one store).
+__device__ __forceinline__ bool poll_pair(const u64* g, uint32_t epoch, float& v0, float& v1, int* err) {
     long long t0 = 0;
+    const u32x4* p = reinterpret_cast<const u32x4*>(g);
     for (uint32_t spins = 0;; ++spins) {
-        u64 x[N];
-#pragma unroll
-        for (int i = 0; i < N; ++i)
-            x[i] = __hip_atomic_load(g + (size_t)i * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        bool all = true;
-#pragma unroll
-        for (int i = 0; i < N; ++i) all &= (uint32_t)(x[i] >> 32) == epoch;
-        if (all) {
-            float s = 0.f;
-#pragma unroll
-            for (int i = 0; i < N; ++i) s += __uint_as_float((uint32_t)x[i]);
-            sum = s;
-            return true;
-        }
+        u32x4 x;
+        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(x) : "v"(p) : "memory");
+        if (x.y == epoch && x.w == epoch) { v0 = __uint_as_float(x.x); v1 = __uint_as_float(x.z); return true; }
         if ((spins & 1023) == 1023) {
             const long long now = wall_clock64();
             if (t0 == 0) t0 = now;
-            else if (now - t0 > 200000000LL) { *err = 1; sum = 0.f; return false; }
-            if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { sum = 0.f; return false; }
+            else if (now - t0 > 200000000LL) { *err = 1; v0 = v1 = 0.f; return false; }
+            if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { v0 = v1 = 0.f; return false; }
         }
     }
 }
 
+// Roles (wave-uniform, via readfirstlane => scalar branches): the first NCW threads are the cell
+// waves -- they own the pointwise backward and every bookkeeping store, and never poll; the
+// remaining waves gather the G partials of every (row, unit) with ONE 16-byte load per thread and
+// hand them over through LDS, where the cell threads sum them in fixed order (reproducible).
 template <int H, int R>
 __global__ __launch_bounds__(512) void lstm_rec_bwd_kernel(LstmBwdArgs a) {
     constexpr int HS = 32, NT = 512;
     constexpr int G = H / HS;          // workgroups per group (<= 16)
     constexpr int KG = H / 32;         // output rows k per lane
     constexpr int CS = 12;             // padded LDS chunk stride (8 values + 4)
+    constexpr int NCELL = R * HS;
+    constexpr int NCW = (NCELL + 63) / 64 * 64;
+    constexpr int NPOLL = NT - NCW;
+    static_assert(NCW < NT, "need at least one polling wave");
     __shared__ __attribute__((aligned(16))) float dgl[R * 16 * CS];
+    __shared__ __attribute__((aligned(16))) float part[G * R * HS];
+    __shared__ __attribute__((aligned(16))) float pub[R * H];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nc = lane & 15, kg = wave * 4 + (lane >> 4);
@@ -99,53 +97,68 @@ __global__ __launch_bounds__(512) void lstm_rec_bwd_kernel(LstmBwdArgs a) {
             }
     }
     int S = 0;
-    for (int r = 0; r < R; ++r) {
-        const int l = (r0 + r < a.B) ? min(a.len[r0 + r], a.T) : 0;
-        S = max(S, l);
-    }
-    // cell threads: tid < R*HS -> (row r = tid % R, unit u = tid / R)
-    const bool cell = tid < R * HS;
-    const int cr = tid % R, cu = tid / R;
+    for (int r = 0; r < R; ++r) S = max(S, (r0 + r < a.B) ? min(a.len[r0 + r], a.T) : 0);
+    const bool cell = tid < NCELL;
+    const bool cell_wave = __builtin_amdgcn_readfirstlane(tid) < NCW;
+    const int cr = min(tid / HS, R - 1), cu = tid % HS;
     const int cb = r0 + cr;
+    const int cb_safe = min(cb, a.B - 1);
     const int clen = (cell && cb < a.B) ? min(a.len[cb], a.T) : 0;
     const int cj = j0 + cu;
     float dc = 0.f;
     u64* hxg = a.hx + (size_t)grp * 2 * G * G * R * HS;
 
+    // software-pipelined operands of the cell (loop-carried registers, no in-loop init)
+    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
+    float dout_v = 0.f;
+    auto prefetch = [&](int s) {
+        const int t = dir ? s : (clen - 1 - s);
+        const int ts = min(max(t, 0), a.T - 1);
+        const float4* rp = reinterpret_cast<const float4*>(a.act + ((((size_t)cb_safe * a.T + ts) * a.ND + dir) * H + cj) * 8);
+        ra = rp[0]; rb = rp[1];
+        dout_v = a.dout[((size_t)cb_safe * a.Tout + ts) * (a.ND * H) + dir * H + cj];
+    };
+    if (cell_wave) prefetch(0);
+
     for (int s = 0; s < S; ++s) {
         const bool live = cell && s < clen;
         const int t = dir ? s : (clen - 1 - s);          // reverse of the forward walk
-        float gi = 0.f, gj = 0.f, gf = 0.f, go = 0.f, cc = 0.f, cp = 0.f, dh = 0.f;
-        float* gp = nullptr;
-        if (live) {      // operands that do not depend on the exchange: issue first
-            gp = a.gates + (((size_t)cb * a.T + t) * a.ND + dir) * H4 + cj;
-            gi = gp[0]; gj = gp[H]; gf = gp[2 * H]; go = gp[3 * H];
-            const float* cs = a.csave + (((size_t)cb * a.T + t) * a.ND + dir) * H + cj;
-            cc = cs[0];
-            const int tp = dir ? t + 1 : t - 1;           // time index of the forward's previous step
-            cp = (tp >= 0 && tp < clen) ? cs[(ptrdiff_t)(tp - t) * a.ND * H] : 0.f;
-            dh = a.dout[((size_t)cb * a.Tout + t) * (a.ND * H) + dir * H + cj];
-            if (a.keep < 1.0f)
-                dh *= keep_scale(a.seed, (uint32_t)((a.boff + cb) * a.Tout + t), (uint32_t)(dir * H + cj), a.keep);
-        }
-        if (live && s > 0) {     // recurrent part: sum of the G partials addressed to (row, unit)
-            float rec;
-            const u64* src = hxg + ((size_t)((s - 1) & 1) * G + mem) * G * R * HS + (size_t)cr * HS + cu;
-            poll_sum<G>(src, R * HS, (uint32_t)s, rec, a.err);
-            dh += rec;
+        if (s > 0) {
+            if (!cell_wave) {
+                // partials addressed to this workgroup: [src m][r][u], pairs over u
+                const u64* src = hxg + ((size_t)((s - 1) & 1) * G + mem) * G * R * HS;
+                for (int pidx = tid - NCW; pidx < G * R * HS / 2; pidx += NPOLL) {
+                    const int idx = 2 * pidx;
+                    const int r = (idx / HS) % R;
+                    float v0 = 0.f, v1 = 0.f;
+                    if (r0 + r < a.B) poll_pair(src + idx, (uint32_t)s, v0, v1, a.err);
+                    *reinterpret_cast<float2*>(part + idx) = make_float2(v0, v1);
+                }
+            }
+            __syncthreads();
         }
         float4 dg = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (live) {
-            const float tc = fast_tanh(cc);
-            const float dct = dc + dh * go * (1.f - tc * tc);
-            dg.x = dct * gj * gi * (1.f - gi);
-            dg.y = dct * gi * (1.f - gj * gj);
-            dg.z = dct * cp * gf * (1.f - gf);
-            dg.w = dh * tc * go * (1.f - go);
-            dc = dct * gf;
-            gp[0] = dg.x; gp[H] = dg.y; gp[2 * H] = dg.z; gp[3 * H] = dg.w;
-        }
-        if (cell) {   // local column n = 4*cu + gate -> chunk cu/2, offset 4*(cu&1)
+        if (cell_wave && cell) {
+            float dh = dout_v;
+            if (a.keep < 1.0f)
+                dh *= keep_scale(a.seed, (uint32_t)((a.boff + cb) * a.Tout + t), (uint32_t)(dir * H + cj), a.keep);
+            if (s > 0) {
+                float rec = 0.f;
+#pragma unroll
+                for (int m = 0; m < G; ++m) rec += part[(m * R + cr) * HS + cu];
+                dh += rec;
+            }
+            if (live) {
+                const float gi = ra.x, gj = ra.y, gf = ra.z, go = ra.w, cc = rb.x, cp = rb.y;
+                const float tc = fast_tanh(cc);
+                const float dct = dc + dh * go * (1.f - tc * tc);
+                dg.x = dct * gj * gi * (1.f - gi);
+                dg.y = dct * gi * (1.f - gj * gj);
+                dg.z = dct * cp * gf * (1.f - gf);
+                dg.w = dh * tc * go * (1.f - go);
+                dc = dct * gf;
+            }
+            // local column n = 4*cu + gate -> chunk cu/2, offset 4*(cu&1)
             *reinterpret_cast<float4*>(dgl + (cr * 16 + (cu >> 1)) * CS + 4 * (cu & 1)) = dg;
         }
         __syncthreads();
@@ -165,21 +178,39 @@ __global__ __launch_bounds__(512) void lstm_rec_bwd_kernel(LstmBwdArgs a) {
                     acc[r][i] = row16_allreduce_sum(x);
                 }
             }
-            // publish: lane nc sends value(s) vi = nc, nc+16, ... of the row's R*KG results
-            u64* dstb = hxg + (size_t)(s & 1) * G * G * R * HS;
+            // hand the R*H partial sums to the cell waves through LDS, laid out like the granule
+            // block of each destination ([dst m'][r][u']); only the cell waves (which never poll)
+            // issue stores, so a polling wave's vmcnt(0) never waits on a write-through ack
 #pragma unroll
             for (int r = 0; r < R; ++r)
 #pragma unroll
                 for (int i = 0; i < KG; ++i) {
-                    if (((r * KG + i) & 15) == nc && r0 + r < a.B) {
+                    if (((r * KG + i) & 15) == nc) {
                         const int k = kg * KG + i;
-                        u64* dst = dstb + ((size_t)(k / HS) * G + mem) * R * HS + (size_t)r * HS + (k % HS);
-                        __hip_atomic_store(dst, ((u64)(uint32_t)(s + 1) << 32) | __float_as_uint(acc[r][i]),
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        pub[((k / HS) * R + r) * HS + (k % HS)] = acc[r][i];
                     }
                 }
         }
-        __syncthreads();     // dgl is rewritten next step
+        __syncthreads();
+        if (cell_wave && s + 1 < S) {
+            u64* dstb = hxg + (size_t)(s & 1) * G * G * R * HS;
+            for (int idx = tid; idx < R * H; idx += NCW) {
+                const int md = idx / (R * HS), rem = idx % (R * HS);
+                if (r0 + rem / HS < a.B)
+                    __hip_atomic_store(dstb + ((size_t)md * G + mem) * R * HS + rem,
+                                       ((u64)(uint32_t)(s + 1) << 32) | __float_as_uint(pub[idx]),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (cell_wave && cell) {       // bookkeeping, off the critical path
+            if (live) {
+                float* gp = a.gates + (((size_t)cb * a.T + t) * a.ND + dir) * H4 + cj;
+                gp[0] = dg.x; gp[H] = dg.y; gp[2 * H] = dg.z; gp[3 * H] = dg.w;
+            }
+            if (s + 1 < S) prefetch(s + 1);
+        }
+        // (dgl / part are rewritten only after the next step's first barrier, which every wave
+        //  reaches after finishing this step's reads)
     }
     // dG = 0 past each row's length (the weight/input GEMMs read every row)
     for (int r = 0; r < R; ++r) {
@@ -218,18 +249,18 @@ extern "C" size_t asr_lstm_bwd_ws_bytes(int B, int H, int ndir) {
     return (size_t)ndir * (size_t)((B + 7) / 8 * 8) * 2 * G * H * sizeof(u64);
 }
 
-// Backward of asr_lstm_layer_fwd.  gates/csave/hprev are the forward's saved tensors; gates is
-// overwritten with dG.  dx [B,T,in] (may be NULL for the first layer) receives the input
+// Backward of asr_lstm_layer_fwd.  act/hprev are the forward's saved tensors; gates (the
+// forward's input-projection buffer) is overwritten with dG.  dx [B,T,in] (may be NULL for the first layer) receives the input
 // gradient; dkernel_*/dbias_* are ACCUMULATED into (TF layout [in+H,4H] / [4H]).
 extern "C" int asr_lstm_layer_bwd(void* stream, const float* x, int B, int T, int in_dim, int ldx,
                                   const int* len, int H, int ndir,
                                   const float* kernel_fw, const float* kernel_bw,
-                                  const float* dout, int Tout, float* gates, const float* csave,
+                                  const float* dout, int Tout, float* gates, const float* act,
                                   const float* hprev, float* dx,
                                   float* dkernel_fw, float* dbias_fw, float* dkernel_bw, float* dbias_bw,
                                   void* hx_ws, size_t hx_bytes, int* err_flag, float keep_prob, unsigned seed) {
     using namespace asr;
-    if (!x || !len || !kernel_fw || !dout || !gates || !csave || !hprev || !dkernel_fw || !dbias_fw || !hx_ws || !err_flag)
+    if (!x || !len || !kernel_fw || !dout || !gates || !act || !hprev || !dkernel_fw || !dbias_fw || !hx_ws || !err_flag)
         return ASR_EINVAL;
     if (ndir != 1 && ndir != 2) return ASR_EINVAL;
     if (ndir == 2 && (!kernel_bw || !dkernel_bw || !dbias_bw)) return ASR_EINVAL;
@@ -238,7 +269,7 @@ extern "C" int asr_lstm_layer_bwd(void* stream, const float* x, int B, int T, in
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int H4 = 4 * H, G = H / 32;
     LstmBwdArgs a;
-    a.gates = gates; a.csave = csave; a.dout = dout;
+    a.gates = gates; a.act = act; a.dout = dout;
     a.kh[0] = kernel_fw + (size_t)in_dim * H4;
     a.kh[1] = ndir == 2 ? kernel_bw + (size_t)in_dim * H4 : nullptr;
     a.len = len; a.hx = static_cast<u64*>(hx_ws); a.err = err_flag;
@@ -252,7 +283,7 @@ extern "C" int asr_lstm_layer_bwd(void* stream, const float* x, int B, int T, in
         c.B = (B - b0 < rows_per_launch) ? (B - b0) : rows_per_launch;
         c.boff = b0;
         c.gates = gates + (size_t)b0 * T * ndir * H4;
-        c.csave = csave + (size_t)b0 * T * ndir * H;
+        c.act = act + (size_t)b0 * T * ndir * H * 8;
         c.dout = dout + (size_t)b0 * Tout * ndir * H;
         c.len = len + b0;
         int rc;

@@ -86,7 +86,7 @@ def lstm_layer_fwd(x, seq_len, kernel_fw, bias_fw, kernel_bw=None, bias_bw=None,
     """One (Bi)LSTM layer (encoder.py:55-91).  x [B,T,in] batch-major, seq_len int32 [B].
 
     Returns out [B,t_out,ndir*H] (zeros past each length) and, when save=True, the
-    activated gates [B,T,ndir,4H] and cell states [B,T,ndir,H] for the backward pass.
+    gates workspace, activation records [B,T,ndir,H,8] and hprev [B,T,ndir,H] for the backward pass.
     """
     _f32(x, "x"); _i32(seq_len, "seq_len")
     B, T, IN = x.shape
@@ -98,7 +98,7 @@ def lstm_layer_fwd(x, seq_len, kernel_fw, bias_fw, kernel_bw=None, bias_bw=None,
     dev = x.device
     out = torch.empty((B, t_out, ndir * H), device=dev, dtype=torch.float32)
     gates = torch.empty((B, T, ndir, 4 * H), device=dev, dtype=torch.float32)
-    csave = torch.empty((B, T, ndir, H), device=dev, dtype=torch.float32) if save else None
+    act = torch.empty((B, T, ndir, H, 8), device=dev, dtype=torch.float32) if save else None
     hprev = torch.empty((B, T, ndir, H), device=dev, dtype=torch.float32) if save else None
     L = _lib.lib()
     nbytes = L.asr_lstm_ws_bytes(B, H, ndir)
@@ -106,10 +106,10 @@ def lstm_layer_fwd(x, seq_len, kernel_fw, bias_fw, kernel_bw=None, bias_bw=None,
     rc = L.asr_lstm_layer_fwd(_stream(), _p(x), B, T, IN, IN, _p(seq_len), H, ndir,
                               _p(_f32(kernel_fw, "kernel_fw")), _p(_f32(bias_fw, "bias_fw")),
                               _p(_f32(kernel_bw, "kernel_bw")), _p(_f32(bias_bw, "bias_bw")),
-                              _p(out), t_out, _p(gates), _p(csave), _p(hprev), _p(hx), nbytes,
+                              _p(out), t_out, _p(gates), _p(act), _p(hprev), _p(hx), nbytes,
                               _p(_Flag.get(dev)), float(keep_prob), int(seed) & 0xFFFFFFFF)
     _check(rc, "asr_lstm_layer_fwd")
-    return (out, gates, csave, hprev) if save else out
+    return (out, gates, act, hprev) if save else out
 
 
 def _hx(dev, nbytes):
@@ -119,7 +119,7 @@ def _hx(dev, nbytes):
     return _hx_cache[key]
 
 
-def lstm_layer_bwd(x, seq_len, kernel_fw, kernel_bw, dout, gates, csave, hprev, dk_fw, db_fw, dk_bw=None,
+def lstm_layer_bwd(x, seq_len, kernel_fw, kernel_bw, dout, gates, act, hprev, dk_fw, db_fw, dk_bw=None,
                    db_bw=None, need_dx=True, keep_prob=1.0, seed=0):
     """Backward of lstm_layer_fwd.  `gates` is overwritten with dG; weight/bias gradients are
     ACCUMULATED into dk_*/db_* (views of the flat gradient buffer).  Returns dx [B,T,in] or None."""
@@ -131,7 +131,7 @@ def lstm_layer_bwd(x, seq_len, kernel_fw, kernel_bw, dout, gates, csave, hprev, 
     L = _lib.lib()
     nbytes = L.asr_lstm_bwd_ws_bytes(B, H, ndir)
     rc = L.asr_lstm_layer_bwd(_stream(), _p(x), B, T, IN, IN, _p(seq_len), H, ndir, _p(kernel_fw), _p(kernel_bw),
-                              _p(_f32(dout, "dout")), dout.shape[1], _p(gates), _p(csave), _p(hprev), _p(dx),
+                              _p(_f32(dout, "dout")), dout.shape[1], _p(gates), _p(act), _p(hprev), _p(dx),
                               _p(dk_fw), _p(db_fw), _p(dk_bw), _p(db_bw), _p(_hx(dev, nbytes)), nbytes,
                               _p(_Flag.get(dev)), float(keep_prob), int(seed) & 0xFFFFFFFF)
     _check(rc, "asr_lstm_layer_bwd")

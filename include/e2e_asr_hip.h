@@ -31,9 +31,9 @@ int asr_gemm_f32(void* stream, int transA, int transB, int M, int N, int K,
  * (bidirectional_dynamic_rnn / dynamic_rnn over BasicLSTMCell with sequence_length).
  * x [B,T,in] batch-major (row stride ldx); out [B,Tout,ndir*H] with fw in [:H], bw in
  * [H:]; rows t >= len[b] (and the pad frames T..Tout-1 of the pyramid, encoder.py:104-110)
- * are written as exact zeros.  gates [B,T,ndir,4H] is workspace; with csave != NULL it
- * leaves the activated gates, csave [B,T,ndir,H] the cell states and hprev [B,T,ndir,H] the
- * (undropped) previous hidden states for the backward pass.
+ * are written as exact zeros.  gates [B,T,ndir,4H] is workspace (x.K_x + b).  For training pass
+ * act [B,T,ndir,H,8] (records {i,j,f,o | c, c_prev, -, -}) and hprev [B,T,ndir,H] (undropped
+ * previous hidden states); both NULL for inference.
  * keep_prob < 1 applies DropoutWrapper(output_keep_prob) (encoder.py:49-52) to `out`.
  * err_flag: device int, set non-zero if an inter-workgroup wait timed out. H in {64,128,256,512}. */
 size_t asr_lstm_ws_bytes(int B, int H, int ndir);
@@ -41,7 +41,7 @@ int asr_lstm_layer_fwd(void* stream, const float* x, int B, int T, int in_dim, i
                        const int* len, int H, int ndir,
                        const float* kernel_fw, const float* bias_fw,
                        const float* kernel_bw, const float* bias_bw,
-                       float* out, int Tout, float* gates, float* csave, float* hprev,
+                       float* out, int Tout, float* gates, float* act, float* hprev,
                        void* hx_ws, size_t hx_bytes, int* err_flag,
                        float keep_prob, unsigned seed);
 
@@ -52,7 +52,7 @@ size_t asr_lstm_bwd_ws_bytes(int B, int H, int ndir);
 int asr_lstm_layer_bwd(void* stream, const float* x, int B, int T, int in_dim, int ldx,
                        const int* len, int H, int ndir,
                        const float* kernel_fw, const float* kernel_bw,
-                       const float* dout, int Tout, float* gates, const float* csave,
+                       const float* dout, int Tout, float* gates, const float* act,
                        const float* hprev, float* dx,
                        float* dkernel_fw, float* dbias_fw, float* dkernel_bw, float* dbias_bw,
                        void* hx_ws, size_t hx_bytes, int* err_flag, float keep_prob, unsigned seed);
@@ -184,6 +184,8 @@ int asr_scatter_add_rows_ld(void* stream, float* table_grad, const int* idx, con
  * tag: 0 lstm recurrent fwd, 1 lstm recurrent bwd, 2 gemm, 3 decoder fwd, 4 decoder bwd, 5 optimizer.
  * asr_prof_read is a HOST call that synchronises on the recorded events. */
 int asr_prof_enable(int on);
+/* Diagnostic: device buffer (>= 8 u64) for in-kernel phase stamps of the stamped LSTM build (ASR_LSTM_STAMP=1). */
+int asr_debug_set_buffer(void* dev_buf);
 int asr_prof_read(int tag, double* total_ms, int* launches);
 
 #ifdef __cplusplus

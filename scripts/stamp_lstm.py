@@ -1,0 +1,25 @@
+"""Diagnostic: per-phase cycle shares of one recurrent LSTM step (stamped build; shares only)."""
+import os, sys
+os.environ["ASR_LSTM_STAMP"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from e2e_asr_amd import ops, _lib
+dev = torch.device("cuda:0")
+dbg = torch.zeros(16, dtype=torch.int64, device=dev)
+_lib.lib().asr_debug_set_buffer(dbg.data_ptr())
+rng = np.random.default_rng(0)
+B, T, IN, H = 32, 800, 80, 256
+x = torch.from_numpy(rng.standard_normal((B, T, IN)).astype(np.float32)).to(dev)
+k = torch.from_numpy(rng.uniform(-0.075, 0.075, (IN + H, 4 * H)).astype(np.float32)).to(dev)
+bz = torch.zeros(4 * H, device=dev)
+ln = torch.full((B,), T, dtype=torch.int32, device=dev)
+for _ in range(3):
+    ops.lstm_layer_fwd(x, ln, k, bz, k, bz)
+torch.cuda.synchronize()
+names = ["prefetch", "poll+lds-write", "barrier1", "matvec+dpp+sums", "barrier2", "cell+store+publish"]
+for who, off in (("cell wave (tid 0)", 0), ("polling wave (last tid)", 8)):
+    d = dbg.cpu().numpy()[off:off + 8]
+    S = int(d[6]); tot = d[:6].sum()
+    print(who, "steps", S, "cycles/step", tot / S)
+    for n, v in zip(names, d[:6]):
+        print("   %-22s %8.1f cyc/step  %5.1f%%" % (n, v / S, 100.0 * v / tot))
