@@ -34,7 +34,7 @@ class DecWs(C.Structure):
 
 class DecBwdWs(C.Structure):
     _fields_ = [(n, vp) for n in ("dP", "dQC", "dY", "dXH", "dLC", "dlm", "dEH", "dc_dec", "dc_lm", "dhf",
-                                  "dv_part", "emb_all")]
+                                  "dv_part", "dctx", "emb_all")]
 
 
 class DecGrads(C.Structure):
@@ -48,6 +48,8 @@ class DecGrads(C.Structure):
 SIGNATURES = {
     "asr_gemm_f32": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp,
                                C.c_int, vp, C.c_int, vp, C.c_int]),
+    "asr_gemm_f32_batched": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_longlong, vp,
+                                       C.c_int, C.c_longlong, vp, C.c_int, C.c_longlong, vp, C.c_int, C.c_int]),
     "asr_lstm_ws_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "asr_lstm_layer_fwd": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int,
                                      vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, C.c_size_t, vp,

@@ -10,7 +10,7 @@
 // common exp(-max) and the full-length denominator cancel), so only the live positions
 // are ever read: padded hf/enc rows cost no bandwidth.
 //
-// One workgroup (256 threads) per utterance; HBM/L2-bound streaming of hf (Te x A) and
+// One workgroup (512 threads) per utterance; HBM/L2-bound streaming of hf (Te x A) and
 // enc (Te x D) with 16-byte loads; 16-lane DPP-row reductions for the per-position
 // score, wavefront reductions for the softmax; nothing but alpha/ctx is written.
 #include "common.h"
@@ -29,9 +29,12 @@ struct AttnArgs {
 };
 
 // dynamic LDS: qs[H] | y[A] | e[Te] | part[NT*4]
-__global__ __launch_bounds__(256) void attention_fwd_kernel(AttnArgs a) {
+// 512 threads; every phase issues ALL of its global loads before consuming any (one memory round
+// trip per phase instead of one per pass): up to PB float4 per thread per batch.
+constexpr int ATT_NT = 512;
+__global__ __launch_bounds__(ATT_NT) void attention_fwd_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int NT = 256;
+    constexpr int NT = ATT_NT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x;
     const int A = a.A, H = a.H, D = a.D;
@@ -39,12 +42,12 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(AttnArgs a) {
     float* ys = qs + ((H + 3) & ~3);
     float* es = ys + ((A + 3) & ~3);
     float* part = es + ((a.Te + 3) & ~3);
-    __shared__ float wred[8];
+    __shared__ float wred[16];
     const int L = min(max(a.enc_len[b], 0), a.Te);
 
     for (int k = tid; k < H; k += NT) qs[k] = a.q[(size_t)b * a.ldq + k];
     __syncthreads();
-    // ---- y = q.W_att + b_att : thread -> (a4 = 4 columns, kp = K part), all loads in flight
+    // ---- y = q.W_att + b_att : thread -> (a4 = 4 columns, kp = K part); PB loads in flight
     {
         const int na4 = A >> 2;
         const int kparts = max(1, NT / na4);
@@ -53,12 +56,19 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(AttnArgs a) {
         if (kp < kparts) {
             const int kc = (H + kparts - 1) / kparts;
             const int k0 = kp * kc, k1 = min(H, k0 + kc);
-#pragma unroll 8
-            for (int k = k0; k < k1; ++k) {
-                const float4 wv = *reinterpret_cast<const float4*>(a.w_att + (size_t)k * A + 4 * a4);
-                const float qk = qs[k];
-                s.x = fmaf(qk, wv.x, s.x); s.y = fmaf(qk, wv.y, s.y);
-                s.z = fmaf(qk, wv.z, s.z); s.w = fmaf(qk, wv.w, s.w);
+            constexpr int PB = 16;
+            for (int kb = k0; kb < k1; kb += PB) {
+                float4 wv[PB];
+#pragma unroll
+                for (int i = 0; i < PB; ++i)
+                    wv[i] = (kb + i < k1) ? *reinterpret_cast<const float4*>(a.w_att + (size_t)(kb + i) * A + 4 * a4)
+                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int i = 0; i < PB; ++i) {
+                    const float qk = (kb + i < k1) ? qs[kb + i] : 0.f;
+                    s.x = fmaf(qk, wv[i].x, s.x); s.y = fmaf(qk, wv[i].y, s.y);
+                    s.z = fmaf(qk, wv[i].z, s.z); s.w = fmaf(qk, wv[i].w, s.w);
+                }
             }
         }
         *reinterpret_cast<float4*>(part + 4 * tid) = s;
@@ -70,23 +80,60 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(AttnArgs a) {
         }
         __syncthreads();
     }
-    // ---- scores: one DPP row (16 lanes) per position, 16 positions in flight per pass
+    // ---- scores: one DPP row (16 lanes) per position; NT/16 positions per pass, PP passes in flight
     {
         const int kq = lane & 15, rr = tid >> 4;
-        for (int tau = rr; tau < L; tau += NT / 16) {
-            const float* hp = a.hf + ((size_t)b * a.Te + tau) * A;
-            float s = 0.f;
-            for (int a4 = kq; a4 < (A >> 2); a4 += 16) {
-                const float4 hv = *reinterpret_cast<const float4*>(hp + 4 * a4);
-                const float4 yv = *reinterpret_cast<const float4*>(ys + 4 * a4);
-                const float4 vv = *reinterpret_cast<const float4*>(a.v + 4 * a4);
-                s = fmaf(vv.x, fast_tanh(hv.x + yv.x), s);
-                s = fmaf(vv.y, fast_tanh(hv.y + yv.y), s);
-                s = fmaf(vv.z, fast_tanh(hv.z + yv.z), s);
-                s = fmaf(vv.w, fast_tanh(hv.w + yv.w), s);
+        constexpr int RW = NT / 16, PP = 4, CH = 2;     // CH float4 chunks per lane per row (A <= 128 fast path)
+        const int nch = ((A >> 2) + 15) / 16;
+        for (int t0 = 0; t0 < L; t0 += RW * PP) {
+            if (nch <= CH) {
+                float4 hv[PP][CH];
+#pragma unroll
+                for (int p = 0; p < PP; ++p) {
+                    const int tau = t0 + p * RW + rr;
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) {
+                        const int a4 = kq + 16 * c;
+                        hv[p][c] = (tau < L && a4 < (A >> 2))
+                            ? *reinterpret_cast<const float4*>(a.hf + ((size_t)b * a.Te + tau) * A + 4 * a4)
+                            : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                }
+#pragma unroll
+                for (int p = 0; p < PP; ++p) {
+                    const int tau = t0 + p * RW + rr;
+                    float sc = 0.f;
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) {
+                        const int a4 = kq + 16 * c;
+                        if (a4 < (A >> 2)) {
+                            const float4 yv = *reinterpret_cast<const float4*>(ys + 4 * a4);
+                            const float4 vv = *reinterpret_cast<const float4*>(a.v + 4 * a4);
+                            sc = fmaf(vv.x, fast_tanh(hv[p][c].x + yv.x), sc);
+                            sc = fmaf(vv.y, fast_tanh(hv[p][c].y + yv.y), sc);
+                            sc = fmaf(vv.z, fast_tanh(hv[p][c].z + yv.z), sc);
+                            sc = fmaf(vv.w, fast_tanh(hv[p][c].w + yv.w), sc);
+                        }
+                    }
+                    sc = row16_allreduce_sum(sc);
+                    if (kq == 0 && tau < L) es[tau] = sc;
+                }
+            } else {      // wide attention vectors: plain loop
+                for (int p = 0; p < PP; ++p) {
+                    const int tau = t0 + p * RW + rr;
+                    float sc = 0.f;
+                    if (tau < L)
+                        for (int a4 = kq; a4 < (A >> 2); a4 += 16) {
+                            const float4 h4 = *reinterpret_cast<const float4*>(a.hf + ((size_t)b * a.Te + tau) * A + 4 * a4);
+                            const float4 yv = *reinterpret_cast<const float4*>(ys + 4 * a4);
+                            const float4 vv = *reinterpret_cast<const float4*>(a.v + 4 * a4);
+                            sc = fmaf(vv.x, fast_tanh(h4.x + yv.x), sc); sc = fmaf(vv.y, fast_tanh(h4.y + yv.y), sc);
+                            sc = fmaf(vv.z, fast_tanh(h4.z + yv.z), sc); sc = fmaf(vv.w, fast_tanh(h4.w + yv.w), sc);
+                        }
+                    sc = row16_allreduce_sum(sc);
+                    if (kq == 0 && tau < L) es[tau] = sc;
+                }
             }
-            s = row16_allreduce_sum(s);
-            if (kq == 0) es[tau] = s;
         }
         __syncthreads();
     }
@@ -96,20 +143,25 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(AttnArgs a) {
     m = wave_allreduce_max(m);
     if (lane == 0) wred[wave] = m;
     __syncthreads();
-    m = fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]));
+    m = wred[0];
+#pragma unroll
+    for (int i = 1; i < NT / 64; ++i) m = fmaxf(m, wred[i]);
     float sum = 0.f;
     for (int tau = tid; tau < L; tau += NT) { const float p = __expf(es[tau] - m); es[tau] = p; sum += p; }
     sum = wave_allreduce_sum(sum);
-    if (lane == 0) wred[4 + wave] = sum;
+    if (lane == 0) wred[8 + wave] = sum;
     __syncthreads();
-    const float inv = 1.0f / (wred[4] + wred[5] + wred[6] + wred[7]);
+    float tot = 0.f;
+#pragma unroll
+    for (int i = 0; i < NT / 64; ++i) tot += wred[8 + i];
+    const float inv = 1.0f / tot;
     for (int tau = tid; tau < a.Te; tau += NT) {
         const float p = tau < L ? es[tau] * inv : 0.f;
         if (tau < L) es[tau] = p;
         a.alpha[(size_t)b * a.Te + tau] = p;
     }
     __syncthreads();
-    // ---- ctx = alpha . enc : thread -> (d4 = 4 columns, tp = tau part)
+    // ---- ctx = alpha . enc : thread -> (d4 = 4 columns, tp = tau part); PB rows in flight per batch
     {
         const int nd4 = D >> 2;
         for (int base = 0; base < nd4; base += NT) {
@@ -119,12 +171,21 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(AttnArgs a) {
             float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
             if (tp < tparts) {
                 const float* ep = a.enc + (size_t)b * a.Te * D + 4 * d4;
-#pragma unroll 8
-                for (int tau = tp; tau < L; tau += tparts) {
-                    const float4 ev = *reinterpret_cast<const float4*>(ep + (size_t)tau * D);
-                    const float al = es[tau];
-                    s.x = fmaf(al, ev.x, s.x); s.y = fmaf(al, ev.y, s.y);
-                    s.z = fmaf(al, ev.z, s.z); s.w = fmaf(al, ev.w, s.w);
+                constexpr int PB = 13;
+                for (int tb = tp; tb < L; tb += tparts * PB) {
+                    float4 ev[PB];
+#pragma unroll
+                    for (int i = 0; i < PB; ++i) {
+                        const int tau = tb + i * tparts;
+                        ev[i] = tau < L ? *reinterpret_cast<const float4*>(ep + (size_t)tau * D) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+#pragma unroll
+                    for (int i = 0; i < PB; ++i) {
+                        const int tau = tb + i * tparts;
+                        const float al = tau < L ? es[tau] : 0.f;
+                        s.x = fmaf(al, ev[i].x, s.x); s.y = fmaf(al, ev[i].y, s.y);
+                        s.z = fmaf(al, ev[i].z, s.z); s.w = fmaf(al, ev[i].w, s.w);
+                    }
                 }
             }
             *reinterpret_cast<float4*>(part + 4 * tid) = s;
@@ -145,7 +206,7 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(AttnArgs a) {
 }  // namespace asr
 
 extern "C" size_t asr_attention_lds_bytes(int Te, int H, int A) {
-    return sizeof(float) * (size_t)(((H + 3) & ~3) + ((A + 3) & ~3) + ((Te + 3) & ~3) + 256 * 4);
+    return sizeof(float) * (size_t)(((H + 3) & ~3) + ((A + 3) & ~3) + ((Te + 3) & ~3) + 512 * 4);
 }
 
 extern "C" int asr_attention_fwd(void* stream, const float* q, int ldq, const float* w_att,
@@ -157,7 +218,7 @@ extern "C" int asr_attention_fwd(void* stream, const float* q, int ldq, const fl
     const size_t lds = asr_attention_lds_bytes(Te, H, A);
     if (lds > 150 * 1024) return ASR_EUNSUPPORTED;
     asr::AttnArgs a{q, ldq, w_att, b_att, v, hf, enc, enc_len, alpha, ctx, B, Te, H, A, D};
-    hipLaunchKernelGGL(asr::attention_fwd_kernel, dim3(B), dim3(256), lds, static_cast<hipStream_t>(stream), a);
+    hipLaunchKernelGGL(asr::attention_fwd_kernel, dim3(B), dim3(asr::ATT_NT), lds, static_cast<hipStream_t>(stream), a);
     ASR_CHECK_LAUNCH();
     return ASR_OK;
 }

@@ -27,7 +27,7 @@ struct DecBwdStepArgs {
     const float* hf; const float* enc; const int* enc_len; const float* alpha;
     const float* dqc;          // [B][H+D]: dq_ap | dctx_ap for this step
     const float* dctx_carry; int ld_carry;   // dLC[i+1][:, P:] or nullptr
-    float* dhf; float* denc;   // accumulators [B][Te][A], [B][Te][D]
+    float* dhf; float* dctx_out;   // accumulator [B][Te][A]; this step's total dctx [B][D]
     float* dy;                 // [B][A] this step
     float* dv_part;            // [B][A] accumulated over steps
     // outer cell operands
@@ -38,10 +38,12 @@ struct DecBwdStepArgs {
     int B, Te, H, A, D;
 };
 
-// dynamic LDS: dctx[D] | al[Te] (alpha, then de) | ys[A] | qs[H] | dys[A] | part[256*4]
-__global__ __launch_bounds__(256) void dec_attn_cell_bwd_kernel(DecBwdStepArgs a) {
+// dynamic LDS: dctx[D] | al[Te] (alpha, then de) | ys[A] | qs[H] | dys[A] | part[...]
+// 512 threads; each phase issues all of its global loads before consuming any.
+constexpr int DBW_NT = 512;
+__global__ __launch_bounds__(DBW_NT) void dec_attn_cell_bwd_kernel(DecBwdStepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int NT = 256;
+    constexpr int NT = DBW_NT, RW = NT / 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x;
     const int A = a.A, H = a.H, D = a.D, Te = a.Te;
@@ -51,44 +53,79 @@ __global__ __launch_bounds__(256) void dec_attn_cell_bwd_kernel(DecBwdStepArgs a
     float* qs = ys + ((A + 3) & ~3);
     float* dys = qs + ((H + 3) & ~3);
     float* part = dys + ((A + 3) & ~3);
-    __shared__ float wred[4];
+    __shared__ float wred[8];
     const int L = min(max(a.enc_len[b], 0), Te);
 
     for (int d = tid; d < D; d += NT) {
         float x = a.dqc[(size_t)b * (H + D) + H + d];
         if (a.dctx_carry) x += a.dctx_carry[(size_t)b * a.ld_carry + d];
         dctx[d] = x;
+        a.dctx_out[(size_t)b * D + d] = x;        // denc = sum_i alpha_i^T . dctx_i is a post-loop batched GEMM
     }
     for (int t = tid; t < Te; t += NT) al[t] = a.alpha[(size_t)b * Te + t];
     for (int k = tid; k < H; k += NT) qs[k] = a.q[(size_t)b * H + k];
     __syncthreads();
-    // ---- dalpha[tau] = dctx . enc[tau];  denc[tau] += alpha[tau] * dctx   (one DPP row per tau)
     const int kq = lane & 15, rr = tid >> 4;
-    float sdot = 0.f;      // sum_tau alpha*dalpha (lanes kq==0 only)
-    for (int tau = rr; tau < L; tau += NT / 16) {
-        const float* ep = a.enc + ((size_t)b * Te + tau) * D;
-        float* gp = a.denc + ((size_t)b * Te + tau) * D;
-        const float at = al[tau];
-        float s = 0.f;
-        for (int d4 = kq; d4 < (D >> 2); d4 += 16) {
-            const float4 ev = *reinterpret_cast<const float4*>(ep + 4 * d4);
-            const float4 dv = *reinterpret_cast<const float4*>(dctx + 4 * d4);
-            float4 gv = *reinterpret_cast<float4*>(gp + 4 * d4);
-            s = fmaf(ev.x, dv.x, s); s = fmaf(ev.y, dv.y, s); s = fmaf(ev.z, dv.z, s); s = fmaf(ev.w, dv.w, s);
-            gv.x = fmaf(at, dv.x, gv.x); gv.y = fmaf(at, dv.y, gv.y); gv.z = fmaf(at, dv.z, gv.z); gv.w = fmaf(at, dv.w, gv.w);
-            *reinterpret_cast<float4*>(gp + 4 * d4) = gv;
+    // ---- dalpha[tau] = dctx . enc[tau]  (one DPP row per tau; PP passes x CD chunks in flight)
+    {
+        constexpr int PP = 4, CD = 8;                 // D <= 512 fast path (CD*16 float4 per row)
+        const int nch = ((D >> 2) + 15) / 16;
+        float sdot = 0.f;
+        for (int t0 = 0; t0 < L; t0 += RW * PP) {
+            if (nch <= CD) {
+                float4 ev[PP][CD];
+#pragma unroll
+                for (int p = 0; p < PP; ++p) {
+                    const int tau = t0 + p * RW + rr;
+#pragma unroll
+                    for (int c = 0; c < CD; ++c) {
+                        const int d4 = kq + 16 * c;
+                        ev[p][c] = (tau < L && d4 < (D >> 2))
+                            ? *reinterpret_cast<const float4*>(a.enc + ((size_t)b * Te + tau) * D + 4 * d4)
+                            : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                }
+#pragma unroll
+                for (int p = 0; p < PP; ++p) {
+                    const int tau = t0 + p * RW + rr;
+                    float sc = 0.f;
+#pragma unroll
+                    for (int c = 0; c < CD; ++c) {
+                        const int d4 = kq + 16 * c;
+                        if (d4 < (D >> 2)) {
+                            const float4 dv = *reinterpret_cast<const float4*>(dctx + 4 * d4);
+                            sc = fmaf(ev[p][c].x, dv.x, sc); sc = fmaf(ev[p][c].y, dv.y, sc);
+                            sc = fmaf(ev[p][c].z, dv.z, sc); sc = fmaf(ev[p][c].w, dv.w, sc);
+                        }
+                    }
+                    sc = row16_allreduce_sum(sc);
+                    if (kq == 0 && tau < L) { part[tau] = sc; sdot += al[tau] * sc; }
+                }
+            } else {
+                for (int p = 0; p < PP; ++p) {
+                    const int tau = t0 + p * RW + rr;
+                    float sc = 0.f;
+                    if (tau < L)
+                        for (int d4 = kq; d4 < (D >> 2); d4 += 16) {
+                            const float4 e4 = *reinterpret_cast<const float4*>(a.enc + ((size_t)b * Te + tau) * D + 4 * d4);
+                            const float4 dv = *reinterpret_cast<const float4*>(dctx + 4 * d4);
+                            sc = fmaf(e4.x, dv.x, sc); sc = fmaf(e4.y, dv.y, sc); sc = fmaf(e4.z, dv.z, sc); sc = fmaf(e4.w, dv.w, sc);
+                        }
+                    sc = row16_allreduce_sum(sc);
+                    if (kq == 0 && tau < L) { part[tau] = sc; sdot += al[tau] * sc; }
+                }
+            }
         }
-        s = row16_allreduce_sum(s);
-        if (kq == 0) { part[tau] = s; sdot += at * s; }      // part[0..Te) holds dalpha for now
+        sdot = wave_allreduce_sum(kq == 0 ? sdot : 0.f);
+        if (lane == 0) wred[wave] = sdot;
+        __syncthreads();
+        float S = 0.f;
+#pragma unroll
+        for (int i = 0; i < NT / 64; ++i) S += wred[i];
+        for (int t = tid; t < L; t += NT) al[t] = al[t] * (part[t] - S);     // de[tau]
+        __syncthreads();
     }
-    // block sum of sdot in fixed order: lanes -> waves
-    sdot = wave_allreduce_sum(kq == 0 ? sdot : 0.f);
-    if (lane == 0) wred[wave] = sdot;
-    __syncthreads();
-    const float S = (wred[0] + wred[1]) + (wred[2] + wred[3]);
-    for (int t = tid; t < L; t += NT) al[t] = al[t] * (part[t] - S);     // de[tau]
-    __syncthreads();
-    // ---- y = q.W_att + b_att (recomputed; same decomposition as the forward kernel)
+    // ---- y = q.W_att + b_att (recomputed)
     {
         const int na4 = A >> 2;
         const int kparts = max(1, NT / na4);
@@ -97,11 +134,18 @@ __global__ __launch_bounds__(256) void dec_attn_cell_bwd_kernel(DecBwdStepArgs a
         if (kp < kparts) {
             const int kc = (H + kparts - 1) / kparts;
             const int k0 = kp * kc, k1 = min(H, k0 + kc);
-#pragma unroll 8
-            for (int k = k0; k < k1; ++k) {
-                const float4 wv = *reinterpret_cast<const float4*>(a.w_att + (size_t)k * A + 4 * a4);
-                const float qk = qs[k];
-                s.x = fmaf(qk, wv.x, s.x); s.y = fmaf(qk, wv.y, s.y); s.z = fmaf(qk, wv.z, s.z); s.w = fmaf(qk, wv.w, s.w);
+            constexpr int PB = 16;
+            for (int kb = k0; kb < k1; kb += PB) {
+                float4 wv[PB];
+#pragma unroll
+                for (int i = 0; i < PB; ++i)
+                    wv[i] = (kb + i < k1) ? *reinterpret_cast<const float4*>(a.w_att + (size_t)(kb + i) * A + 4 * a4)
+                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int i = 0; i < PB; ++i) {
+                    const float qk = (kb + i < k1) ? qs[kb + i] : 0.f;
+                    s.x = fmaf(qk, wv[i].x, s.x); s.y = fmaf(qk, wv[i].y, s.y); s.z = fmaf(qk, wv[i].z, s.z); s.w = fmaf(qk, wv[i].w, s.w);
+                }
             }
         }
         *reinterpret_cast<float4*>(part + 4 * tid) = s;
@@ -114,37 +158,61 @@ __global__ __launch_bounds__(256) void dec_attn_cell_bwd_kernel(DecBwdStepArgs a
         __syncthreads();
     }
     // ---- tanh backward: ds = de*v*(1-th^2); dhf += ds; dy[a] = sum_tau ds; dv[a] += sum_tau de*th
-    // lane kq owns float4 chunks a4 = kq, kq+16, ... (<= 4 chunks => A <= 256)
+    // lane kq owns float4 chunks a4 = kq, kq+16, ... (<= 4 chunks => A <= 256); PP passes in flight
     {
-        float4 dyl[4], dvl[4];
+        constexpr int PP = 4, CA = 4;
+        float4 dyl[CA], dvl[CA];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { dyl[c] = make_float4(0.f, 0.f, 0.f, 0.f); dvl[c] = dyl[c]; }
-        for (int tau = rr; tau < L; tau += NT / 16) {
-            const float de = al[tau];
-            const float* hp = a.hf + ((size_t)b * Te + tau) * A;
-            float* gp = a.dhf + ((size_t)b * Te + tau) * A;
+        for (int c = 0; c < CA; ++c) { dyl[c] = make_float4(0.f, 0.f, 0.f, 0.f); dvl[c] = dyl[c]; }
+        const bool two = (A >> 2) <= 32;              // A <= 128: 2 chunks per lane, keep 4 passes in flight
+        for (int t0 = 0; t0 < L; t0 += RW * PP) {
+            float4 hv[PP][2], gv[PP][2];
+            if (two) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int a4 = kq + 16 * c;
-                if (a4 < (A >> 2)) {
-                    const float4 hv = *reinterpret_cast<const float4*>(hp + 4 * a4);
-                    const float4 yv = *reinterpret_cast<const float4*>(ys + 4 * a4);
-                    const float4 vv = *reinterpret_cast<const float4*>(a.v + 4 * a4);
-                    float4 gv = *reinterpret_cast<float4*>(gp + 4 * a4);
-                    float th, ds;
-#define ASR_TB(f) th = fast_tanh(hv.f + yv.f); ds = de * vv.f * (1.f - th * th); gv.f += ds; dyl[c].f += ds; dvl[c].f = fmaf(de, th, dvl[c].f);
-                    ASR_TB(x) ASR_TB(y) ASR_TB(z) ASR_TB(w)
+                for (int p = 0; p < PP; ++p) {
+                    const int tau = t0 + p * RW + rr;
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const int a4 = kq + 16 * c;
+                        const bool ok = tau < L && a4 < (A >> 2);
+                        const size_t off = ((size_t)b * Te + (ok ? tau : 0)) * A + 4 * (ok ? a4 : 0);
+                        hv[p][c] = ok ? *reinterpret_cast<const float4*>(a.hf + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        gv[p][c] = ok ? *reinterpret_cast<const float4*>(a.dhf + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < PP; ++p) {
+                const int tau = t0 + p * RW + rr;
+                if (tau < L) {
+                    const float de = al[tau];
+#pragma unroll
+                    for (int c = 0; c < CA; ++c) {
+                        const int a4 = kq + 16 * c;
+                        if (a4 < (A >> 2) && (!two || c < 2)) {
+                            float* gp = a.dhf + ((size_t)b * Te + tau) * A + 4 * a4;
+                            float4 h4, g4;
+                            if (two) { h4 = hv[p][c & 1]; g4 = gv[p][c & 1]; }
+                            else { h4 = *reinterpret_cast<const float4*>(a.hf + ((size_t)b * Te + tau) * A + 4 * a4);
+                                   g4 = *reinterpret_cast<float4*>(gp); }
+                            const float4 yv = *reinterpret_cast<const float4*>(ys + 4 * a4);
+                            const float4 vv = *reinterpret_cast<const float4*>(a.v + 4 * a4);
+                            float th, ds;
+#define ASR_TB(f) th = fast_tanh(h4.f + yv.f); ds = de * vv.f * (1.f - th * th); g4.f += ds; dyl[c].f += ds; dvl[c].f = fmaf(de, th, dvl[c].f);
+                            ASR_TB(x) ASR_TB(y) ASR_TB(z) ASR_TB(w)
 #undef ASR_TB
-                    *reinterpret_cast<float4*>(gp + 4 * a4) = gv;
+                            *reinterpret_cast<float4*>(gp) = g4;
+                        }
+                    }
                 }
             }
         }
-        // reduce the 16 DPP rows of the block: through LDS, fixed order
+        // reduce the RW DPP rows of the block through LDS, fixed order
         __syncthreads();
-        float* pdy = part;                 // [16 rows][A]
-        float* pdv = part + 16 * A;        // needs 32*A floats <= 256*4 + slack (A <= 256 checked by the host)
+        float* pdy = part;                 // [RW rows][A]
+        float* pdv = part + RW * A;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < CA; ++c) {
             const int a4 = kq + 16 * c;
             if (a4 < (A >> 2)) {
                 *reinterpret_cast<float4*>(pdy + rr * A + 4 * a4) = dyl[c];
@@ -154,39 +222,59 @@ __global__ __launch_bounds__(256) void dec_attn_cell_bwd_kernel(DecBwdStepArgs a
         __syncthreads();
         for (int aa = tid; aa < A; aa += NT) {
             float sy = 0.f, sv = 0.f;
-            for (int r = 0; r < 16; ++r) { sy += pdy[r * A + aa]; sv += pdv[r * A + aa]; }
+            for (int r = 0; r < RW; ++r) { sy += pdy[r * A + aa]; sv += pdv[r * A + aa]; }
             dys[aa] = sy;
             a.dy[(size_t)b * A + aa] = sy;
             a.dv_part[(size_t)b * A + aa] += sv;
         }
         __syncthreads();
     }
-    // ---- dq = dq_ap + dy.W_att^T + dc_carry, then the outer cell's pointwise backward
-    for (int k = tid; k < H; k += NT) {
-        const float* wr = a.w_att + (size_t)k * A;
-        float s0 = 0.f, s1 = 0.f;
-        for (int a4 = 0; a4 < (A >> 2); a4 += 2) {
-            const float4 w0 = *reinterpret_cast<const float4*>(wr + 4 * a4);
-            const float4 y0 = *reinterpret_cast<const float4*>(dys + 4 * a4);
-            s0 = fmaf(w0.x, y0.x, s0); s0 = fmaf(w0.y, y0.y, s0); s0 = fmaf(w0.z, y0.z, s0); s0 = fmaf(w0.w, y0.w, s0);
-            if (a4 + 1 < (A >> 2)) {
-                const float4 w1 = *reinterpret_cast<const float4*>(wr + 4 * a4 + 4);
-                const float4 y1 = *reinterpret_cast<const float4*>(dys + 4 * a4 + 4);
-                s1 = fmaf(w1.x, y1.x, s1); s1 = fmaf(w1.y, y1.y, s1); s1 = fmaf(w1.z, y1.z, s1); s1 = fmaf(w1.w, y1.w, s1);
+    // ---- dq = dq_ap + dy.W_att^T + dc_carry : NT/H threads per k share the A range through LDS
+    {
+        const int tpk = max(1, NT / H);               // threads per output k
+        const int k = tid / tpk, sub = tid % tpk;
+        float s0 = 0.f;
+        if (k < H) {
+            const int na4 = A >> 2;
+            const int c0 = sub * ((na4 + tpk - 1) / tpk), c1 = min(na4, c0 + (na4 + tpk - 1) / tpk);
+            const float* wr = a.w_att + (size_t)k * A;
+            constexpr int PB = 16;
+            for (int cb = c0; cb < c1; cb += PB) {
+                float4 wv[PB];
+#pragma unroll
+                for (int i = 0; i < PB; ++i)
+                    wv[i] = (cb + i < c1) ? *reinterpret_cast<const float4*>(wr + 4 * (cb + i)) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int i = 0; i < PB; ++i)
+                    if (cb + i < c1) {
+                        const float4 y0 = *reinterpret_cast<const float4*>(dys + 4 * (cb + i));
+                        s0 = fmaf(wv[i].x, y0.x, s0); s0 = fmaf(wv[i].y, y0.y, s0); s0 = fmaf(wv[i].z, y0.z, s0); s0 = fmaf(wv[i].w, y0.w, s0);
+                    }
             }
         }
-        const float dq = a.dqc[(size_t)b * (H + D) + k] + (s0 + s1) + a.dc_carry[(size_t)b * H + k];
-        const float dh = a.dh_carry ? a.dh_carry[(size_t)b * a.ld_dh + k] : 0.f;
-        float* gp = a.gates + (size_t)b * 4 * H + k;
-        const float gi = gp[0], gj = gp[H], gf = gp[2 * H], go = gp[3 * H];
-        const float cp = a.c_prev ? a.c_prev[(size_t)b * H + k] : 0.f;
-        const float tc = fast_tanh(qs[k]);
-        const float dct = dq + dh * go * (1.f - tc * tc);
-        gp[0] = dct * gj * gi * (1.f - gi);
-        gp[H] = dct * gi * (1.f - gj * gj);
-        gp[2 * H] = dct * cp * gf * (1.f - gf);
-        gp[3 * H] = dh * tc * go * (1.f - go);
-        a.dc_carry[(size_t)b * H + k] = dct * gf;
+        part[tid] = s0;
+        __syncthreads();
+        // ---- outer cell pointwise backward (one thread per unit)
+        for (int kk = tid; kk < H; kk += NT) {
+            float dq_att = 0.f;
+            if (kk * tpk + tpk <= NT) { for (int i = 0; i < tpk; ++i) dq_att += part[kk * tpk + i]; }
+            else {       // H > NT: recompute serially (not hit at the supported sizes)
+                const float* wr = a.w_att + (size_t)kk * A;
+                for (int aa = 0; aa < A; ++aa) dq_att = fmaf(wr[aa], dys[aa], dq_att);
+            }
+            const float dq = a.dqc[(size_t)b * (H + D) + kk] + dq_att + a.dc_carry[(size_t)b * H + kk];
+            const float dh = a.dh_carry ? a.dh_carry[(size_t)b * a.ld_dh + kk] : 0.f;
+            float* gp = a.gates + (size_t)b * 4 * H + kk;
+            const float gi = gp[0], gj = gp[H], gf = gp[2 * H], go = gp[3 * H];
+            const float cp = a.c_prev ? a.c_prev[(size_t)b * H + kk] : 0.f;
+            const float tc = fast_tanh(qs[kk]);
+            const float dct = dq + dh * go * (1.f - tc * tc);
+            gp[0] = dct * gj * gi * (1.f - gi);
+            gp[H] = dct * gi * (1.f - gj * gj);
+            gp[2 * H] = dct * cp * gf * (1.f - gf);
+            gp[3 * H] = dh * tc * go * (1.f - go);
+            a.dc_carry[(size_t)b * H + kk] = dct * gf;
+        }
     }
 }
 
@@ -224,7 +312,7 @@ extern "C" int asr_scatter_add_rows_ld(void*, float*, const int*, const float*, 
 
 static size_t dec_bwd_lds(int Te, int H, int A, int D) {
     auto r4 = [](int x) { return (size_t)((x + 3) & ~3); };
-    const size_t part = std::max<size_t>(256 * 4, std::max<size_t>(32 * (size_t)A, r4(Te)));
+    const size_t part = std::max<size_t>(512 * 4, std::max<size_t>(64 * (size_t)A, r4(Te)));
     return sizeof(float) * (r4(D) + r4(Te) + 2 * r4(A) + r4(H) + part);
 }
 
@@ -261,13 +349,13 @@ extern "C" int asr_attn_decoder_bwd(void* stream, const asr_dec_weights* w, cons
         a.hf = ws->hf; a.enc = enc; a.enc_len = enc_len; a.alpha = ws->alpha + o * Te;
         a.dqc = bw->dQC + o * (H + D);
         a.dctx_carry = last ? nullptr : bw->dLC + (o + B) * ldLC + P; a.ld_carry = ldLC;
-        a.dhf = bw->dhf; a.denc = denc; a.dy = bw->dY + o * A; a.dv_part = bw->dv_part;
+        a.dhf = bw->dhf; a.dctx_out = bw->dctx + o * D; a.dy = bw->dY + o * A; a.dv_part = bw->dv_part;
         a.gates = ws->dec_gates + o * 4 * H;
         a.c_prev = i ? ws->dec_c + (o - B) * H : nullptr;
         a.dh_carry = last ? nullptr : bw->dXH + (o + B) * ldXH + E; a.ld_dh = ldXH;
         a.dc_carry = bw->dc_dec;
         a.B = B; a.Te = Te; a.H = H; a.A = A; a.D = D;
-        hipLaunchKernelGGL(dec_attn_cell_bwd_kernel, dim3(B), dim3(256), lds, s, a);
+        hipLaunchKernelGGL(dec_attn_cell_bwd_kernel, dim3(B), dim3(DBW_NT), lds, s, a);
         // [dx | dh_prev] = dG_dec . K_dec^T
         if ((rc = asr_linear_wt_fwd(stream, ws->dec_gates + o * 4 * H, 4 * H, 4 * H, w->dec_kernel, 4 * H,
                                     bw->dXH + o * ldXH, ldXH, B, E + H, 0))) return rc;
@@ -333,6 +421,9 @@ extern "C" int asr_attn_decoder_bwd(void* stream, const asr_dec_weights* w, cons
                              gw + (size_t)E * 4 * lmH))) return rc;
     if ((rc = asr_colsum_f32(stream, ws->lm_gates, 4 * lmH, TB, 4 * lmH, const_cast<float*>(g->lm_bias), 1))) return rc;
     if ((rc = asr_scatter_add_rows_ld(stream, const_cast<float*>(g->embedding), ws->tok, bw->dEH, TB, E, ldEH))) return rc;
+    // denc[b] += sum_i alpha_i[b,:]^T . dctx_i[b,:]  -- one batched GEMM over the B utterances
+    if ((rc = asr_gemm_f32_batched(stream, 1, 0, Te, D, T, ws->alpha, B * Te, Te, bw->dctx, B * D, D, denc, D,
+                                   (long long)Te * D, nullptr, 1, B))) return rc;
     // AttnW and the encoder-state gradient through hf = enc.AttnW
     if ((rc = wgrad(D, A, B * Te, enc, D, bw->dhf, A, const_cast<float*>(g->attn_enc_w)))) return rc;
     if ((rc = asr_gemm_f32(stream, 0, 1, B * Te, D, A, bw->dhf, A, w->attn_enc_w, A, denc, D, nullptr, 1))) return rc;

@@ -26,6 +26,7 @@ struct GemmArgs {
     int accumulate;   // C += result
     int splits;       // K split over blockIdx.y; >1 => atomicAdd epilogue into a pre-zeroed / accumulated C
     int vecA, vecB;   // 16-B vector loads legal for this operand
+    long long sA, sB, sC;   // batch strides (elements); batch index = blockIdx.z
 };
 
 // Load 4 consecutive floats p[0..3] where element i is valid iff i < nvalid.
@@ -88,6 +89,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
     __shared__ __attribute__((aligned(16))) float Bs[BK * LDT];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid >> 1, wc = wid & 1;
+    a.A += (size_t)blockIdx.z * a.sA; a.B += (size_t)blockIdx.z * a.sB; a.C += (size_t)blockIdx.z * a.sC;
 
     // XCD-aware tile order: blocks b and b+8 share an L2, so give each XCD label a
     // contiguous run of row-tiles that re-use the same B panel / neighbouring A panels.
@@ -165,10 +167,21 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
 // ---------------------------------------------------------------------------------
 // C ABI (declared in include/e2e_asr_hip.h)
 // ---------------------------------------------------------------------------------
+extern "C" int asr_gemm_f32_batched(void* stream, int transA, int transB, int M, int N, int K,
+                                    const float* A, int lda, long long strideA, const float* B, int ldb, long long strideB,
+                                    float* C, int ldc, long long strideC, const float* bias, int accumulate, int batch);
+
 extern "C" int asr_gemm_f32(void* stream, int transA, int transB, int M, int N, int K,
                             const float* A, int lda, const float* B, int ldb,
                             float* C, int ldc, const float* bias, int accumulate) {
+    return asr_gemm_f32_batched(stream, transA, transB, M, N, K, A, lda, 0, B, ldb, 0, C, ldc, 0, bias, accumulate, 1);
+}
+
+extern "C" int asr_gemm_f32_batched(void* stream, int transA, int transB, int M, int N, int K,
+                                    const float* A, int lda, long long strideA, const float* B, int ldb, long long strideB,
+                                    float* C, int ldc, long long strideC, const float* bias, int accumulate, int batch) {
     using namespace asr;
+    if (batch <= 0) return ASR_EINVAL;
     if (M < 0 || N < 0 || K < 0 || !C || (K > 0 && (!A || !B))) return ASR_EINVAL;
     if (M == 0 || N == 0) return ASR_OK;
     if (lda < (transA ? M : K) || ldb < (transB ? K : N) || ldc < N) return ASR_EINVAL;
@@ -176,8 +189,9 @@ extern "C" int asr_gemm_f32(void* stream, int transA, int transB, int M, int N, 
     g.A = A; g.B = B; g.C = C; g.bias = bias;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.accumulate = accumulate;
-    g.vecA = ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && (lda % 4 == 0);
-    g.vecB = ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && (ldb % 4 == 0);
+    g.sA = strideA; g.sB = strideB; g.sC = strideC;
+    g.vecA = ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && (lda % 4 == 0) && (strideA % 4 == 0);
+    g.vecB = ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && (ldb % 4 == 0) && (strideB % 4 == 0);
     const int nwg = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     hipStream_t s = static_cast<hipStream_t>(stream);
     // Few output tiles but a long K (weight gradients X^T.dY with K = B*T): split K over
@@ -185,7 +199,7 @@ extern "C" int asr_gemm_f32(void* stream, int transA, int transB, int M, int N, 
     // (summation order, hence the last bits, may differ from run to run).
     int splits = 1;
     const int nk = (K + BK - 1) / BK;
-    if (transA && nwg < 192 && nk >= 64) {     // weight-gradient form only: forward products stay bit-reproducible
+    if (transA && batch == 1 && nwg < 192 && nk >= 64) {     // weight-gradient form only: forward products stay bit-reproducible
         splits = std::min((768 + nwg - 1) / nwg, nk / 16);
         if (const char* e = getenv("ASR_GEMM_SPLITK")) splits = std::max(1, atoi(e));
     }
@@ -193,10 +207,10 @@ extern "C" int asr_gemm_f32(void* stream, int transA, int transB, int M, int N, 
     if (splits > 1 && !accumulate) {
         if (hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, s) != hipSuccess) return ASR_ELAUNCH;
     }
-    if (transA && transB)       hipLaunchKernelGGL((gemm_f32_kernel<true, true>), dim3(nwg, splits), dim3(256), 0, s, g);
-    else if (transA)            hipLaunchKernelGGL((gemm_f32_kernel<true, false>), dim3(nwg, splits), dim3(256), 0, s, g);
-    else if (transB)            hipLaunchKernelGGL((gemm_f32_kernel<false, true>), dim3(nwg, splits), dim3(256), 0, s, g);
-    else                        hipLaunchKernelGGL((gemm_f32_kernel<false, false>), dim3(nwg, splits), dim3(256), 0, s, g);
+    if (transA && transB)       hipLaunchKernelGGL((gemm_f32_kernel<true, true>), dim3(nwg, splits, batch), dim3(256), 0, s, g);
+    else if (transA)            hipLaunchKernelGGL((gemm_f32_kernel<true, false>), dim3(nwg, splits, batch), dim3(256), 0, s, g);
+    else if (transB)            hipLaunchKernelGGL((gemm_f32_kernel<false, true>), dim3(nwg, splits, batch), dim3(256), 0, s, g);
+    else                        hipLaunchKernelGGL((gemm_f32_kernel<false, false>), dim3(nwg, splits, batch), dim3(256), 0, s, g);
     ASR_CHECK_LAUNCH();
     return ASR_OK;
 }

@@ -348,7 +348,7 @@ def attn_decoder_bwd(wt, gt, ws, enc, enc_len, dlogits, denc, keep_lm=1.0, seed=
     P = H if wt.get("simple_w") is not None else lmH
     bw = dict(dP=f(T, B, H), dQC=f(T, B, H + D), dY=f(T, B, A), dXH=f(T, B, E + H), dLC=f(T, B, P + D),
               dlm=f(T, B, lmH) if wt.get("simple_w") is not None else None, dEH=f(T, B, E + lmH),
-              dc_dec=f(B, H), dc_lm=f(B, lmH), dhf=f(B, Te, A), dv_part=f(B, A), emb_all=f(T, B, E))
+              dc_dec=f(B, H), dc_lm=f(B, lmH), dhf=f(B, Te, A), dv_part=f(B, A), dctx=f(T, B, D), emb_all=f(T, B, E))
     cw = _dec_struct(_lib.DecWeights, wt)
     cg = _dec_struct(_lib.DecWeights, gt)
     cd = _lib.DecDims(B, Te, D, A, H, lmH, E, V, T)

@@ -27,6 +27,11 @@ int asr_gemm_f32(void* stream, int transA, int transB, int M, int N, int K,
                  const float* A, int lda, const float* B, int ldb,
                  float* C, int ldc, const float* bias, int accumulate);
 
+/* Batched form: batch b uses A + b*strideA, B + b*strideB, C + b*strideC (strides in elements). */
+int asr_gemm_f32_batched(void* stream, int transA, int transB, int M, int N, int K,
+                         const float* A, int lda, long long strideA, const float* B, int ldb, long long strideB,
+                         float* C, int ldc, long long strideC, const float* bias, int accumulate, int batch);
+
 /* One (Bi)LSTM encoder layer over a whole padded batch -- encoder.py:55-91
  * (bidirectional_dynamic_rnn / dynamic_rnn over BasicLSTMCell with sequence_length).
  * x [B,T,in] batch-major (row stride ldx); out [B,Tout,ndir*H] with fw in [:H], bw in
@@ -168,6 +173,7 @@ typedef struct {              /* backward scratch (device), sized by the caller 
     float* dc_lm;             /* [B,lmH] carry */
     float* dhf;               /* [B,Te,A] */
     float* dv_part;           /* [B,A] */
+    float* dctx;              /* [T_out,B,D] total gradient w.r.t. each step's context */
     float* emb_all;           /* [T_out,B,E] gathered embeddings */
 } asr_dec_bwd_ws;
 
