@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--mode", default="auto", choices=["auto", "train", "fwd"])
     ap.add_argument("--variable-len", action="store_true", help="lengths U[400,800] (masking run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="EXPERIMENT: replay one captured step as a hipGraph (step-varying scalars frozen)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -118,7 +119,19 @@ def main():
         one_step()
     torch.cuda.synchronize()
     ops.check_device_flag(dev)
-    ops.prof_enable(True)
+    if args.graph:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            one_step()
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            one_step()
+        eager_step = one_step
+        one_step = g.replay
+        one_step(); torch.cuda.synchronize()
+    ops.prof_enable(not args.graph)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()

@@ -9,6 +9,7 @@ import torch
 
 from . import ops
 from .decoder import Decoder
+from .devcache import dev_i32
 from .weights import dec_name
 
 
@@ -62,9 +63,9 @@ class AttnDecoder(Decoder):
         keep_lm = p.out_prob_dec if self.isTraining else 1.0
         tok = decoder_inp if decoder_inp.dtype == torch.int32 else decoder_inp.to(torch.int32)
         enc = encoder_hidden_states.contiguous()
-        enc_len_dev = torch.from_numpy(np.asarray(seq_len_inp).astype(np.int32)).to(dev)
+        enc_len_dev = dev_i32(seq_len_inp, dev)
         logits, ws = ops.attn_decoder_fwd(
-            self.weight_tensors(), tok.to(dev), torch.from_numpy(seq_len.astype(np.int32)).to(dev),
+            self.weight_tensors(), tok.to(dev), dev_i32(seq_len, dev),
             enc, enc_len_dev, mode=mode, coin=coin, samp_prob=p.samp_prob, keep_lm=keep_lm,
             seed=self.rng_seed, t_out=t_out)
         self.saved = dict(ws=ws, seq_len=seq_len, t_out=t_out, keep_lm=keep_lm, seed=self.rng_seed,

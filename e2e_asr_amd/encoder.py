@@ -12,6 +12,7 @@ import torch
 
 from . import ops
 from .base_params import BaseParams, Bunch
+from .devcache import dev_i32
 from .weights import enc_name
 
 
@@ -81,7 +82,7 @@ class Encoder(BaseParams):
             B, T, _ = x.shape
             reduce_after = params.skip_step > 1 and i != max_depth - 1 and res < params.max_scaling_down
             t_out = self._pyramid_plan(T, lens) if reduce_after else T
-            lens_dev = torch.from_numpy(lens.astype(np.int32)).to(x.device)
+            lens_dev = dev_i32(lens, x.device)
             kf, bf, kb, bb = self._layer_weights(d)
             seed = (self.dropout_seed * 1000003 + d * 7919) & 0x7FFFFFFF
             r = ops.lstm_layer_fwd(x, lens_dev, kf, bf, kb, bb, t_out=t_out, save=save,

@@ -3,6 +3,7 @@ import numpy as np
 import torch
 
 from . import ops
+from .devcache import dev_i32
 
 
 class LossUtils(object):
@@ -12,7 +13,7 @@ class LossUtils(object):
         Masked sparse softmax CE, per-utterance length-normalised, batch mean."""
         dev = logits.device
         tg = targets.to(device=dev, dtype=torch.int32).contiguous()
-        ln = torch.as_tensor(np.asarray(seq_len_target).astype(np.int32)).to(dev)
+        ln = dev_i32(seq_len_target, dev)
         loss, lse = ops.masked_ce(logits, tg, ln)
         if return_ws:
             return loss, dict(lse=lse, targets=tg, len=ln)

@@ -13,6 +13,7 @@ import torch
 from . import ops
 from .attn_decoder import AttnDecoder
 from .base_params import BaseParams, Bunch
+from .devcache import dev_i32
 from .encoder import Encoder
 from .losses import LossUtils
 from .variables import VariableStore
@@ -23,7 +24,7 @@ def create_shifted_targets(dec_input, seq_len):
     """tf_utils.py:4-12: targets = dec_input[1:]; weights = time-major length mask, flattened."""
     targets = dec_input[1:]
     T = targets.shape[0]
-    ln = torch.as_tensor(np.asarray(seq_len)).to(targets.device)
+    ln = dev_i32(seq_len, targets.device)
     w = (torch.arange(T, device=targets.device)[:, None] < ln[None, :]).to(torch.float32)
     return targets, w.reshape(-1)
 
@@ -102,8 +103,11 @@ class Seq2SeqModel(BaseParams):
             x = torch.cat(parts, 2)
         dec_in, dec_len = {}, {}
         for task in self.params.tasks:
-            ids = torch.as_tensor(np.asarray(batch[task])).to(dev)
-            dec_in[task] = ids.t().contiguous().to(torch.int32)         # :189
+            ids = batch[task]
+            if torch.is_tensor(ids):
+                dec_in[task] = ids.to(dev).t().contiguous().to(torch.int32)
+            else:
+                dec_in[task] = dev_i32(np.asarray(ids).T, dev)            # :189 (time-major)
             ln = np.asarray(batch[task + "_len"]).astype(np.int64)
             if not self.isTraining:                                       # :191-193
                 ln = np.ones_like(ln) * self.params.max_output[task]
