@@ -70,6 +70,7 @@ SIGNATURES = {
                                     vp, vp, vp, vp, C.c_float, C.c_uint, C.c_uint]),
     "asr_attention_lds_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "asr_attention_fwd": (C.c_int, [vp, vp, C.c_int] + [vp] * 8 + [C.c_int] * 5),
+    "asr_attention_shared_fwd": (C.c_int, [vp, vp, C.c_int] + [vp] * 8 + [C.c_int] * 6),
     "asr_masked_ce_fwd": (C.c_int, [vp] * 7 + [C.c_int] * 3),
     "asr_masked_ce_bwd": (C.c_int, [vp] * 7 + [C.c_int] * 3),
     "asr_next_token": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_uint, C.c_uint]),

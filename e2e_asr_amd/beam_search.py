@@ -1,0 +1,199 @@
+"""Beam search with LM shallow fusion, batch 1 -- device counterpart of the reference's
+beam_search.py (31-338).
+
+The reference runs everything in NumPy float64, one hypothesis at a time.  Here the k live
+hypotheses of a step are the rows of one small batch on the GPU: both LSTM cells, the
+projections, the attention (encoder states shared by all rows) and the external LM run through
+the same HIP step kernels as training.  What stays on the host is what the reference's
+semantics are defined by: log-softmax + `log p_dec + lm_weight * log p_lm` in float64 on the
+device logits, `np.argpartition` top-k per hypothesis and over the k*k continuations
+(:214, :300), parent = idx // k (:306), EOS shrinking the beam (:323-327) and first-max
+selection of the result (:336).  Token indices therefore equal the float64 oracle's unless two
+candidates tie within float32 logit resolution (~1e-6).
+"""
+import numpy as np
+import torch
+
+from . import data_utils, ops
+from .base_params import BaseParams, Bunch
+from .beam_entry import BeamEntry
+
+
+def _log_softmax64(x):
+    x = x.astype(np.float64)
+    e = np.exp(x - x.max(axis=-1, keepdims=True))
+    return np.log(e / e.sum(axis=-1, keepdims=True))          # num_utils.softmax then np.log (:196-198)
+
+
+class BeamSearch(BaseParams):
+    @classmethod
+    def class_params(cls):
+        # beam_search.py:19-29
+        return Bunch(beam_size=4, lm_weight=0.0, lm_path="", word_ins_penalty=0, cov_penalty=0.0)
+
+    def __init__(self, ckpt_path, search_params=None, device="cuda:0"):
+        """ckpt_path: dict name -> array, or an .npz holding TF-named variables (the reference
+        reads a TF checkpoint through tf_utils.get_matching_variables, tf_utils.py:66-90)."""
+        self.device = torch.device(device)
+        self.search_params = self.class_params() if search_params is None else search_params
+        self.dec_params = self.map_dec_variables(self.get_model_params(ckpt_path))
+        sp = self.search_params
+        self.use_lm = not (sp.lm_path is None or sp.lm_weight == 0.0)
+        if not self.use_lm:
+            print("No separate LM used")
+        # the reference always loads LM params, even when lm_weight == 0 (beam_search.py:45-46)
+        lm_src = sp.lm_path if sp.lm_path not in (None, "") else ckpt_path
+        self.lm_params = self.map_lm_variables(self.get_model_params(lm_src))
+        print("Using a beam size of %d" % sp.beam_size)
+
+    # ---- weights -------------------------------------------------------------------
+    def get_model_params(self, ckpt_path):
+        """Variables whose name contains 'rnn_decoder_char', skipping optimizer slots."""
+        if isinstance(ckpt_path, dict):
+            arrays = ckpt_path
+        else:
+            arrays = dict(np.load(ckpt_path))
+        return {k: np.asarray(v) for k, v in arrays.items() if "rnn_decoder_char" in k and "Adam" not in k}
+
+    def _t(self, a):
+        return None if a is None else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.device)
+
+    def map_dec_variables(self, var_dict):
+        """beam_search.py:53-109 (AttnW squeezed to [D,A])."""
+        pre = "model/rnn_decoder_char/"
+        g = lambda leaf: var_dict[pre + leaf]
+        opt = lambda leaf: var_dict.get(pre + leaf)
+        aw = g("AttnW")
+        p = Bunch(
+            lm_lstm_w=g("rnn/basic_lstm_cell/kernel"), lm_lstm_b=g("rnn/basic_lstm_cell/bias"),
+            dec_lstm_w=g("rnn/basic_lstm_cell_1/kernel"), dec_lstm_b=g("rnn/basic_lstm_cell_1/bias"),
+            attn_dec_w=g("rnn/Attention/kernel"), attn_dec_b=g("rnn/Attention/bias"),
+            inp_w=g("rnn/InputProjection/kernel"), inp_b=g("rnn/InputProjection/bias"),
+            attn_proj_w=g("rnn/AttnProjection/kernel"), attn_proj_b=g("rnn/AttnProjection/bias"),
+            out_w=g("rnn/OutputProjection/kernel"), out_b=g("rnn/OutputProjection/bias"),
+            simple_w=opt("rnn/SimpleProjection/kernel"), simple_b=opt("rnn/SimpleProjection/bias"),
+            attn_enc_w=aw.reshape(aw.shape[-2], aw.shape[-1]), attn_v=g("AttnV"), embedding=g("decoder/embedding"))
+        total = sum(int(np.prod(v.shape)) for v in p.values() if v is not None)
+        print("Total parameters in decoder (in million): %.2f" % (total / 1e6))
+        return Bunch({k: self._t(v) for k, v in p.items()})
+
+    def map_lm_variables(self, var_dict):
+        """beam_search.py:111-134."""
+        pre = "model/rnn_decoder_char/"
+        g = lambda leaf: var_dict[pre + leaf]
+        opt = lambda leaf: var_dict.get(pre + leaf)
+        p = Bunch(lstm_w=g("rnn/basic_lstm_cell/kernel"), lstm_b=g("rnn/basic_lstm_cell/bias"),
+                  simple_w=opt("rnn/SimpleProjection/kernel"), simple_b=opt("rnn/SimpleProjection/bias"),
+                  out_w=g("rnn/OutputProjection/kernel"), out_b=g("rnn/OutputProjection/bias"),
+                  embedding=g("decoder/embedding"))
+        return Bunch({k: self._t(v) for k, v in p.items()})
+
+    # ---- one step for all live hypotheses ------------------------------------------------
+    def calc_attention(self, encoder_hidden_states):
+        """beam_search.py:137-161: the encoder term enc . W_enc is computed once (one MFMA GEMM);
+        returns a closure q[k,H] -> (ctx[k,D], alpha[k,T])."""
+        enc = encoder_hidden_states
+        if enc.ndim == 3:
+            enc = enc[0]
+        enc = torch.as_tensor(np.ascontiguousarray(enc, dtype=np.float32)).to(self.device) \
+            if not torch.is_tensor(enc) else enc.to(self.device, torch.float32).contiguous()
+        p = self.dec_params
+        hf = ops.gemm(enc, p.attn_enc_w)
+        ln = torch.tensor([enc.shape[0]], dtype=torch.int32, device=self.device)
+
+        def attention(q):
+            return ops.attention(q, p.attn_dec_w, p.attn_dec_b, p.attn_v, hf, enc, ln, shared=True)
+        attention.enc = enc
+        return attention
+
+    def top_k_setup_with_lm(self, encoder_hidden_states):
+        """beam_search.py:163-221, batched over hypotheses.  state = dict of device tensors with one
+        row per hypothesis: dec (c,h), dec_lm (c,h), lm (c,h), ctx."""
+        p, lp, sp = self.dec_params, self.lm_params, self.search_params
+        attention = self.calc_attention(encoder_hidden_states)
+
+        def get_top_k(tokens, state, beam_size=sp.beam_size):
+            tok = torch.as_tensor(np.asarray(tokens, dtype=np.int32)).to(self.device)
+            dlc, dlh = ops.lstm_cell(p.embedding, state["dlh"], state["dlc"], p.lm_lstm_w, p.lm_lstm_b, gather=tok)
+            o = dlh
+            if p.simple_w is not None:
+                o = ops.linear(o, p.simple_w, p.simple_b)
+            x_dec = ops.linear(o, p.inp_w, p.inp_b, x2=state["ctx"])                       # :188-189
+            dc, dh = ops.lstm_cell(x_dec, state["dh"], state["dc"], p.dec_lstm_w, p.dec_lstm_b)
+            ctx, _ = attention(dc)                                                        # :193 (query = c)
+            proj = ops.linear(dc, p.attn_proj_w, p.attn_proj_b, x2=ctx)
+            logits = ops.linear(proj, p.out_w, p.out_b)
+            lc, lh = ops.lstm_cell(lp.embedding, state["lh"], state["lc"], lp.lstm_w, lp.lstm_b, gather=tok)  # :200
+            lo = lh
+            if lp.simple_w is not None:
+                lo = ops.linear(lo, lp.simple_w, lp.simple_b)
+            logits_lm = ops.linear(lo, lp.out_w, lp.out_b)
+            both = torch.stack((logits, logits_lm)).cpu().numpy()                         # one D2H copy per step
+            comb = _log_softmax64(both[0]) + sp.lm_weight * _log_softmax64(both[1])       # :208
+            score = comb + 0.0                                                            # :210-212
+            new_state = dict(dc=dc, dh=dh, dlc=dlc, dlh=dlh, lc=lc, lh=lh, ctx=ctx)
+            out = []
+            for r in range(comb.shape[0]):
+                idx = np.argpartition(score[r], -beam_size)[-beam_size:]                  # :214
+                out.append((idx, comb[r][idx], score[r][idx]))
+            return out, new_state
+        return get_top_k
+
+    def _zero_state(self, k, D):
+        p, lp = self.dec_params, self.lm_params
+        z = lambda n: torch.zeros((k, n), device=self.device, dtype=torch.float32)
+        return dict(dc=z(p.dec_lstm_w.shape[1] // 4), dh=z(p.dec_lstm_w.shape[1] // 4),
+                    dlc=z(p.lm_lstm_w.shape[1] // 4), dlh=z(p.lm_lstm_w.shape[1] // 4),
+                    lc=z(lp.lstm_w.shape[1] // 4), lh=z(lp.lstm_w.shape[1] // 4), ctx=z(D))
+
+    def __call__(self, encoder_hidden_states):
+        """Beam search for batch size 1 (beam_search.py:224-338)."""
+        sp = self.search_params
+        get_top_k = self.top_k_setup_with_lm(encoder_hidden_states)
+        D = encoder_hidden_states.shape[-1]
+        k = sp.beam_size
+        output_list, final_output_list = [], []
+        # step 0 from the GO symbol and zero states (:232-266)
+        res, state = get_top_k([data_utils.GO_ID], self._zero_state(1, D), beam_size=k)
+        idx, mscore, _ = res[0]
+        rows = []
+        for i in range(idx.shape[0]):
+            tup = (BeamEntry([int(idx[i])], 0, 0), mscore[i])
+            if idx[i] == data_utils.EOS_ID:
+                final_output_list.append(tup); k -= 1
+            else:
+                output_list.append(tup); rows.append(0)
+        step_count = 1
+        while step_count < 120 and k > 0:                                                   # :269
+            sel = torch.as_tensor(np.asarray(rows, dtype=np.int64)).to(self.device)
+            cur = {n: t.index_select(0, sel) for n, t in state.items()}                      # one row per live hypothesis
+            res, state = get_top_k([c.get_last_output() for c, _ in output_list], cur, beam_size=k)
+            score_list = [r[2] + cs for r, (_, cs) in zip(res, output_list)]                 # :290
+            model_score_list = [r[1] + cs for r, (_, cs) in zip(res, output_list)]
+            all_scores = np.concatenate(score_list); all_model = np.concatenate(model_score_list)
+            all_indices = np.concatenate([r[0] for r in res])
+            top = np.argpartition(all_scores, -k)[-k:]                                       # :300
+            nxt, tsc = all_indices[top], all_model[top]
+            orig = top // k                                                                  # :306
+            new_list, rows = [], []
+            for j in range(k):
+                oc = int(orig[j])
+                seq = output_list[oc][0].get_index_seq() + [int(nxt[j])]
+                tup = (BeamEntry(seq, oc, oc), tsc[j] + sp.word_ins_penalty * len(seq))        # :320-322
+                if nxt[j] == data_utils.EOS_ID:
+                    final_output_list.append(tup); k -= 1
+                else:
+                    new_list.append(tup); rows.append(oc)
+            output_list = new_list
+            step_count += 1
+        final_output_list += output_list                                                     # :334
+        best = max(final_output_list, key=lambda t: t[1])                                    # :336
+        return np.stack(best[0].get_index_seq(), axis=0)
+
+    @classmethod
+    def add_parse_options(cls, parser):
+        # beam_search.py:340-350
+        parser.add_argument("-beam_size", default=1, type=int, help="Beam size")
+        parser.add_argument("-lm_weight", default=0.0, type=float, help="LM weight in decoding")
+        parser.add_argument("-lm_path", default="", type=str, help="LM ckpt path")
+        parser.add_argument("-cov_penalty", default=0.0, type=float, help="Coverage penalty")

@@ -26,6 +26,8 @@ struct AttnArgs {
     float* alpha;                     // [B][Te]
     float* ctx;                       // [B][D]
     int B, Te, H, A, D;
+    int len_shared;
+    long long hf_bs, enc_bs;          // batch strides (elements); 0 = one utterance shared by all rows (beam search)
 };
 
 // dynamic LDS: qs[H] | y[A] | e[Te] | part[NT*4]
@@ -43,7 +45,7 @@ __global__ __launch_bounds__(ATT_NT) void attention_fwd_kernel(AttnArgs a) {
     float* es = ys + ((A + 3) & ~3);
     float* part = es + ((a.Te + 3) & ~3);
     __shared__ float wred[16];
-    const int L = min(max(a.enc_len[b], 0), a.Te);
+    const int L = min(max(a.enc_len[a.len_shared ? 0 : b], 0), a.Te);
 
     for (int k = tid; k < H; k += NT) qs[k] = a.q[(size_t)b * a.ldq + k];
     __syncthreads();
@@ -95,7 +97,7 @@ __global__ __launch_bounds__(ATT_NT) void attention_fwd_kernel(AttnArgs a) {
                     for (int c = 0; c < CH; ++c) {
                         const int a4 = kq + 16 * c;
                         hv[p][c] = (tau < L && a4 < (A >> 2))
-                            ? *reinterpret_cast<const float4*>(a.hf + ((size_t)b * a.Te + tau) * A + 4 * a4)
+                            ? *reinterpret_cast<const float4*>(a.hf + (size_t)b * a.hf_bs + (size_t)tau * A + 4 * a4)
                             : make_float4(0.f, 0.f, 0.f, 0.f);
                     }
                 }
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(ATT_NT) void attention_fwd_kernel(AttnArgs a) {
                     float sc = 0.f;
                     if (tau < L)
                         for (int a4 = kq; a4 < (A >> 2); a4 += 16) {
-                            const float4 h4 = *reinterpret_cast<const float4*>(a.hf + ((size_t)b * a.Te + tau) * A + 4 * a4);
+                            const float4 h4 = *reinterpret_cast<const float4*>(a.hf + (size_t)b * a.hf_bs + (size_t)tau * A + 4 * a4);
                             const float4 yv = *reinterpret_cast<const float4*>(ys + 4 * a4);
                             const float4 vv = *reinterpret_cast<const float4*>(a.v + 4 * a4);
                             sc = fmaf(vv.x, fast_tanh(h4.x + yv.x), sc); sc = fmaf(vv.y, fast_tanh(h4.y + yv.y), sc);
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(ATT_NT) void attention_fwd_kernel(AttnArgs a) {
             const int d4 = base + tid % cols, tp = tid / cols;
             float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
             if (tp < tparts) {
-                const float* ep = a.enc + (size_t)b * a.Te * D + 4 * d4;
+                const float* ep = a.enc + (size_t)b * a.enc_bs + 4 * d4;
                 constexpr int PB = 13;
                 for (int tb = tp; tb < L; tb += tparts * PB) {
                     float4 ev[PB];
@@ -209,15 +211,32 @@ extern "C" size_t asr_attention_lds_bytes(int Te, int H, int A) {
     return sizeof(float) * (size_t)(((H + 3) & ~3) + ((A + 3) & ~3) + ((Te + 3) & ~3) + 512 * 4);
 }
 
+extern "C" int asr_attention_shared_fwd(void* stream, const float* q, int ldq, const float* w_att,
+                                        const float* b_att, const float* v, const float* hf,
+                                        const float* enc, const int* enc_len, float* alpha, float* ctx,
+                                        int B, int Te, int H, int A, int D, int shared);
+
 extern "C" int asr_attention_fwd(void* stream, const float* q, int ldq, const float* w_att,
                                  const float* b_att, const float* v, const float* hf,
                                  const float* enc, const int* enc_len, float* alpha, float* ctx,
                                  int B, int Te, int H, int A, int D) {
+    return asr_attention_shared_fwd(stream, q, ldq, w_att, b_att, v, hf, enc, enc_len, alpha, ctx, B, Te, H, A, D, 0);
+}
+
+// shared != 0: hf/enc/enc_len describe ONE utterance attended by all B query rows (beam search).
+extern "C" int asr_attention_shared_fwd(void* stream, const float* q, int ldq, const float* w_att,
+                                        const float* b_att, const float* v, const float* hf,
+                                        const float* enc, const int* enc_len, float* alpha, float* ctx,
+                                        int B, int Te, int H, int A, int D, int shared) {
     if (!q || !w_att || !b_att || !v || !hf || !enc || !enc_len || !alpha || !ctx) return ASR_EINVAL;
     if (B <= 0 || Te <= 0 || H <= 0 || (A & 3) || (D & 3) || A <= 0 || D <= 0 || A > 1024) return ASR_EINVAL;
     const size_t lds = asr_attention_lds_bytes(Te, H, A);
     if (lds > 150 * 1024) return ASR_EUNSUPPORTED;
-    asr::AttnArgs a{q, ldq, w_att, b_att, v, hf, enc, enc_len, alpha, ctx, B, Te, H, A, D};
+    asr::AttnArgs a{};
+    a.q = q; a.ldq = ldq; a.w_att = w_att; a.b_att = b_att; a.v = v; a.hf = hf; a.enc = enc; a.enc_len = enc_len;
+    a.alpha = alpha; a.ctx = ctx; a.B = B; a.Te = Te; a.H = H; a.A = A; a.D = D;
+    a.len_shared = shared;
+    a.hf_bs = shared ? 0 : (long long)Te * A; a.enc_bs = shared ? 0 : (long long)Te * D;
     hipLaunchKernelGGL(asr::attention_fwd_kernel, dim3(B), dim3(asr::ATT_NT), lds, static_cast<hipStream_t>(stream), a);
     ASR_CHECK_LAUNCH();
     return ASR_OK;

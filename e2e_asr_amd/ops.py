@@ -229,11 +229,23 @@ def lstm_cell(x, h_prev, c_prev, kernel, bias, gather=None, keep_prob=1.0, seed=
     return res
 
 
-def attention(q, w_att, b_att, v, hf, enc, enc_len):
-    """Fused Bahdanau attention (attn_decoder.py:77-93) -> (ctx [B,D], alpha [B,Te])."""
+def attention(q, w_att, b_att, v, hf, enc, enc_len, shared=False):
+    """Fused Bahdanau attention (attn_decoder.py:77-93) -> (ctx [B,D], alpha [B,Te]).
+    shared=True: hf [Te,A] / enc [Te,D] / enc_len[0] describe one utterance attended by every
+    query row (the hypotheses of a beam, beam_search.py:137-161)."""
     for n, t in (("q", q), ("w_att", w_att), ("b_att", b_att), ("v", v), ("hf", hf), ("enc", enc)):
         _f32(t, n)
     _i32(enc_len, "enc_len")
+    if shared:
+        B = q.shape[0]
+        Te, D = enc.shape[-2], enc.shape[-1]
+        H, A = w_att.shape
+        alpha = torch.empty((B, Te), device=q.device, dtype=torch.float32)
+        ctx = torch.empty((B, D), device=q.device, dtype=torch.float32)
+        rc = _lib.lib().asr_attention_shared_fwd(_stream(), _p(q), q.shape[1], _p(w_att), _p(b_att), _p(v), _p(hf),
+                                                 _p(enc), _p(enc_len), _p(alpha), _p(ctx), B, Te, H, A, D, 1)
+        _check(rc, "asr_attention_shared_fwd")
+        return ctx, alpha
     B, Te, D = enc.shape
     H, A = w_att.shape
     alpha = torch.empty((B, Te), device=q.device, dtype=torch.float32)

@@ -103,6 +103,13 @@ int asr_attention_fwd(void* stream, const float* q, int ldq, const float* w_att,
                       const float* enc, const int* enc_len, float* alpha, float* ctx,
                       int B, int Te, int H, int A, int D);
 
+/* Same, with ONE utterance (hf [Te,A], enc [Te,D], enc_len[0]) attended by all B query rows --
+ * the hypotheses of a beam (beam_search.py:137-161). */
+int asr_attention_shared_fwd(void* stream, const float* q, int ldq, const float* w_att,
+                             const float* b_att, const float* v, const float* hf,
+                             const float* enc, const int* enc_len, float* alpha, float* ctx,
+                             int B, int Te, int H, int A, int D, int shared);
+
 /* losses.py:7-35.  logits [T*B,V] time-major; targets [T,B]; nll_ws,lse_ws [T*B]. */
 int asr_masked_ce_fwd(void* stream, const float* logits, const int* targets, const int* len,
                       float* nll_ws, float* lse_ws, float* loss, int T, int B, int V);

@@ -1,0 +1,49 @@
+"""GPU: device beam search (config 5) against the float64 oracle restatement of
+beam_search.py:224-338 -- identical token indices; plus the reference's own greedy chain."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import asr_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _weights(g, prefix):
+    return {k[len(prefix):]: g[k] for k in g.files if k.startswith(prefix)}
+
+
+@pytest.mark.parametrize("variant", ["plain", "simple"])
+@pytest.mark.parametrize("k,lm_weight", [(1, 0.0), (4, 0.0), (4, 0.1), (16, 0.1)])
+def test_beam_search_golden_weights_vs_oracle(golden_dir, variant, k, lm_weight):
+    from e2e_asr_amd.beam_search import BeamSearch
+    g = np.load(os.path.join(golden_dir, "decoder_step_%s.npz" % variant))
+    wd, wl = _weights(g, "w_dec/"), _weights(g, "w_lm/")
+    sp = BeamSearch.class_params()
+    sp.beam_size = k; sp.lm_weight = lm_weight; sp.lm_path = wl
+    bs = BeamSearch(wd, sp)
+    enc = g["enc_T100"]
+    got = bs(enc)
+    ref = O.beam_search(enc, wd, wl, beam_size=k, lm_weight=lm_weight)
+    np.testing.assert_array_equal(got, ref)
+    if k == 1 and lm_weight == 0.0:          # and the REFERENCE's own get_top_k chain (golden)
+        toks = g["greedy_lm0_tokens"]
+        np.testing.assert_array_equal(got[:len(toks)], toks)
+
+
+def test_beam_search_config5_shapes():
+    """BASELINE config 5: enc [100,512], beam 16, lm_weight 0.1, separate LM weight set, real sizes."""
+    from e2e_asr_amd.beam_search import BeamSearch
+    from e2e_asr_amd.weights import init_weights
+    rng = np.random.default_rng(0)
+    wd = {k: v for k, v in init_weights(seed=3).items() if "rnn_decoder_char" in k}
+    wl = {k: v for k, v in init_weights(seed=4).items() if "rnn_decoder_char" in k}
+    enc = (rng.standard_normal((100, 512)) * 0.3).astype(np.float32)
+    sp = BeamSearch.class_params()
+    sp.beam_size = 16; sp.lm_weight = 0.1; sp.lm_path = wl
+    got = BeamSearch(wd, sp)(enc)
+    ref = O.beam_search(enc, wd, wl, beam_size=16, lm_weight=0.1)
+    np.testing.assert_array_equal(got, ref)
+    assert got.dtype.kind == "i" and 1 <= len(got) <= 120
