@@ -1,0 +1,185 @@
+"""Training loop -- mirror of the reference's train.py (37-430) around the HIP train step.
+
+`Train(model_params, train_params).train()` keeps the reference's loop policy: length-bucketed
+training sets consumed smallest-bucket-first until each is exhausted (261-295, 379-383), optional
+LM steps with probability lm_prob (269-291), every `steps_per_checkpoint` steps a greedy dev
+decode (322), LR halving when the dev error is no better than the worst of the last three after
+`min_steps` while lr > 1e-4 (334-343), stop after 10 non-improving checkpoints at floor LR
+(346-349, check_progess 153-158), `best.txt` / `asr_err.txt` / keep-all + best checkpoints
+(353-371).  TFRecord reading is out of scope: datasets are injected as lists of
+re-iterable batch sources (anything yielding the speech_dataset.py:43-45 dict)."""
+import copy
+import math
+import os
+import random
+import sys
+import time
+
+from . import checkpoint
+from .base_params import BaseParams, Bunch
+from .eval_model import Eval
+from .lm_encoder import LMEncoder
+from .lm_model import LMModel
+from .seq2seq_model import Seq2SeqModel
+
+
+class Train(BaseParams):
+    @classmethod
+    def class_params(cls):
+        # train.py:39-72
+        return Bunch(batch_size=128, buck_batch_size=[128, 128, 64, 64, 32], max_epochs=30, min_steps=25000,
+                     feat_length=80, data_dir="", lm_data_dir="", vocab_dir="", train_base_dir="",
+                     train_dir="/tmp/asr_train", best_model_dir="/tmp/asr_train/best", lm_prob=0.0,
+                     lm_params=LMModel.class_params(), lm_enc_params=LMEncoder.class_params(), run_id=1,
+                     steps_per_checkpoint=500, pretrain_lm_path="", pretrain_phone_path="", chaos=False, subset_file="")
+
+    def __init__(self, model_params, train_params=None, device="cuda:0"):
+        self.params = self.class_params() if train_params is None else train_params
+        self.seq2seq_params = model_params
+        self.eval_model = None
+        self.device = device
+
+    @staticmethod
+    def check_progess(previous_errs, num=10):
+        """train.py:153-158 (sic): False when the best error is older than the last `num` checkpoints."""
+        if len(previous_errs) > num:
+            if min(previous_errs) != min(previous_errs[-num:]):
+                return False
+        return True
+
+    @staticmethod
+    def should_decay(previous_errs, asr_err_cur, global_step, min_steps, lr):
+        """train.py:334-343: decay when past min_steps, >3 checkpoints seen, the current error is no
+        better than the worst of the previous three, and lr is still above 1e-4."""
+        return (global_step >= min_steps and len(previous_errs) > 3 and asr_err_cur >= max(previous_errs[-3:])
+                and lr > 1e-4)
+
+    def create_eval_model(self, variables):
+        """train.py:138-151: second model over the SAME variables, isTraining=False, char task only."""
+        p = copy.deepcopy(self.seq2seq_params)
+        p.tasks = ["char"]
+        p.num_layers = {"char": p.num_layers["char"]}
+        model_dev = Seq2SeqModel(None, isTraining=False, params=p, variables=variables, device=self.device,
+                                 feat_length=self.params.feat_length)
+        self.eval_model = Eval(model_dev, params=Bunch(best_model_dir=self.params.best_model_dir, vocab_dir=self.params.vocab_dir))
+        return model_dev
+
+    def train(self, buck_train_sets, dev_set, lm_set=None, max_steps=None):
+        """buck_train_sets: list (shortest bucket first) of re-iterable batch sources; dev_set: a
+        re-iterable of dev batches; lm_set: re-iterable of LM batches (needed when lm_prob > 0)."""
+        params = self.params
+        random.seed(int(time.time()) if params.chaos else 10)                       # train.py:167-174
+        os.makedirs(params.train_dir, exist_ok=True)
+        os.makedirs(params.best_model_dir, exist_ok=True)
+        model = Seq2SeqModel(None, True, self.seq2seq_params, device=self.device, feat_length=params.feat_length)
+        self.model = model
+        self.create_eval_model(model.variables)
+        lm_model = None
+        if params.lm_prob > 0:
+            lm_model = LMModel(LMEncoder(params=params.lm_enc_params, variables=model.variables), params=params.lm_params)
+        latest = os.path.join(params.train_dir, "checkpoint.txt")
+        asr_err_best = 1.0
+        if os.path.isfile(latest):                                                  # resume (train.py:205-215)
+            ck = open(latest).read().strip()
+            model.global_step, lr = checkpoint.restore(model.variables, ck)
+            if lr is not None:
+                model.learning_rate = lr
+            score_file = os.path.join(params.train_dir, "best.txt")
+            if os.path.isfile(score_file):
+                try:
+                    asr_err_best = float(open(score_file).readline().strip("\n"))
+                except ValueError:
+                    pass
+        else:
+            if params.pretrain_lm_path:
+                checkpoint.restore_common_variables(model.variables, params.pretrain_lm_path)
+            if params.pretrain_phone_path:
+                checkpoint.restore_common_variables(model.variables, params.pretrain_phone_path)
+        print("\nBest ASR error rate - %f" % asr_err_best)
+        previous_errs = []
+        try:
+            with open(os.path.join(params.train_dir, "asr_err.txt")) as f:
+                previous_errs = [float(l.strip()) for l in f]
+        except IOError:
+            pass
+        loss, current_step, lm_loss, lm_steps = 0.0, 0, 0.0, 0
+        ckpt_start = time.time()
+        lm_iter = iter(lm_set) if lm_set is not None else None
+        epoch = model.epoch
+        while epoch <= params.max_epochs:
+            print("\nEpochs done: %d" % epoch)
+            active = [iter(s) for s in buck_train_sets]                              # train.py:261-266
+            while active:
+                if max_steps is not None and current_step >= max_steps:
+                    return model
+                if lm_model is not None and params.lm_prob > random.random():        # :269-291
+                    try:
+                        lm_batch = next(lm_iter)
+                    except StopIteration:
+                        lm_model.epoch_incr()
+                        lm_iter = iter(lm_set)
+                        continue
+                    lm_loss += float(lm_model.step(lm_batch).item()) / params.steps_per_checkpoint
+                    lm_steps += 1
+                    if lm_steps % params.steps_per_checkpoint == 0:
+                        print("LM steps: %d, Perplexity: %f" % (lm_model.lm_global_step,
+                                                                math.exp(lm_loss) if lm_loss < 300 else float("inf")))
+                        lm_loss = 0.0
+                    continue
+                try:
+                    batch = next(active[0])                                           # smallest bucket first (:295)
+                except StopIteration:
+                    del active[0]                                                     # :379-383
+                    continue
+                step_loss = model.step(batch)["char"]
+                current_step += 1
+                loss += float(step_loss.item()) / params.steps_per_checkpoint
+                if current_step % params.steps_per_checkpoint:
+                    continue
+                perplexity = math.exp(loss) if loss < 300 else float("inf")           # :305-312
+                print("Step %d Learning rate %.4f Checkpoint time %.2f Perplexity %.2f" % (
+                    model.global_step, model.learning_rate, time.time() - ckpt_start, perplexity))
+                asr_err_cur = self.eval_model.greedy_decode(dev_set)                  # :322
+                print("ASR error: %.4f" % asr_err_cur)
+                with open(os.path.join(params.train_dir, "asr_err.txt"), "a") as f:
+                    f.write(str(asr_err_cur) + "\n")
+                if self.should_decay(previous_errs, asr_err_cur, model.global_step, params.min_steps, model.learning_rate):
+                    model.learning_rate_decay_op()
+                    print("Learning rate decreased !!")
+                previous_errs.append(asr_err_cur)
+                if not (model.learning_rate > 1e-4) and not self.check_progess(previous_errs):
+                    print("No improvement in 10 checkpoints")
+                    return model
+                if asr_err_best > asr_err_cur:                                         # :353-367
+                    asr_err_best = asr_err_cur
+                    print("Best ASR Error rate: %.4f\nSaving the best model !!" % asr_err_best)
+                    with open(os.path.join(params.train_dir, "best.txt"), "w") as f:
+                        f.write(str(asr_err_best))
+                    checkpoint.save(os.path.join(params.best_model_dir, "asr.ckpt-%d" % model.global_step),
+                                    model.variables, model.global_step, model.learning_rate)
+                ck = checkpoint.save(os.path.join(params.train_dir, "asr.ckpt-%d" % model.global_step),
+                                     model.variables, model.global_step, model.learning_rate)   # :370-371
+                with open(latest, "w") as f:
+                    f.write(ck)
+                ckpt_start, loss = time.time(), 0.0
+                sys.stdout.flush()
+            model.epoch_incr()
+            epoch += 1
+        return model
+
+    @classmethod
+    def add_parse_options(cls, parser):
+        # train.py:396-429
+        parser.add_argument("-lm_prob", default=0.0, type=float, help="Prob. of running the LM task")
+        parser.add_argument("-run_id", "--run_id", default=0, type=int, help="Run ID")
+        parser.add_argument("-data_dir", default="", type=str, help="Data directory")
+        parser.add_argument("-lm_data_dir", default="", type=str, help="Data directory")
+        parser.add_argument("-vocab_dir", "--vocab_dir", default="", type=str, help="Vocab directory")
+        parser.add_argument("-tb_dir", "--train_base_dir", default="", type=str, help="Training directory")
+        parser.add_argument("-feat_len", "--feat_length", default=80, type=int, help="Number of features per frame")
+        parser.add_argument("-steps_per_checkpoint", default=500, type=int, help="Gradient steps per checkpoint")
+        parser.add_argument("-min_steps", "--min_steps", default=25000, type=int, help="Min steps BEFORE DECREASING LEARNING RATE")
+        parser.add_argument("-pretrain_lm_path", default="", type=str, help="Pretrain language model path")
+        parser.add_argument("-pretrain_phone_path", default="", type=str, help="Pretrain phone model path")
+        parser.add_argument("-chaos", default=False, action="store_true", help="Random seed is not controlled if set")
+        parser.add_argument("-subset_file", default="", type=str, help="Subset file")

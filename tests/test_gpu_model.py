@@ -291,3 +291,99 @@ def test_train_steps_match_reference_optimizer():
     for name in got:
         np.testing.assert_allclose(got[name], w[name], rtol=0, atol=2e-5)
     assert m.global_step == 3
+
+
+def test_lm_model_shares_decoder_variables_and_trains():
+    """lm_model.py:39-115 / lm_encoder.py:90-111: the char LM runs on the decoder's inner LSTM,
+    embedding and OutputProjection; loss and gradients against autograd; AdamLM touches only those."""
+    from e2e_asr_amd.lm_encoder import LMEncoder
+    from e2e_asr_amd.lm_model import LMModel
+    from oracle import torch_ref as R
+    rng = np.random.default_rng(12)
+    m = _model(enc_update=dict(hidden_size=64), num_layers={"char": 2},
+               dec_update=dict(hidden_size_dec=64, lm_hidden_size=64, emb_size=24, attention_vec_size=16), vocab={"char": 31})
+    ep = LMEncoder.class_params()
+    ep.out_prob = 1.0; ep.lm_hidden_size = 64; ep.proj_size = 64; ep.emb_size = 24; ep.vocab_size = 31
+    lm = LMModel(LMEncoder(isTraining=True, params=ep, variables=m.variables))
+    B, T = 6, 11
+    lens = np.array([11, 3, 7, 1, 11, 5])
+    ids = np.zeros((B, T + 1), np.int64)
+    for b in range(B):
+        ids[b, :lens[b] + 1] = rng.integers(1, 31, lens[b] + 1)
+    batch = {"char": ids, "char_len": lens}
+    before = m.variables.to_arrays()
+    loss = lm.step(batch)
+    # reference
+    W = R.weights_to_torch({k: v.astype(np.float64) for k, v in before.items()})
+    pre = "model/rnn_decoder_char/"
+    emb = W[pre + "decoder/embedding"]
+    x = emb[torch.tensor(ids[:, :-1].T)]                                   # [T,B,E]
+    h = R.lstm_layer(x, lens, W[pre + "rnn/basic_lstm_cell/kernel"], W[pre + "rnn/basic_lstm_cell/bias"])
+    logits = h.reshape(T * B, -1) @ W[pre + "rnn/OutputProjection/kernel"] + W[pre + "rnn/OutputProjection/bias"]
+    ref = R.cross_entropy_loss(logits, ids[:, 1:].T, lens)
+    np.testing.assert_allclose(loss.item(), ref.item(), rtol=2e-5)
+    ref.backward()
+    for name in m.variables.names():
+        got = m.variables.grad_of(name).cpu().numpy()
+        want = W[name].grad
+        if want is None:
+            assert not got.any(), name                                     # untouched variables: zero gradient
+        else:
+            want = want.numpy()
+            assert np.abs(got - want).max() <= 2e-3 * max(1e-3, np.abs(want).max()), name
+    after = m.variables.to_arrays()
+    changed = sorted(k for k in after if not np.array_equal(after[k], before[k]))
+    assert changed == sorted(pre + l for l in ("decoder/embedding", "rnn/basic_lstm_cell/kernel", "rnn/basic_lstm_cell/bias",
+                                               "rnn/OutputProjection/kernel", "rnn/OutputProjection/bias"))
+    assert lm.lm_global_step == 1 and m.global_step == 0
+
+
+def test_train_loop_checkpoint_resume_and_eval(tmp_path):
+    """train.py:160-394 policy on a tiny synthetic task: loss falls, checkpoints carry TF names,
+    best.txt/asr_err.txt are written, resume restores step/lr/weights, eval graph decodes."""
+    from e2e_asr_amd import checkpoint
+    from e2e_asr_amd.attn_decoder import AttnDecoder
+    from e2e_asr_amd.seq2seq_model import Seq2SeqModel
+    from e2e_asr_amd.train import Train
+    from e2e_asr_amd.weights import synthetic_batch
+    p = Seq2SeqModel.class_params()
+    p.num_layers = {"char": 2}; p.max_output = {"char": 8}
+    p.encoder_params.use_lstm = True; p.encoder_params.hidden_size = 64; p.encoder_params.out_prob = 1.0
+    dp = AttnDecoder.class_params()
+    dp.hidden_size_dec = 64; dp.lm_hidden_size = 64; dp.emb_size = 32; dp.attention_vec_size = 16; dp.vocab_size = 12
+    dp.out_prob_dec = 1.0; dp.samp_prob = 0.0
+    p.decoder_params = {"char": dp}
+    tp = Train.class_params()
+    tp.train_dir = str(tmp_path / "run"); tp.best_model_dir = str(tmp_path / "run" / "best")
+    tp.steps_per_checkpoint = 4; tp.feat_length = 20; tp.max_epochs = 100; tp.min_steps = 0
+    b0 = synthetic_batch(B=4, T=16, F=20, t_dec=9, vocab=12, seed=1)
+    b1 = synthetic_batch(B=4, T=24, F=20, t_dec=9, vocab=12, seed=2)
+    tr = Train(p, tp, device=DEV)
+    model = tr.train([[b0, b0], [b1, b1]], [b0], max_steps=12)
+    assert model.global_step == 12
+    errs = [float(l) for l in open(os.path.join(tp.train_dir, "asr_err.txt"))]
+    assert len(errs) == 3 and os.path.isfile(os.path.join(tp.train_dir, "best.txt"))
+    ck = open(os.path.join(tp.train_dir, "checkpoint.txt")).read().strip()
+    arrs = checkpoint.load(ck)
+    assert "model/encoder/RNNLayer1/bidirectional_rnn/fw/basic_lstm_cell/kernel" in arrs
+    assert "model/rnn_decoder_char/rnn/OutputProjection/kernel/Adam_1" in arrs and int(arrs["global_step"]) == 12
+    # the loss on the memorised batch fell
+    first = Seq2SeqModel(None, True, p, device=DEV, feat_length=20)
+    first.forward(b0); l0 = first.total_loss.item()
+    model.forward(b0); l1 = model.total_loss.item()
+    assert l1 < l0 - 0.1, (l0, l1)
+    # resume continues from the saved step with identical weights
+    tr2 = Train(p, tp, device=DEV)
+    m2 = tr2.train([[b0]], [b0], max_steps=0)
+    assert m2.global_step == 12
+    for k, v in m2.variables.to_arrays().items():
+        np.testing.assert_array_equal(v, arrs[k])
+    # name-intersection warm start + beam search straight from the checkpoint file
+    from e2e_asr_amd.beam_search import BeamSearch
+    m3 = Seq2SeqModel(None, True, p, device=DEV, feat_length=20, seed=99)
+    got = checkpoint.restore_common_variables(m3.variables, ck)
+    assert len(got) == len(m3.variables.names())
+    sp = BeamSearch.class_params(); sp.beam_size = 2
+    enc = model.encoder_hidden_states[2][0, :int(model.seq_len_encs[2][0])].cpu().numpy()
+    ids = BeamSearch(ck, sp, device=DEV)(enc)
+    assert ids.ndim == 1 and len(ids) >= 1

@@ -1,0 +1,73 @@
+"""CPU: host-side logic that mirrors the reference's non-arithmetic behaviour."""
+import argparse
+
+import numpy as np
+
+from e2e_asr_amd.base_params import BaseParams, Bunch
+
+
+def test_get_updated_params_requires_matching_types():
+    """base_params.py:21-28: an option overrides a default only when key exists AND types match."""
+    class P(BaseParams):
+        @classmethod
+        def class_params(cls):
+            return Bunch(a=1, b=0.5, c=True, d={"x": 1})
+    p = P.get_updated_params(dict(a=7, b=3, c=False, d="no", e=9))
+    assert p.a == 7 and p.b == 0.5 and p.c is False and p.d == {"x": 1} and "e" not in p
+
+
+def test_class_params_defaults_match_reference():
+    from e2e_asr_amd.attn_decoder import AttnDecoder
+    from e2e_asr_amd.encoder import Encoder
+    from e2e_asr_amd.seq2seq_model import Seq2SeqModel
+    e = Encoder.class_params()          # encoder.py:18-31
+    assert (e.bi_dir, e.hidden_size, e.out_prob, e.skip_step, e.initial_res_fac, e.use_lstm, e.stack_cons,
+            e.max_scaling_down) == (True, 256, 0.9, 2, 1, False, 1, 8)
+    d = AttnDecoder.class_params()      # decoder.py:22-35 + attn_decoder.py:21-28
+    assert (d.out_prob_dec, d.hidden_size_dec, d.num_layers_dec, d.emb_size, d.vocab_size, d.samp_prob, d.max_output,
+            d.attention_vec_size, d.lm_hidden_size, d.ind_softmax) == (0.9, 256, 1, 256, 1000, 0.1, 400, 128, 256, False)
+    s = Seq2SeqModel.class_params()     # seq2seq_model.py:28-48
+    assert s.tasks == ["char"] and s.num_layers == {"char": 4} and s.max_output == {"char": 120}
+    assert (s.learning_rate, s.learning_rate_decay_factor, s.max_gradient_norm, s.avg) == (1e-3, 0.5, 5.0, True)
+
+
+def test_parse_options_flags_exist():
+    from e2e_asr_amd.attn_decoder import AttnDecoder
+    from e2e_asr_amd.beam_search import BeamSearch
+    from e2e_asr_amd.encoder import Encoder
+    from e2e_asr_amd.seq2seq_model import Seq2SeqModel
+    from e2e_asr_amd.train import Train
+    ap = argparse.ArgumentParser()
+    for c in (Encoder, AttnDecoder, Seq2SeqModel, Train, BeamSearch):
+        c.add_parse_options(ap)
+    a = ap.parse_args([])
+    assert a.use_lstm is True and a.hidden_size == 256 and a.skip_step == 2        # encoder.py:187: always LSTM from the CLI
+    assert a.samp_prob == 0.1 and a.attention_vec_size == 128 and a.beam_size == 1 and a.steps_per_checkpoint == 500
+
+
+def test_train_policy_functions():
+    from e2e_asr_amd.train import Train
+    assert Train.check_progess([0.5] * 5)                                           # <= num entries: always True
+    assert Train.check_progess([0.9, 0.8] + [0.85] * 9 + [0.7])                     # best is recent
+    assert not Train.check_progess([0.5] + [0.6] * 10)                              # best older than last 10
+    assert Train.should_decay([0.5, 0.4, 0.45, 0.44], 0.46, 30000, 25000, 1e-3)
+    assert not Train.should_decay([0.5, 0.4, 0.45, 0.44], 0.43, 30000, 25000, 1e-3)  # improved on the worst of 3
+    assert not Train.should_decay([0.5, 0.4, 0.45, 0.44], 0.46, 100, 25000, 1e-3)    # before min_steps
+    assert not Train.should_decay([0.5, 0.4, 0.45, 0.44], 0.46, 30000, 25000, 1e-4)  # at floor LR
+
+
+def test_eval_edit_distance_and_eos_cut():
+    from e2e_asr_amd.eval_model import Eval, edit_distance
+    assert edit_distance([1, 2, 3], [1, 3]) == 1 and edit_distance([], [4, 5]) == 2 and edit_distance("kitten", "sitting") == 3
+    assert Eval.cut_at_eos([5, 6, 2, 7]) == [5, 6] and Eval.cut_at_eos([5, 6]) == [5, 6]
+    rev = [b"<pad>", b"<go>", b"<eos>", u"▁he".encode("utf-8"), b"llo", u"▁you".encode("utf-8")]
+    assert Eval.wp_array_to_sent([3, 4, 5, 2, 4], rev) == "hello you"
+
+
+def test_encoder_layer_input_widths():
+    from e2e_asr_amd.weights import encoder_layer_inputs, init_weights
+    assert encoder_layer_inputs(80, 256, True, 4) == [80, 1024, 1024, 1024]
+    assert encoder_layer_inputs(40, 128, False, 1) == [40]
+    assert encoder_layer_inputs(80, 256, True, 5) == [80, 1024, 1024, 1024, 512]   # max_scaling_down 8 stops the pyramid
+    w = init_weights()
+    assert sum(v.size for v in w.values()) == 10616552
