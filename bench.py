@@ -43,37 +43,34 @@ def build_model(dev, training=True):
     return Seq2SeqModel(None, isTraining=training, params=p, device=dev, feat_length=F, seed=10)
 
 
-def cpu_baseline(seconds_budget=25.0):
-    """The CPU oracle (oracle/asr_oracle.py, 'port' of the reference graph: per-timestep
-    BasicLSTMCell loop with masking, float32) on a bounded sample of the SAME workload:
-    the first `bs` utterances of the synthetic batch, forward pass.  NumPy's BLAS uses the
-    host cores it is given; cores = threads actually used."""
+def cpu_baseline():
+    """CPU 'port' baseline: the torch twin of the oracle (oracle/torch_ref.py: per-timestep
+    BasicLSTMCell loops with masking exactly as dynamic_rnn/raw_rnn run them, float32, autograd
+    backward, TF clip + Adam arithmetic) doing ONE full train step on a bounded sample of the same
+    workload: the full batch of 32 utterances, same architecture, but T=192 frames and 30 target
+    tokens instead of 800/120 (cost per frame is independent of T: every layer is linear in T).
+    Threads = torch's intra-op pool on this host."""
+    import torch as th
     from e2e_asr_amd.weights import init_weights, synthetic_batch
-    from oracle import asr_oracle as O
-    try:
-        import threadpoolctl
-        nthreads = max(i["num_threads"] for i in threadpoolctl.threadpool_info() if i.get("user_api") == "blas")
-    except Exception:
-        nthreads = os.cpu_count()
-    w = init_weights(seed=10)
-    bs = 4
-    batch = synthetic_batch(B=B, T=T, F=F, t_dec=TDEC, vocab=V)
-    sub = {k: (v[:bs] if hasattr(v, "__len__") else v) for k, v in batch.items()}
-    sub["char"] = sub["char"][:, :int(sub["char_len"].max()) + 1]     # T_dec - 1 == max(len) (tf_utils.py:4-12)
+    from oracle import torch_ref as R
+    Ts, tdec = 192, 31
+    w = {k: v.astype(np.float32) for k, v in init_weights(seed=10).items()}
+    batch = synthetic_batch(B=B, T=Ts, F=F, t_dec=tdec, vocab=V)
     t0 = time.time()
-    O.seq2seq_forward(sub, w, is_training=True)
+    W = R.weights_to_torch(w, dtype=th.float32)
+    total, _, _ = R.seq2seq_loss(batch, W)
+    total.backward()
+    with th.no_grad():      # clip_by_global_norm + Adam (cost only; arithmetic as seq2seq_model.py:137-155)
+        gn = th.sqrt(sum((p.grad.double() ** 2).sum() for p in W.values()))
+        sc = 5.0 / max(float(gn), 5.0)
+        for p in W.values():
+            g = p.grad * sc
+            m = 0.1 * g; v = 0.001 * g * g
+            p -= 1e-3 * m / (v.sqrt() + 1e-8)
     dt = time.time() - t0
-    reps = 1
-    if dt < seconds_budget / 3:
-        n = min(3, int(seconds_budget / 3 / max(dt, 1e-3)))
-        t0 = time.time()
-        for _ in range(n):
-            O.seq2seq_forward(sub, w, is_training=True)
-        dt = (time.time() - t0) / n
-        reps = n
-    return dict(value=bs * T / dt, unit="frames/s", cores=int(nthreads), kind="port",
-                sample="forward pass (encoder+decoder+loss, float32 NumPy oracle) of %d of the %d utterances "
-                       "x %d frames, %d rep(s), %.1f s each; forward only (the oracle has no backward)" % (bs, B, T, reps, dt))
+    return dict(value=B * Ts / dt, unit="frames/s", cores=int(th.get_num_threads()), kind="port",
+                sample="one full train step (fwd+bwd+clip+Adam, float32 torch twin of the oracle, per-timestep loops) on "
+                       "32 utterances x %d frames x 80 mel, %d target tokens; %.1f s" % (Ts, tdec - 1, dt))
 
 
 def main():
@@ -159,14 +156,19 @@ def main():
     frames = world * B * T
     value = frames / (dt / args.steps)
     flop_per_frame = (REC_FLOP_FWD + PROJ_FLOP_FWD + 14.25e9) / (B * T) * (3 if mode == "train" else 1)
-    # dominant kernel: the persistent recurrent LSTM kernel (4 launches/step: T=800/400/200/100)
+    # dominant kernel family by GPU time: the persistent recurrent LSTM pair (4 launches/step each,
+    # T=800/400/200/100); report the slower of the two.  Same algorithmic FLOPs (h.K_h resp. dG.K_h^T).
     rec_per_step_ms = rec_ms / args.steps
-    achieved = REC_FLOP_FWD / (rec_per_step_ms * 1e-3) / 1e12 if rec_ms > 0 else None
+    recb_per_step_ms = recb_ms / args.steps
+    use_bwd = mode == "train" and recb_per_step_ms > rec_per_step_ms
+    dom_ms = recb_per_step_ms if use_bwd else rec_per_step_ms
+    dom_name = "lstm_rec_bwd_kernel<256,2> (persistent BPTT)" if use_bwd else "lstm_rec_fwd_kernel<256,32,2> (persistent recurrent LSTM)"
+    achieved = REC_FLOP_FWD / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else None
     traffic = None
     tp = os.path.join(ROOT, "profiles", "traffic_r01.json")
     if os.path.exists(tp):
         try:
-            traffic = json.load(open(tp)).get("lstm_rec_fwd_bytes_per_launch")
+            traffic = json.load(open(tp)).get("lstm_rec_bwd_bytes_per_launch" if use_bwd else "lstm_rec_fwd_bytes_per_launch")
         except Exception:
             traffic = None
     out = {
@@ -180,11 +182,12 @@ def main():
                                    ", variable lengths" if args.variable_len else ", all lengths 800"),
                    "mode": mode, "global_batch": world * B, "frames_per_utt": T, "parallelism": "dp%d" % world},
         "model_tflops": value * flop_per_frame / 1e12,
-        "roofline": {"bound": "mfma", "kernel": "lstm_rec_fwd_kernel<256,32,2> (persistent recurrent LSTM, 4 launches/step)",
+        "roofline": {"bound": "mfma", "kernel": dom_name + ", 4 launches/step",
                      "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": (achieved / PEAK_F32_MFMA_TFLOPS) if achieved else None, "traffic": traffic,
-                     "avg_launch_ms": rec_ms / max(rec_n, 1), "launches": rec_n,
-                     "serial_chain_steps": sum(ENC_LAYER_T), "us_per_recurrent_step": rec_per_step_ms * 1e3 / sum(ENC_LAYER_T)},
+                     "avg_launch_ms": dom_ms / 4.0, "launches": (recb_n if use_bwd else rec_n),
+                     "serial_chain_steps": sum(ENC_LAYER_T), "us_per_recurrent_step": dom_ms * 1e3 / sum(ENC_LAYER_T),
+                     "note": "latency-bound serial chain of 1500 dependent steps; fp32 VALU/MFMA peak is the same 157.3 TF"},
         "phases_ms_per_step": {"lstm_rec_fwd": rec_per_step_ms, "lstm_rec_bwd": recb_ms / args.steps,
                                "decoder_fwd": decf_ms / args.steps},
     }
