@@ -77,6 +77,8 @@ SIGNATURES = {
     "asr_attn_decoder_bwd": (C.c_int, [vp, C.POINTER(DecWeights), C.POINTER(DecWeights), C.POINTER(DecDims),
                                        C.POINTER(DecWs), C.POINTER(DecBwdWs), vp, vp, vp, vp, C.c_float, C.c_uint]),
     "asr_scatter_add_rows_ld": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int]),
+    "asr_side_join": (C.c_int, [vp]),
+    "asr_zero_finished_rows": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int]),
     "asr_prof_enable": (C.c_int, [C.c_int]),
     "asr_debug_set_buffer": (C.c_int, [vp]),
     "asr_prof_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]),

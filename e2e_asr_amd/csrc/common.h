@@ -30,6 +30,9 @@ namespace asr {
 
 void prof_begin(int tag, hipStream_t s);   // prof.hip
 void prof_end(int tag, hipStream_t s);
+hipStream_t side_stream();                 // prof.hip: library-owned side stream + pooled events
+hipEvent_t next_event();
+void set_pending_join(hipEvent_t e);
 
 // ---- math: v_exp_f32 / v_rcp_f32 based, ~1-2 ulp; saturate cleanly at +-inf ----
 // (__frcp_rn would expand to the ~10-instruction IEEE divide; v_rcp_f32 is 1 ulp and one instruction)

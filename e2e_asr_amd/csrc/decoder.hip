@@ -18,6 +18,14 @@
 #include "common.h"
 #include "../../include/e2e_asr_hip.h"
 
+extern "C" int asr_zero_finished_rows(void* stream, float* logits, const int* len, int T, int B, int V);
+
+// Two streams.  The LM cell chain (attn_decoder.py:148-151) depends only on the fed tokens, so it
+// runs on the library's side stream AHEAD of the attention chain and re-synchronises only after a
+// step whose token is produced on the device (argmax / sampled feedback).  AttnProjection and
+// OutputProjection (:116-125) are not on the per-step dependency chain either: outside feedback
+// steps they are computed for all steps at once by MFMA GEMMs after the loop.  Per step the main
+// stream runs three kernels: InputProjection, outer cell, fused attention.
 extern "C" int asr_attn_decoder_fwd(void* stream, const asr_dec_weights* w, const asr_dec_dims* d,
                                     const asr_dec_ws* ws, const float* enc, const int* enc_len,
                                     const int* seq_len, int mode, const float* coin_host, float samp_prob,
@@ -28,27 +36,43 @@ extern "C" int asr_attn_decoder_fwd(void* stream, const asr_dec_weights* w, cons
     if (B <= 0 || T <= 0) return ASR_EINVAL;
     if (keep_lm < 1.0f && !ws->lm_hd) return ASR_EINVAL;
     if (w->simple_w && !ws->sp) return ASR_EINVAL;
+    hipStream_t ms = static_cast<hipStream_t>(stream);
+    hipStream_t ss = asr::side_stream();
+    void* side = static_cast<void*>(ss);
     int rc;
+    asr::prof_begin(ASR_PROF_DECODER_FWD, ms);
+    hipEvent_t e_fork = asr::next_event();
+    if (hipEventRecord(e_fork, ms) != hipSuccess || hipStreamWaitEvent(ss, e_fork, 0) != hipSuccess) return ASR_ELAUNCH;
     // hf = enc . AttnW   (attn_decoder.py:70-73)
     if ((rc = asr_gemm_f32(stream, 0, 0, B * Te, A, D, enc, D, w->attn_enc_w, A, ws->hf, A, nullptr, 0))) return rc;
     const int P = w->simple_w ? H : lmH;
-    asr::prof_begin(ASR_PROF_DECODER_FWD, static_cast<hipStream_t>(stream));
+    auto feedback = [&](int i) {       // is tok[i+1] produced on the device from step i's logits?
+        if (i < 0 || i + 1 >= T) return false;
+        if (mode == 1) return true;
+        return mode == 2 && samp_prob > 0.f && !(coin_host[i] < 1.0f - samp_prob);
+    };
+    hipEvent_t e_tok = nullptr;
     for (int i = 0; i < T; ++i) {
         const size_t o = (size_t)i * B;
+        // ---- side stream: LM cell of step i
+        if (feedback(i - 1) && hipStreamWaitEvent(ss, e_tok, 0) != hipSuccess) return ASR_ELAUNCH;
         const float* lm_hp = i ? ws->lm_h + (o - B) * lmH : ws->zeros;
         const float* lm_cp = i ? ws->lm_c + (o - B) * lmH : nullptr;
-        if ((rc = asr_lstm_cell_fwd(stream, w->embedding, E, E, ws->tok + o, lm_hp, lm_cp, w->lm_kernel,
+        if ((rc = asr_lstm_cell_fwd(side, w->embedding, E, E, ws->tok + o, lm_hp, lm_cp, w->lm_kernel,
                                     w->lm_bias, lmH, B, ws->lm_c + o * lmH, ws->lm_h + o * lmH,
                                     keep_lm < 1.0f ? ws->lm_hd + o * lmH : nullptr,
                                     ws->lm_gates ? ws->lm_gates + o * 4 * lmH : nullptr, keep_lm, seed, (unsigned)i)))
             return rc;
         const float* lm_out = keep_lm < 1.0f ? ws->lm_hd + o * lmH : ws->lm_h + o * lmH;
         if (w->simple_w) {
-            if ((rc = asr_linear_fwd(stream, lm_out, lmH, lmH, nullptr, nullptr, 0, 0, w->simple_w, H,
+            if ((rc = asr_linear_fwd(side, lm_out, lmH, lmH, nullptr, nullptr, 0, 0, w->simple_w, H,
                                      w->simple_b, ws->sp + o * H, H, B, H, nullptr, 0)))
                 return rc;
             lm_out = ws->sp + o * H;
         }
+        hipEvent_t e_lm = asr::next_event();
+        if (hipEventRecord(e_lm, ss) != hipSuccess || hipStreamWaitEvent(ms, e_lm, 0) != hipSuccess) return ASR_ELAUNCH;
+        // ---- main stream: the attention chain of step i
         const float* ctx_prev = i ? ws->ctx + (o - B) * D : ws->zeros;
         if ((rc = asr_linear_fwd(stream, lm_out, P, P, nullptr, ctx_prev, D, D, w->inp_w, E, w->inp_b,
                                  ws->x + o * E, E, B, E, nullptr, 0)))
@@ -62,20 +86,29 @@ extern "C" int asr_attn_decoder_fwd(void* stream, const asr_dec_weights* w, cons
         if ((rc = asr_attention_fwd(stream, ws->dec_c + o * H, H, w->attn_w, w->attn_b, w->attn_v, ws->hf, enc,
                                     enc_len, ws->alpha + o * Te, ws->ctx + o * D, B, Te, H, A, D)))
             return rc;
-        if ((rc = asr_linear_fwd(stream, ws->dec_c + o * H, H, H, nullptr, ws->ctx + o * D, D, D, w->ap_w, H,
-                                 w->ap_b, ws->p + o * H, H, B, H, nullptr, 0)))
-            return rc;
-        if ((rc = asr_linear_fwd(stream, ws->p + o * H, H, H, nullptr, nullptr, 0, 0, w->out_w, V, w->out_b,
-                                 logits + o * V, V, B, V, seq_len, i)))
-            return rc;
-        if (i + 1 < T) {
-            const bool sample = mode == 2 && samp_prob > 0.f && !(coin_host[i] < 1.0f - samp_prob);
-            if (mode == 1 || sample)
-                if ((rc = asr_next_token(stream, logits + o * V, B, V, V, ws->tok + o + B, sample ? 1 : 0, seed,
-                                         (unsigned)i)))
+        if (feedback(i) || mode == 1) {      // this step's logits feed the next token (or eval mode): project now
+            if ((rc = asr_linear_fwd(stream, ws->dec_c + o * H, H, H, nullptr, ws->ctx + o * D, D, D, w->ap_w, H,
+                                     w->ap_b, ws->p + o * H, H, B, H, nullptr, 0)))
+                return rc;
+            if ((rc = asr_linear_fwd(stream, ws->p + o * H, H, H, nullptr, nullptr, 0, 0, w->out_w, V, w->out_b,
+                                     logits + o * V, V, B, V, seq_len, i)))
+                return rc;
+            if (feedback(i)) {
+                if ((rc = asr_next_token(stream, logits + o * V, B, V, V, ws->tok + o + B, mode == 2 ? 1 : 0, seed, (unsigned)i)))
                     return rc;
+                e_tok = asr::next_event();
+                if (hipEventRecord(e_tok, ms) != hipSuccess) return ASR_ELAUNCH;
+            }
         }
     }
-    asr::prof_end(ASR_PROF_DECODER_FWD, static_cast<hipStream_t>(stream));
+    if (mode != 1) {
+        // p = [q | ctx] . W_ap + b and logits = p . W_out + b for ALL steps at once
+        const int TB = T * B;
+        if ((rc = asr_gemm_f32(stream, 0, 0, TB, H, H, ws->dec_c, H, w->ap_w, H, ws->p, H, w->ap_b, 0))) return rc;
+        if ((rc = asr_gemm_f32(stream, 0, 0, TB, H, D, ws->ctx, D, w->ap_w + (size_t)H * H, H, ws->p, H, nullptr, 1))) return rc;
+        if ((rc = asr_gemm_f32(stream, 0, 0, TB, V, H, ws->p, H, w->out_w, V, logits, V, w->out_b, 0))) return rc;
+        if ((rc = asr_zero_finished_rows(stream, logits, seq_len, T, B, V))) return rc;
+    }
+    asr::prof_end(ASR_PROF_DECODER_FWD, ms);
     return ASR_OK;
 }

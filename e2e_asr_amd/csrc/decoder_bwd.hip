@@ -333,11 +333,14 @@ extern "C" int asr_attn_decoder_bwd(void* stream, const asr_dec_weights* w, cons
     const int P = w->simple_w ? H : lmH;
     int rc;
     prof_begin(ASR_PROF_DECODER_BWD, s);
+    hipStream_t ss = side_stream();
+    void* side = static_cast<void*>(ss);
+    hipEvent_t e_fork = next_event();
+    if (hipEventRecord(e_fork, s) != hipSuccess || hipStreamWaitEvent(ss, e_fork, 0) != hipSuccess) return ASR_ELAUNCH;
     // ---- hoisted data gradients: dP = dLogits.W_out^T ; dQC = dP.W_ap^T
     if ((rc = asr_gemm_f32(stream, 0, 1, TB, H, V, dlogits, V, w->out_w, V, bw->dP, H, nullptr, 0))) return rc;
     if ((rc = asr_gemm_f32(stream, 0, 1, TB, H + D, H, bw->dP, H, w->ap_w, H, bw->dQC, H + D, nullptr, 0))) return rc;
     if (hipMemsetAsync(bw->dc_dec, 0, sizeof(float) * B * H, s) != hipSuccess) return ASR_ELAUNCH;
-    if (hipMemsetAsync(bw->dc_lm, 0, sizeof(float) * B * lmH, s) != hipSuccess) return ASR_ELAUNCH;
     if (hipMemsetAsync(bw->dhf, 0, sizeof(float) * (size_t)B * Te * A, s) != hipSuccess) return ASR_ELAUNCH;
     if (hipMemsetAsync(bw->dv_part, 0, sizeof(float) * B * A, s) != hipSuccess) return ASR_ELAUNCH;
     const int ldXH = E + H, ldLC = P + D, ldEH = E + lmH;
@@ -362,9 +365,19 @@ extern "C" int asr_attn_decoder_bwd(void* stream, const asr_dec_weights* w, cons
         // [dlm_out | dctx_prev] = dx . W_inp^T
         if ((rc = asr_linear_wt_fwd(stream, bw->dXH + o * ldXH, ldXH, E, w->inp_w, E, bw->dLC + o * ldLC, ldLC, B, P + D, 0)))
             return rc;
+    }
+    // ---- LM chain backward on the side stream: it needs only dLC[i] (all produced above) and its
+    // own carries, so it runs concurrently with the weight-gradient GEMMs below and with the
+    // encoder's BPTT that the caller launches next.  asr_side_join() orders it before the optimizer.
+    hipEvent_t e_loop = next_event();
+    if (hipEventRecord(e_loop, s) != hipSuccess || hipStreamWaitEvent(ss, e_loop, 0) != hipSuccess) return ASR_ELAUNCH;
+    if (hipMemsetAsync(bw->dc_lm, 0, sizeof(float) * B * lmH, ss) != hipSuccess) return ASR_ELAUNCH;
+    for (int i = T - 1; i >= 0; --i) {
+        const size_t o = (size_t)i * B;
+        const bool last = i == T - 1;
         const float* dlo = bw->dLC + o * ldLC; int ld_dlo = ldLC;
         if (w->simple_w) {
-            if ((rc = asr_linear_wt_fwd(stream, bw->dLC + o * ldLC, ldLC, H, w->simple_w, H, bw->dlm + o * lmH, lmH, B, lmH, 0)))
+            if ((rc = asr_linear_wt_fwd(side, bw->dLC + o * ldLC, ldLC, H, w->simple_w, H, bw->dlm + o * lmH, lmH, B, lmH, 0)))
                 return rc;
             dlo = bw->dlm + o * lmH; ld_dlo = lmH;
         }
@@ -373,10 +386,23 @@ extern "C" int asr_attn_decoder_bwd(void* stream, const asr_dec_weights* w, cons
         l.dlo = dlo; l.ld_dlo = ld_dlo;
         l.dh_carry = last ? nullptr : bw->dEH + (o + B) * ldEH + E; l.ld_dh = ldEH;
         l.dc_carry = bw->dc_lm; l.B = B; l.H = lmH; l.keep = keep_lm; l.seed = seed; l.step = (uint32_t)i;
-        hipLaunchKernelGGL(lm_cell_bwd_kernel, dim3((B * lmH + 255) / 256), dim3(256), 0, s, l);
+        hipLaunchKernelGGL(lm_cell_bwd_kernel, dim3((B * lmH + 255) / 256), dim3(256), 0, ss, l);
         // [demb | dlm_h_prev] = dG_lm . K_lm^T
-        if ((rc = asr_linear_wt_fwd(stream, ws->lm_gates + o * 4 * lmH, 4 * lmH, 4 * lmH, w->lm_kernel, 4 * lmH,
+        if ((rc = asr_linear_wt_fwd(side, ws->lm_gates + o * 4 * lmH, 4 * lmH, 4 * lmH, w->lm_kernel, 4 * lmH,
                                     bw->dEH + o * ldEH, ldEH, B, E + lmH, 0))) return rc;
+    }
+    {
+        float* gwl = nullptr;
+        if ((rc = asr_gather_rows(side, w->embedding, ws->tok, bw->emb_all, TB, E))) return rc;
+        gwl = const_cast<float*>(g->lm_kernel);
+        if ((rc = asr_gemm_f32(side, 1, 0, E, 4 * lmH, TB, bw->emb_all, E, ws->lm_gates, 4 * lmH, gwl, 4 * lmH, nullptr, 1))) return rc;
+        if (T > 1 && (rc = asr_gemm_f32(side, 1, 0, lmH, 4 * lmH, TB - B, ws->lm_h, lmH, ws->lm_gates + (size_t)B * 4 * lmH, 4 * lmH,
+                                        gwl + (size_t)E * 4 * lmH, 4 * lmH, nullptr, 1))) return rc;
+        if ((rc = asr_colsum_f32(side, ws->lm_gates, 4 * lmH, TB, 4 * lmH, const_cast<float*>(g->lm_bias), 1))) return rc;
+        if ((rc = asr_scatter_add_rows_ld(side, const_cast<float*>(g->embedding), ws->tok, bw->dEH, TB, E, ldEH))) return rc;
+        hipEvent_t e_done = next_event();
+        if (hipEventRecord(e_done, ss) != hipSuccess) return ASR_ELAUNCH;
+        set_pending_join(e_done);
     }
     if (hipGetLastError() != hipSuccess) return ASR_ELAUNCH;
     // ---- weight gradients: X^T . dY over all steps (accumulate into g)
@@ -413,14 +439,6 @@ extern "C" int asr_attn_decoder_bwd(void* stream, const asr_dec_weights* w, cons
         if ((rc = wgrad(lmH, H, TB, lmo, lmH, bw->dLC, ldLC, const_cast<float*>(g->simple_w)))) return rc;
         if ((rc = asr_colsum_f32(stream, bw->dLC, ldLC, TB, H, const_cast<float*>(g->simple_b), 1))) return rc;
     }
-    // lm cell kernel: rows [emb[tok] | lm_h_prev]; embedding gradient
-    if ((rc = asr_gather_rows(stream, w->embedding, ws->tok, bw->emb_all, TB, E))) return rc;
-    gw = const_cast<float*>(g->lm_kernel);
-    if ((rc = wgrad(E, 4 * lmH, TB, bw->emb_all, E, ws->lm_gates, 4 * lmH, gw))) return rc;
-    if (T > 1 && (rc = wgrad(lmH, 4 * lmH, TB - B, ws->lm_h, lmH, ws->lm_gates + (size_t)B * 4 * lmH, 4 * lmH,
-                             gw + (size_t)E * 4 * lmH))) return rc;
-    if ((rc = asr_colsum_f32(stream, ws->lm_gates, 4 * lmH, TB, 4 * lmH, const_cast<float*>(g->lm_bias), 1))) return rc;
-    if ((rc = asr_scatter_add_rows_ld(stream, const_cast<float*>(g->embedding), ws->tok, bw->dEH, TB, E, ldEH))) return rc;
     // denc[b] += sum_i alpha_i[b,:]^T . dctx_i[b,:]  -- one batched GEMM over the B utterances
     if ((rc = asr_gemm_f32_batched(stream, 1, 0, Te, D, T, ws->alpha, B * Te, Te, bw->dctx, B * D, D, denc, D,
                                    (long long)Te * D, nullptr, 1, B))) return rc;

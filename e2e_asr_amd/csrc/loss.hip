@@ -91,7 +91,23 @@ __global__ __launch_bounds__(256) void next_token_kernel(const float* logits, in
     if (threadIdx.x == 0) tok_out[b] = bi[0] == 0x7fffffff ? 0 : bi[0];
 }
 
+// raw_rnn emit: rows (t,b) with t >= len[b] are zeros (attn_decoder.py:170 output convention)
+__global__ __launch_bounds__(256) void zero_finished_rows_kernel(float* logits, const int* len, int T, int B, int V) {
+    const int row = blockIdx.x;
+    const int t = row / B, b = row % B;
+    if (t < len[b]) return;
+    float* p = logits + (size_t)row * V;
+    for (int v = threadIdx.x; v < V; v += 256) p[v] = 0.f;
+}
+
 }  // namespace asr
+
+extern "C" int asr_zero_finished_rows(void* stream, float* logits, const int* len, int T, int B, int V) {
+    if (!logits || !len || T <= 0 || B <= 0 || V <= 0) return ASR_EINVAL;
+    hipLaunchKernelGGL(asr::zero_finished_rows_kernel, dim3(T * B), dim3(256), 0, static_cast<hipStream_t>(stream), logits, len, T, B, V);
+    ASR_CHECK_LAUNCH();
+    return ASR_OK;
+}
 
 extern "C" int asr_masked_ce_fwd(void* stream, const float* logits, const int* targets, const int* len,
                                  float* nll_ws, float* lse_ws, float* loss, int T, int B, int V) {

@@ -46,3 +46,40 @@ extern "C" int asr_prof_read(int tag, double* total_ms, int* launches) {
     *total_ms = t; *launches = (int)p.used;
     return ASR_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Side stream for the decoder's LM chain (decoder.hip / decoder_bwd.hip): created once, lazily.
+// Events are pooled and reused; record/wait pairs are legal inside hipGraph capture (fork/join).
+// ---------------------------------------------------------------------------------------------
+namespace asr {
+static hipStream_t g_side = nullptr;
+static std::vector<hipEvent_t> g_events;
+static size_t g_ev_next = 0;
+static hipEvent_t g_join = nullptr;      // last event recorded on the side stream, not yet joined
+
+hipStream_t side_stream() {
+    if (!g_side) (void)hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking);
+    return g_side;
+}
+hipEvent_t next_event() {
+    if (g_ev_next == g_events.size()) {
+        hipEvent_t e;
+        (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        g_events.push_back(e);
+    }
+    hipEvent_t e = g_events[g_ev_next++];
+    if (g_ev_next >= 4096) g_ev_next = 0;        // ring: far more than one step's worth
+    return e;
+}
+void set_pending_join(hipEvent_t e) { g_join = e; }
+}  // namespace asr
+
+// Make `stream` wait for everything the library has queued on its side stream (LM-chain work of
+// asr_attn_decoder_bwd).  Must be called before the gradients are consumed.
+extern "C" int asr_side_join(void* stream) {
+    if (asr::g_join) {
+        if (hipStreamWaitEvent(static_cast<hipStream_t>(stream), asr::g_join, 0) != hipSuccess) return ASR_ELAUNCH;
+        asr::g_join = nullptr;
+    }
+    return ASR_OK;
+}

@@ -385,3 +385,8 @@ def prof_read(tag):
     ms, n = C.c_double(0), C.c_int(0)
     _check(_lib.lib().asr_prof_read(PROF_TAGS[tag], C.byref(ms), C.byref(n)), "asr_prof_read")
     return ms.value, n.value
+
+
+def side_join():
+    """Order the library's side-stream work (LM-chain gradients) before the current stream."""
+    _check(_lib.lib().asr_side_join(_stream()), "asr_side_join")

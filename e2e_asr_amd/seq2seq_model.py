@@ -172,10 +172,13 @@ class Seq2SeqModel(BaseParams):
             if d not in d_states:
                 d_states[d] = torch.zeros_like(self.decoder[task].saved["enc"])
             self.decoder[task].backward(dlogits, d_states[d])
-        if self.dist is not None:
-            self.dist.grad_ready(0, v.grad)        # decoder gradients are final: start their all-reduce
+        # the decoders' LM-chain gradients are still in flight on the library's side stream and
+        # overlap the encoder BPTT; encoder buckets all-reduce as they finish, the decoder bucket last
         self.encoder.backward(d_states, on_layer_done=(
             (lambda depth: self.dist.grad_ready(depth, v.grad)) if self.dist is not None else None))
+        ops.side_join()
+        if self.dist is not None:
+            self.dist.grad_ready(0, v.grad)
 
     def apply_gradients(self, slot="Adam", lr=None):
         """[data-parallel all-reduce ->] tf.clip_by_global_norm -> AdamOptimizer.apply_gradients

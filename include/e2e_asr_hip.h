@@ -193,6 +193,12 @@ int asr_attn_decoder_bwd(void* stream, const asr_dec_weights* w, const asr_dec_w
                          float* denc, float keep_lm, unsigned seed);
 int asr_scatter_add_rows_ld(void* stream, float* table_grad, const int* idx, const float* g, int rows, int width, int ldg);
 
+/* The decoder entry points run the LM cell chain on a library-owned side stream (forked from and
+ * ordered against `stream` with events; legal under hipGraph capture).  asr_attn_decoder_bwd leaves
+ * LM-chain gradient work in flight on it: call asr_side_join(stream) before reading the gradients. */
+int asr_side_join(void* stream);
+int asr_zero_finished_rows(void* stream, float* logits, const int* len, int T, int B, int V);
+
 /* Optional per-kernel HIP-event timing on the launch stream (bench.py roofline leg).
  * tag: 0 lstm recurrent fwd, 1 lstm recurrent bwd, 2 gemm, 3 decoder fwd, 4 decoder bwd, 5 optimizer.
  * asr_prof_read is a HOST call that synchronises on the recorded events. */
