@@ -29,7 +29,7 @@ class DecDims(C.Structure):
 class DecWs(C.Structure):
     _fields_ = [(n, vp) for n in (
         "hf", "tok", "lm_gates", "lm_c", "lm_h", "lm_hd", "sp", "x", "dec_gates", "dec_c",
-        "dec_h", "alpha", "ctx", "p", "zeros")]
+        "dec_h", "alpha", "ctx", "p", "zeros", "y")]
 
 
 class DecBwdWs(C.Structure):

@@ -25,6 +25,7 @@ struct AttnArgs {
     const int* enc_len;               // [B]
     float* alpha;                     // [B][Te]
     float* ctx;                       // [B][D]
+    float* y_out;                     // [B][A] query projection, saved for the backward (or nullptr)
     int B, Te, H, A, D;
     int len_shared;
     long long hf_bs, enc_bs;          // batch strides (elements); 0 = one utterance shared by all rows (beam search)
@@ -79,6 +80,7 @@ __global__ __launch_bounds__(ATT_NT) void attention_fwd_kernel(AttnArgs a) {
             float acc = a.b_att[aa];
             for (int p = 0; p < kparts; ++p) acc += part[4 * (p * na4 + (aa >> 2)) + (aa & 3)];
             ys[aa] = acc;
+            if (a.y_out) a.y_out[(size_t)b * A + aa] = acc;
         }
         __syncthreads();
     }
@@ -215,6 +217,8 @@ extern "C" int asr_attention_shared_fwd(void* stream, const float* q, int ldq, c
                                         const float* b_att, const float* v, const float* hf,
                                         const float* enc, const int* enc_len, float* alpha, float* ctx,
                                         int B, int Te, int H, int A, int D, int shared);
+static float* g_att_y_out = nullptr;      // set by the decoder loop for its next launch (host-side, same thread)
+extern "C" void asr_attention_set_y_out(float* y) { g_att_y_out = y; }
 
 extern "C" int asr_attention_fwd(void* stream, const float* q, int ldq, const float* w_att,
                                  const float* b_att, const float* v, const float* hf,
@@ -236,6 +240,7 @@ extern "C" int asr_attention_shared_fwd(void* stream, const float* q, int ldq, c
     a.q = q; a.ldq = ldq; a.w_att = w_att; a.b_att = b_att; a.v = v; a.hf = hf; a.enc = enc; a.enc_len = enc_len;
     a.alpha = alpha; a.ctx = ctx; a.B = B; a.Te = Te; a.H = H; a.A = A; a.D = D;
     a.len_shared = shared;
+    a.y_out = g_att_y_out; g_att_y_out = nullptr;
     a.hf_bs = shared ? 0 : (long long)Te * A; a.enc_bs = shared ? 0 : (long long)Te * D;
     hipLaunchKernelGGL(asr::attention_fwd_kernel, dim3(B), dim3(asr::ATT_NT), lds, static_cast<hipStream_t>(stream), a);
     ASR_CHECK_LAUNCH();

@@ -25,6 +25,7 @@ struct DecBwdStepArgs {
     // attention operands
     const float* q; const float* w_att; const float* b_att; const float* v;
     const float* hf; const float* enc; const int* enc_len; const float* alpha;
+    const float* y_saved;      // [B][A] from the forward, or nullptr (then recomputed)
     const float* dqc;          // [B][H+D]: dq_ap | dctx_ap for this step
     const float* dctx_carry; int ld_carry;   // dLC[i+1][:, P:] or nullptr
     float* dhf; float* dctx_out;   // accumulator [B][Te][A]; this step's total dctx [B][D]
@@ -125,8 +126,11 @@ __global__ __launch_bounds__(DBW_NT) void dec_attn_cell_bwd_kernel(DecBwdStepArg
         for (int t = tid; t < L; t += NT) al[t] = al[t] * (part[t] - S);     // de[tau]
         __syncthreads();
     }
-    // ---- y = q.W_att + b_att (recomputed)
-    {
+    // ---- y = q.W_att + b_att: taken from the forward when saved, else recomputed
+    if (a.y_saved) {
+        for (int aa = tid; aa < A; aa += NT) ys[aa] = a.y_saved[(size_t)b * A + aa];
+        __syncthreads();
+    } else {
         const int na4 = A >> 2;
         const int kparts = max(1, NT / na4);
         const int a4 = tid % na4, kp = tid / na4;
@@ -350,6 +354,7 @@ extern "C" int asr_attn_decoder_bwd(void* stream, const asr_dec_weights* w, cons
         DecBwdStepArgs a;
         a.q = ws->dec_c + o * H; a.w_att = w->attn_w; a.b_att = w->attn_b; a.v = w->attn_v;
         a.hf = ws->hf; a.enc = enc; a.enc_len = enc_len; a.alpha = ws->alpha + o * Te;
+        a.y_saved = ws->y ? ws->y + o * A : nullptr;
         a.dqc = bw->dQC + o * (H + D);
         a.dctx_carry = last ? nullptr : bw->dLC + (o + B) * ldLC + P; a.ld_carry = ldLC;
         a.dhf = bw->dhf; a.dctx_out = bw->dctx + o * D; a.dy = bw->dY + o * A; a.dv_part = bw->dv_part;

@@ -52,7 +52,29 @@ __global__ __launch_bounds__(256) void skinny_kernel(SkinnyArgs a) {
     }
     const int chunk = ((K + 63) / 64) * 16;
     const int kbeg = w * chunk, kend = min(K, kbeg + chunk);
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    // epilogue operands (wave 0 only) are requested NOW so that their latency hides under the
+    // weight stream instead of forming a second dependent memory round trip after the reduction
+    float eb0 = 0.f, eb1 = 0.f, eb2 = 0.f, eb3 = 0.f, ecp = 0.f;
+    bool ez = false;
+    if (w == 0 && rowok) {
+        if (LSTM) {
+            const int j = blockIdx.x * 4 + g4;
+            if (j < a.H) {
+                eb0 = a.bias[j]; eb1 = a.bias[a.H + j]; eb2 = a.bias[2 * a.H + j]; eb3 = a.bias[3 * a.H + j];
+                if (a.c_prev) ecp = a.c_prev[(size_t)brow * a.H + j];
+            }
+        } else {
+            const int n = blockIdx.x * 16 + 4 * g4;
+            if (a.bias) {
+                if (n < a.N) eb0 = a.bias[n];
+                if (n + 1 < a.N) eb1 = a.bias[n + 1];
+                if (n + 2 < a.N) eb2 = a.bias[n + 2];
+                if (n + 3 < a.N) eb3 = a.bias[n + 3];
+            }
+            ez = a.zero_from && a.zero_t >= a.zero_from[brow];
+        }
+    }
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};   // two independent MFMA chains
     // All loads of a group of IT k-steps are issued before the first MFMA consumes one, so
     // a wave pays ~one memory round trip per group instead of one per k-step.
     constexpr int IT = 12;
@@ -79,11 +101,13 @@ __global__ __launch_bounds__(256) void skinny_kernel(SkinnyArgs a) {
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[it].x, xv[it].x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[it].y, xv[it].y, acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[it].y, xv[it].y, acc2, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[it].z, xv[it].z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[it].w, xv[it].w, acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[it].w, xv[it].w, acc2, 0, 0, 0);
         }
     }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] += acc2[r];
     if (w > 0) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) red[w - 1][r][lane] = acc[r];
@@ -99,11 +123,11 @@ __global__ __launch_bounds__(256) void skinny_kernel(SkinnyArgs a) {
         const int j = blockIdx.x * 4 + g4;
         if (j >= a.H) return;
         const int H = a.H;
-        const float gi = fast_sigmoid(acc[0] + a.bias[j]);
-        const float gj = fast_tanh(acc[1] + a.bias[H + j]);
-        const float gf = fast_sigmoid(acc[2] + a.bias[2 * H + j] + 1.0f);
-        const float go = fast_sigmoid(acc[3] + a.bias[3 * H + j]);
-        const float cp = a.c_prev ? a.c_prev[(size_t)b * H + j] : 0.f;
+        const float gi = fast_sigmoid(acc[0] + eb0);
+        const float gj = fast_tanh(acc[1] + eb1);
+        const float gf = fast_sigmoid(acc[2] + eb2 + 1.0f);
+        const float go = fast_sigmoid(acc[3] + eb3);
+        const float cp = ecp;
         const float c = cp * gf + gi * gj;
         const float h = go * fast_tanh(c);
         a.c_out[(size_t)b * H + j] = c;
@@ -116,12 +140,13 @@ __global__ __launch_bounds__(256) void skinny_kernel(SkinnyArgs a) {
         }
     } else {
         const int n = blockIdx.x * 16 + 4 * g4;
-        const bool z = a.zero_from && a.zero_t >= a.zero_from[b];
+        const bool z = ez;
+        const float eb[4] = {eb0, eb1, eb2, eb3};
         float* op = a.out + (size_t)b * a.ldo + n;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             if (n + r < a.N) {
-                float v = z ? 0.f : acc[r] + (a.bias ? a.bias[n + r] : 0.f);
+                float v = z ? 0.f : acc[r] + eb[r];
                 if (a.accumulate) v += op[r];
                 op[r] = v;
             }

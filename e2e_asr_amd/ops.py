@@ -333,7 +333,7 @@ def attn_decoder_fwd(wt, dec_inp, seq_len, enc, enc_len, mode=0, coin=None, samp
               sp=f(T, B, H) if wt.get("simple_w") is not None else None, x=f(T, B, E),
               dec_gates=f(T, B, 4 * H), dec_c=f(T, B, H), dec_h=f(T, B, H), alpha=f(T, B, Te),
               ctx=f(T, B, D), p=f(T, B, H),
-              zeros=torch.zeros(B * max(H, lmH, D), device=dev, dtype=torch.float32))
+              zeros=torch.zeros(B * max(H, lmH, D), device=dev, dtype=torch.float32), y=f(T, B, A))
     logits = f(T * B, V)
     cw = _dec_struct(_lib.DecWeights, wt)
     cd = _lib.DecDims(B, Te, D, A, H, lmH, E, V, T)

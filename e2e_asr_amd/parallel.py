@@ -19,7 +19,14 @@ import torch.distributed as dist
 
 
 class DataParallel(object):
-    def __init__(self, model, process_group=None, overlap=True):
+    def __init__(self, model, process_group=None, overlap=None):
+        """overlap=None reads ASR_DP_OVERLAP (default off): the default path is ONE blocking all-reduce of
+        the whole flat gradient after backward -- 42.5 MB, well under a millisecond of a >20 ms step,
+        and the simplest thing that is correct by construction.  overlap=True launches the per-bucket
+        all-reduces asynchronously under the encoder BPTT."""
+        import os
+        if overlap is None:
+            overlap = os.environ.get("ASR_DP_OVERLAP", "0") == "1"
         if not dist.is_initialized():
             raise RuntimeError("DataParallel needs torch.distributed.init_process_group() first")
         self.group = process_group

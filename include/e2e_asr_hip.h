@@ -159,6 +159,7 @@ typedef struct {              /* activations: outputs of the forward, inputs of 
     float* ctx;               /* [T_out,B,D] */
     float* p;                 /* [T_out,B,H] */
     float* zeros;             /* [B*max(H,lmH,D)] zeros */
+    float* y;                 /* [T_out,B,A] attention query projection (saved for the backward; may be NULL) */
 } asr_dec_ws;
 
 /* mode 0: teacher forcing; 1: greedy (eval, decoder.py:139-154); 2: scheduled sampling

@@ -23,7 +23,7 @@ class _FakeModel(object):
         self.dist = None
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, rank_mode='overlap'):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -34,7 +34,7 @@ def _worker(rank, world, port, q):
                          attn_vec=4, seed=1 + rank)              # ranks start DIFFERENT: broadcast must fix it
         st = VariableStore.from_arrays(w, "cpu")
         model = _FakeModel(st)
-        dp = DataParallel(model)
+        dp = DataParallel(model, overlap=(rank_mode == 'overlap'))
         batch = synthetic_batch(B=4, T=9, F=10, t_dec=6, vocab=13, variable_len=True, seed=5)
         mine = shard_batch(batch, rank, world)
         mine["logmel"] = mine["logmel"].astype(np.float64)
@@ -53,11 +53,12 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_dp_two_ranks_equals_global_batch():
+@pytest.mark.parametrize("mode", ["overlap", "blocking"])
+def test_dp_two_ranks_equals_global_batch(mode):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, mode)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=180) for _ in procs], key=lambda r: r[0])
