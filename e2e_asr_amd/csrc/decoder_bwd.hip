@@ -405,51 +405,55 @@ extern "C" int asr_attn_decoder_bwd(void* stream, const asr_dec_weights* w, cons
                                         gwl + (size_t)E * 4 * lmH, 4 * lmH, nullptr, 1))) return rc;
         if ((rc = asr_colsum_f32(side, ws->lm_gates, 4 * lmH, TB, 4 * lmH, const_cast<float*>(g->lm_bias), 1))) return rc;
         if ((rc = asr_scatter_add_rows_ld(side, const_cast<float*>(g->embedding), ws->tok, bw->dEH, TB, E, ldEH))) return rc;
-        hipEvent_t e_done = next_event();
-        if (hipEventRecord(e_done, ss) != hipSuccess) return ASR_ELAUNCH;
-        set_pending_join(e_done);
     }
     if (hipGetLastError() != hipSuccess) return ASR_ELAUNCH;
-    // ---- weight gradients: X^T . dY over all steps (accumulate into g)
+    // ---- the encoder-state gradient is what the caller's stream needs next: do it first, there
+    // denc[b] += sum_i alpha_i[b,:]^T . dctx_i[b,:]  -- one batched GEMM over the B utterances
+    if ((rc = asr_gemm_f32_batched(stream, 1, 0, Te, D, T, ws->alpha, B * Te, Te, bw->dctx, B * D, D, denc, D,
+                                   (long long)Te * D, nullptr, 1, B))) return rc;
+    if ((rc = asr_gemm_f32(stream, 0, 1, B * Te, D, A, bw->dhf, A, w->attn_enc_w, A, denc, D, nullptr, 1))) return rc;
+    // ---- weight gradients: X^T . dY over all steps (accumulate into g), on the side stream
+    void* stream_w = side;
     auto wgrad = [&](int M, int N, int K, const float* Ap, int lda, const float* Bp, int ldb, float* C) {
-        return asr_gemm_f32(stream, 1, 0, M, N, K, Ap, lda, Bp, ldb, C, N, nullptr, 1);
+        return asr_gemm_f32(stream_w, 1, 0, M, N, K, Ap, lda, Bp, ldb, C, N, nullptr, 1);
     };
     float* gw = nullptr;
     // OutputProjection
     gw = const_cast<float*>(g->out_w);
     if ((rc = wgrad(H, V, TB, ws->p, H, dlogits, V, gw))) return rc;
-    if ((rc = asr_colsum_f32(stream, dlogits, V, TB, V, const_cast<float*>(g->out_b), 1))) return rc;
+    if ((rc = asr_colsum_f32(stream_w, dlogits, V, TB, V, const_cast<float*>(g->out_b), 1))) return rc;
     // AttnProjection: rows [q | ctx]
     gw = const_cast<float*>(g->ap_w);
     if ((rc = wgrad(H, H, TB, ws->dec_c, H, bw->dP, H, gw))) return rc;
     if ((rc = wgrad(D, H, TB, ws->ctx, D, bw->dP, H, gw + (size_t)H * H))) return rc;
-    if ((rc = asr_colsum_f32(stream, bw->dP, H, TB, H, const_cast<float*>(g->ap_b), 1))) return rc;
+    if ((rc = asr_colsum_f32(stream_w, bw->dP, H, TB, H, const_cast<float*>(g->ap_b), 1))) return rc;
     // Attention query projection, AttnV
     if ((rc = wgrad(H, A, TB, ws->dec_c, H, bw->dY, A, const_cast<float*>(g->attn_w)))) return rc;
-    if ((rc = asr_colsum_f32(stream, bw->dY, A, TB, A, const_cast<float*>(g->attn_b), 1))) return rc;
-    if ((rc = asr_colsum_f32(stream, bw->dv_part, A, B, A, const_cast<float*>(g->attn_v), 1))) return rc;
+    if ((rc = asr_colsum_f32(stream_w, bw->dY, A, TB, A, const_cast<float*>(g->attn_b), 1))) return rc;
+    if ((rc = asr_colsum_f32(stream_w, bw->dv_part, A, B, A, const_cast<float*>(g->attn_v), 1))) return rc;
     // outer cell kernel: rows [x | h_prev]
     gw = const_cast<float*>(g->dec_kernel);
     if ((rc = wgrad(E, 4 * H, TB, ws->x, E, ws->dec_gates, 4 * H, gw))) return rc;
     if (T > 1 && (rc = wgrad(H, 4 * H, TB - B, ws->dec_h, H, ws->dec_gates + (size_t)B * 4 * H, 4 * H, gw + (size_t)E * 4 * H))) return rc;
-    if ((rc = asr_colsum_f32(stream, ws->dec_gates, 4 * H, TB, 4 * H, const_cast<float*>(g->dec_bias), 1))) return rc;
+    if ((rc = asr_colsum_f32(stream_w, ws->dec_gates, 4 * H, TB, 4 * H, const_cast<float*>(g->dec_bias), 1))) return rc;
     // InputProjection: rows [lm_out' | ctx_prev]
     const float* lo = w->simple_w ? ws->sp : (keep_lm < 1.0f ? ws->lm_hd : ws->lm_h);
     gw = const_cast<float*>(g->inp_w);
     if ((rc = wgrad(P, E, TB, lo, P, bw->dXH, ldXH, gw))) return rc;
     if (T > 1 && (rc = wgrad(D, E, TB - B, ws->ctx, D, bw->dXH + (size_t)B * ldXH, ldXH, gw + (size_t)P * E))) return rc;
-    if ((rc = asr_colsum_f32(stream, bw->dXH, ldXH, TB, E, const_cast<float*>(g->inp_b), 1))) return rc;
+    if ((rc = asr_colsum_f32(stream_w, bw->dXH, ldXH, TB, E, const_cast<float*>(g->inp_b), 1))) return rc;
     if (w->simple_w) {
         const float* lmo = keep_lm < 1.0f ? ws->lm_hd : ws->lm_h;
         if ((rc = wgrad(lmH, H, TB, lmo, lmH, bw->dLC, ldLC, const_cast<float*>(g->simple_w)))) return rc;
-        if ((rc = asr_colsum_f32(stream, bw->dLC, ldLC, TB, H, const_cast<float*>(g->simple_b), 1))) return rc;
+        if ((rc = asr_colsum_f32(stream_w, bw->dLC, ldLC, TB, H, const_cast<float*>(g->simple_b), 1))) return rc;
     }
-    // denc[b] += sum_i alpha_i[b,:]^T . dctx_i[b,:]  -- one batched GEMM over the B utterances
-    if ((rc = asr_gemm_f32_batched(stream, 1, 0, Te, D, T, ws->alpha, B * Te, Te, bw->dctx, B * D, D, denc, D,
-                                   (long long)Te * D, nullptr, 1, B))) return rc;
     // AttnW and the encoder-state gradient through hf = enc.AttnW
     if ((rc = wgrad(D, A, B * Te, enc, D, bw->dhf, A, const_cast<float*>(g->attn_enc_w)))) return rc;
-    if ((rc = asr_gemm_f32(stream, 0, 1, B * Te, D, A, bw->dhf, A, w->attn_enc_w, A, denc, D, nullptr, 1))) return rc;
+    {
+        hipEvent_t e_done = next_event();
+        if (hipEventRecord(e_done, ss) != hipSuccess) return ASR_ELAUNCH;
+        set_pending_join(e_done);
+    }
     prof_end(ASR_PROF_DECODER_BWD, s);
     return ASR_OK;
 }

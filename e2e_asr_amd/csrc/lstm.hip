@@ -222,6 +222,8 @@ __global__ __launch_bounds__(16 * HS) void lstm_rec_fwd_kernel(LstmRecArgs a) {
             // every other workgroup of the group.  ONE 8-byte sc1 store.
             if (cb < a.B && s + 1 < S) {
                 u64* dst = hxg + ((size_t)(s & 1) * R + cr) * H + cj;
+                // (measured: a plain store + sc1 load is 12 % faster when the whole group sits on one
+                //  XCD, but stale across XCDs -- needs a runtime XCC-ID agreement first)
                 __hip_atomic_store(dst, ((u64)(uint32_t)(s + 1) << 32) | __float_as_uint(h),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }

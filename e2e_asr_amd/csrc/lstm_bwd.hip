@@ -297,20 +297,34 @@ extern "C" int asr_lstm_layer_bwd(void* stream, const float* x, int B, int T, in
         prof_end(ASR_PROF_LSTM_REC_BWD, s);
         if (rc) return rc;
     }
-    // input / weight gradients: three GEMMs + a column sum per direction
+    // Input gradient dX = dG.K_x^T stays on the caller's stream (the next layer's BPTT needs it).
+    // The weight/bias gradients (dK_x = X^T.dG, dK_h = Hprev^T.dG, db = colsum dG) are needed only
+    // by the optimizer: they go to the library's side stream and overlap the next layer's BPTT,
+    // whose workgroups mostly wait on the exchange and leave the matrix pipes idle.
+    // asr_side_join() orders them before the gradients are consumed.
     const int M = B * T;
+    for (int d = 0; d < ndir && dx; ++d) {
+        int rc;
+        if ((rc = asr_gemm_f32(stream, 0, 1, M, in_dim, H4, gates + (size_t)d * H4, ndir * H4, d ? kernel_bw : kernel_fw, H4,
+                               dx, in_dim, nullptr, d > 0))) return rc;
+    }
+    hipStream_t ss = side_stream();
+    void* side = static_cast<void*>(ss);
+    hipEvent_t e_dg = next_event();
+    if (hipEventRecord(e_dg, s) != hipSuccess || hipStreamWaitEvent(ss, e_dg, 0) != hipSuccess) return ASR_ELAUNCH;
     for (int d = 0; d < ndir; ++d) {
         const float* dG = gates + (size_t)d * H4;
         const int ldg = ndir * H4;
-        const float* K = d ? kernel_bw : kernel_fw;
         float* dK = d ? dkernel_bw : dkernel_fw;
         float* dB = d ? dbias_bw : dbias_fw;
         int rc;
-        if (dx && (rc = asr_gemm_f32(stream, 0, 1, M, in_dim, H4, dG, ldg, K, H4, dx, in_dim, nullptr, d > 0))) return rc;
-        if ((rc = asr_gemm_f32(stream, 1, 0, in_dim, H4, M, x, ldx, dG, ldg, dK, H4, nullptr, 1))) return rc;
-        if ((rc = asr_gemm_f32(stream, 1, 0, H, H4, M, hprev + (size_t)d * H, ndir * H, dG, ldg,
+        if ((rc = asr_gemm_f32(side, 1, 0, in_dim, H4, M, x, ldx, dG, ldg, dK, H4, nullptr, 1))) return rc;
+        if ((rc = asr_gemm_f32(side, 1, 0, H, H4, M, hprev + (size_t)d * H, ndir * H, dG, ldg,
                                dK + (size_t)in_dim * H4, H4, nullptr, 1))) return rc;
-        if ((rc = asr_colsum_f32(stream, dG, ldg, M, H4, dB, 1))) return rc;
+        if ((rc = asr_colsum_f32(side, dG, ldg, M, H4, dB, 1))) return rc;
     }
+    hipEvent_t e_done = next_event();
+    if (hipEventRecord(e_done, ss) != hipSuccess) return ASR_ELAUNCH;
+    set_pending_join(e_done);
     return ASR_OK;
 }

@@ -135,7 +135,8 @@ class Encoder(BaseParams):
                 kf, kb = v[names[0]], None
                 g = [v.grad_of(n) for n in names] + [None, None]
             dx = ops.lstm_layer_bwd(sv["x"], sv["lens_dev"], kf, kb, dout.contiguous(), sv["gates"], sv["c"], sv["hprev"],
-                                    g[0], g[1], g[2], g[3], need_dx=d > 1, keep_prob=sv["keep"], seed=sv["seed"])
+                                    g[0], g[1], g[2], g[3], need_dx=d > 1, keep_prob=sv["keep"], seed=sv["seed"],
+                                    join=False)
             if on_layer_done is not None:
                 on_layer_done(d)
         self.saved = None

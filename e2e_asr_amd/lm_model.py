@@ -60,6 +60,7 @@ class LMModel(BaseParams):
         one = torch.ones(1, device=v.device)
         dlogits = ops.masked_ce_bwd(self.outputs, lw["targets"], lw["lse"], lw["len"], one)
         self.encoder.backward(dlogits)
+        ops.side_join()
         n = self.dist.all_reduce_grads(v.grad) if self.dist is not None else 1
         m, vv = v.ensure_adam("AdamLM")                                   # lm_model.py:76
         self._gnorm_sq = ops.sumsq(v.grad)

@@ -120,9 +120,11 @@ def _hx(dev, nbytes):
 
 
 def lstm_layer_bwd(x, seq_len, kernel_fw, kernel_bw, dout, gates, act, hprev, dk_fw, db_fw, dk_bw=None,
-                   db_bw=None, need_dx=True, keep_prob=1.0, seed=0):
+                   db_bw=None, need_dx=True, keep_prob=1.0, seed=0, join=True):
     """Backward of lstm_layer_fwd.  `gates` is overwritten with dG; weight/bias gradients are
-    ACCUMULATED into dk_*/db_* (views of the flat gradient buffer).  Returns dx [B,T,in] or None."""
+    ACCUMULATED into dk_*/db_* (views of the flat gradient buffer) on the library's side stream:
+    join=False leaves them in flight (overlapping the next layer's BPTT) until ops.side_join().
+    Returns dx [B,T,in] or None."""
     B, T, IN = x.shape
     H = kernel_fw.shape[1] // 4
     ndir = 1 if kernel_bw is None else 2
@@ -135,6 +137,9 @@ def lstm_layer_bwd(x, seq_len, kernel_fw, kernel_bw, dout, gates, act, hprev, dk
                               _p(dk_fw), _p(db_fw), _p(dk_bw), _p(db_bw), _p(_hx(dev, nbytes)), nbytes,
                               _p(_Flag.get(dev)), float(keep_prob), int(seed) & 0xFFFFFFFF)
     _check(rc, "asr_lstm_layer_bwd")
+    keep_until_join(x, dout, gates, act, hprev, seq_len)
+    if join:          # weight/bias gradients are produced on the library's side stream
+        side_join()
     return dx
 
 
@@ -370,6 +375,7 @@ def attn_decoder_bwd(wt, gt, ws, enc, enc_len, dlogits, denc, keep_lm=1.0, seed=
                                          C.byref(cbw), _p(enc), _p(enc_len), _p(_f32(dlogits, "dlogits")),
                                          _p(_f32(denc, "denc")), float(keep_lm), int(seed) & 0xFFFFFFFF)
     _check(rc, "asr_attn_decoder_bwd")
+    keep_until_join(bw, ws, wt, gt, enc, enc_len, dlogits)
     return bw
 
 
@@ -387,6 +393,16 @@ def prof_read(tag):
     return ms.value, n.value
 
 
+_keepalive = []      # tensors still read by side-stream kernels: PyTorch's allocator only tracks the
+                     # current stream, so they must not be freed (and re-used) before the join
+
+
+def keep_until_join(*objs):
+    _keepalive.append(objs)
+
+
 def side_join():
-    """Order the library's side-stream work (LM-chain gradients) before the current stream."""
+    """Order the library's side-stream work (weight/bias and LM-chain gradients) before the current
+    stream; after it, buffers those kernels read may be released."""
     _check(_lib.lib().asr_side_join(_stream()), "asr_side_join")
+    _keepalive.clear()

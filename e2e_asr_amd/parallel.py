@@ -61,6 +61,9 @@ class DataParallel(object):
         """Called by the model's backward when bucket `key` is final: launch its all-reduce."""
         if not self.overlap or self.world == 1:
             return
+        if flat_grad.is_cuda:
+            from . import ops
+            ops.side_join()                  # weight gradients are produced on the side stream
         for k, (lo, hi) in self.buckets:
             if k == key:
                 self._pending.append(dist.all_reduce(flat_grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group,
