@@ -94,6 +94,9 @@ __global__ __launch_bounds__(16 * HS) void lstm_rec_fwd_kernel(LstmRecArgs a) {
     unsigned long long stamp[6] = {0, 0, 0, 0, 0, 0};
     unsigned long long tlast = STAMP ? __builtin_amdgcn_s_memtime() : 0;
 
+    // latency-critical serial chain: win issue arbitration against co-resident throughput kernels
+    // (the weight-gradient GEMMs of the layer above run concurrently on the side stream)
+    __builtin_amdgcn_s_setprio(3);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kq = lane & 15, cgl = lane >> 4;
     const int NG = (a.B + R - 1) / R;

@@ -72,6 +72,9 @@ __global__ __launch_bounds__(512) void lstm_rec_bwd_kernel(LstmBwdArgs a) {
     __shared__ __attribute__((aligned(16))) float part[G * R * HS];
     __shared__ __attribute__((aligned(16))) float pub[R * H];
 
+    // latency-critical serial chain: win issue arbitration against co-resident throughput kernels
+    // (the weight-gradient GEMMs of the layer above run concurrently on the side stream)
+    __builtin_amdgcn_s_setprio(3);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nc = lane & 15, kg = wave * 4 + (lane >> 4);
     const int NG = (a.B + R - 1) / R;
