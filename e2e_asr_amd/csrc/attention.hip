@@ -217,8 +217,6 @@ extern "C" int asr_attention_shared_fwd(void* stream, const float* q, int ldq, c
                                         const float* b_att, const float* v, const float* hf,
                                         const float* enc, const int* enc_len, float* alpha, float* ctx,
                                         int B, int Te, int H, int A, int D, int shared);
-static float* g_att_y_out = nullptr;      // set by the decoder loop for its next launch (host-side, same thread)
-extern "C" void asr_attention_set_y_out(float* y) { g_att_y_out = y; }
 
 extern "C" int asr_attention_fwd(void* stream, const float* q, int ldq, const float* w_att,
                                  const float* b_att, const float* v, const float* hf,
@@ -227,11 +225,22 @@ extern "C" int asr_attention_fwd(void* stream, const float* q, int ldq, const fl
     return asr_attention_shared_fwd(stream, q, ldq, w_att, b_att, v, hf, enc, enc_len, alpha, ctx, B, Te, H, A, D, 0);
 }
 
+int asr_attention_launch(void* stream, const float* q, int ldq, const float* w_att, const float* b_att, const float* v,
+                         const float* hf, const float* enc, const int* enc_len, float* alpha, float* ctx, float* y_out,
+                         int B, int Te, int H, int A, int D, int shared);
+
 // shared != 0: hf/enc/enc_len describe ONE utterance attended by all B query rows (beam search).
 extern "C" int asr_attention_shared_fwd(void* stream, const float* q, int ldq, const float* w_att,
                                         const float* b_att, const float* v, const float* hf,
                                         const float* enc, const int* enc_len, float* alpha, float* ctx,
                                         int B, int Te, int H, int A, int D, int shared) {
+    return asr_attention_launch(stream, q, ldq, w_att, b_att, v, hf, enc, enc_len, alpha, ctx, nullptr, B, Te, H, A, D, shared);
+}
+
+// internal (C++ linkage): also saves the query projection y [B,A] for the backward pass
+int asr_attention_launch(void* stream, const float* q, int ldq, const float* w_att, const float* b_att, const float* v,
+                         const float* hf, const float* enc, const int* enc_len, float* alpha, float* ctx, float* y_out,
+                         int B, int Te, int H, int A, int D, int shared) {
     if (!q || !w_att || !b_att || !v || !hf || !enc || !enc_len || !alpha || !ctx) return ASR_EINVAL;
     if (B <= 0 || Te <= 0 || H <= 0 || (A & 3) || (D & 3) || A <= 0 || D <= 0 || A > 1024) return ASR_EINVAL;
     const size_t lds = asr_attention_lds_bytes(Te, H, A);
@@ -240,7 +249,7 @@ extern "C" int asr_attention_shared_fwd(void* stream, const float* q, int ldq, c
     a.q = q; a.ldq = ldq; a.w_att = w_att; a.b_att = b_att; a.v = v; a.hf = hf; a.enc = enc; a.enc_len = enc_len;
     a.alpha = alpha; a.ctx = ctx; a.B = B; a.Te = Te; a.H = H; a.A = A; a.D = D;
     a.len_shared = shared;
-    a.y_out = g_att_y_out; g_att_y_out = nullptr;
+    a.y_out = y_out;
     a.hf_bs = shared ? 0 : (long long)Te * A; a.enc_bs = shared ? 0 : (long long)Te * D;
     hipLaunchKernelGGL(asr::attention_fwd_kernel, dim3(B), dim3(asr::ATT_NT), lds, static_cast<hipStream_t>(stream), a);
     ASR_CHECK_LAUNCH();

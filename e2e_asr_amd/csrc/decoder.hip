@@ -19,7 +19,9 @@
 #include "../../include/e2e_asr_hip.h"
 
 extern "C" int asr_zero_finished_rows(void* stream, float* logits, const int* len, int T, int B, int V);
-extern "C" void asr_attention_set_y_out(float* y);
+int asr_attention_launch(void* stream, const float* q, int ldq, const float* w_att, const float* b_att, const float* v,
+                         const float* hf, const float* enc, const int* enc_len, float* alpha, float* ctx, float* y_out,
+                         int B, int Te, int H, int A, int D, int shared);
 
 // Two streams.  The LM cell chain (attn_decoder.py:148-151) depends only on the fed tokens, so it
 // runs on the library's side stream AHEAD of the attention chain and re-synchronises only after a
@@ -84,9 +86,9 @@ extern "C" int asr_attn_decoder_fwd(void* stream, const asr_dec_weights* w, cons
                                     ws->dec_c + o * H, ws->dec_h + o * H, nullptr,
                                     ws->dec_gates ? ws->dec_gates + o * 4 * H : nullptr, 1.0f, 0, 0)))
             return rc;
-        if (ws->y) asr_attention_set_y_out(ws->y + o * A);
-        if ((rc = asr_attention_fwd(stream, ws->dec_c + o * H, H, w->attn_w, w->attn_b, w->attn_v, ws->hf, enc,
-                                    enc_len, ws->alpha + o * Te, ws->ctx + o * D, B, Te, H, A, D)))
+        if ((rc = asr_attention_launch(stream, ws->dec_c + o * H, H, w->attn_w, w->attn_b, w->attn_v, ws->hf, enc,
+                                       enc_len, ws->alpha + o * Te, ws->ctx + o * D, ws->y ? ws->y + o * A : nullptr,
+                                       B, Te, H, A, D, 0)))
             return rc;
         if (feedback(i) || mode == 1) {      // this step's logits feed the next token (or eval mode): project now
             if ((rc = asr_linear_fwd(stream, ws->dec_c + o * H, H, H, nullptr, ws->ctx + o * D, D, D, w->ap_w, H,

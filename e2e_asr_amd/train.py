@@ -15,7 +15,7 @@ import random
 import sys
 import time
 
-from . import checkpoint
+from . import checkpoint, ops
 from .base_params import BaseParams, Bunch
 from .eval_model import Eval
 from .lm_encoder import LMEncoder
@@ -139,6 +139,7 @@ class Train(BaseParams):
                 perplexity = math.exp(loss) if loss < 300 else float("inf")           # :305-312
                 print("Step %d Learning rate %.4f Checkpoint time %.2f Perplexity %.2f" % (
                     model.global_step, model.learning_rate, time.time() - ckpt_start, perplexity))
+                ops.check_device_flag(model.device)      # a persistent kernel that timed out raises here
                 asr_err_cur = self.eval_model.greedy_decode(dev_set)                  # :322
                 print("ASR error: %.4f" % asr_err_cur)
                 with open(os.path.join(params.train_dir, "asr_err.txt"), "a") as f:

@@ -1,0 +1,100 @@
+"""GPU: edge cases -- batch 1, single frame, length-1 rows, single encoder position,
+argument validation.  The reference's own NumPy attention raises at T=1 (beam_search.py:154-157);
+the TF graph handles it, and so does this path."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import asr_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+def T(x, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(x))
+    return (t if dtype is None else t.to(dtype)).to(DEV)
+
+
+@pytest.mark.parametrize("B,Tn,lens", [(1, 1, [1]), (1, 9, [9]), (3, 1, [1, 1, 1]), (2, 5, [1, 5]), (33, 3, None)])
+def test_lstm_tiny_shapes(B, Tn, lens):
+    from e2e_asr_amd import ops
+    rng = np.random.default_rng(B * 10 + Tn)
+    IN, H = 8, 64
+    lens = np.asarray(lens if lens is not None else rng.integers(1, Tn + 1, B))
+    x = rng.standard_normal((B, Tn, IN)).astype(np.float32)
+    k = rng.uniform(-0.3, 0.3, (IN + H, 4 * H)).astype(np.float32)
+    bz = rng.uniform(-0.3, 0.3, 4 * H).astype(np.float32)
+    out, gates, act, hp = ops.lstm_layer_fwd(T(x), T(lens, torch.int32), T(k), T(bz), T(k), T(bz), save=True)
+    ops.check_device_flag(DEV)
+    ref = O.bilstm_layer(np.transpose(x, (1, 0, 2)).astype(np.float64), lens, k.astype(np.float64), bz.astype(np.float64),
+                         k.astype(np.float64), bz.astype(np.float64))
+    np.testing.assert_allclose(out.cpu().numpy(), np.transpose(ref, (1, 0, 2)), rtol=0, atol=2e-5)
+    dk = [torch.zeros_like(T(k)), torch.zeros_like(T(bz)), torch.zeros_like(T(k)), torch.zeros_like(T(bz))]
+    dx = ops.lstm_layer_bwd(T(x), T(lens, torch.int32), T(k), T(k), torch.ones_like(out), gates, act, hp, *dk)
+    ops.check_device_flag(DEV)
+    assert torch.isfinite(dx).all() and all(torch.isfinite(d).all() for d in dk)
+    for b in range(B):                       # no gradient flows into padding frames
+        assert not dx[b, lens[b]:].any()
+
+
+def test_attention_single_position_and_zero_length():
+    from e2e_asr_amd import ops
+    rng = np.random.default_rng(0)
+    B, Te, H, A, D = 3, 4, 32, 16, 48
+    enc = rng.standard_normal((B, Te, D)).astype(np.float32)
+    q = rng.standard_normal((B, H)).astype(np.float32)
+    w = rng.uniform(-0.3, 0.3, (H, A)).astype(np.float32); bb = np.zeros(A, np.float32)
+    v = rng.uniform(-0.3, 0.3, A).astype(np.float32)
+    hf = rng.standard_normal((B, Te, A)).astype(np.float32)
+    lens = np.array([1, 4, 0])
+    ctx, alpha = ops.attention(T(q), T(w), T(bb), T(v), T(hf), T(enc), T(lens, torch.int32))
+    a = alpha.cpu().numpy(); c = ctx.cpu().numpy()
+    np.testing.assert_allclose(a[0], [1, 0, 0, 0], atol=0)          # one live position: all the mass
+    np.testing.assert_allclose(c[0], enc[0, 0], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(a[1].sum(), 1.0, rtol=1e-6)
+    assert not a[2].any() and not c[2].any()                          # zero-length: zeros, never NaN
+
+
+def test_model_batch1_single_target_token():
+    """Whole train step at B=1 with a 1-token target and T=2 frames (every loop runs once or twice)."""
+    from e2e_asr_amd.attn_decoder import AttnDecoder
+    from e2e_asr_amd.seq2seq_model import Seq2SeqModel
+    from oracle import torch_ref as R
+    p = Seq2SeqModel.class_params()
+    p.num_layers = {"char": 2}; p.max_output = {"char": 4}
+    p.encoder_params.use_lstm = True; p.encoder_params.hidden_size = 64; p.encoder_params.out_prob = 1.0
+    dp = AttnDecoder.class_params()
+    dp.hidden_size_dec = 32; dp.lm_hidden_size = 32; dp.emb_size = 16; dp.attention_vec_size = 8; dp.vocab_size = 9
+    dp.out_prob_dec = 1.0; dp.samp_prob = 0.0
+    p.decoder_params = {"char": dp}
+    m = Seq2SeqModel(None, True, p, device="cuda:0", feat_length=12, seed=5)
+    batch = {"logmel": np.random.default_rng(1).standard_normal((1, 2, 12)).astype(np.float32), "logmel_len": np.array([2]),
+             "char": np.array([[1, 2]]), "char_len": np.array([1])}
+    w = {k: v.astype(np.float64) for k, v in m.variables.to_arrays().items()}
+    m.forward(batch); loss = m.total_loss.item(); m.backward()
+    W = R.weights_to_torch(w)
+    b64 = dict(batch); b64["logmel"] = batch["logmel"].astype(np.float64)
+    total, _, _ = R.seq2seq_loss(b64, W, num_layers={"char": 2})
+    np.testing.assert_allclose(loss, total.item(), rtol=1e-5)
+    total.backward()
+    for name in m.variables.names():
+        ref = W[name].grad.numpy()
+        np.testing.assert_allclose(m.variables.grad_of(name).cpu().numpy(), ref, rtol=0, atol=2e-3 * max(1e-3, np.abs(ref).max()))
+
+
+def test_argument_validation_raises_valueerror():
+    from e2e_asr_amd import ops
+    x = torch.zeros(2, 4, 8, device=DEV); ln = torch.tensor([4, 4], dtype=torch.int32, device=DEV)
+    k96 = torch.zeros(8 + 96, 4 * 96, device=DEV); b96 = torch.zeros(4 * 96, device=DEV)
+    with pytest.raises(ValueError, match="unsupported"):             # H=96 is not an instantiated recurrent size
+        ops.lstm_layer_fwd(x, ln, k96, b96)
+    k = torch.zeros(9 + 64, 256, device=DEV)
+    with pytest.raises(ValueError, match="kernel rows"):
+        ops.lstm_layer_fwd(x, ln, k, torch.zeros(256, device=DEV))
+    with pytest.raises(ValueError, match="inner dimensions"):
+        ops.gemm(torch.zeros(3, 4, device=DEV), torch.zeros(5, 6, device=DEV))
+    with pytest.raises(ValueError):                                  # K1 not a multiple of 4
+        ops.linear(torch.zeros(2, 6, device=DEV), torch.zeros(6, 8, device=DEV))
+    with pytest.raises(ValueError, match="contiguous float32"):
+        ops.gemm(torch.zeros(4, 4, device=DEV).t(), torch.zeros(4, 4, device=DEV))
