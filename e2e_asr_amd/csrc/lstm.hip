@@ -39,6 +39,7 @@ struct LstmRecArgs {
     unsigned long long* dbg;  // diagnostic stamps (STAMP build) or nullptr
     float* hprev;          // [B][T][ND][H] or nullptr: h_{t-1} (undropped) for dK_h = Hprev^T.dG
     u64* hx;               // exchange granules [ND*NG][2][R][H]
+    u64* xcc_slots;        // [ND*NG][16] XCC-ID agreement slots (zeroed with hx)
     int* err;              // set to 1 on poll timeout
     int B, T, Tout, ND, boff;
     float keep; uint32_t seed;
@@ -140,6 +141,7 @@ __global__ __launch_bounds__(16 * HS) void lstm_rec_fwd_kernel(LstmRecArgs a) {
     const int cb_safe = min(cb, a.B - 1);
     float c = 0.f, h = 0.f;
     u64* hxg = a.hx + (size_t)grp * 2 * R * H;
+    const bool fast = group_shares_xcd(a.xcc_slots + (size_t)grp * 16, G, mem, tid, a.err);
     // x.Kx+b of the NEXT step is loaded at the end of each cell phase (software pipelining): the
     // registers are loop-carried, never re-initialised, so the loop head needs no vmcnt wait and the
     // load latency hides under the next step's exchange.
@@ -225,10 +227,9 @@ __global__ __launch_bounds__(16 * HS) void lstm_rec_fwd_kernel(LstmRecArgs a) {
             // every other workgroup of the group.  ONE 8-byte sc1 store.
             if (cb < a.B && s + 1 < S) {
                 u64* dst = hxg + ((size_t)(s & 1) * R + cr) * H + cj;
-                // (measured: a plain store + sc1 load is 12 % faster when the whole group sits on one
-                //  XCD, but stale across XCDs -- needs a runtime XCC-ID agreement first)
-                __hip_atomic_store(dst, ((u64)(uint32_t)(s + 1) << 32) | __float_as_uint(h),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const u64 gv = ((u64)(uint32_t)(s + 1) << 32) | __float_as_uint(h);
+                if (fast) asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(dst), "v"(gv) : "memory");   // stays in this XCD's L2
+                else __hip_atomic_store(dst, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                 // write-through (sc1)
             }
             if (live) {       // bookkeeping stores, off the critical path
                 const size_t ridx = (((size_t)cb * a.T + t) * a.ND + dir) * H + cj;
@@ -305,9 +306,12 @@ int asr_lstm_pick_rows(int B, int ND, int G) {
     return 8;
 }
 
-extern "C" size_t asr_lstm_ws_bytes(int B, int H, int ndir) {
+static size_t lstm_hx_bytes(int B, int H, int ndir) {
     // worst case R=1: ND * B groups * 2 parities * H granules; R>1 never needs more
     return (size_t)ndir * (size_t)((B + 7) / 8 * 8) * 2 * H * sizeof(u64);
+}
+extern "C" size_t asr_lstm_ws_bytes(int B, int H, int ndir) {
+    return lstm_hx_bytes(B, H, ndir) + (size_t)ndir * (size_t)((B + 7) / 8 * 8) * 16 * sizeof(u64);   // + XCC slots
 }
 
 extern "C" int asr_lstm_layer_fwd(void* stream, const float* x, int B, int T, int in_dim, int ldx,
@@ -338,6 +342,7 @@ extern "C" int asr_lstm_layer_fwd(void* stream, const float* x, int B, int T, in
     a.kh[0] = kernel_fw + (size_t)in_dim * H4;
     a.kh[1] = ndir == 2 ? kernel_bw + (size_t)in_dim * H4 : nullptr;
     a.len = len; a.out = out; a.act = act; a.hprev = hprev; a.boff = 0; a.hx = static_cast<u64*>(hx_ws); a.err = err_flag;
+    a.xcc_slots = reinterpret_cast<u64*>(static_cast<char*>(hx_ws) + lstm_hx_bytes(B, H, ndir));
     a.B = B; a.T = T; a.Tout = Tout; a.ND = ndir; a.keep = keep_prob; a.seed = seed;
     const int R = asr_lstm_pick_rows(B, ndir, H / 32);
     // batches too large for one resident grid run as consecutive launches over row ranges

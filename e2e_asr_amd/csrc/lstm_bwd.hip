@@ -31,6 +31,7 @@ struct LstmBwdArgs {
     const float* kh[2];
     const int* len;
     u64* hx;               // [groups][2][G dst][G src][R][32] granules
+    u64* xcc_slots;        // [groups][16] XCC-ID agreement slots (zeroed with hx)
     int* err;
     int B, T, Tout, ND, boff;
     float keep; uint32_t seed;
@@ -110,6 +111,7 @@ __global__ __launch_bounds__(512) void lstm_rec_bwd_kernel(LstmBwdArgs a) {
     const int cj = j0 + cu;
     float dc = 0.f;
     u64* hxg = a.hx + (size_t)grp * 2 * G * G * R * HS;
+    const bool fast = group_shares_xcd(a.xcc_slots + (size_t)grp * 16, G, mem, tid, a.err);
 
     // software-pipelined operands of the cell (loop-carried registers, no in-loop init)
     float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
@@ -199,10 +201,12 @@ __global__ __launch_bounds__(512) void lstm_rec_bwd_kernel(LstmBwdArgs a) {
             u64* dstb = hxg + (size_t)(s & 1) * G * G * R * HS;
             for (int idx = tid; idx < R * H; idx += NCW) {
                 const int md = idx / (R * HS), rem = idx % (R * HS);
-                if (r0 + rem / HS < a.B)
-                    __hip_atomic_store(dstb + ((size_t)md * G + mem) * R * HS + rem,
-                                       ((u64)(uint32_t)(s + 1) << 32) | __float_as_uint(pub[idx]),
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (r0 + rem / HS < a.B) {
+                    u64* dst = dstb + ((size_t)md * G + mem) * R * HS + rem;
+                    const u64 gv = ((u64)(uint32_t)(s + 1) << 32) | __float_as_uint(pub[idx]);
+                    if (fast) asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(dst), "v"(gv) : "memory");
+                    else __hip_atomic_store(dst, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
         }
         if (cell_wave && cell) {       // bookkeeping, off the critical path
@@ -247,9 +251,12 @@ extern "C" int asr_gemm_f32(void*, int, int, int, int, int, const float*, int, c
 extern "C" int asr_colsum_f32(void* stream, const float* x, int ldx, int M, int N, float* out, int accumulate);
 int asr_lstm_pick_rows(int B, int ND, int G);
 
-extern "C" size_t asr_lstm_bwd_ws_bytes(int B, int H, int ndir) {
+static size_t lstm_bwd_hx_bytes(int B, int H, int ndir) {
     const size_t G = H / 32;
     return (size_t)ndir * (size_t)((B + 7) / 8 * 8) * 2 * G * H * sizeof(u64);
+}
+extern "C" size_t asr_lstm_bwd_ws_bytes(int B, int H, int ndir) {
+    return lstm_bwd_hx_bytes(B, H, ndir) + (size_t)ndir * (size_t)((B + 7) / 8 * 8) * 16 * sizeof(u64);   // + XCC slots
 }
 
 // Backward of asr_lstm_layer_fwd.  act/hprev are the forward's saved tensors; gates (the
@@ -276,6 +283,7 @@ extern "C" int asr_lstm_layer_bwd(void* stream, const float* x, int B, int T, in
     a.kh[0] = kernel_fw + (size_t)in_dim * H4;
     a.kh[1] = ndir == 2 ? kernel_bw + (size_t)in_dim * H4 : nullptr;
     a.len = len; a.hx = static_cast<u64*>(hx_ws); a.err = err_flag;
+    a.xcc_slots = reinterpret_cast<u64*>(static_cast<char*>(hx_ws) + lstm_bwd_hx_bytes(B, H, ndir));
     a.B = B; a.T = T; a.Tout = Tout; a.ND = ndir; a.boff = 0; a.keep = keep_prob; a.seed = seed;
     const int R = asr_lstm_pick_rows(B, ndir, G);
     const int max_groups = 256 / G / ndir;
