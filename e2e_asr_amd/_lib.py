@@ -29,7 +29,7 @@ class DecDims(C.Structure):
 class DecWs(C.Structure):
     _fields_ = [(n, vp) for n in (
         "hf", "tok", "lm_gates", "lm_c", "lm_h", "lm_hd", "sp", "x", "dec_gates", "dec_c",
-        "dec_h", "alpha", "ctx", "p", "zeros", "y")]
+        "dec_h", "alpha", "ctx", "p", "zeros", "y", "w2k", "chain_ws", "err")]
 
 
 class DecBwdWs(C.Structure):
@@ -78,6 +78,8 @@ SIGNATURES = {
                                        C.POINTER(DecWs), C.POINTER(DecBwdWs), vp, vp, vp, vp, C.c_float, C.c_uint]),
     "asr_scatter_add_rows_ld": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int]),
     "asr_side_join": (C.c_int, [vp]),
+    "asr_decoder_chain_supported": (C.c_int, [C.c_int] * 5),
+    "asr_decoder_chain_ws_bytes": (C.c_size_t, [C.c_int] * 4),
     "asr_zero_finished_rows": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int]),
     "asr_prof_enable": (C.c_int, [C.c_int]),
     "asr_debug_set_buffer": (C.c_int, [vp]),

@@ -76,8 +76,10 @@ __device__ __forceinline__ float wave_allreduce_max(float v) {
 // protocol; if all G ids are equal the group's granules may be published with PLAIN stores: the line
 // then stays in that XCD's L2, where the peers' L1-bypassing sc1 loads find it (measured -12 % per
 // recurrent step), instead of being written through to the fabric.  Any other placement keeps sc1.
-__device__ __forceinline__ bool group_shares_xcd(u64* slots, int G, int mem, int tid, int* err) {
-    __shared__ int s_same;
+__device__ __forceinline__ bool group_shares_xcd(u64* slots, int G, int mem, int tid, int* err, int* lds_flag = nullptr) {
+    __shared__ int s_same_static;
+    int* s_same_p = lds_flag ? lds_flag : &s_same_static;   // kernels with dynamic LDS pass their own word (G17)
+#define s_same (*s_same_p)
     if (tid == 0) {
         const uint32_t xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 0xF;   // HW_REG_XCC_ID[3:0]
         __hip_atomic_store(slots + mem, (0xA5A50000ull << 32) | xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -93,7 +95,9 @@ __device__ __forceinline__ bool group_shares_xcd(u64* slots, int G, int mem, int
         s_same = same ? 1 : 0;
     }
     __syncthreads();
-    return s_same != 0;
+    const bool res = s_same != 0;
+#undef s_same
+    return res;
 }
 
 // ---- counter-based uniform [0,1) for dropout (same value in fwd and bwd) ----

@@ -19,6 +19,11 @@
 #include "../../include/e2e_asr_hip.h"
 
 extern "C" int asr_zero_finished_rows(void* stream, float* logits, const int* len, int T, int B, int V);
+extern "C" int asr_decoder_chain_supported(int B, int Te, int D, int A, int H);
+int asr_decoder_chain_fwd(void* stream, float* gates, const float* wh, const float* wc, const float* w_att,
+                          const float* b_att, const float* v, const float* hf, const float* enc, const int* enc_len,
+                          float* dec_c, float* dec_h, float* alpha, float* ctx, float* y, void* ws, int* err,
+                          int B, int Te, int D, int A, int H, int t0, int t1);
 int asr_attention_launch(void* stream, const float* q, int ldq, const float* w_att, const float* b_att, const float* v,
                          const float* hf, const float* enc, const int* enc_len, float* alpha, float* ctx, float* y_out,
                          int B, int Te, int H, int A, int D, int shared);
@@ -55,7 +60,69 @@ extern "C" int asr_attn_decoder_fwd(void* stream, const asr_dec_weights* w, cons
         return mode == 2 && samp_prob > 0.f && !(coin_host[i] < 1.0f - samp_prob);
     };
     hipEvent_t e_tok = nullptr;
-    for (int i = 0; i < T; ++i) {
+    // ---- persistent chain path: the per-step attention chain of a whole SEGMENT (steps up to and
+    // including the next feedback step) runs in one launch of csrc/decoder_chain.hip
+    const bool use_chain = mode != 1 && ws->chain_ws && ws->w2k && ws->err && ws->y && ws->dec_gates &&
+                           asr_decoder_chain_supported(B, Te, D, A, H) && B <= 32;
+    if (use_chain) {
+        // W2K = W_inp[P:, :] . K_x   ([D,E].[E,4H]): the context half of InputProjection folded into the cell
+        if ((rc = asr_gemm_f32(stream, 0, 0, D, 4 * H, E, w->inp_w + (size_t)P * E, E, w->dec_kernel, 4 * H, ws->w2k, 4 * H, nullptr, 0)))
+            return rc;
+        const float* lm_base = w->simple_w ? ws->sp : (keep_lm < 1.0f ? ws->lm_hd : ws->lm_h);
+        int t0 = 0;
+        while (t0 < T) {
+            int t1 = t0;
+            while (t1 < T && !feedback(t1)) ++t1;
+            t1 = t1 < T ? t1 + 1 : T;                       // the feedback step closes the segment
+            // side stream: LM cells of the segment (they need the token produced by the previous segment)
+            if (feedback(t0 - 1) && hipStreamWaitEvent(ss, e_tok, 0) != hipSuccess) return ASR_ELAUNCH;
+            for (int i = t0; i < t1; ++i) {
+                const size_t o = (size_t)i * B;
+                const float* lm_hp = i ? ws->lm_h + (o - B) * lmH : ws->zeros;
+                const float* lm_cp = i ? ws->lm_c + (o - B) * lmH : nullptr;
+                if ((rc = asr_lstm_cell_fwd(side, w->embedding, E, E, ws->tok + o, lm_hp, lm_cp, w->lm_kernel,
+                                            w->lm_bias, lmH, B, ws->lm_c + o * lmH, ws->lm_h + o * lmH,
+                                            keep_lm < 1.0f ? ws->lm_hd + o * lmH : nullptr,
+                                            ws->lm_gates ? ws->lm_gates + o * 4 * lmH : nullptr, keep_lm, seed, (unsigned)i)))
+                    return rc;
+                if (w->simple_w) {
+                    const float* lo = keep_lm < 1.0f ? ws->lm_hd + o * lmH : ws->lm_h + o * lmH;
+                    if ((rc = asr_linear_fwd(side, lo, lmH, lmH, nullptr, nullptr, 0, 0, w->simple_w, H,
+                                             w->simple_b, ws->sp + o * H, H, B, H, nullptr, 0)))
+                        return rc;
+                }
+            }
+            hipEvent_t e_lm = asr::next_event();
+            if (hipEventRecord(e_lm, ss) != hipSuccess || hipStreamWaitEvent(ms, e_lm, 0) != hipSuccess) return ASR_ELAUNCH;
+            const int rows = (t1 - t0) * B;
+            const size_t o0 = (size_t)t0 * B;
+            // x_lm = lm_out . W_inp[:P] + b_inp  (kept in ws->x; the context half is added after the loop)
+            if ((rc = asr_gemm_f32(stream, 0, 0, rows, E, P, lm_base + o0 * P, P, w->inp_w, E, ws->x + o0 * E, E, w->inp_b, 0))) return rc;
+            // preG = x_lm . K_x + b_dec  -> the gates buffer (the chain kernel overwrites it with the activations)
+            if ((rc = asr_gemm_f32(stream, 0, 0, rows, 4 * H, E, ws->x + o0 * E, E, w->dec_kernel, 4 * H,
+                                   ws->dec_gates + o0 * 4 * H, 4 * H, w->dec_bias, 0))) return rc;
+            if ((rc = asr_decoder_chain_fwd(stream, ws->dec_gates, w->dec_kernel + (size_t)E * 4 * H, ws->w2k, w->attn_w, w->attn_b,
+                                            w->attn_v, ws->hf, enc, enc_len, ws->dec_c, ws->dec_h, ws->alpha, ws->ctx, ws->y,
+                                            ws->chain_ws, ws->err, B, Te, D, A, H, t0, t1))) return rc;
+            const int i = t1 - 1;
+            if (feedback(i)) {
+                const size_t o = (size_t)i * B;
+                if ((rc = asr_linear_fwd(stream, ws->dec_c + o * H, H, H, nullptr, ws->ctx + o * D, D, D, w->ap_w, H,
+                                         w->ap_b, ws->p + o * H, H, B, H, nullptr, 0))) return rc;
+                if ((rc = asr_linear_fwd(stream, ws->p + o * H, H, H, nullptr, nullptr, 0, 0, w->out_w, V, w->out_b,
+                                         logits + o * V, V, B, V, seq_len, i))) return rc;
+                if ((rc = asr_next_token(stream, logits + o * V, B, V, V, ws->tok + o + B, mode == 2 ? 1 : 0, seed, (unsigned)i)))
+                    return rc;
+                e_tok = asr::next_event();
+                if (hipEventRecord(e_tok, ms) != hipSuccess) return ASR_ELAUNCH;
+            }
+            t0 = t1;
+        }
+        // x (saved for the backward) = x_lm + ctx_prev . W_inp[P:]   -- one GEMM over steps 1..T-1
+        if (T > 1 && (rc = asr_gemm_f32(stream, 0, 0, (T - 1) * B, E, D, ws->ctx, D, w->inp_w + (size_t)P * E, E,
+                                        ws->x + (size_t)B * E, E, nullptr, 1))) return rc;
+    }
+    for (int i = 0; i < T && !use_chain; ++i) {
         const size_t o = (size_t)i * B;
         // ---- side stream: LM cell of step i
         if (feedback(i - 1) && hipStreamWaitEvent(ss, e_tok, 0) != hipSuccess) return ASR_ELAUNCH;

@@ -1,0 +1,449 @@
+// Persistent attention-decoder chain, forward: steps [t0,t1) of the raw_rnn loop
+// (attn_decoder.py:76-162) in ONE launch.
+//
+// What is on the per-step dependency chain of the decoder is short:
+//     [h_{i-1}, ctx_{i-1}] -> outer cell (gates = preG_i + h.K_h + ctx.(W2.K_x)) -> q = c_i
+//       -> y = q.W_att + b -> e[tau] = v.tanh(hf[tau] + y) -> alpha = softmax -> ctx_i
+// everything else is hoisted by the caller (decoder.hip): the LM cell chain (side stream),
+// preG_i = (lm_out_i.W1 + b_inp).K_x + b_dec and W2.K_x as MFMA GEMMs before the launch,
+// x_i (needed only by the backward), AttnProjection and OutputProjection as GEMMs after it.
+// As separate launches those chain stages cost ~27 us per step (start/drain latency of three
+// dependent kernels); here a step is four granule exchanges inside a persistent kernel.
+//
+// Decomposition (same recipe as csrc/lstm.hip): groups of R = 2 utterances never synchronise
+// with each other; inside a group G = 16 workgroups each own H/16 hidden units (all 4 gates),
+// A/16 attention columns, a slice of ceil(Te/16) encoder positions and D/16 context columns.
+// Weights stay on chip for the whole segment: the [(H+D) x 4H/16] slice of [K_h ; W2.K_x] and the
+// W_att slice in registers, the hf / enc slices in LDS.  Exchanges are all-gathers of tagged
+// 8-byte granules (tag = step+1, one store each, polled with 16-byte sc1 loads), double-buffered;
+// wave 0 is the cell/publisher wave (owns every global store, never polls), waves 1-7 poll.
+// The same-XCD plain-store fast path is used when the group's XCC ids agree.
+#include "common.h"
+#include <cstdlib>
+
+extern "C" int asr_decoder_chain_supported(int B, int Te, int D, int A, int H);
+extern "C" size_t asr_decoder_chain_ws_bytes(int B, int D, int A, int H);
+
+namespace asr {
+
+struct ChainArgs {
+    float* gates;            // [T][B][4H] in: preG rows of the segment; out: activated i,j,f,o
+    const float* wh;         // [H][4H]  K_h  (rows E.. of the outer cell's TF kernel)
+    const float* wc;         // [D][4H]  W2.K_x
+    const float* w_att; const float* b_att; const float* v;     // [H][A], [A], [A]
+    const float* hf;         // [B][Te][A]
+    const float* enc;        // [B][Te][D]
+    const int* enc_len;      // [B]
+    float* dec_c; float* dec_h; float* alpha; float* ctx; float* y;   // [T][B][.] saved activations
+    u64* gx;                 // granules: [groups][2 parities][S | Q | Y | E]
+    u64* xcc_slots;          // [groups][16]
+    int* err;
+    int B, Te, t0, t1;
+};
+
+typedef unsigned int u32x4c __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bool chain_poll2(const u64* g, uint32_t epoch, float& v0, float& v1, int* err) {
+    long long t0 = 0;
+    const u32x4c* p = reinterpret_cast<const u32x4c*>(g);
+    for (uint32_t spins = 0;; ++spins) {
+        u32x4c x;
+        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(x) : "v"(p) : "memory");
+        if (x.y == epoch && x.w == epoch) { v0 = __uint_as_float(x.x); v1 = __uint_as_float(x.z); return true; }
+        if ((spins & 1023) == 1023) {
+            const long long now = wall_clock64();
+            if (t0 == 0) t0 = now;
+            else if (now - t0 > 200000000LL) { *err = 1; v0 = v1 = 0.f; return false; }
+            if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { v0 = v1 = 0.f; return false; }
+        }
+    }
+}
+__device__ __forceinline__ void chain_publish(u64* dst, uint32_t epoch, float v, bool fast) {
+    const u64 gv = ((u64)epoch << 32) | __float_as_uint(v);
+    if (fast) asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(dst), "v"(gv) : "memory");
+    else __hip_atomic_store(dst, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// H: decoder hidden; D: encoder state width; A: attention width.  R = 2 rows, G = 16 workgroups.
+template <int H, int D, int A>
+__global__ __launch_bounds__(512) void decoder_chain_fwd_kernel(ChainArgs a) {
+    constexpr int R = 2, G = 16, NT = 512;
+    constexpr int HS = H / G;            // hidden units per workgroup
+    constexpr int AS = A / G;            // attention columns per workgroup
+    constexpr int DS = D / G;            // context columns per workgroup
+    constexpr int KS = H + D;            // state width [h | ctx]
+    constexpr int KSP = (KS + 127) / 128 * 128;   // ... padded so that 32 chunks of a multiple of 4 cover it
+    constexpr int KC = KSP / 32;         // state values per lane in the cell matvec (32 chunks)
+    constexpr int KCP = KC + 4;          // padded chunk stride in LDS
+    constexpr int QP = (H + 127) / 128 * 128;     // padded query length
+    constexpr int QC = QP / 32;          // q values per lane in the y matvec
+    constexpr int MAXTS = 16;            // encoder positions per workgroup (Te <= 256)
+    static_assert(HS * G == H && AS * G == A && DS * G == D && HS <= 16 && AS <= 8, "sizes");
+    static_assert(KC % 4 == 0 && QC % 4 == 0 && KS % 2 == 0 && H % 2 == 0 && A % 2 == 0, "mapping");
+    constexpr int H4 = 4 * H;
+    constexpr int NTP = (NT / (DS * R)) < 8 ? (NT / (DS * R)) : 8;     // tau parts of the context sum
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // LDS carve (floats)
+    int* lds_flag = reinterpret_cast<int*>(smem);   // 4 words reserved (XCC agreement)
+    float* sl = smem + 4;                           // state [R][32 chunks][KCP]
+    float* sums = sl + R * 32 * KCP;                // [2 parts][HS][R][4]
+    float* ql = sums + 2 * HS * R * 4;              // q [R][QP]
+    float* ysum = ql + R * QP;                      // [2 parts][AS][R]
+    float* yl = ysum + 2 * AS * R + 4;              // y [R][A]
+    float* el = yl + R * A;                         // e / alpha [R][G*MAXTS]
+    float* eout = el + R * G * MAXTS;               // [32] scores of this workgroup
+    float* cpart = eout + 32;                       // [8][R][DS]
+    float* hfl = cpart + 8 * R * DS;                // hf slice [R][TS][A]
+    const int Te = a.Te;
+    const int TS = (Te + G - 1) / G;
+    float* encl = hfl + R * MAXTS * A;              // enc slice [R][Te][DS]
+
+    __builtin_amdgcn_s_setprio(3);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kq = lane & 15, row = tid >> 4;       // 32 DPP rows
+    const int NG = (a.B + R - 1) / R;
+    int grp, mem;
+    if ((NG & 7) == 0) { mem = (blockIdx.x >> 3) % G; grp = (blockIdx.x & 7) + 8 * (blockIdx.x / (8 * G)); }
+    else { grp = blockIdx.x / G; mem = blockIdx.x % G; }
+    const int r0 = grp * R;
+    const bool wave0 = __builtin_amdgcn_readfirstlane(tid) < 64;
+    const int brow0 = min(r0, a.B - 1), brow1 = min(r0 + 1, a.B - 1);
+    const int blen0 = min(max(a.enc_len[brow0], 0), Te);
+    const int blen1 = (r0 + 1 < a.B) ? min(max(a.enc_len[brow1], 0), Te) : 0;
+    auto browf = [&](int r) { return r ? brow1 : brow0; };
+    auto blenf = [&](int r) { return r ? blen1 : blen0; };
+    // granule areas of this group
+    constexpr int NS = R * KS, NQ = R * H, NY = R * A, NE = R * G * MAXTS;
+    constexpr int NPAR = NS + NQ + NY + NE;
+    u64* gbase = a.gx + (size_t)grp * 2 * NPAR;
+    const bool fast = group_shares_xcd(a.xcc_slots + (size_t)grp * 16, G, mem, tid, a.err, lds_flag);
+
+    // ---- resident operands -----------------------------------------------------------------
+    // cell matvec: DPP row -> (unit u = row % HS..., part): rows [0,16) take chunks 0..15, rows [16,32) chunks 16..31
+    // generic in HS: pair index p = row % 16 -> unit up = p % HS (rows beyond HS*... idle when HS < 16)
+    const int cu = row % 16, cpart_id = row / 16;            // unit slot (0..15), K part
+    const bool cact = cu < HS;
+    const int cchunk = cpart_id * 16 + kq;                   // chunk 0..31 of the state vector
+    float wb[KC][4];
+    {
+        const int j = mem * HS + (cact ? cu : 0);
+#pragma unroll
+        for (int i = 0; i < KC; ++i) {
+            const int k = cchunk * KC + i;                   // 0..KSP-1: [h | ctx | zero pad]
+            const bool kok = cact && k < KS;
+            const float* wr = (k < H) ? a.wh + (size_t)k * H4 : a.wc + (size_t)(kok ? k - H : 0) * H4;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) wb[i][g] = kok ? wr[g * H + j] : 0.f;
+        }
+    }
+    // y matvec: DPP row -> (col ya = row % 8 ..., r, part)
+    const int ya = row % 8, yr = (row / 8) % 2, ypart = row / 16;
+    const bool yact = ya < AS;
+    float wy[QC];
+    {
+        const int acol = mem * AS + (yact ? ya : 0);
+#pragma unroll
+        for (int i = 0; i < QC; ++i) {
+            const int k = (ypart * 16 + kq) * QC + i;
+            wy[i] = (yact && k < H) ? a.w_att[(size_t)k * A + acol] : 0.f;
+        }
+    }
+    // hf / enc slices -> LDS (once)
+    const int tau0 = mem * TS;
+    for (int idx = tid; idx < R * TS * A; idx += NT) {
+        const int r = idx / (TS * A), rem = idx % (TS * A), tl = rem / A, aa = rem % A;
+        const int tau = tau0 + tl;
+        hfl[(r * MAXTS + tl) * A + aa] = (tau < Te) ? a.hf[((size_t)browf(r) * Te + tau) * A + aa] : 0.f;
+    }
+    for (int idx = tid; idx < R * Te * DS; idx += NT) {
+        const int r = idx / (Te * DS), rem = idx % (Te * DS), tau = rem / DS, dd = rem % DS;
+        encl[idx] = a.enc[((size_t)browf(r) * Te + tau) * D + mem * DS + dd];
+    }
+    // cell threads (wave 0): (unit = tid % HS, r = tid / HS) for tid < R*HS
+    const bool cell = tid < R * HS;
+    const int cr = cell ? tid / HS : 0, cuu = tid % HS;
+    const int cj = mem * HS + cuu;
+    const int cb = r0 + cr;
+    const bool cb_ok = cell && cb < a.B;
+    float c_state = 0.f, h_state = 0.f;
+    if (cb_ok && a.t0 > 0) {
+        c_state = a.dec_c[((size_t)(a.t0 - 1) * a.B + cb) * H + cj];
+        h_state = a.dec_h[((size_t)(a.t0 - 1) * a.B + cb) * H + cj];
+    }
+    // initial state vector [h | ctx] of step t0-1 -> LDS (plain loads: written by earlier launches)
+    for (int idx = tid; idx < R * 32 * KCP; idx += NT) sl[idx] = 0.f;
+    for (int idx = tid; idx < R * QP; idx += NT) ql[idx] = 0.f;
+    __syncthreads();
+    for (int idx = tid; idx < R * KS; idx += NT) {
+        const int r = idx / KS, k = idx % KS;
+        float v = 0.f;
+        if (a.t0 > 0 && r0 + r < a.B) {
+            const size_t rowi = (size_t)(a.t0 - 1) * a.B + browf(r);
+            v = (k < H) ? a.dec_h[rowi * H + k] : a.ctx[rowi * D + (k - H)];
+        }
+        sl[(r * 32 + k / KC) * KCP + (k % KC)] = v;
+    }
+    float pg0 = 0.f, pg1 = 0.f, pg2 = 0.f, pg3 = 0.f;       // preG of the next step (software-pipelined)
+    auto prefetch = [&](int i) {
+        const float* gp = a.gates + ((size_t)i * a.B + min(cb, a.B - 1)) * H4 + cj;
+        pg0 = gp[0]; pg1 = gp[H]; pg2 = gp[2 * H]; pg3 = gp[3 * H];
+    };
+    if (wave0) prefetch(a.t0);
+    __syncthreads();
+
+    const int nsteps = a.t1 - a.t0;
+    for (int s = 0; s < nsteps; ++s) {
+        const int i = a.t0 + s;
+        const uint32_t ep = (uint32_t)(s + 1);
+        u64* gpar = gbase + (size_t)(s & 1) * NPAR;
+        u64* gS = gpar; u64* gQ = gpar + NS; u64* gY = gQ + NQ; u64* gE = gY + NY;
+        // ---- (1) gather the state [h_{i-1} | ctx_{i-1}] published at the previous step
+        if (s > 0) {
+            if (!wave0) {
+                const u64* src = gbase + (size_t)((s - 1) & 1) * NPAR;
+                for (int p = tid - 64; p < NS / 2; p += NT - 64) {
+                    const int idx = 2 * p, r = idx / KS, k = idx % KS;
+                    float v0 = 0.f, v1 = 0.f;
+                    if (r0 + r < a.B) chain_poll2(src + idx, (uint32_t)s, v0, v1, a.err);
+                    *reinterpret_cast<float2*>(sl + (r * 32 + k / KC) * KCP + (k % KC)) = make_float2(v0, v1);
+                }
+            }
+            __syncthreads();
+        }
+        // ---- (2) outer cell: gates = preG + [h|ctx].[K_h ; W2K]  (K split over 32 chunks)
+        {
+            float acc[R][4];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                acc[r][0] = acc[r][1] = acc[r][2] = acc[r][3] = 0.f;
+                const float4* sp = reinterpret_cast<const float4*>(sl + (r * 32 + cchunk) * KCP);
+#pragma unroll
+                for (int i4 = 0; i4 < KC / 4; ++i4) {
+                    const float4 sv = sp[i4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        acc[r][g] = fmaf(sv.x, wb[4 * i4 + 0][g], acc[r][g]);
+                        acc[r][g] = fmaf(sv.y, wb[4 * i4 + 1][g], acc[r][g]);
+                        acc[r][g] = fmaf(sv.z, wb[4 * i4 + 2][g], acc[r][g]);
+                        acc[r][g] = fmaf(sv.w, wb[4 * i4 + 3][g], acc[r][g]);
+                    }
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[r][g] = row16_allreduce_sum(acc[r][g]);
+            }
+            if (kq == 0 && cact) {
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    *reinterpret_cast<float4*>(sums + ((cpart_id * HS + cu) * R + r) * 4) =
+                        make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
+            }
+        }
+        __syncthreads();
+        if (wave0 && cell) {
+            const float4 s0 = *reinterpret_cast<const float4*>(sums + ((0 * HS + cuu) * R + cr) * 4);
+            const float4 s1 = *reinterpret_cast<const float4*>(sums + ((1 * HS + cuu) * R + cr) * 4);
+            const float gi = fast_sigmoid(pg0 + s0.x + s1.x);
+            const float gj = fast_tanh(pg1 + s0.y + s1.y);
+            const float gf = fast_sigmoid(pg2 + s0.z + s1.z + 1.0f);
+            const float go = fast_sigmoid(pg3 + s0.w + s1.w);
+            c_state = c_state * gf + gi * gj;
+            h_state = go * fast_tanh(c_state);
+            if (cb_ok) {
+                chain_publish(gQ + (size_t)cr * H + cj, ep, c_state, fast);          // q = cell state c (decoder.py:79-80)
+                chain_publish(gS + (size_t)cr * KS + cj, ep, h_state, fast);         // h part of the next state
+                const size_t rowi = (size_t)i * a.B + cb;
+                float* gp = a.gates + rowi * H4 + cj;
+                gp[0] = gi; gp[H] = gj; gp[2 * H] = gf; gp[3 * H] = go;
+                a.dec_c[rowi * H + cj] = c_state;
+                a.dec_h[rowi * H + cj] = h_state;
+            }
+            if (s + 1 < nsteps) prefetch(i + 1);
+        }
+        // ---- (3) gather q, y slice = q.W_att[:, slice] + b
+        if (!wave0) {
+            for (int p = tid - 64; p < NQ / 2; p += NT - 64) {
+                const int idx = 2 * p, r = idx / H;
+                float v0 = 0.f, v1 = 0.f;
+                if (r0 + r < a.B) chain_poll2(gQ + idx, ep, v0, v1, a.err);
+                *reinterpret_cast<float2*>(ql + r * QP + (idx % H)) = make_float2(v0, v1);
+            }
+        }
+        __syncthreads();
+        {
+            float acc = 0.f;
+            const float4* qp = reinterpret_cast<const float4*>(ql + yr * QP + (ypart * 16 + kq) * QC);
+#pragma unroll
+            for (int i4 = 0; i4 < QC / 4; ++i4) {
+                const float4 qv = qp[i4];
+                acc = fmaf(qv.x, wy[4 * i4 + 0], acc); acc = fmaf(qv.y, wy[4 * i4 + 1], acc);
+                acc = fmaf(qv.z, wy[4 * i4 + 2], acc); acc = fmaf(qv.w, wy[4 * i4 + 3], acc);
+            }
+            acc = row16_allreduce_sum(acc);
+            if (kq == 0 && yact) ysum[(ypart * AS + ya) * R + yr] = acc;
+        }
+        __syncthreads();
+        if (wave0 && tid < R * AS) {
+            const int r = tid / AS, aa = tid % AS, acol = mem * AS + aa;
+            const float yv = a.b_att[acol] + ysum[(0 * AS + aa) * R + r] + ysum[(1 * AS + aa) * R + r];
+            if (r0 + r < a.B) {
+                chain_publish(gY + (size_t)r * A + acol, ep, yv, fast);
+                a.y[((size_t)i * a.B + r0 + r) * A + acol] = yv;
+            }
+        }
+        // ---- (4) gather y, scores on this workgroup's position slice
+        if (!wave0) {
+            for (int p = tid - 64; p < NY / 2; p += NT - 64) {
+                const int idx = 2 * p, r = idx / A;
+                float v0 = 0.f, v1 = 0.f;
+                if (r0 + r < a.B) chain_poll2(gY + idx, ep, v0, v1, a.err);
+                *reinterpret_cast<float2*>(yl + idx) = make_float2(v0, v1);
+            }
+        }
+        __syncthreads();
+        {
+            // DPP row -> (tl = row % 16, r = row / 16); lane kq -> A/16 consecutive a (float4 steps)
+            const int tl = row % 16, r = row / 16;
+            float sc = 0.f;
+            if (tl < TS) {
+                constexpr int AL = A / 16;
+                const float* hp = hfl + (r * MAXTS + tl) * A + kq * AL;
+                const float* yp = yl + r * A + kq * AL;
+#pragma unroll
+                for (int q4 = 0; q4 < AL; ++q4) sc = fmaf(a.v[kq * AL + q4], fast_tanh(hp[q4] + yp[q4]), sc);
+            }
+            sc = row16_allreduce_sum(sc);
+            if (kq == 0) eout[row] = sc;
+        }
+        __syncthreads();
+        if (wave0 && tid < 32) {
+            const int tl = tid % 16, r = tid / 16;
+            if (tl < TS && r0 + r < a.B)
+                chain_publish(gE + (size_t)r * G * MAXTS + mem * MAXTS + tl, ep, eout[tid], fast);
+        }
+        // ---- (5) gather all scores, softmax over tau < len (replicated), context slice
+        if (!wave0) {
+            const int pairs = (TS + 1) / 2;                       // per (r, source workgroup)
+            for (int p = tid - 64; p < R * G * pairs; p += NT - 64) {
+                const int r = p / (G * pairs), rem = p % (G * pairs), m = rem / pairs, tp = rem % pairs;
+                const int off = r * G * MAXTS + m * MAXTS + 2 * tp;
+                float v0 = 0.f, v1 = 0.f;
+                if (r0 + r < a.B) {
+                    if (2 * tp + 1 < TS) chain_poll2(gE + off, ep, v0, v1, a.err);
+                    else {   // odd tail: a single granule
+                        long long t0w = 0;
+                        for (uint32_t spins = 0;; ++spins) {
+                            const u64 x = __hip_atomic_load(gE + off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if ((uint32_t)(x >> 32) == ep) { v0 = __uint_as_float((uint32_t)x); break; }
+                            if ((spins & 1023) == 1023) {
+                                const long long now = wall_clock64();
+                                if (t0w == 0) t0w = now; else if (now - t0w > 200000000LL) { *a.err = 1; break; }
+                            }
+                        }
+                    }
+                }
+                el[off] = v0;
+                if (2 * tp + 1 < MAXTS) el[off + 1] = v1;
+            }
+        }
+        __syncthreads();
+        if (wave < R) {      // wave r: softmax of row r over tau < len (tau = m*TS + tl  <->  slot m*MAXTS + tl)
+            const int r = wave, L = blenf(r);
+            float m = -INFINITY;
+            for (int tau = lane; tau < L; tau += 64) m = fmaxf(m, el[r * G * MAXTS + (tau / TS) * MAXTS + (tau % TS)]);
+            m = wave_allreduce_max(m);
+            float sum = 0.f;
+            for (int tau = lane; tau < L; tau += 64) {
+                float* ep2 = el + r * G * MAXTS + (tau / TS) * MAXTS + (tau % TS);
+                const float pv = __expf(*ep2 - m); *ep2 = pv; sum += pv;
+            }
+            sum = wave_allreduce_sum(sum);
+            const float inv = L > 0 ? 1.0f / sum : 0.f;
+            for (int tau = lane; tau < Te; tau += 64) {
+                float* ep2 = el + r * G * MAXTS + (tau / TS) * MAXTS + (tau % TS);
+                const float pv = tau < L ? *ep2 * inv : 0.f;
+                *ep2 = pv;
+            }
+        }
+        __syncthreads();
+        {
+            const int dd = tid % DS, r = (tid / DS) % R, tp = tid / (DS * R);
+            float cs = 0.f;
+            if (tp < NTP) {
+                const int L = blenf(r);
+                for (int tau = tp; tau < L; tau += NTP)
+                    cs = fmaf(el[r * G * MAXTS + (tau / TS) * MAXTS + (tau % TS)], encl[(r * Te + tau) * DS + dd], cs);
+                cpart[(tp * R + r) * DS + dd] = cs;
+            }
+        }
+        __syncthreads();
+        if (wave0 && tid < R * DS) {
+            const int r = tid / DS, dd = tid % DS;
+            float cs = 0.f;
+#pragma unroll
+            for (int tp = 0; tp < NTP; ++tp) cs += cpart[(tp * R + r) * DS + dd];
+            if (r0 + r < a.B) {
+                if (s + 1 < nsteps) chain_publish(gS + (size_t)r * KS + H + mem * DS + dd, ep, cs, fast);
+                a.ctx[((size_t)i * a.B + r0 + r) * D + mem * DS + dd] = cs;
+            }
+        }
+        if (wave0 && mem == 0) {       // alpha of this step -> global (bookkeeping, off the critical path)
+            for (int idx = lane; idx < R * Te; idx += 64) {
+                const int r = idx / Te, tau = idx % Te;
+                if (r0 + r < a.B)
+                    a.alpha[((size_t)i * a.B + r0 + r) * Te + tau] = el[r * G * MAXTS + (tau / TS) * MAXTS + (tau % TS)];
+            }
+        }
+        // (LDS buffers are rewritten only after later barriers of the next step)
+    }
+}
+
+}  // namespace asr
+
+extern "C" int asr_decoder_chain_supported(int B, int Te, int D, int A, int H) {
+    if (getenv("ASR_DEC_CHAIN") && atoi(getenv("ASR_DEC_CHAIN")) == 0) return 0;
+    if (Te > 256 || B <= 0) return 0;
+    return (H == 256 && D == 512 && A == 128) || (H == 64 && D == 128 && A == 16);
+}
+
+extern "C" size_t asr_decoder_chain_ws_bytes(int B, int D, int A, int H) {
+    const size_t groups = (B + 1) / 2;
+    const size_t npar = 2 * (size_t)(H + D) + 2 * (size_t)H + 2 * (size_t)A + 2 * 16 * 16;
+    return groups * 2 * npar * sizeof(u64) + groups * 16 * sizeof(u64);
+}
+
+template <int H, int D, int A>
+static int chain_launch(hipStream_t s, asr::ChainArgs& a, int Te) {
+    constexpr int R = 2, G = 16;
+    const int groups = (a.B + R - 1) / R;
+    constexpr int KSP = (H + D + 127) / 128 * 128, KCP = KSP / 32 + 4, QP = (H + 127) / 128 * 128;
+    const size_t lds = sizeof(float) * (4 + (size_t)R * 32 * KCP + 2 * (H / G) * R * 4 + R * QP + 2 * (A / G) * R + 4 + R * A +
+                                        R * G * 16 + 32 + 8 * R * (D / G) + R * 16 * A + (size_t)R * Te * (D / G));
+    if (lds > 64 * 1024) return ASR_EUNSUPPORTED;
+    hipLaunchKernelGGL((asr::decoder_chain_fwd_kernel<H, D, A>), dim3(groups * G), dim3(512), lds, s, a);
+    return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
+}
+
+// Steps [t0,t1) of the decoder chain for B <= 32 utterances per launch (larger batches: chunks).
+// gates holds preG for those steps on entry.  ws: asr_decoder_chain_ws_bytes().
+int asr_decoder_chain_fwd(void* stream, float* gates, const float* wh, const float* wc, const float* w_att,
+                          const float* b_att, const float* v, const float* hf, const float* enc, const int* enc_len,
+                          float* dec_c, float* dec_h, float* alpha, float* ctx, float* y, void* ws, int* err,
+                          int B, int Te, int D, int A, int H, int t0, int t1) {
+    using namespace asr;
+    if (!asr_decoder_chain_supported(B, Te, D, A, H) || t1 <= t0) return ASR_EUNSUPPORTED;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // NOTE: all batch rows of a launch share the [T][B][.] row stride B, so chunking is by group range only
+    if (B > 32) return ASR_EUNSUPPORTED;
+    const size_t bytes = asr_decoder_chain_ws_bytes(B, D, A, H);
+    if (hipMemsetAsync(ws, 0, bytes, s) != hipSuccess) return ASR_ELAUNCH;
+    ChainArgs a;
+    a.gates = gates; a.wh = wh; a.wc = wc; a.w_att = w_att; a.b_att = b_att; a.v = v; a.hf = hf; a.enc = enc;
+    a.enc_len = enc_len; a.dec_c = dec_c; a.dec_h = dec_h; a.alpha = alpha; a.ctx = ctx; a.y = y;
+    a.gx = static_cast<u64*>(ws);
+    const size_t groups = (B + 1) / 2;
+    const size_t npar = 2 * (size_t)(H + D) + 2 * (size_t)H + 2 * (size_t)A + 2 * 16 * 16;
+    a.xcc_slots = a.gx + groups * 2 * npar;
+    a.err = err; a.B = B; a.Te = Te; a.t0 = t0; a.t1 = t1;
+    if (H == 256) return chain_launch<256, 512, 128>(s, a, Te);
+    return chain_launch<64, 128, 16>(s, a, Te);
+}

@@ -339,6 +339,11 @@ def attn_decoder_fwd(wt, dec_inp, seq_len, enc, enc_len, mode=0, coin=None, samp
               dec_gates=f(T, B, 4 * H), dec_c=f(T, B, H), dec_h=f(T, B, H), alpha=f(T, B, Te),
               ctx=f(T, B, D), p=f(T, B, H),
               zeros=torch.zeros(B * max(H, lmH, D), device=dev, dtype=torch.float32), y=f(T, B, A))
+    L = _lib.lib()
+    if mode != 1 and L.asr_decoder_chain_supported(B, Te, D, A, H):       # persistent decoder-chain path
+        ws["w2k"] = f(D, 4 * H)
+        ws["chain_ws"] = _hx(dev, L.asr_decoder_chain_ws_bytes(B, D, A, H))
+        ws["err"] = _Flag.get(dev)
     logits = f(T * B, V)
     cw = _dec_struct(_lib.DecWeights, wt)
     cd = _lib.DecDims(B, Te, D, A, H, lmH, E, V, T)

@@ -160,6 +160,9 @@ typedef struct {              /* activations: outputs of the forward, inputs of 
     float* p;                 /* [T_out,B,H] */
     float* zeros;             /* [B*max(H,lmH,D)] zeros */
     float* y;                 /* [T_out,B,A] attention query projection (saved for the backward; may be NULL) */
+    float* w2k;               /* [D,4H] scratch for W_inp[P:].K_x (persistent chain path; NULL disables it) */
+    void*  chain_ws;          /* asr_decoder_chain_ws_bytes() granule workspace (NULL disables the chain path) */
+    int*   err;               /* device int set on an exchange timeout */
 } asr_dec_ws;
 
 /* mode 0: teacher forcing; 1: greedy (eval, decoder.py:139-154); 2: scheduled sampling
@@ -198,6 +201,9 @@ int asr_scatter_add_rows_ld(void* stream, float* table_grad, const int* idx, con
  * ordered against `stream` with events; legal under hipGraph capture).  asr_attn_decoder_bwd leaves
  * LM-chain gradient work in flight on it: call asr_side_join(stream) before reading the gradients. */
 int asr_side_join(void* stream);
+/* Persistent decoder chain (csrc/decoder_chain.hip): used inside asr_attn_decoder_fwd when supported. */
+int asr_decoder_chain_supported(int B, int Te, int D, int A, int H);
+size_t asr_decoder_chain_ws_bytes(int B, int D, int A, int H);
 int asr_zero_finished_rows(void* stream, float* logits, const int* len, int T, int B, int V);
 
 /* Optional per-kernel HIP-event timing on the launch stream (bench.py roofline leg).

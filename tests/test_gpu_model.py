@@ -387,3 +387,59 @@ def test_train_loop_checkpoint_resume_and_eval(tmp_path):
     enc = model.encoder_hidden_states[2][0, :int(model.seq_len_encs[2][0])].cpu().numpy()
     ids = BeamSearch(ck, sp, device=DEV)(enc)
     assert ids.ndim == 1 and len(ids) >= 1
+
+
+# ------------------------------------------------------------------ persistent decoder chain
+def _chain_model(samp=0.0, seed=3):
+    return _model(enc_update=dict(hidden_size=64), num_layers={"char": 2}, seed=seed,
+                  dec_update=dict(hidden_size_dec=64, lm_hidden_size=64, emb_size=24, attention_vec_size=16, samp_prob=samp))
+
+
+def test_decoder_chain_path_vs_oracle_and_autograd():
+    """csrc/decoder_chain.hip (persistent decoder chain; H=64, D=128, A=16 instantiation): logits and
+    loss vs the float64 oracle, and every gradient vs autograd (the backward consumes the activations
+    the chain kernel saved), ragged lengths, odd batch (last group half empty)."""
+    from e2e_asr_amd import _lib
+    from oracle import torch_ref as R
+    assert _lib.lib().asr_decoder_chain_supported(5, 10, 128, 16, 64) == 1
+    rng = np.random.default_rng(21)
+    m = _chain_model()
+    b = _batch(rng, 5, 37, 20, 11, 50)
+    m.forward(b)
+    assert m.decoder["char"].saved["ws"].get("chain_ws") is not None          # the chain path really ran
+    out = m.outputs["char"].cpu().numpy()
+    w = _f64(m.variables.to_arrays())
+    b64 = dict(b); b64["logmel"] = b["logmel"].astype(np.float64)
+    r = O.seq2seq_forward(b64, w, num_layers={"char": 2}, is_training=True)
+    np.testing.assert_allclose(out, r["outputs"]["char"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(m.total_loss.item(), r["total_loss"], rtol=1e-5)
+    m.backward()
+    from e2e_asr_amd import ops
+    ops.check_device_flag(torch.device(DEV))
+    W = R.weights_to_torch(w)
+    total, _, _ = R.seq2seq_loss(b64, W, num_layers={"char": 2})
+    total.backward()
+    for name in m.variables.names():
+        ref = W[name].grad.numpy()
+        err = np.abs(m.variables.grad_of(name).cpu().numpy() - ref).max() / max(1e-3, np.abs(ref).max())
+        assert err < 2e-3, (name, err)
+
+
+def test_decoder_chain_equals_launch_path_under_scheduled_sampling(monkeypatch):
+    """Scheduled sampling cuts the sequence into segments (one persistent launch each); the result
+    must equal the per-step launch path: same sampled tokens, same logits."""
+    rng = np.random.default_rng(22)
+    b = _batch(rng, 6, 24, 20, 13, 50)
+    outs = []
+    for chain in ("1", "0"):
+        monkeypatch.setenv("ASR_DEC_CHAIN", chain)
+        m = _chain_model(samp=0.4, seed=7)
+        m.decoder["char"].coin_rng = np.random.default_rng(5)
+        m.forward(b)
+        ws = m.decoder["char"].saved["ws"]
+        assert (ws.get("chain_ws") is not None) == (chain == "1")
+        outs.append((m.outputs["char"].cpu().numpy(), ws["tok"].cpu().numpy(), m.total_loss.item()))
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+    assert (outs[0][1][1:] != np.asarray(b["char"]).T[1:outs[0][1].shape[0]]).any()   # some tokens really were sampled
+    np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(outs[0][2], outs[1][2], rtol=1e-6)
