@@ -65,9 +65,12 @@ extern "C" int asr_attn_decoder_fwd(void* stream, const asr_dec_weights* w, cons
     const bool use_chain = mode != 1 && ws->chain_ws && ws->w2k && ws->err && ws->y && ws->dec_gates &&
                            asr_decoder_chain_supported(B, Te, D, A, H) && B <= 32;
     if (use_chain) {
-        // W2K = W_inp[P:, :] . K_x   ([D,E].[E,4H]): the context half of InputProjection folded into the cell
-        if ((rc = asr_gemm_f32(stream, 0, 0, D, 4 * H, E, w->inp_w + (size_t)P * E, E, w->dec_kernel, 4 * H, ws->w2k, 4 * H, nullptr, 0)))
-            return rc;
+        // WK = W_inp . K_x  ([P+D,E].[E,4H]) and b' = b_inp . K_x + b_dec: InputProjection folded into the
+        // outer cell, so that gates_i = lm_out_i . WK[:P] + ctx_{i-1} . WK[P:] + h_{i-1} . K_h + b'
+        float* wk = ws->w2k;                       // [(P+D), 4H] followed by b' [4H]
+        float* bprime = wk + (size_t)(P + D) * 4 * H;
+        if ((rc = asr_gemm_f32(stream, 0, 0, P + D, 4 * H, E, w->inp_w, E, w->dec_kernel, 4 * H, wk, 4 * H, nullptr, 0))) return rc;
+        if ((rc = asr_gemm_f32(stream, 0, 0, 1, 4 * H, E, w->inp_b, E, w->dec_kernel, 4 * H, bprime, 4 * H, w->dec_bias, 0))) return rc;
         const float* lm_base = w->simple_w ? ws->sp : (keep_lm < 1.0f ? ws->lm_hd : ws->lm_h);
         int t0 = 0;
         while (t0 < T) {
@@ -96,12 +99,14 @@ extern "C" int asr_attn_decoder_fwd(void* stream, const asr_dec_weights* w, cons
             if (hipEventRecord(e_lm, ss) != hipSuccess || hipStreamWaitEvent(ms, e_lm, 0) != hipSuccess) return ASR_ELAUNCH;
             const int rows = (t1 - t0) * B;
             const size_t o0 = (size_t)t0 * B;
-            // x_lm = lm_out . W_inp[:P] + b_inp  (kept in ws->x; the context half is added after the loop)
-            if ((rc = asr_gemm_f32(stream, 0, 0, rows, E, P, lm_base + o0 * P, P, w->inp_w, E, ws->x + o0 * E, E, w->inp_b, 0))) return rc;
-            // preG = x_lm . K_x + b_dec  -> the gates buffer (the chain kernel overwrites it with the activations)
-            if ((rc = asr_gemm_f32(stream, 0, 0, rows, 4 * H, E, ws->x + o0 * E, E, w->dec_kernel, 4 * H,
-                                   ws->dec_gates + o0 * 4 * H, 4 * H, w->dec_bias, 0))) return rc;
-            if ((rc = asr_decoder_chain_fwd(stream, ws->dec_gates, w->dec_kernel + (size_t)E * 4 * H, ws->w2k, w->attn_w, w->attn_b,
+            // preG = lm_out . WK[:P] + b'  -> the gates buffer (the chain kernel overwrites it with the
+            // activations); short segments through the skinny MFMA kernel, long ones through the GEMM
+            if (rows <= 512) {
+                if ((rc = asr_linear_fwd(stream, lm_base + o0 * P, P, P, nullptr, nullptr, 0, 0, wk, 4 * H, bprime,
+                                         ws->dec_gates + o0 * 4 * H, 4 * H, rows, 4 * H, nullptr, 0))) return rc;
+            } else if ((rc = asr_gemm_f32(stream, 0, 0, rows, 4 * H, P, lm_base + o0 * P, P, wk, 4 * H,
+                                          ws->dec_gates + o0 * 4 * H, 4 * H, bprime, 0))) return rc;
+            if ((rc = asr_decoder_chain_fwd(stream, ws->dec_gates, w->dec_kernel + (size_t)E * 4 * H, wk + (size_t)P * 4 * H, w->attn_w, w->attn_b,
                                             w->attn_v, ws->hf, enc, enc_len, ws->dec_c, ws->dec_h, ws->alpha, ws->ctx, ws->y,
                                             ws->chain_ws, ws->err, B, Te, D, A, H, t0, t1))) return rc;
             const int i = t1 - 1;
@@ -118,7 +123,8 @@ extern "C" int asr_attn_decoder_fwd(void* stream, const asr_dec_weights* w, cons
             }
             t0 = t1;
         }
-        // x (saved for the backward) = x_lm + ctx_prev . W_inp[P:]   -- one GEMM over steps 1..T-1
+        // x (saved for the backward) = lm_out . W_inp[:P] + b_inp + ctx_prev . W_inp[P:]  -- two GEMMs over all steps
+        if ((rc = asr_gemm_f32(stream, 0, 0, T * B, E, P, lm_base, P, w->inp_w, E, ws->x, E, w->inp_b, 0))) return rc;
         if (T > 1 && (rc = asr_gemm_f32(stream, 0, 0, (T - 1) * B, E, D, ws->ctx, D, w->inp_w + (size_t)P * E, E,
                                         ws->x + (size_t)B * E, E, nullptr, 1))) return rc;
     }

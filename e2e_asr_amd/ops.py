@@ -341,7 +341,8 @@ def attn_decoder_fwd(wt, dec_inp, seq_len, enc, enc_len, mode=0, coin=None, samp
               zeros=torch.zeros(B * max(H, lmH, D), device=dev, dtype=torch.float32), y=f(T, B, A))
     L = _lib.lib()
     if mode != 1 and L.asr_decoder_chain_supported(B, Te, D, A, H):       # persistent decoder-chain path
-        ws["w2k"] = f(D, 4 * H)
+        P_ = H if wt.get("simple_w") is not None else lmH
+        ws["w2k"] = f(P_ + D + 1, 4 * H)          # W_inp.K_x [(P+D),4H] followed by the composed bias [4H]
         ws["chain_ws"] = _hx(dev, L.asr_decoder_chain_ws_bytes(B, D, A, H))
         ws["err"] = _Flag.get(dev)
     logits = f(T * B, V)

@@ -160,7 +160,7 @@ typedef struct {              /* activations: outputs of the forward, inputs of 
     float* p;                 /* [T_out,B,H] */
     float* zeros;             /* [B*max(H,lmH,D)] zeros */
     float* y;                 /* [T_out,B,A] attention query projection (saved for the backward; may be NULL) */
-    float* w2k;               /* [D,4H] scratch for W_inp[P:].K_x (persistent chain path; NULL disables it) */
+    float* w2k;               /* [(P+D+1),4H] scratch: W_inp.K_x and the composed bias (persistent chain path; NULL disables it) */
     void*  chain_ws;          /* asr_decoder_chain_ws_bytes() granule workspace (NULL disables the chain path) */
     int*   err;               /* device int set on an exchange timeout */
 } asr_dec_ws;
