@@ -34,7 +34,7 @@ class DecWs(C.Structure):
 
 class DecBwdWs(C.Structure):
     _fields_ = [(n, vp) for n in ("dP", "dQC", "dY", "dXH", "dLC", "dlm", "dEH", "dc_dec", "dc_lm", "dhf",
-                                  "dv_part", "dctx", "emb_all")]
+                                  "dv_part", "dctx", "emb_all", "chain_ws", "wc")]
 
 
 class DecGrads(C.Structure):
@@ -80,6 +80,7 @@ SIGNATURES = {
     "asr_side_join": (C.c_int, [vp]),
     "asr_decoder_chain_supported": (C.c_int, [C.c_int] * 5),
     "asr_decoder_chain_ws_bytes": (C.c_size_t, [C.c_int] * 4),
+    "asr_decoder_chain_bwd_ws_bytes": (C.c_size_t, [C.c_int] * 4),
     "asr_zero_finished_rows": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int]),
     "asr_prof_enable": (C.c_int, [C.c_int]),
     "asr_debug_set_buffer": (C.c_int, [vp]),

@@ -16,6 +16,7 @@
 // A finished row (t >= seq_len[b]) has dLogits = 0 and zero loss weight, so its state carries
 // no gradient; raw_rnn's copy-through therefore needs no special case (see decoder.hip).
 #include "common.h"
+#include <cstdlib>
 #include <algorithm>
 #include "../../include/e2e_asr_hip.h"
 
@@ -311,6 +312,11 @@ __global__ __launch_bounds__(256) void lm_cell_bwd_kernel(LmBwdArgs a) {
 }  // namespace asr
 
 extern "C" int asr_colsum_f32(void*, const float*, int, int, int, float*, int);
+extern "C" int asr_decoder_chain_supported(int B, int Te, int D, int A, int H);
+int asr_decoder_chain_bwd(void* stream, float* gates, const float* dec_c, const float* alpha, const float* y,
+                          const float* ctx, const float* dqc, const float* wh, const float* wc, const float* w_att,
+                          const float* v, const float* hf, const float* enc, const int* enc_len, float* dY, float* dctx,
+                          float* dhf, float* dv_part, void* ws, int* err, int B, int Te, int D, int A, int H, int T);
 extern "C" int asr_gather_rows(void*, const float*, const int*, float*, int, int);
 extern "C" int asr_scatter_add_rows_ld(void*, float*, const int*, const float*, int, int, int);
 
@@ -348,7 +354,25 @@ extern "C" int asr_attn_decoder_bwd(void* stream, const asr_dec_weights* w, cons
     if (hipMemsetAsync(bw->dhf, 0, sizeof(float) * (size_t)B * Te * A, s) != hipSuccess) return ASR_ELAUNCH;
     if (hipMemsetAsync(bw->dv_part, 0, sizeof(float) * B * A, s) != hipSuccess) return ASR_ELAUNCH;
     const int ldXH = E + H, ldLC = P + D, ldEH = E + lmH;
-    for (int i = T - 1; i >= 0; --i) {
+    // ---- persistent chain (csrc/decoder_chain_bwd.hip): the whole reverse-time recursion in one launch
+    const bool use_chain = bw->chain_ws && bw->wc && ws->y && ws->err && B <= 32 &&
+                           asr_decoder_chain_supported(B, Te, D, A, H);
+    int dv_rows = B;
+    if (use_chain) {
+        // wc = W_inp[P:] . K_x : the context rows of the composed input weight (decoder.hip, forward chain)
+        if ((rc = asr_gemm_f32(stream, 0, 0, D, 4 * H, E, w->inp_w + (size_t)P * E, E, w->dec_kernel, 4 * H, bw->wc, 4 * H, nullptr, 0)))
+            return rc;
+        if ((rc = asr_decoder_chain_bwd(stream, ws->dec_gates, ws->dec_c, ws->alpha, ws->y, ws->ctx, bw->dQC,
+                                        w->dec_kernel + (size_t)E * 4 * H, bw->wc, w->attn_w, w->attn_v, ws->hf, enc, enc_len,
+                                        bw->dY, bw->dctx, bw->dhf, bw->dv_part, bw->chain_ws, ws->err, B, Te, D, A, H, T)))
+            return rc;
+        dv_rows = ((B + 1) / 2) * 16;
+        // dx = dG . K_x^T for all steps, then dlm_out = dx . W_inp[:P]^T (the dh / dctx carries stayed on chip)
+        if ((rc = asr_gemm_f32(stream, 0, 1, TB, E, 4 * H, ws->dec_gates, 4 * H, w->dec_kernel, 4 * H, bw->dXH, ldXH, nullptr, 0)))
+            return rc;
+        if ((rc = asr_gemm_f32(stream, 0, 1, TB, P, E, bw->dXH, ldXH, w->inp_w, E, bw->dLC, ldLC, nullptr, 0))) return rc;
+    }
+    for (int i = T - 1; i >= 0 && !use_chain; --i) {
         const size_t o = (size_t)i * B;
         const bool last = i == T - 1;
         DecBwdStepArgs a;
@@ -430,7 +454,7 @@ extern "C" int asr_attn_decoder_bwd(void* stream, const asr_dec_weights* w, cons
     // Attention query projection, AttnV
     if ((rc = wgrad(H, A, TB, ws->dec_c, H, bw->dY, A, const_cast<float*>(g->attn_w)))) return rc;
     if ((rc = asr_colsum_f32(stream_w, bw->dY, A, TB, A, const_cast<float*>(g->attn_b), 1))) return rc;
-    if ((rc = asr_colsum_f32(stream_w, bw->dv_part, A, B, A, const_cast<float*>(g->attn_v), 1))) return rc;
+    if ((rc = asr_colsum_f32(stream_w, bw->dv_part, A, dv_rows, A, const_cast<float*>(g->attn_v), 1))) return rc;
     // outer cell kernel: rows [x | h_prev]
     gw = const_cast<float*>(g->dec_kernel);
     if ((rc = wgrad(E, 4 * H, TB, ws->x, E, ws->dec_gates, 4 * H, gw))) return rc;

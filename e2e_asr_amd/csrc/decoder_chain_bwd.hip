@@ -1,0 +1,442 @@
+// Persistent attention-decoder chain, backward: all T steps of the reverse-time recursion in ONE
+// launch (the gradient of csrc/decoder_chain.hip; replaces the per-step launches K1/S1/S2 of
+// decoder_bwd.hip when the shape is supported).
+//
+// Per step i (T-1 .. 0), for a group of R = 2 utterances over G = 16 workgroups (same ownership as the
+// forward: H/16 units, A/16 attention columns, ceil(Te/16) positions, D/16 context columns each):
+//   X4  gather  [dh_i | dctx_carry] for my units / my D-slice = sum of the 16 partials of step i+1
+//       dctx_tot = dctx_ap[i] + dctx_carry   (saved: the caller turns sum_i alpha_i^T.dctx_i into denc)
+//   (b) partial dalpha[tau] over my D-slice for ALL positions, and the partial of the softmax scalar
+//       S = sum_tau alpha.dalpha = dctx_tot . ctx_i  (identity: ctx = sum alpha.enc)     -> X1 publish
+//   X1  gather dalpha for my positions (+ S); de = alpha (dalpha - S)
+//   (d) tanh backward on my positions: ds = de v (1 - th^2); dhf slice += ds (LDS, written once at the
+//       end); dv += de th (registers); partial dy[a] over my positions               -> X2 publish
+//   X2  gather dy for my A-slice (saved: dW_att = q^T.dy after the loop); partial dq[k] = dy.W_att[k, slice]
+//                                                                                    -> X3 publish
+//   X3  gather dq_att for my units; cell pointwise backward -> dG (in place over the saved gates), dc carry
+//   (f) partial [dh_{i-1} | dctx_{i-1}] = dG_slice . [K_h ; W_inp[P:].K_x]^T over my 4*H/16 gate columns,
+//       for all H + D outputs                                                        -> X4 publish
+// Every exchange is a reduce-scatter of tagged granules: destination-major [dst][src][slot]; ONE wave
+// gathers, each lane issuing its 16 source loads together and summing in fixed order (reproducible).
+// Wave 0 owns every global store.  dx = dG.K_x^T and dlm_out = dx.W_inp[:P]^T are GEMMs after the loop.
+#include "common.h"
+#include <cstdlib>
+
+extern "C" int asr_decoder_chain_supported(int B, int Te, int D, int A, int H);
+
+namespace asr {
+
+struct ChainBwdArgs {
+    float* gates;              // [T][B][4H] in: activated gates; out: dG
+    const float* dec_c;        // [T][B][H]
+    const float* alpha;        // [T][B][Te]
+    const float* y;            // [T][B][A]
+    const float* ctx;          // [T][B][D]
+    const float* dqc;          // [T][B][H+D]  dq_ap | dctx_ap (hoisted GEMMs)
+    const float* wh;           // [H][4H]
+    const float* wc;           // [D][4H]
+    const float* w_att; const float* v;    // [H][A], [A]
+    const float* hf;           // [B][Te][A]
+    const float* enc;          // [B][Te][D]
+    const int* enc_len;
+    float* dY;                 // [T][B][A]
+    float* dctx;               // [T][B][D]
+    float* dhf;                // [B][Te][A]   (written once)
+    float* dv_part;            // [groups*16][A]
+    u64* gx; u64* xcc_slots; int* err;
+    int B, Te, T;
+};
+
+typedef unsigned int u32x4d __attribute__((ext_vector_type(4)));
+
+// Sum over the 16 sources of one slot: all 16 loads in flight (compiler-tracked relaxed agent-scope
+// atomic loads = global_load_dwordx2 sc1), re-polled together, fixed summation order (reproducible).
+template <int src_stride>
+__device__ __forceinline__ bool gather16_one(const u64* base, uint32_t epoch, float& s0, int* err) {
+    long long t0 = 0;
+    for (uint32_t spins = 0;; ++spins) {
+        u64 x[16];
+#pragma unroll
+        for (int m = 0; m < 16; ++m) x[m] = __hip_atomic_load(base + m * src_stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool all = true;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) all &= (uint32_t)(x[m] >> 32) == epoch;
+        if (all) {
+            float a0 = 0.f;
+#pragma unroll
+            for (int m = 0; m < 16; ++m) a0 += __uint_as_float((uint32_t)x[m]);
+            s0 = a0;
+            return true;
+        }
+        if ((spins & 1023) == 1023) {
+            const long long now = wall_clock64();
+            if (t0 == 0) t0 = now;
+            else if (now - t0 > 200000000LL) { *err = 1; s0 = 0.f; return false; }
+            if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { s0 = 0.f; return false; }
+        }
+    }
+}
+__device__ __forceinline__ void pubg(u64* dst, uint32_t epoch, float v, bool fast) {
+    const u64 gv = ((u64)epoch << 32) | __float_as_uint(v);
+    if (fast) asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(dst), "v"(gv) : "memory");
+    else __hip_atomic_store(dst, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int H, int D, int A>
+__global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) {
+    constexpr int R = 2, G = 16, NT = 512;
+    constexpr int HS = H / G, AS = A / G, DS = D / G;
+    constexpr int KS = H + D;
+    constexpr int NCOL = 4 * HS;                      // gate columns owned by this workgroup
+    constexpr int CP = NCOL / 2;                      // phase (f): a thread covers half of the gate columns of an output k
+    constexpr int KPT = (2 * KS + NT - 1) / NT;       // (k, half) items per thread
+    constexpr int MAXTS = 16;
+    constexpr int AL = A / 16;                        // a values per lane in the tanh phase
+    constexpr int H4 = 4 * H;
+    // slots per (dst, src): even counts so that pairs never straddle
+    constexpr int S4 = R * (HS + DS);                 // X4: [r][dh units | dctx cols]
+    constexpr int S1 = R * (MAXTS + 2);               // X1: [r][dalpha positions | S | pad]
+    constexpr int S2 = R * ((AS + 1) & ~1);           // X2: [r][dy a-slice]
+    constexpr int S3 = R * ((HS + 1) & ~1);           // X3: [r][dq units]
+    constexpr int AS2 = (AS + 1) & ~1, HS2 = (HS + 1) & ~1;
+    static_assert((HS + DS) % 2 == 0 && HS * G == H && AS * G == A && DS * G == D, "sizes");
+    constexpr int NPAR = G * G * (S4 + S1 + S2 + S3);  // granules per parity per group
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int* lds_flag = reinterpret_cast<int*>(smem);
+    float* dctl = smem + 4;                           // dctx_tot slice [R][DS]
+    float* dhl = dctl + R * DS;                       // dh for my units [R][HS]
+    float* dal = dhl + R * HS2;                       // partial dalpha [R][G*MAXTS] (all positions)  -> X1 publish
+    float* sp = dal + R * G * MAXTS;                  // partial S [R] (+pad 2)
+    float* del = sp + 4;                              // de for my positions [R][MAXTS]
+    float* yl = del + R * MAXTS;                      // y_i [R][A]
+    float* dyrow = yl + R * A;                        // per DPP row partial dy [32 rows][A]
+    float* dyp = dyrow + 32 * A;                      // partial dy [R][A]                            -> X2 publish
+    float* dys = dyp + R * A;                         // dy for my a-slice [R][AS2]
+    float* dqp = dys + R * AS2;                       // partial dq [R][H]                            -> X3 publish
+    float* dql = dqp + R * H;                         // gathered dq_att for my units [R][HS2]
+    float* dgl = dql + R * HS2;                       // dG slice [R][NCOL]
+    float* outp = dgl + R * NCOL;                     // partial [dh|dctx] [R][KS]                    -> X4 publish
+    float* hfl = outp + R * KS;                       // hf slice [R][MAXTS][A]
+    float* dhfl = hfl + R * MAXTS * A;                // dhf accumulator [R][MAXTS][A]
+    const int Te = a.Te;
+    const int TS = (Te + G - 1) / G;
+    float* wal = dhfl + R * MAXTS * A;                // W_att[:, my a-slice] [H][AS]
+    float* vl = wal + H * AS;                         // v [A]
+    float* encl = vl + A;                             // enc slice [R][Te][DS]
+    float* alf = encl + R * Te * DS;                  // alpha_i [R][Te]
+
+    __builtin_amdgcn_s_setprio(3);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kq = lane & 15, row = tid >> 4;
+    const int NG = (a.B + R - 1) / R;
+    int grp, mem;
+    if ((NG & 7) == 0) { mem = (blockIdx.x >> 3) % G; grp = (blockIdx.x & 7) + 8 * (blockIdx.x / (8 * G)); }
+    else { grp = blockIdx.x / G; mem = blockIdx.x % G; }
+    const int r0 = grp * R;
+    const bool wave0 = __builtin_amdgcn_readfirstlane(tid) < 64;
+    const bool wave1 = !wave0 && __builtin_amdgcn_readfirstlane(tid) < 128;     // the gathering wave
+    const int brow0 = min(r0, a.B - 1), brow1 = min(r0 + 1, a.B - 1);
+    const int blen0 = min(max(a.enc_len[brow0], 0), Te);
+    const int blen1 = (r0 + 1 < a.B) ? min(max(a.enc_len[brow1], 0), Te) : 0;
+    auto browf = [&](int r) { return r ? brow1 : brow0; };
+    auto blenf = [&](int r) { return r ? blen1 : blen0; };
+    auto rok = [&](int r) { return r0 + r < a.B; };
+    u64* gbase = a.gx + (size_t)grp * 2 * NPAR;
+    const bool fast = group_shares_xcd(a.xcc_slots + (size_t)grp * 16, G, mem, tid, a.err, lds_flag);
+
+    // ---- resident operands
+    // phase (f): item = tid + 512*p -> (k = item / 2, column half = item % 2): adjacent lanes share k and add
+    // their halves through DPP; weights over my gate columns n = 4*unit + gate, n in [half*CP, half*CP + CP)
+    float wf[KPT][CP];
+#pragma unroll
+    for (int p = 0; p < KPT; ++p) {
+        const int it = tid + NT * p, k = it >> 1, n0 = (it & 1) * CP;
+        const bool kok = k < KS;
+        const float* wr = (k < H) ? a.wh + (size_t)(kok ? k : 0) * H4 : a.wc + (size_t)(kok ? k - H : 0) * H4;
+#pragma unroll
+        for (int n = 0; n < CP; ++n) wf[p][n] = kok ? wr[((n0 + n) & 3) * H + mem * HS + ((n0 + n) >> 2)] : 0.f;
+    }
+    // phase (e): thread -> (r = tid / H, k = tid % H) (R*H <= 512): W_att[k][my a-slice]
+    const int ek = tid % H, er = tid / H;
+    const bool eact = tid < R * H;
+    for (int idx = tid; idx < H * AS; idx += NT) wal[idx] = a.w_att[(size_t)(idx / AS) * A + mem * AS + idx % AS];
+    for (int idx = tid; idx < A; idx += NT) vl[idx] = a.v[idx];
+    // hf / enc slices -> LDS, dhf accumulator = 0
+    const int tau0 = mem * TS;
+    for (int idx = tid; idx < R * MAXTS * A; idx += NT) {
+        const int r = idx / (MAXTS * A), rem = idx % (MAXTS * A), tl = rem / A, aa = rem % A;
+        const int tau = tau0 + tl;
+        hfl[idx] = (tl < TS && tau < Te) ? a.hf[((size_t)browf(r) * Te + tau) * A + aa] : 0.f;
+        dhfl[idx] = 0.f;
+    }
+    for (int idx = tid; idx < R * Te * DS; idx += NT) {
+        const int r = idx / (Te * DS), rem = idx % (Te * DS), tau = rem / DS, dd = rem % DS;
+        encl[idx] = a.enc[((size_t)browf(r) * Te + tau) * D + mem * DS + dd];
+    }
+    // tanh-phase mapping: DPP row -> (tl = row % 16, r = row / 16), lane kq -> AL consecutive a
+    const int trow_tl = row % 16, trow_r = row / 16;
+    float dvacc[AL];
+#pragma unroll
+    for (int q = 0; q < AL; ++q) dvacc[q] = 0.f;
+    // cell threads (wave 0): (unit = tid % HS, r = tid / HS)
+    const bool cell = tid < R * HS;
+    const int cr = cell ? tid / HS : 0, cuu = tid % HS;
+    const int cj = mem * HS + cuu;
+    const int cb = r0 + cr;
+    const bool cb_ok = cell && cb < a.B;
+    float dc = 0.f;
+    __syncthreads();
+
+    for (int s = 0; s < a.T; ++s) {
+        const int i = a.T - 1 - s;
+        const uint32_t ep = (uint32_t)(s + 1);
+        u64* gpar = gbase + (size_t)(s & 1) * NPAR;
+        u64* g4 = gpar; u64* g1 = g4 + G * G * S4; u64* g2 = g1 + G * G * S1; u64* g3 = g2 + G * G * S2;
+        const u64* g4prev = gbase + (size_t)((s - 1) & 1) * NPAR;     // X4 of the previous (later-time) step
+        // ---- operands of this step that do not depend on any exchange (waves >= 2 fetch them)
+        if (tid >= 192) {
+            for (int idx = tid - 192; idx < R * A; idx += NT - 192)
+                yl[idx] = rok(idx / A) ? a.y[((size_t)i * a.B + browf(idx / A)) * A + (idx % A)] : 0.f;
+            for (int idx = tid - 192; idx < R * Te; idx += NT - 192)
+                alf[idx] = rok(idx / Te) ? a.alpha[((size_t)i * a.B + browf(idx / Te)) * Te + (idx % Te)] : 0.f;
+        }
+        // ---- X4 gather: [dh | dctx_carry] for my slices, summed over the 16 sources (one lane per slot)
+        if (tid >= 64 && tid < 64 + S4) {
+            const int slot = tid - 64, r = slot / (HS + DS), q = slot % (HS + DS);
+            float v0 = 0.f;
+            if (s > 0 && rok(r)) gather16_one<S4>(g4prev + ((size_t)mem * G) * S4 + slot, (uint32_t)s, v0, a.err);
+            if (q < HS) dhl[r * HS2 + q] = v0; else dctl[r * DS + (q - HS)] = v0;
+        }
+        __syncthreads();
+        // dctx_tot = dctx_ap + carry (D-slice), saved for the denc GEMM; partial S = dctx_tot . ctx_i
+        if (wave0) {
+            float sprt = 0.f;
+            const int r = lane / 32, dd0 = lane % 32;      // 2 rows x 32 lanes
+            for (int dd = dd0; dd < DS; dd += 32) {
+                float x = dctl[r * DS + dd];
+                if (rok(r)) {
+                    const size_t rowi = (size_t)i * a.B + r0 + r;
+                    x += a.dqc[rowi * (H + D) + H + mem * DS + dd];
+                    a.dctx[rowi * D + mem * DS + dd] = x;
+                    sprt = fmaf(x, a.ctx[rowi * D + mem * DS + dd], sprt);
+                }
+                dctl[r * DS + dd] = x;
+            }
+            // reduce the 32 lanes of each half-wave
+            sprt += __shfl_xor(sprt, 16); sprt = row16_allreduce_sum(sprt);
+            if (dd0 == 0) sp[r] = sprt;
+        }
+        __syncthreads();
+        // ---- (b) partial dalpha over my D-slice, all positions: thread -> (r, tau)
+        for (int idx = tid; idx < R * G * MAXTS; idx += NT) {
+            const int r = idx / (G * MAXTS), slot = idx % (G * MAXTS), tau = (slot / MAXTS) * TS + (slot % MAXTS);
+            float x = 0.f;
+            if ((slot % MAXTS) < TS && tau < blenf(r)) {
+                const float* ep2 = encl + (r * Te + tau) * DS;
+                const float* dp = dctl + r * DS;
+#pragma unroll
+                for (int dd = 0; dd < DS; ++dd) x = fmaf(ep2[dd], dp[dd], x);
+            }
+            dal[idx] = x;
+        }
+        __syncthreads();
+        if (wave0) {     // X1 publish: to the owner of each position slice, plus my S partial to everyone
+            for (int idx = lane; idx < R * G * MAXTS; idx += 64) {
+                const int r = idx / (G * MAXTS), slot = idx % (G * MAXTS), md = slot / MAXTS, tl = slot % MAXTS;
+                if (rok(r) && tl < TS)
+                    pubg(g1 + ((size_t)md * G + mem) * S1 + r * (MAXTS + 2) + tl, ep, dal[idx], fast);
+            }
+            for (int idx = lane; idx < R * G; idx += 64) {
+                const int r = idx / G, md = idx % G;
+                if (rok(r)) pubg(g1 + ((size_t)md * G + mem) * S1 + r * (MAXTS + 2) + MAXTS, ep, sp[r], fast);
+            }
+        }
+        // ---- X1 gather: dalpha for my positions and S; de = alpha (dalpha - S)
+        if (wave1 && tid - 64 < S1) {
+            const int slot = tid - 64, r = slot / (MAXTS + 2), q = slot % (MAXTS + 2);
+            float v0 = 0.f;
+            // slots beyond TS (except the S slot) are never published: skip them
+            if (rok(r) && (q < TS || q == MAXTS)) gather16_one<S1>(g1 + ((size_t)mem * G) * S1 + slot, ep, v0, a.err);
+            if (q == MAXTS) sp[2 + r] = v0;                           // total S of row r
+            else if (q < MAXTS) del[r * MAXTS + q] = v0;
+        }
+        __syncthreads();
+        // ---- (d) tanh backward on my positions
+        {
+            const int r = trow_r, tl = trow_tl, tau = tau0 + tl;
+            float de = 0.f;
+            if (tl < TS && tau < blenf(r)) de = alf[r * Te + tau] * (del[r * MAXTS + tl] - sp[2 + r]);
+            float* hp = hfl + (r * MAXTS + tl) * A + kq * AL;
+            float* gp = dhfl + (r * MAXTS + tl) * A + kq * AL;
+            const float* yp = yl + r * A + kq * AL;
+#pragma unroll
+            for (int q = 0; q < AL; ++q) {
+                const float th = fast_tanh(hp[q] + yp[q]);
+                const float ds = de * vl[kq * AL + q] * (1.f - th * th);
+                gp[q] += ds;
+                dvacc[q] = fmaf(de, th, dvacc[q]);
+                dyrow[row * A + kq * AL + q] = ds;
+            }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < R * A; idx += NT) {        // partial dy[r][a] = sum over my positions (16 DPP rows)
+            const int r = idx / A, aa = idx % A;
+            float x = 0.f;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) x += dyrow[(r * 16 + t) * A + aa];
+            dyp[idx] = x;
+        }
+        __syncthreads();
+        if (wave0) {     // X2 publish: to the owner of each A-slice
+            for (int idx = lane; idx < R * A; idx += 64) {
+                const int r = idx / A, aa = idx % A, md = aa / AS, al = aa % AS;
+                if (rok(r)) pubg(g2 + ((size_t)md * G + mem) * S2 + r * AS2 + al, ep, dyp[idx], fast);
+            }
+        }
+        // ---- X2 gather: dy for my A-slice
+        if (wave1 && tid - 64 < S2) {
+            const int slot = tid - 64, r = slot / AS2, q = slot % AS2;
+            float v0 = 0.f;
+            if (rok(r) && q < AS) gather16_one<S2>(g2 + ((size_t)mem * G) * S2 + slot, ep, v0, a.err);
+            dys[r * AS2 + q] = v0;
+        }
+        __syncthreads();
+        if (wave0 && tid < R * AS) {      // save dy (dW_att = q^T . dy after the loop)
+            const int r = tid / AS, al = tid % AS;
+            if (rok(r)) a.dY[((size_t)i * a.B + r0 + r) * A + mem * AS + al] = dys[r * AS2 + al];
+        }
+        // ---- (e) partial dq[r][k] = dy[r][my a-slice] . W_att[k][my a-slice]
+        if (eact) {
+            float x = 0.f;
+#pragma unroll
+            for (int q = 0; q < AS; ++q) x = fmaf(dys[er * AS2 + q], wal[ek * AS + q], x);
+            dqp[tid] = x;
+        }
+        __syncthreads();
+        if (wave0) {     // X3 publish: to the owner of each unit slice
+            for (int idx = lane; idx < R * H; idx += 64) {
+                const int r = idx / H, k = idx % H, md = k / HS, u = k % HS;
+                if (rok(r)) pubg(g3 + ((size_t)md * G + mem) * S3 + r * HS2 + u, ep, dqp[idx], fast);
+            }
+        }
+        // ---- X3 gather: dq_att for my units
+        if (wave1 && tid - 64 < S3) {
+            const int slot = tid - 64, r = slot / HS2, q = slot % HS2;
+            float v0 = 0.f;
+            if (rok(r) && q < HS) gather16_one<S3>(g3 + ((size_t)mem * G) * S3 + slot, ep, v0, a.err);
+            dql[r * HS2 + q] = v0;
+        }
+        __syncthreads();
+        // ---- cell pointwise backward (wave 0) -> dG slice
+        if (wave0 && cell) {
+            float4 dg = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (cb_ok) {
+                const size_t rowi = (size_t)i * a.B + cb;
+                float* gp = a.gates + rowi * H4 + cj;
+                const float gi = gp[0], gj = gp[H], gf = gp[2 * H], go = gp[3 * H];
+                const float cc = a.dec_c[rowi * H + cj];
+                const float cp = i > 0 ? a.dec_c[(rowi - a.B) * H + cj] : 0.f;
+                const float dq = a.dqc[rowi * (H + D) + cj] + dql[cr * HS2 + cuu] + dc;
+                const float dh = dhl[cr * HS2 + cuu];
+                const float tc = fast_tanh(cc);
+                const float dct = dq + dh * go * (1.f - tc * tc);
+                dg.x = dct * gj * gi * (1.f - gi);
+                dg.y = dct * gi * (1.f - gj * gj);
+                dg.z = dct * cp * gf * (1.f - gf);
+                dg.w = dh * tc * go * (1.f - go);
+                dc = dct * gf;
+                gp[0] = dg.x; gp[H] = dg.y; gp[2 * H] = dg.z; gp[3 * H] = dg.w;
+            }
+            *reinterpret_cast<float4*>(dgl + cr * NCOL + 4 * cuu) = dg;
+        }
+        __syncthreads();
+        // ---- (f) partial [dh_{i-1} | dctx_{i-1}] over my gate columns, for all KS outputs
+        if (s + 1 < a.T) {
+#pragma unroll
+            for (int p = 0; p < KPT; ++p) {
+                const int it = tid + NT * p, k = it >> 1, n0 = (it & 1) * CP;
+                float o0 = 0.f, o1 = 0.f;
+#pragma unroll
+                for (int n4 = 0; n4 < CP / 4; ++n4) {
+                    const float4 d0 = *reinterpret_cast<const float4*>(dgl + n0 + 4 * n4);
+                    const float4 d1 = *reinterpret_cast<const float4*>(dgl + NCOL + n0 + 4 * n4);
+                    o0 = fmaf(d0.x, wf[p][4 * n4], o0); o0 = fmaf(d0.y, wf[p][4 * n4 + 1], o0);
+                    o0 = fmaf(d0.z, wf[p][4 * n4 + 2], o0); o0 = fmaf(d0.w, wf[p][4 * n4 + 3], o0);
+                    o1 = fmaf(d1.x, wf[p][4 * n4], o1); o1 = fmaf(d1.y, wf[p][4 * n4 + 1], o1);
+                    o1 = fmaf(d1.z, wf[p][4 * n4 + 2], o1); o1 = fmaf(d1.w, wf[p][4 * n4 + 3], o1);
+                }
+                o0 += __shfl_xor(o0, 1); o1 += __shfl_xor(o1, 1);
+                if (!(it & 1) && k < KS) { outp[k] = o0; outp[KS + k] = o1; }
+            }
+            __syncthreads();
+            if (wave0) {     // X4 publish: dh part to the unit owner, dctx part to the D-slice owner
+                for (int idx = lane; idx < R * KS; idx += 64) {
+                    const int r = idx / KS, k = idx % KS;
+                    if (!rok(r)) continue;
+                    int md, q;
+                    if (k < H) { md = k / HS; q = k % HS; } else { md = (k - H) / DS; q = HS + (k - H) % DS; }
+                    pubg(g4 + ((size_t)md * G + mem) * S4 + r * (HS + DS) + q, ep, outp[idx], fast);
+                }
+            }
+        }
+        // (LDS buffers written by wave 1 / the compute phases are rewritten only after later barriers)
+    }
+    // ---- epilogue: dhf slice and dv partial
+    __syncthreads();
+    for (int idx = tid; idx < R * MAXTS * A; idx += NT) {
+        const int r = idx / (MAXTS * A), rem = idx % (MAXTS * A), tl = rem / A, aa = rem % A;
+        const int tau = tau0 + tl;
+        if (rok(r) && tl < TS && tau < Te) a.dhf[((size_t)(r0 + r) * Te + tau) * A + aa] = dhfl[idx];
+    }
+#pragma unroll
+    for (int q = 0; q < AL; ++q) dyrow[row * A + kq * AL + q] = dvacc[q];
+    __syncthreads();
+    for (int aa = tid; aa < A; aa += NT) {
+        float x = 0.f;
+        for (int t = 0; t < 32; ++t) x += dyrow[t * A + aa];
+        a.dv_part[(size_t)blockIdx.x * A + aa] = x;
+    }
+}
+
+}  // namespace asr
+
+extern "C" size_t asr_decoder_chain_bwd_ws_bytes(int B, int D, int A, int H) {
+    const size_t groups = (B + 1) / 2, G = 16, R = 2, HS = H / 16, AS = A / 16, DS = D / 16;
+    const size_t s4 = R * (HS + DS), s1 = R * (16 + 2), s2 = R * ((AS + 1) & ~(size_t)1), s3 = R * ((HS + 1) & ~(size_t)1);
+    return groups * 2 * G * G * (s4 + s1 + s2 + s3) * sizeof(u64) + groups * 16 * sizeof(u64);
+}
+
+template <int H, int D, int A>
+static int chain_bwd_launch(hipStream_t s, asr::ChainBwdArgs& a) {
+    constexpr int R = 2, G = 16, HS = H / G, AS = A / G, DS = D / G, HS2 = (HS + 1) & ~1, AS2 = (AS + 1) & ~1;
+    const int groups = (a.B + R - 1) / R;
+    const size_t lds = sizeof(float) * (4 + R * DS + R * HS2 + R * G * 16 + 4 + R * 16 + R * A + 32 * A + R * A + R * AS2 +
+                                        R * H + R * HS2 + R * 4 * HS + R * (H + D) + 2 * R * 16 * A + H * AS + A + (size_t)R * a.Te * DS +
+                                        (size_t)R * a.Te + 16);
+    if (lds > 150 * 1024) return ASR_EUNSUPPORTED;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asr::decoder_chain_bwd_kernel<H, D, A>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((asr::decoder_chain_bwd_kernel<H, D, A>), dim3(groups * G), dim3(512), lds, s, a);
+    return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
+}
+
+// All T steps of the decoder chain backward.  gates holds the activated gates on entry and dG on exit.
+int asr_decoder_chain_bwd(void* stream, float* gates, const float* dec_c, const float* alpha, const float* y,
+                          const float* ctx, const float* dqc, const float* wh, const float* wc, const float* w_att,
+                          const float* v, const float* hf, const float* enc, const int* enc_len, float* dY, float* dctx,
+                          float* dhf, float* dv_part, void* ws, int* err, int B, int Te, int D, int A, int H, int T) {
+    using namespace asr;
+    if (!asr_decoder_chain_supported(B, Te, D, A, H) || B > 32 || T <= 0) return ASR_EUNSUPPORTED;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t bytes = asr_decoder_chain_bwd_ws_bytes(B, D, A, H);
+    if (hipMemsetAsync(ws, 0, bytes, s) != hipSuccess) return ASR_ELAUNCH;
+    ChainBwdArgs a;
+    a.gates = gates; a.dec_c = dec_c; a.alpha = alpha; a.y = y; a.ctx = ctx; a.dqc = dqc; a.wh = wh; a.wc = wc;
+    a.w_att = w_att; a.v = v; a.hf = hf; a.enc = enc; a.enc_len = enc_len; a.dY = dY; a.dctx = dctx; a.dhf = dhf;
+    a.dv_part = dv_part; a.gx = static_cast<u64*>(ws);
+    a.xcc_slots = reinterpret_cast<u64*>(static_cast<char*>(ws) + bytes) - ((size_t)((B + 1) / 2) * 16);
+    a.err = err; a.B = B; a.Te = Te; a.T = T;
+    if (H == 256) return chain_bwd_launch<256, 512, 128>(s, a);
+    return chain_bwd_launch<64, 128, 16>(s, a);
+}

@@ -183,9 +183,11 @@ typedef struct {              /* backward scratch (device), sized by the caller 
     float* dc_dec;            /* [B,H]  carry */
     float* dc_lm;             /* [B,lmH] carry */
     float* dhf;               /* [B,Te,A] */
-    float* dv_part;           /* [B,A] */
+    float* dv_part;           /* [max(B, 16*ceil(B/2)),A] */
     float* dctx;              /* [T_out,B,D] total gradient w.r.t. each step's context */
     float* emb_all;           /* [T_out,B,E] gathered embeddings */
+    void*  chain_ws;          /* asr_decoder_chain_bwd_ws_bytes() bytes, or NULL: per-step launches */
+    float* wc;                /* [D,4H] W_inp[P:] . K_x (persistent chain only, else NULL) */
 } asr_dec_bwd_ws;
 
 /* Backward of asr_attn_decoder_fwd.  Weight gradients are ACCUMULATED into `g` (same field
@@ -204,6 +206,7 @@ int asr_side_join(void* stream);
 /* Persistent decoder chain (csrc/decoder_chain.hip): used inside asr_attn_decoder_fwd when supported. */
 int asr_decoder_chain_supported(int B, int Te, int D, int A, int H);
 size_t asr_decoder_chain_ws_bytes(int B, int D, int A, int H);
+size_t asr_decoder_chain_bwd_ws_bytes(int B, int D, int A, int H);
 int asr_zero_finished_rows(void* stream, float* logits, const int* len, int T, int B, int V);
 
 /* Optional per-kernel HIP-event timing on the launch stream (bench.py roofline leg).

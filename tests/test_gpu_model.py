@@ -427,7 +427,8 @@ def test_decoder_chain_path_vs_oracle_and_autograd():
 
 def test_decoder_chain_equals_launch_path_under_scheduled_sampling(monkeypatch):
     """Scheduled sampling cuts the sequence into segments (one persistent launch each); the result
-    must equal the per-step launch path: same sampled tokens, same logits."""
+    must equal the per-step launch path: same sampled tokens, same logits, and the persistent backward
+    chain (csrc/decoder_chain_bwd.hip) must give the per-step backward's gradients."""
     rng = np.random.default_rng(22)
     b = _batch(rng, 6, 24, 20, 13, 50)
     outs = []
@@ -438,7 +439,15 @@ def test_decoder_chain_equals_launch_path_under_scheduled_sampling(monkeypatch):
         m.forward(b)
         ws = m.decoder["char"].saved["ws"]
         assert (ws.get("chain_ws") is not None) == (chain == "1")
-        outs.append((m.outputs["char"].cpu().numpy(), ws["tok"].cpu().numpy(), m.total_loss.item()))
+        m.backward()
+        from e2e_asr_amd import ops
+        ops.check_device_flag(torch.device(DEV))
+        grads = {n: m.variables.grad_of(n).cpu().numpy().copy() for n in m.variables.names()}
+        outs.append((m.outputs["char"].cpu().numpy(), ws["tok"].cpu().numpy(), m.total_loss.item(), grads))
+    for n, g1 in outs[0][3].items():
+        g0 = outs[1][3][n]
+        err = np.abs(g1 - g0).max() / max(1e-3, np.abs(g0).max())
+        assert err < 1e-4, (n, err)
     np.testing.assert_array_equal(outs[0][1], outs[1][1])
     assert (outs[0][1][1:] != np.asarray(b["char"]).T[1:outs[0][1].shape[0]]).any()   # some tokens really were sampled
     np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=0, atol=2e-5)
