@@ -21,4 +21,14 @@ for name, M, N, K, ta, tb in shapes:
         ops.gemm(a, b, None, bool(ta), bool(tb), out=c, accumulate=bool(ta))
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / n
-    print("%-14s M=%5d N=%5d K=%5d  %8.1f us  %6.1f TF/s" % (name, M, N, K, ms * 1e3, 2.0 * M * N * K / ms / 1e9))
+    # rocBLAS (torch.matmul) on the same operands, for orientation only
+    at, bt = (a.t() if ta else a), (b.t() if tb else b)
+    for _ in range(3):
+        torch.matmul(at, bt, out=c)
+    e0.record()
+    for _ in range(n):
+        torch.matmul(at, bt, out=c)
+    e1.record(); torch.cuda.synchronize()
+    ms2 = e0.elapsed_time(e1) / n
+    print("%-14s M=%5d N=%5d K=%5d  %8.1f us  %6.1f TF/s   | rocBLAS %8.1f us %6.1f TF/s" % (
+        name, M, N, K, ms * 1e3, 2.0 * M * N * K / ms / 1e9, ms2 * 1e3, 2.0 * M * N * K / ms2 / 1e9))
