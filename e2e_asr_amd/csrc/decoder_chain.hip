@@ -93,7 +93,9 @@ __global__ __launch_bounds__(512) void decoder_chain_fwd_kernel(ChainArgs a) {
     float* el = yl + R * A;                         // e / alpha [R][G*MAXTS]
     float* eout = el + R * G * MAXTS;               // [32] scores of this workgroup
     float* cpart = eout + 32;                       // [8][R][DS]
-    float* hfl = cpart + 8 * R * DS;                // hf slice [R][TS][A]
+    float* pgl = cpart + 8 * R * DS;                // preG of the current step for my units [R][HS][4]
+    float* vl = pgl + R * HS * 4;                   // v [A]
+    float* hfl = vl + A;                            // hf slice [R][TS][A]
     const int Te = a.Te;
     const int TS = (Te + G - 1) / G;
     float* encl = hfl + R * MAXTS * A;              // enc slice [R][Te][DS]
@@ -107,6 +109,10 @@ __global__ __launch_bounds__(512) void decoder_chain_fwd_kernel(ChainArgs a) {
     else { grp = blockIdx.x / G; mem = blockIdx.x % G; }
     const int r0 = grp * R;
     const bool wave0 = __builtin_amdgcn_readfirstlane(tid) < 64;
+    // wave 7 neither polls nor stores: it fetches the next step's preG one step ahead (its loads never wait
+    // behind a publish, and the cell wave never waits on a load)
+    const bool wave7 = __builtin_amdgcn_readfirstlane(tid) >= NT - 64;
+    constexpr int NPOLL = NT - 128;                 // waves 1..6 poll
     const int brow0 = min(r0, a.B - 1), brow1 = min(r0 + 1, a.B - 1);
     const int blen0 = min(max(a.enc_len[brow0], 0), Te);
     const int blen1 = (r0 + 1 < a.B) ? min(max(a.enc_len[brow1], 0), Te) : 0;
@@ -183,12 +189,21 @@ __global__ __launch_bounds__(512) void decoder_chain_fwd_kernel(ChainArgs a) {
         }
         sl[(r * 32 + k / KC) * KCP + (k % KC)] = v;
     }
-    float pg0 = 0.f, pg1 = 0.f, pg2 = 0.f, pg3 = 0.f;       // preG of the next step (software-pipelined)
+    // preG of the next step, in wave 7's registers (software-pipelined): item = lane + 64*j -> (r, unit, gate)
+    constexpr int NPG = (R * HS * 4 + 63) / 64;
+    float pgr[NPG];
     auto prefetch = [&](int i) {
-        const float* gp = a.gates + ((size_t)i * a.B + min(cb, a.B - 1)) * H4 + cj;
-        pg0 = gp[0]; pg1 = gp[H]; pg2 = gp[2 * H]; pg3 = gp[3 * H];
+#pragma unroll
+        for (int j = 0; j < NPG; ++j) {
+            const int idx = lane + 64 * j, r = idx / (HS * 4), uu = (idx >> 2) % HS, g = idx & 3;
+            pgr[j] = (idx < R * HS * 4 && r0 + r < a.B) ? a.gates[((size_t)i * a.B + r0 + r) * H4 + g * H + mem * HS + uu] : 0.f;
+        }
     };
-    if (wave0) prefetch(a.t0);
+#pragma unroll
+    for (int j = 0; j < NPG; ++j) pgr[j] = 0.f;
+    if (wave7) prefetch(a.t0);
+    for (int idx = tid; idx < A; idx += NT) vl[idx] = a.v[idx];
+    const float batt = (tid < R * AS) ? a.b_att[mem * AS + tid % AS] : 0.f;
     __syncthreads();
 
     const int nsteps = a.t1 - a.t0;
@@ -197,11 +212,17 @@ __global__ __launch_bounds__(512) void decoder_chain_fwd_kernel(ChainArgs a) {
         const uint32_t ep = (uint32_t)(s + 1);
         u64* gpar = gbase + (size_t)(s & 1) * NPAR;
         u64* gS = gpar; u64* gQ = gpar + NS; u64* gY = gQ + NQ; u64* gE = gY + NY;
+        if (wave7) {
+#pragma unroll
+            for (int j = 0; j < NPG; ++j)
+                if (lane + 64 * j < R * HS * 4) pgl[lane + 64 * j] = pgr[j];
+            if (s + 1 < nsteps) prefetch(i + 1);
+        }
         // ---- (1) gather the state [h_{i-1} | ctx_{i-1}] published at the previous step
         if (s > 0) {
-            if (!wave0) {
+            if (!wave0 && !wave7) {
                 const u64* src = gbase + (size_t)((s - 1) & 1) * NPAR;
-                for (int p = tid - 64; p < NS / 2; p += NT - 64) {
+                for (int p = tid - 64; p < NS / 2; p += NPOLL) {
                     const int idx = 2 * p, r = idx / KS, k = idx % KS;
                     float v0 = 0.f, v1 = 0.f;
                     if (r0 + r < a.B) chain_poll2(src + idx, (uint32_t)s, v0, v1, a.err);
@@ -242,10 +263,11 @@ __global__ __launch_bounds__(512) void decoder_chain_fwd_kernel(ChainArgs a) {
         if (wave0 && cell) {
             const float4 s0 = *reinterpret_cast<const float4*>(sums + ((0 * HS + cuu) * R + cr) * 4);
             const float4 s1 = *reinterpret_cast<const float4*>(sums + ((1 * HS + cuu) * R + cr) * 4);
-            const float gi = fast_sigmoid(pg0 + s0.x + s1.x);
-            const float gj = fast_tanh(pg1 + s0.y + s1.y);
-            const float gf = fast_sigmoid(pg2 + s0.z + s1.z + 1.0f);
-            const float go = fast_sigmoid(pg3 + s0.w + s1.w);
+            const float* pg = pgl + (cr * HS + cuu) * 4;
+            const float gi = fast_sigmoid(pg[0] + s0.x + s1.x);
+            const float gj = fast_tanh(pg[1] + s0.y + s1.y);
+            const float gf = fast_sigmoid(pg[2] + s0.z + s1.z + 1.0f);
+            const float go = fast_sigmoid(pg[3] + s0.w + s1.w);
             c_state = c_state * gf + gi * gj;
             h_state = go * fast_tanh(c_state);
             if (cb_ok) {
@@ -257,11 +279,10 @@ __global__ __launch_bounds__(512) void decoder_chain_fwd_kernel(ChainArgs a) {
                 a.dec_c[rowi * H + cj] = c_state;
                 a.dec_h[rowi * H + cj] = h_state;
             }
-            if (s + 1 < nsteps) prefetch(i + 1);
         }
         // ---- (3) gather q, y slice = q.W_att[:, slice] + b
-        if (!wave0) {
-            for (int p = tid - 64; p < NQ / 2; p += NT - 64) {
+        if (!wave0 && !wave7) {
+            for (int p = tid - 64; p < NQ / 2; p += NPOLL) {
                 const int idx = 2 * p, r = idx / H;
                 float v0 = 0.f, v1 = 0.f;
                 if (r0 + r < a.B) chain_poll2(gQ + idx, ep, v0, v1, a.err);
@@ -284,15 +305,15 @@ __global__ __launch_bounds__(512) void decoder_chain_fwd_kernel(ChainArgs a) {
         __syncthreads();
         if (wave0 && tid < R * AS) {
             const int r = tid / AS, aa = tid % AS, acol = mem * AS + aa;
-            const float yv = a.b_att[acol] + ysum[(0 * AS + aa) * R + r] + ysum[(1 * AS + aa) * R + r];
+            const float yv = batt + ysum[(0 * AS + aa) * R + r] + ysum[(1 * AS + aa) * R + r];
             if (r0 + r < a.B) {
                 chain_publish(gY + (size_t)r * A + acol, ep, yv, fast);
                 a.y[((size_t)i * a.B + r0 + r) * A + acol] = yv;
             }
         }
         // ---- (4) gather y, scores on this workgroup's position slice
-        if (!wave0) {
-            for (int p = tid - 64; p < NY / 2; p += NT - 64) {
+        if (!wave0 && !wave7) {
+            for (int p = tid - 64; p < NY / 2; p += NPOLL) {
                 const int idx = 2 * p, r = idx / A;
                 float v0 = 0.f, v1 = 0.f;
                 if (r0 + r < a.B) chain_poll2(gY + idx, ep, v0, v1, a.err);
@@ -309,7 +330,7 @@ __global__ __launch_bounds__(512) void decoder_chain_fwd_kernel(ChainArgs a) {
                 const float* hp = hfl + (r * MAXTS + tl) * A + kq * AL;
                 const float* yp = yl + r * A + kq * AL;
 #pragma unroll
-                for (int q4 = 0; q4 < AL; ++q4) sc = fmaf(a.v[kq * AL + q4], fast_tanh(hp[q4] + yp[q4]), sc);
+                for (int q4 = 0; q4 < AL; ++q4) sc = fmaf(vl[kq * AL + q4], fast_tanh(hp[q4] + yp[q4]), sc);
             }
             sc = row16_allreduce_sum(sc);
             if (kq == 0) eout[row] = sc;
@@ -321,9 +342,9 @@ __global__ __launch_bounds__(512) void decoder_chain_fwd_kernel(ChainArgs a) {
                 chain_publish(gE + (size_t)r * G * MAXTS + mem * MAXTS + tl, ep, eout[tid], fast);
         }
         // ---- (5) gather all scores, softmax over tau < len (replicated), context slice
-        if (!wave0) {
+        if (!wave0 && !wave7) {
             const int pairs = (TS + 1) / 2;                       // per (r, source workgroup)
-            for (int p = tid - 64; p < R * G * pairs; p += NT - 64) {
+            for (int p = tid - 64; p < R * G * pairs; p += NPOLL) {
                 const int r = p / (G * pairs), rem = p % (G * pairs), m = rem / pairs, tp = rem % pairs;
                 const int off = r * G * MAXTS + m * MAXTS + 2 * tp;
                 float v0 = 0.f, v1 = 0.f;
@@ -417,8 +438,10 @@ static int chain_launch(hipStream_t s, asr::ChainArgs& a, int Te) {
     const int groups = (a.B + R - 1) / R;
     constexpr int KSP = (H + D + 127) / 128 * 128, KCP = KSP / 32 + 4, QP = (H + 127) / 128 * 128;
     const size_t lds = sizeof(float) * (4 + (size_t)R * 32 * KCP + 2 * (H / G) * R * 4 + R * QP + 2 * (A / G) * R + 4 + R * A +
-                                        R * G * 16 + 32 + 8 * R * (D / G) + R * 16 * A + (size_t)R * Te * (D / G));
-    if (lds > 64 * 1024) return ASR_EUNSUPPORTED;
+                                        R * G * 16 + 32 + 8 * R * (D / G) + R * (H / G) * 4 + A + R * 16 * A + (size_t)R * Te * (D / G));
+    if (lds > 150 * 1024) return ASR_EUNSUPPORTED;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asr::decoder_chain_fwd_kernel<H, D, A>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((asr::decoder_chain_fwd_kernel<H, D, A>), dim3(groups * G), dim3(512), lds, s, a);
     return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
 }

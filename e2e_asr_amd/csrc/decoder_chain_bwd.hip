@@ -109,8 +109,7 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
     float* dal = dhl + R * HS2;                       // partial dalpha [R][G*MAXTS] (all positions)  -> X1 publish
     float* sp = dal + R * G * MAXTS;                  // partial S [R] (+pad 2)
     float* del = sp + 4;                              // de for my positions [R][MAXTS]
-    float* yl = del + R * MAXTS;                      // y_i [R][A]
-    float* dyrow = yl + R * A;                        // per DPP row partial dy [32 rows][A]
+    float* dyrow = del + R * MAXTS;                        // per DPP row partial dy [32 rows][A]
     float* dyp = dyrow + 32 * A;                      // partial dy [R][A]                            -> X2 publish
     float* dys = dyp + R * A;                         // dy for my a-slice [R][AS2]
     float* dqp = dys + R * AS2;                       // partial dq [R][H]                            -> X3 publish
@@ -124,7 +123,19 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
     float* wal = dhfl + R * MAXTS * A;                // W_att[:, my a-slice] [H][AS]
     float* vl = wal + H * AS;                         // v [A]
     float* encl = vl + A;                             // enc slice [R][Te][DS]
-    float* alf = encl + R * Te * DS;                  // alpha_i [R][Te]
+    // operands of the CURRENT step that depend on no exchange: fetched one step ahead by the prefetch waves
+    // (threads >= 192, which neither poll nor store) -- item order below = LDS order
+    const int TeP = (Te + 1) & ~1;
+    float* pfl = encl + R * Te * DS;
+    float* yl = pfl;                                  // y_i [R][A]
+    float* alf = yl + R * A;                          // alpha_i [R][TeP]
+    float* dqcx = alf + R * TeP;                      // dctx_ap slice [R][DS]
+    float* ctxl = dqcx + R * DS;                      // ctx_i slice [R][DS]
+    float* gl = ctxl + R * DS;                        // activated gates of my units [R][HS][4]
+    float* cl = gl + R * HS * 4;                      // c_i [R][HS]
+    float* cpl = cl + R * HS;                         // c_{i-1} [R][HS]
+    float* dqa = cpl + R * HS;                        // dq_ap of my units [R][HS]
+    const int nitems = R * A + R * TeP + 2 * R * DS + R * HS * 4 + 3 * R * HS;
 
     __builtin_amdgcn_s_setprio(3);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -186,6 +197,38 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
     const int cb = r0 + cr;
     const bool cb_ok = cell && cb < a.B;
     float dc = 0.f;
+    constexpr int NPF = 4, PF0 = 192, PFN = NT - PF0;
+    const bool pfw = __builtin_amdgcn_readfirstlane(tid) >= PF0;
+    auto pf_fetch = [&](int i, int idx) -> float {
+        if (idx < R * A) { const int r = idx / A; return rok(r) ? a.y[((size_t)i * a.B + browf(r)) * A + idx % A] : 0.f; }
+        idx -= R * A;
+        if (idx < R * TeP) {
+            const int r = idx / TeP, tau = idx % TeP;
+            return (rok(r) && tau < Te) ? a.alpha[((size_t)i * a.B + browf(r)) * Te + tau] : 0.f;
+        }
+        idx -= R * TeP;
+        if (idx < R * DS) { const int r = idx / DS; return rok(r) ? a.dqc[((size_t)i * a.B + browf(r)) * (H + D) + H + mem * DS + idx % DS] : 0.f; }
+        idx -= R * DS;
+        if (idx < R * DS) { const int r = idx / DS; return rok(r) ? a.ctx[((size_t)i * a.B + browf(r)) * D + mem * DS + idx % DS] : 0.f; }
+        idx -= R * DS;
+        if (idx < R * HS * 4) {
+            const int r = idx / (HS * 4), uu = (idx >> 2) % HS, g = idx & 3;
+            return rok(r) ? a.gates[((size_t)i * a.B + browf(r)) * H4 + g * H + mem * HS + uu] : 0.f;
+        }
+        idx -= R * HS * 4;
+        const int which = idx / (R * HS), rem = idx % (R * HS), r = rem / HS, uu = rem % HS;
+        if (!rok(r)) return 0.f;
+        const size_t rowi = (size_t)i * a.B + browf(r);
+        if (which == 0) return a.dec_c[rowi * H + mem * HS + uu];
+        if (which == 1) return i > 0 ? a.dec_c[(rowi - a.B) * H + mem * HS + uu] : 0.f;
+        return a.dqc[rowi * (H + D) + mem * HS + uu];
+    };
+    float pfr[NPF];
+#pragma unroll
+    for (int j = 0; j < NPF; ++j) {
+        const int idx = tid - PF0 + PFN * j;
+        pfr[j] = (pfw && idx < nitems) ? pf_fetch(a.T - 1, idx) : 0.f;
+    }
     __syncthreads();
 
     for (int s = 0; s < a.T; ++s) {
@@ -195,11 +238,22 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
         u64* g4 = gpar; u64* g1 = g4 + G * G * S4; u64* g2 = g1 + G * G * S1; u64* g3 = g2 + G * G * S2;
         const u64* g4prev = gbase + (size_t)((s - 1) & 1) * NPAR;     // X4 of the previous (later-time) step
         // ---- operands of this step that do not depend on any exchange (waves >= 2 fetch them)
-        if (tid >= 192) {
-            for (int idx = tid - 192; idx < R * A; idx += NT - 192)
-                yl[idx] = rok(idx / A) ? a.y[((size_t)i * a.B + browf(idx / A)) * A + (idx % A)] : 0.f;
-            for (int idx = tid - 192; idx < R * Te; idx += NT - 192)
-                alf[idx] = rok(idx / Te) ? a.alpha[((size_t)i * a.B + browf(idx / Te)) * Te + (idx % Te)] : 0.f;
+        if (pfw) {
+#pragma unroll
+            for (int j = 0; j < NPF; ++j) {
+                const int idx = tid - PF0 + PFN * j;
+                if (idx < nitems) pfl[idx] = pfr[j];
+            }
+            if (s + 1 < a.T) {
+#pragma unroll
+                for (int j = 0; j < NPF; ++j) {
+                    int idx = tid - PF0 + PFN * j;
+                    // opaque per iteration: keeps the item decode (cheap ALU) inside the loop instead of
+                    // loop-invariant address registers held across the register-critical phases
+                    asm volatile("" : "+v"(idx));
+                    if (idx < nitems) pfr[j] = pf_fetch(i - 1, idx);
+                }
+            }
         }
         // ---- X4 gather: [dh | dctx_carry] for my slices, summed over the 16 sources (one lane per slot)
         if (tid >= 64 && tid < 64 + S4) {
@@ -217,9 +271,9 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
                 float x = dctl[r * DS + dd];
                 if (rok(r)) {
                     const size_t rowi = (size_t)i * a.B + r0 + r;
-                    x += a.dqc[rowi * (H + D) + H + mem * DS + dd];
+                    x += dqcx[r * DS + dd];
                     a.dctx[rowi * D + mem * DS + dd] = x;
-                    sprt = fmaf(x, a.ctx[rowi * D + mem * DS + dd], sprt);
+                    sprt = fmaf(x, ctxl[r * DS + dd], sprt);
                 }
                 dctl[r * DS + dd] = x;
             }
@@ -266,7 +320,7 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
         {
             const int r = trow_r, tl = trow_tl, tau = tau0 + tl;
             float de = 0.f;
-            if (tl < TS && tau < blenf(r)) de = alf[r * Te + tau] * (del[r * MAXTS + tl] - sp[2 + r]);
+            if (tl < TS && tau < blenf(r)) de = alf[r * TeP + tau] * (del[r * MAXTS + tl] - sp[2 + r]);
             float* hp = hfl + (r * MAXTS + tl) * A + kq * AL;
             float* gp = dhfl + (r * MAXTS + tl) * A + kq * AL;
             const float* yp = yl + r * A + kq * AL;
@@ -334,10 +388,11 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
             if (cb_ok) {
                 const size_t rowi = (size_t)i * a.B + cb;
                 float* gp = a.gates + rowi * H4 + cj;
-                const float gi = gp[0], gj = gp[H], gf = gp[2 * H], go = gp[3 * H];
-                const float cc = a.dec_c[rowi * H + cj];
-                const float cp = i > 0 ? a.dec_c[(rowi - a.B) * H + cj] : 0.f;
-                const float dq = a.dqc[rowi * (H + D) + cj] + dql[cr * HS2 + cuu] + dc;
+                const float* gv = gl + (cr * HS + cuu) * 4;
+                const float gi = gv[0], gj = gv[1], gf = gv[2], go = gv[3];
+                const float cc = cl[cr * HS + cuu];
+                const float cp = cpl[cr * HS + cuu];
+                const float dq = dqa[cr * HS + cuu] + dql[cr * HS2 + cuu] + dc;
                 const float dh = dhl[cr * HS2 + cuu];
                 const float tc = fast_tanh(cc);
                 const float dct = dq + dh * go * (1.f - tc * tc);
@@ -413,7 +468,7 @@ static int chain_bwd_launch(hipStream_t s, asr::ChainBwdArgs& a) {
     const int groups = (a.B + R - 1) / R;
     const size_t lds = sizeof(float) * (4 + R * DS + R * HS2 + R * G * 16 + 4 + R * 16 + R * A + 32 * A + R * A + R * AS2 +
                                         R * H + R * HS2 + R * 4 * HS + R * (H + D) + 2 * R * 16 * A + H * AS + A + (size_t)R * a.Te * DS +
-                                        (size_t)R * a.Te + 16);
+                                        (size_t)R * (a.Te + 1) + 2 * R * DS + 7 * R * HS + 16);
     if (lds > 150 * 1024) return ASR_EUNSUPPORTED;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asr::decoder_chain_bwd_kernel<H, D, A>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

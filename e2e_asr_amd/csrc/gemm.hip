@@ -12,13 +12,16 @@
 // operands k-major ([k][m] / [k][n]) so that an MFMA operand read is one conflict-free
 // ds_read_b32 per lane (lanes 0-31: consecutive m at k, lanes 32-63: at k+1).  Global ->
 // register prefetch of tile t+1 is issued before the MFMAs of tile t.
+// A second instantiation with a 64x64 block tile (one 32x32 MFMA tile per wave) serves products
+// with few output tiles (the decoder's [3840,256]-shaped ones): 4x the workgroups, so the chip is
+// filled without split-K and the result stays bit-reproducible.
 #include "common.h"
 #include <algorithm>
 #include <cstdlib>
 
 namespace asr {
 
-constexpr int BM = 128, BN = 128, BK = 16, LDT = 132;  // LDT: padded k-row (16-B aligned)
+constexpr int BK = 16;
 
 struct GemmArgs {
     const float* A; const float* B; float* C; const float* bias;
@@ -40,51 +43,58 @@ __device__ __forceinline__ float4 ld4(const float* p, int nvalid, bool vec) {
     return r;
 }
 
-// Operand staging.  "KM" = operand stored [k][m] in memory (contiguous along m/n):
-// thread -> (k = tid>>4, mq = tid&15), two float4 at m = mq*4 and mq*4+64.
-// "MK" = operand stored [m][k] (contiguous along k): thread -> (m = tid>>1, kh = tid&1),
-// two float4 at k = kh*8, kh*8+4, transposed on the LDS store.
-template <bool KMAJOR>
+// Operand staging for a BT-wide tile (BT = 128 or 64), 256 threads.
+// "KM" = operand stored [k][m] in memory (contiguous along m/n): thread -> (k = tid>>4, mq = tid&15),
+// float4 at m = mq*4 (and mq*4+64 for BT = 128).
+// "MK" = operand stored [m][k] (contiguous along k): BT = 128: thread -> (m = tid>>1, kh = tid&1), two
+// float4 at k = kh*8, kh*8+4; BT = 64: thread -> (m = tid>>2, kq = tid&3), one float4 at k = kq*4;
+// transposed on the LDS store.
+template <bool KMAJOR, int BT>
 struct Stager {
+    static constexpr int LDT = BT + 4;   // padded k-row (16-B aligned)
     float4 r0, r1;
     __device__ __forceinline__ void load(const float* P, int ld, int m0, int k0, int Mdim, int Kdim,
                                          bool vec, int tid) {
+        r0 = r1 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (KMAJOR) {
             int k = k0 + (tid >> 4), m = m0 + (tid & 15) * 4;
             if (k < Kdim) {
                 const float* p = P + (size_t)k * ld + m;
                 r0 = ld4(p, Mdim - m, vec);
-                r1 = ld4(p + 64, Mdim - m - 64, vec);
-            } else {
-                r0 = r1 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (BT == 128) r1 = ld4(p + 64, Mdim - m - 64, vec);
             }
-        } else {
+        } else if (BT == 128) {
             int m = m0 + (tid >> 1), k = k0 + (tid & 1) * 8;
             if (m < Mdim) {
                 const float* p = P + (size_t)m * ld + k;
                 r0 = ld4(p, Kdim - k, vec);
                 r1 = ld4(p + 4, Kdim - k - 4, vec);
-            } else {
-                r0 = r1 = make_float4(0.f, 0.f, 0.f, 0.f);
             }
+        } else {
+            int m = m0 + (tid >> 2), k = k0 + (tid & 3) * 4;
+            if (m < Mdim) r0 = ld4(P + (size_t)m * ld + k, Kdim - k, vec);
         }
     }
     __device__ __forceinline__ void store(float* S, int tid) const {
         if (KMAJOR) {
             float* s = S + (tid >> 4) * LDT + (tid & 15) * 4;
             *reinterpret_cast<float4*>(s) = r0;
-            *reinterpret_cast<float4*>(s + 64) = r1;
-        } else {
+            if (BT == 128) *reinterpret_cast<float4*>(s + 64) = r1;
+        } else if (BT == 128) {
             float* s = S + ((tid & 1) * 8) * LDT + (tid >> 1);
             s[0] = r0.x; s[LDT] = r0.y; s[2 * LDT] = r0.z; s[3 * LDT] = r0.w;
             s[4 * LDT] = r1.x; s[5 * LDT] = r1.y; s[6 * LDT] = r1.z; s[7 * LDT] = r1.w;
+        } else {
+            float* s = S + ((tid & 3) * 4) * LDT + (tid >> 2);
+            s[0] = r0.x; s[LDT] = r0.y; s[2 * LDT] = r0.z; s[3 * LDT] = r0.w;
         }
     }
 };
 
 // TA: A is given transposed ([K,M] row-major).  TB: B is given transposed ([N,K] row-major).
-template <bool TA, bool TB>
+template <bool TA, bool TB, int BT = 128>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
+    constexpr int BM = BT, BN = BT, LDT = BT + 4, WT = BT / 2, MI = BT / 64;   // wave tile WT x WT = MI x MI MFMA tiles
     __shared__ __attribute__((aligned(16))) float As[BK * LDT];
     __shared__ __attribute__((aligned(16))) float Bs[BK * LDT];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -102,16 +112,16 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
     }
     const int m0 = (bid / ntn) * BM, n0 = (bid % ntn) * BN;
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][MI];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < MI; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    Stager<TA> sa;    // A natural [M,K] is m-major => KMAJOR = TA
-    Stager<!TB> sb;   // B natural [K,N] is k-major => KMAJOR = !TB
+    Stager<TA, BT> sa;    // A natural [M,K] is m-major => KMAJOR = TA
+    Stager<!TB, BT> sb;   // B natural [K,N] is k-major => KMAJOR = !TB
     // split-K: this block owns k-tiles [kt0, kt1)
     const int nk_all = (a.K + BK - 1) / BK;
     const int per = (nk_all + a.splits - 1) / a.splits;
@@ -129,29 +139,31 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
             sa.load(a.A, a.lda, m0, (kt + 1) * BK, a.M, a.K, a.vecA, tid);
             sb.load(a.B, a.ldb, n0, (kt + 1) * BK, a.N, a.K, a.vecB, tid);
         }
-        const float* ap = As + (lane >> 5) * LDT + wr * 64 + (lane & 31);
-        const float* bp = Bs + (lane >> 5) * LDT + wc * 64 + (lane & 31);
+        const float* ap = As + (lane >> 5) * LDT + wr * WT + (lane & 31);
+        const float* bp = Bs + (lane >> 5) * LDT + wc * WT + (lane & 31);
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
-            float a0 = ap[kk * LDT], a1 = ap[kk * LDT + 32];
-            float b0 = bp[kk * LDT], b1 = bp[kk * LDT + 32];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            float av[MI], bv[MI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) { av[i] = ap[kk * LDT + 32 * i]; bv[i] = bp[kk * LDT + 32 * i]; }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < MI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
         }
     }
     // Epilogue.  C/D map of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            const int n = n0 + wc * 64 + ni * 32 + (lane & 31);
+        for (int ni = 0; ni < MI; ++ni) {
+            const int n = n0 + wc * WT + ni * 32 + (lane & 31);
             if (n >= a.N) continue;
             const float bv = (a.bias && blockIdx.y == 0) ? a.bias[n] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int m = m0 + wr * WT + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (m < a.M) {
                     float* cp = a.C + (size_t)m * a.ldc + n;
                     float v = acc[mi][ni][r] + bv;
@@ -192,7 +204,7 @@ extern "C" int asr_gemm_f32_batched(void* stream, int transA, int transB, int M,
     g.sA = strideA; g.sB = strideB; g.sC = strideC;
     g.vecA = ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && (lda % 4 == 0) && (strideA % 4 == 0);
     g.vecB = ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && (ldb % 4 == 0) && (strideB % 4 == 0);
-    const int nwg = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    int nwg = ((M + 127) / 128) * ((N + 127) / 128);
     hipStream_t s = static_cast<hipStream_t>(stream);
     // Few output tiles but a long K (weight gradients X^T.dY with K = B*T): split K over
     // blockIdx.y so the chip is filled; partial tiles meet in C through float atomics
@@ -206,6 +218,17 @@ extern "C" int asr_gemm_f32_batched(void* stream, int transA, int transB, int M,
     g.splits = splits;
     if (splits > 1 && !accumulate) {
         if (hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, s) != hipSuccess) return ASR_ELAUNCH;
+    }
+    // few output tiles and no split-K: 64x64 block tiles fill the chip 4x better (still reproducible)
+    static const int small_thr = [] { const char* e = getenv("ASR_GEMM_SMALL"); return e ? atoi(e) : 160; }();
+    if (splits == 1 && (long long)nwg * batch < small_thr) {
+        nwg = ((M + 63) / 64) * ((N + 63) / 64);
+        if (transA && transB)       hipLaunchKernelGGL((gemm_f32_kernel<true, true, 64>), dim3(nwg, 1, batch), dim3(256), 0, s, g);
+        else if (transA)            hipLaunchKernelGGL((gemm_f32_kernel<true, false, 64>), dim3(nwg, 1, batch), dim3(256), 0, s, g);
+        else if (transB)            hipLaunchKernelGGL((gemm_f32_kernel<false, true, 64>), dim3(nwg, 1, batch), dim3(256), 0, s, g);
+        else                        hipLaunchKernelGGL((gemm_f32_kernel<false, false, 64>), dim3(nwg, 1, batch), dim3(256), 0, s, g);
+        ASR_CHECK_LAUNCH();
+        return ASR_OK;
     }
     if (transA && transB)       hipLaunchKernelGGL((gemm_f32_kernel<true, true>), dim3(nwg, splits, batch), dim3(256), 0, s, g);
     else if (transA)            hipLaunchKernelGGL((gemm_f32_kernel<true, false>), dim3(nwg, splits, batch), dim3(256), 0, s, g);
