@@ -29,12 +29,13 @@ class DecDims(C.Structure):
 class DecWs(C.Structure):
     _fields_ = [(n, vp) for n in (
         "hf", "tok", "lm_gates", "lm_c", "lm_h", "lm_hd", "sp", "x", "dec_gates", "dec_c",
-        "dec_h", "alpha", "ctx", "p", "zeros", "y", "w2k", "chain_ws", "err")]
+        "dec_h", "alpha", "ctx", "p", "zeros", "y", "w2k", "chain_ws", "err",
+        "lm_act", "lm_hprev", "lm_state", "lm_len", "lm_hx")]
 
 
 class DecBwdWs(C.Structure):
     _fields_ = [(n, vp) for n in ("dP", "dQC", "dY", "dXH", "dLC", "dlm", "dEH", "dc_dec", "dc_lm", "dhf",
-                                  "dv_part", "dctx", "emb_all", "chain_ws", "wc")]
+                                  "dv_part", "dctx", "emb_all", "chain_ws", "wc", "lm_hx")]
 
 
 class DecGrads(C.Structure):
@@ -81,6 +82,7 @@ SIGNATURES = {
     "asr_decoder_chain_supported": (C.c_int, [C.c_int] * 5),
     "asr_decoder_chain_ws_bytes": (C.c_size_t, [C.c_int] * 4),
     "asr_decoder_chain_bwd_ws_bytes": (C.c_size_t, [C.c_int] * 4),
+    "asr_decoder_lm_chain_supported": (C.c_int, [C.c_int] * 2),
     "asr_zero_finished_rows": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int]),
     "asr_prof_enable": (C.c_int, [C.c_int]),
     "asr_debug_set_buffer": (C.c_int, [vp]),

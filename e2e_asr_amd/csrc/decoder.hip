@@ -16,6 +16,7 @@
 // raw_rnn's state copy-through for finished rows is not materialised: a finished row's
 // emit is zero and its loss weight is zero, so its state is unobservable.
 #include "common.h"
+#include <cstdlib>
 #include "../../include/e2e_asr_hip.h"
 
 extern "C" int asr_zero_finished_rows(void* stream, float* logits, const int* len, int T, int B, int V);
@@ -24,6 +25,15 @@ int asr_decoder_chain_fwd(void* stream, float* gates, const float* wh, const flo
                           const float* b_att, const float* v, const float* hf, const float* enc, const int* enc_len,
                           float* dec_c, float* dec_h, float* alpha, float* ctx, float* y, void* ws, int* err,
                           int B, int Te, int D, int A, int H, int t0, int t1);
+bool asr_lstm_tm_supported(int B, int H);
+int asr_lstm_rec_fwd_tm(hipStream_t s, const float* gates, const float* kh, const int* full_len, float* out, int ldo,
+                        float* act, float* hprev, const float* h0, const float* c0, float* h_last, float* c_last,
+                        void* hx_ws, int* err, int B, int T, int H, int toff, float keep, unsigned seed);
+extern "C" int asr_gather_rows(void*, const float*, const int*, float*, int, int);
+extern "C" int asr_decoder_lm_chain_supported(int B, int lmH) {
+    if (getenv("ASR_LM_CHAIN") && atoi(getenv("ASR_LM_CHAIN")) == 0) return 0;
+    return asr_lstm_tm_supported(B, lmH) ? 1 : 0;
+}
 int asr_attention_launch(void* stream, const float* q, int ldq, const float* w_att, const float* b_att, const float* v,
                          const float* hf, const float* enc, const int* enc_len, float* alpha, float* ctx, float* y_out,
                          int B, int Te, int H, int A, int D, int shared);
@@ -72,6 +82,19 @@ extern "C" int asr_attn_decoder_fwd(void* stream, const asr_dec_weights* w, cons
         if ((rc = asr_gemm_f32(stream, 0, 0, P + D, 4 * H, E, w->inp_w, E, w->dec_kernel, 4 * H, wk, 4 * H, nullptr, 0))) return rc;
         if ((rc = asr_gemm_f32(stream, 0, 0, 1, 4 * H, E, w->inp_b, E, w->dec_kernel, 4 * H, bprime, 4 * H, w->dec_bias, 0))) return rc;
         const float* lm_base = w->simple_w ? ws->sp : (keep_lm < 1.0f ? ws->lm_hd : ws->lm_h);
+        // persistent LM cell chain (csrc/lstm.hip, time-major): x.K_x + b of ALL steps from the teacher tokens by one
+        // gather + GEMM up front (the rows of a step fed with a sampled token are redone when it exists), then one
+        // recurrent launch per segment with the previous segment's final (h,c) as initial state.  ws->x is scratch here:
+        // it is (re)built after the loop on the main stream, which by then has waited for this side-stream work.
+        const bool lm_chain = ws->lm_act && ws->lm_hprev && ws->lm_state && ws->lm_len && ws->lm_hx && ws->lm_gates &&
+                              asr_decoder_lm_chain_supported(B, lmH);
+        if (lm_chain) {
+            if ((rc = asr_gather_rows(side, w->embedding, ws->tok, ws->x, T * B, E))) return rc;
+            if ((rc = asr_gemm_f32(side, 0, 0, T * B, 4 * lmH, E, ws->x, E, w->lm_kernel, 4 * lmH, ws->lm_gates, 4 * lmH,
+                                   w->lm_bias, 0))) return rc;
+        }
+        float* lm_out_buf = keep_lm < 1.0f ? ws->lm_hd : ws->lm_h;
+        int seg = 0;
         int t0 = 0;
         while (t0 < T) {
             int t1 = t0;
@@ -79,7 +102,29 @@ extern "C" int asr_attn_decoder_fwd(void* stream, const asr_dec_weights* w, cons
             t1 = t1 < T ? t1 + 1 : T;                       // the feedback step closes the segment
             // side stream: LM cells of the segment (they need the token produced by the previous segment)
             if (feedback(t0 - 1) && hipStreamWaitEvent(ss, e_tok, 0) != hipSuccess) return ASR_ELAUNCH;
-            for (int i = t0; i < t1; ++i) {
+            if (lm_chain) {
+                const size_t o0 = (size_t)t0 * B;
+                if (feedback(t0 - 1) &&       // the sampled token of step t0: redo its rows of x.K_x + b
+                    (rc = asr_linear_fwd(side, w->embedding, E, E, ws->tok + o0, nullptr, 0, 0, w->lm_kernel, 4 * lmH, w->lm_bias,
+                                         ws->lm_gates + o0 * 4 * lmH, 4 * lmH, B, 4 * lmH, nullptr, 0))) return rc;
+                float* st_in = ws->lm_state + (size_t)((seg + 1) & 1) * 2 * B * lmH;
+                float* st_out = ws->lm_state + (size_t)(seg & 1) * 2 * B * lmH;
+                if ((rc = asr_lstm_rec_fwd_tm(ss, ws->lm_gates + o0 * 4 * lmH, w->lm_kernel + (size_t)E * 4 * lmH, ws->lm_len,
+                                              lm_out_buf + o0 * lmH, lmH, ws->lm_act + o0 * lmH * 8, ws->lm_hprev + o0 * lmH,
+                                              t0 ? st_in : nullptr, t0 ? st_in + (size_t)B * lmH : nullptr, st_out,
+                                              st_out + (size_t)B * lmH, ws->lm_hx, ws->err, B, t1 - t0, lmH, t0, keep_lm, seed)))
+                    return rc;
+                if (w->simple_w) {
+                    const int rows = (t1 - t0) * B;
+                    if (rows <= 512) {
+                        if ((rc = asr_linear_fwd(side, lm_out_buf + o0 * lmH, lmH, lmH, nullptr, nullptr, 0, 0, w->simple_w, H,
+                                                 w->simple_b, ws->sp + o0 * H, H, rows, H, nullptr, 0))) return rc;
+                    } else if ((rc = asr_gemm_f32(side, 0, 0, rows, H, lmH, lm_out_buf + o0 * lmH, lmH, w->simple_w, H,
+                                                  ws->sp + o0 * H, H, w->simple_b, 0))) return rc;
+                }
+                ++seg;
+            }
+            for (int i = t0; i < t1 && !lm_chain; ++i) {
                 const size_t o = (size_t)i * B;
                 const float* lm_hp = i ? ws->lm_h + (o - B) * lmH : ws->zeros;
                 const float* lm_cp = i ? ws->lm_c + (o - B) * lmH : nullptr;

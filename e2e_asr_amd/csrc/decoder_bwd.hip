@@ -313,6 +313,9 @@ __global__ __launch_bounds__(256) void lm_cell_bwd_kernel(LmBwdArgs a) {
 
 extern "C" int asr_colsum_f32(void*, const float*, int, int, int, float*, int);
 extern "C" int asr_decoder_chain_supported(int B, int Te, int D, int A, int H);
+extern "C" int asr_decoder_lm_chain_supported(int B, int lmH);
+int asr_lstm_rec_bwd_tm(hipStream_t s, float* gates, const float* act, const float* dout, int ldo, const float* kh,
+                        const int* full_len, void* hx_ws, int* err, int B, int T, int H, float keep, unsigned seed);
 int asr_decoder_chain_bwd(void* stream, float* gates, const float* dec_c, const float* alpha, const float* y,
                           const float* ctx, const float* dqc, const float* wh, const float* wc, const float* w_att,
                           const float* v, const float* hf, const float* enc, const int* enc_len, float* dY, float* dctx,
@@ -401,7 +404,23 @@ extern "C" int asr_attn_decoder_bwd(void* stream, const asr_dec_weights* w, cons
     hipEvent_t e_loop = next_event();
     if (hipEventRecord(e_loop, s) != hipSuccess || hipStreamWaitEvent(ss, e_loop, 0) != hipSuccess) return ASR_ELAUNCH;
     if (hipMemsetAsync(bw->dc_lm, 0, sizeof(float) * B * lmH, ss) != hipSuccess) return ASR_ELAUNCH;
-    for (int i = T - 1; i >= 0; --i) {
+    // persistent LM chain (the forward ran csrc/lstm.hip time-major under the same predicate): one BPTT launch
+    // over all steps (dG overwrites lm_gates), then demb = dG . K_x^T for all steps as one GEMM
+    const bool lm_chain = ws->chain_ws && ws->w2k && ws->err && ws->y && B <= 32 && asr_decoder_chain_supported(B, Te, D, A, H) &&
+                          ws->lm_act && ws->lm_hprev && ws->lm_state && ws->lm_len && ws->lm_hx && bw->lm_hx &&
+                          asr_decoder_lm_chain_supported(B, lmH);
+    if (lm_chain) {
+        const float* dlo = bw->dLC; int ld_dlo = ldLC;
+        if (w->simple_w) {
+            if ((rc = asr_gemm_f32(side, 0, 1, TB, lmH, H, bw->dLC, ldLC, w->simple_w, H, bw->dlm, lmH, nullptr, 0))) return rc;
+            dlo = bw->dlm; ld_dlo = lmH;
+        }
+        if ((rc = asr_lstm_rec_bwd_tm(ss, ws->lm_gates, ws->lm_act, dlo, ld_dlo, w->lm_kernel + (size_t)E * 4 * lmH, ws->lm_len,
+                                      bw->lm_hx, ws->err, B, T, lmH, keep_lm, seed))) return rc;
+        if ((rc = asr_gemm_f32(side, 0, 1, TB, E, 4 * lmH, ws->lm_gates, 4 * lmH, w->lm_kernel, 4 * lmH, bw->dEH, ldEH, nullptr, 0)))
+            return rc;
+    }
+    for (int i = T - 1; i >= 0 && !lm_chain; --i) {
         const size_t o = (size_t)i * B;
         const bool last = i == T - 1;
         const float* dlo = bw->dLC + o * ldLC; int ld_dlo = ldLC;
@@ -425,7 +444,10 @@ extern "C" int asr_attn_decoder_bwd(void* stream, const asr_dec_weights* w, cons
         if ((rc = asr_gather_rows(side, w->embedding, ws->tok, bw->emb_all, TB, E))) return rc;
         gwl = const_cast<float*>(g->lm_kernel);
         if ((rc = asr_gemm_f32(side, 1, 0, E, 4 * lmH, TB, bw->emb_all, E, ws->lm_gates, 4 * lmH, gwl, 4 * lmH, nullptr, 1))) return rc;
-        if (T > 1 && (rc = asr_gemm_f32(side, 1, 0, lmH, 4 * lmH, TB - B, ws->lm_h, lmH, ws->lm_gates + (size_t)B * 4 * lmH, 4 * lmH,
+        if (lm_chain) {      // h_{t-1} of every step was saved by the recurrent kernel (row 0 = zeros)
+            if ((rc = asr_gemm_f32(side, 1, 0, lmH, 4 * lmH, TB, ws->lm_hprev, lmH, ws->lm_gates, 4 * lmH,
+                                   gwl + (size_t)E * 4 * lmH, 4 * lmH, nullptr, 1))) return rc;
+        } else if (T > 1 && (rc = asr_gemm_f32(side, 1, 0, lmH, 4 * lmH, TB - B, ws->lm_h, lmH, ws->lm_gates + (size_t)B * 4 * lmH, 4 * lmH,
                                         gwl + (size_t)E * 4 * lmH, 4 * lmH, nullptr, 1))) return rc;
         if ((rc = asr_colsum_f32(side, ws->lm_gates, 4 * lmH, TB, 4 * lmH, const_cast<float*>(g->lm_bias), 1))) return rc;
         if ((rc = asr_scatter_add_rows_ld(side, const_cast<float*>(g->embedding), ws->tok, bw->dEH, TB, E, ldEH))) return rc;

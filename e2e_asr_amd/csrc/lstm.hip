@@ -43,6 +43,12 @@ struct LstmRecArgs {
     int* err;              // set to 1 on poll timeout
     int B, T, Tout, ND, boff;
     float keep; uint32_t seed;
+    // addressing: row of (b,t) in gates/act/hprev = b*sb + t*st; in out = b*osb + t*ost (leading dim ldo);
+    // dropout counter = (boff+b)*dsb + (toff+t)*dst.  Batch-major encoder layer: sb = T, st = 1, osb = Tout,
+    // ost = 1, ldo = ND*H, dsb = Tout, dst = 1.  Time-major (decoder LM chain): sb = 1, st = B, ...
+    int sb, st, osb, ost, ldo, dsb, dst, toff;
+    const float* h0; const float* c0;      // [B][H] initial state (ND = 1) or nullptr = zeros
+    float* h_last; float* c_last;          // [B][H] final state (ND = 1) or nullptr
 };
 
 __device__ __forceinline__ bool poll_granule(const u64* g, uint32_t epoch, float& val, int* err) {
@@ -140,6 +146,8 @@ __global__ __launch_bounds__(16 * HS) void lstm_rec_fwd_kernel(LstmRecArgs a) {
     const int clen = (cell && cb < a.B) ? min(a.len[cb], a.T) : 0;
     const int cb_safe = min(cb, a.B - 1);
     float c = 0.f, h = 0.f;
+    const bool has_init = a.h0 != nullptr;           // uniform
+    if (has_init && cell && cb < a.B) { h = a.h0[(size_t)cb * H + cj]; c = a.c0[(size_t)cb * H + cj]; }
     u64* hxg = a.hx + (size_t)grp * 2 * R * H;
     const bool fast = group_shares_xcd(a.xcc_slots + (size_t)grp * 16, G, mem, tid, a.err);
     // x.Kx+b of the NEXT step is loaded at the end of each cell phase (software pipelining): the
@@ -149,7 +157,7 @@ __global__ __launch_bounds__(16 * HS) void lstm_rec_fwd_kernel(LstmRecArgs a) {
     auto prefetch = [&](int s) {
         const int t = dir ? (clen - 1 - s) : s;
         const int ts = min(max(t, 0), a.T - 1);
-        const float* gp = a.gates + (((size_t)cb_safe * a.T + ts) * a.ND + dir) * H4 + cj;
+        const float* gp = a.gates + (((size_t)cb_safe * a.sb + (size_t)ts * a.st) * a.ND + dir) * H4 + cj;
         gx0 = gp[0]; gx1 = gp[H]; gx2 = gp[2 * H]; gx3 = gp[3 * H];
     };
     if (cell_wave) prefetch(0);
@@ -163,7 +171,7 @@ __global__ __launch_bounds__(16 * HS) void lstm_rec_fwd_kernel(LstmRecArgs a) {
         for (int r = 0; r < R; ++r)
 #pragma unroll
             for (int g = 0; g < 4; ++g) acc[r][g] = 0.f;
-        if (s > 0) {
+        if (s > 0 || has_init) {
             // (2) polling waves gather h_{s-1} (R x H granules) into LDS; they issue no stores, so
             //     their vmcnt(0) waits only for the poll itself
             if (!cell_wave) {
@@ -174,7 +182,10 @@ __global__ __launch_bounds__(16 * HS) void lstm_rec_fwd_kernel(LstmRecArgs a) {
                     const int idx = 2 * pidx;
                     const int r = idx / H, k = idx % H;
                     float v0 = 0.f, v1 = 0.f;
-                    if (r0 + r < a.B) poll_granule2(src + idx, (uint32_t)s, v0, v1, a.err);
+                    if (r0 + r < a.B) {
+                        if (s > 0) poll_granule2(src + idx, (uint32_t)s, v0, v1, a.err);
+                        else { v0 = a.h0[(size_t)(r0 + r) * H + k]; v1 = a.h0[(size_t)(r0 + r) * H + k + 1]; }
+                    }
                     *reinterpret_cast<float2*>(hl + (r * 16 + k / KPT) * CS + (k % KPT)) = make_float2(v0, v1);
                 }
             }
@@ -213,7 +224,7 @@ __global__ __launch_bounds__(16 * HS) void lstm_rec_fwd_kernel(LstmRecArgs a) {
         // (5) the cell, on the cell waves only
         if (cell_wave && cell) {
             float4 pre = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (s > 0) pre = *reinterpret_cast<const float4*>(sums + (cr * HS + cu) * 4);
+            if (s > 0 || has_init) pre = *reinterpret_cast<const float4*>(sums + (cr * HS + cu) * 4);
             float gi = 0.f, gj = 0.f, gf = 0.f, go = 0.f, h_old = h, c_old = c;
             if (live) {
                 gi = fast_sigmoid(pre.x + gx0);
@@ -232,11 +243,11 @@ __global__ __launch_bounds__(16 * HS) void lstm_rec_fwd_kernel(LstmRecArgs a) {
                 else __hip_atomic_store(dst, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                 // write-through (sc1)
             }
             if (live) {       // bookkeeping stores, off the critical path
-                const size_t ridx = (((size_t)cb * a.T + t) * a.ND + dir) * H + cj;
+                const size_t ridx = (((size_t)cb * a.sb + (size_t)t * a.st) * a.ND + dir) * H + cj;
                 float o = h;
                 if (a.keep < 1.0f)
-                    o *= keep_scale(a.seed, (uint32_t)((a.boff + cb) * a.Tout + t), (uint32_t)(dir * H + cj), a.keep);
-                a.out[((size_t)cb * a.Tout + t) * (a.ND * H) + dir * H + cj] = o;
+                    o *= keep_scale(a.seed, (uint32_t)((a.boff + cb) * a.dsb + (a.toff + t) * a.dst), (uint32_t)(dir * H + cj), a.keep);
+                a.out[((size_t)cb * a.osb + (size_t)t * a.ost) * a.ldo + dir * H + cj] = o;
                 if (a.hprev) a.hprev[ridx] = h_old;
                 if (a.act) {      // one 32-byte record per (b,t,dir,unit): two 16-byte stores
                     float4* rp = reinterpret_cast<float4*>(a.act + ridx * 8);
@@ -248,6 +259,7 @@ __global__ __launch_bounds__(16 * HS) void lstm_rec_fwd_kernel(LstmRecArgs a) {
         }
         ASR_STAMP(5)
     }
+    if (a.h_last && cell && cb < a.B) { a.h_last[(size_t)cb * H + cj] = h; a.c_last[(size_t)cb * H + cj] = c; }
     if (STAMP && a.dbg && blockIdx.x == 0 && (tid == 0 || tid == NT - 1)) {
         unsigned long long* d = a.dbg + (tid == 0 ? 0 : 8);
         for (int i = 0; i < 6; ++i) d[i] = stamp[i];
@@ -260,7 +272,7 @@ __global__ __launch_bounds__(16 * HS) void lstm_rec_fwd_kernel(LstmRecArgs a) {
         const int nz = a.Tout - l;
         for (int idx = tid; idx < nz * HS; idx += NT) {
             const int t = l + idx / HS, uu = idx % HS;
-            a.out[((size_t)(r0 + r) * a.Tout + t) * (a.ND * H) + dir * H + mem * HS + uu] = 0.f;
+            a.out[((size_t)(r0 + r) * a.osb + (size_t)t * a.ost) * a.ldo + dir * H + mem * HS + uu] = 0.f;
         }
     }
 }
@@ -344,6 +356,8 @@ extern "C" int asr_lstm_layer_fwd(void* stream, const float* x, int B, int T, in
     a.len = len; a.out = out; a.act = act; a.hprev = hprev; a.boff = 0; a.hx = static_cast<u64*>(hx_ws); a.err = err_flag;
     a.xcc_slots = reinterpret_cast<u64*>(static_cast<char*>(hx_ws) + lstm_hx_bytes(B, H, ndir));
     a.B = B; a.T = T; a.Tout = Tout; a.ND = ndir; a.keep = keep_prob; a.seed = seed;
+    a.sb = T; a.st = 1; a.osb = Tout; a.ost = 1; a.ldo = ndir * H; a.dsb = Tout; a.dst = 1; a.toff = 0;
+    a.h0 = a.c0 = nullptr; a.h_last = a.c_last = nullptr;
     const int R = asr_lstm_pick_rows(B, ndir, H / 32);
     // batches too large for one resident grid run as consecutive launches over row ranges
     const int max_groups = 256 / (H / 32) / ndir;
@@ -372,4 +386,37 @@ extern "C" int asr_lstm_layer_fwd(void* stream, const float* x, int B, int T, in
             hipMemsetAsync(hx_ws, 0, asr_lstm_ws_bytes(B, H, ndir), s) != hipSuccess) return ASR_ELAUNCH;
     }
     return ASR_OK;
+}
+
+
+// Time-major single-direction launch with an initial state: the decoder's LM cell chain over the steps
+// [toff, toff + T) of a segment (attn_decoder.py:116-121 lm_cell; all rows run every step).  Pointers are
+// already offset to the segment's first step; rows of step t are at t*B + b.  gates holds x.K_x + b on entry.
+// full_len: device [B] ints >= T.  Requires one resident grid: asr_lstm_tm_supported(B, H).
+bool asr_lstm_tm_supported(int B, int H) {
+    if (H != 64 && H != 128 && H != 256 && H != 512) return false;
+    const int G = H / 32;
+    const int R = asr_lstm_pick_rows(B, 1, G);
+    return ((B + R - 1) / R) * G <= 256;
+}
+int asr_lstm_rec_fwd_tm(hipStream_t s, const float* gates, const float* kh, const int* full_len, float* out, int ldo,
+                        float* act, float* hprev, const float* h0, const float* c0, float* h_last, float* c_last,
+                        void* hx_ws, int* err, int B, int T, int H, int toff, float keep, unsigned seed) {
+    using namespace asr;
+    if (!asr_lstm_tm_supported(B, H)) return ASR_EUNSUPPORTED;
+    if (hipMemsetAsync(hx_ws, 0, asr_lstm_ws_bytes(B, H, 1), s) != hipSuccess) return ASR_ELAUNCH;
+    LstmRecArgs a;
+    a.gates = gates; a.act = act; a.kh[0] = kh; a.kh[1] = nullptr; a.len = full_len; a.out = out; a.dbg = nullptr;
+    a.hprev = hprev; a.hx = static_cast<u64*>(hx_ws); a.err = err;
+    a.xcc_slots = reinterpret_cast<u64*>(static_cast<char*>(hx_ws) + lstm_hx_bytes(B, H, 1));
+    a.B = B; a.T = T; a.Tout = T; a.ND = 1; a.boff = 0; a.keep = keep; a.seed = seed;
+    a.sb = 1; a.st = B; a.osb = 1; a.ost = B; a.ldo = ldo; a.dsb = 1; a.dst = B; a.toff = toff;
+    a.h0 = h0; a.c0 = c0; a.h_last = h_last; a.c_last = c_last;
+    const int R = asr_lstm_pick_rows(B, 1, H / 32);
+    switch (H) {
+        case 64: return launch_rec_h<64>(s, a, R);
+        case 128: return launch_rec_h<128>(s, a, R);
+        case 256: return launch_rec_h<256>(s, a, R);
+        default: return launch_rec_h<512>(s, a, R);
+    }
 }

@@ -35,6 +35,9 @@ struct LstmBwdArgs {
     int* err;
     int B, T, Tout, ND, boff;
     float keep; uint32_t seed;
+    // addressing as in LstmRecArgs (csrc/lstm.hip): row of (b,t) in gates/act = b*sb + t*st; in dout =
+    // b*osb + t*ost with leading dimension ldo; dropout counter = (boff+b)*dsb + t*dst
+    int sb, st, osb, ost, ldo, dsb, dst;
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -119,9 +122,9 @@ __global__ __launch_bounds__(512) void lstm_rec_bwd_kernel(LstmBwdArgs a) {
     auto prefetch = [&](int s) {
         const int t = dir ? s : (clen - 1 - s);
         const int ts = min(max(t, 0), a.T - 1);
-        const float4* rp = reinterpret_cast<const float4*>(a.act + ((((size_t)cb_safe * a.T + ts) * a.ND + dir) * H + cj) * 8);
+        const float4* rp = reinterpret_cast<const float4*>(a.act + ((((size_t)cb_safe * a.sb + (size_t)ts * a.st) * a.ND + dir) * H + cj) * 8);
         ra = rp[0]; rb = rp[1];
-        dout_v = a.dout[((size_t)cb_safe * a.Tout + ts) * (a.ND * H) + dir * H + cj];
+        dout_v = a.dout[((size_t)cb_safe * a.osb + (size_t)ts * a.ost) * a.ldo + dir * H + cj];
     };
     if (cell_wave) prefetch(0);
 
@@ -146,7 +149,7 @@ __global__ __launch_bounds__(512) void lstm_rec_bwd_kernel(LstmBwdArgs a) {
         if (cell_wave && cell) {
             float dh = dout_v;
             if (a.keep < 1.0f)
-                dh *= keep_scale(a.seed, (uint32_t)((a.boff + cb) * a.Tout + t), (uint32_t)(dir * H + cj), a.keep);
+                dh *= keep_scale(a.seed, (uint32_t)((a.boff + cb) * a.dsb + t * a.dst), (uint32_t)(dir * H + cj), a.keep);
             if (s > 0) {
                 float rec = 0.f;
 #pragma unroll
@@ -211,7 +214,7 @@ __global__ __launch_bounds__(512) void lstm_rec_bwd_kernel(LstmBwdArgs a) {
         }
         if (cell_wave && cell) {       // bookkeeping, off the critical path
             if (live) {
-                float* gp = a.gates + (((size_t)cb * a.T + t) * a.ND + dir) * H4 + cj;
+                float* gp = a.gates + (((size_t)cb * a.sb + (size_t)t * a.st) * a.ND + dir) * H4 + cj;
                 gp[0] = dg.x; gp[H] = dg.y; gp[2 * H] = dg.z; gp[3 * H] = dg.w;
             }
             if (s + 1 < S) prefetch(s + 1);
@@ -226,7 +229,7 @@ __global__ __launch_bounds__(512) void lstm_rec_bwd_kernel(LstmBwdArgs a) {
         const int nz = a.T - l;
         for (int idx = tid; idx < nz * 4 * HS; idx += NT) {
             const int t = l + idx / (4 * HS), q = idx % (4 * HS);
-            a.gates[(((size_t)(r0 + r) * a.T + t) * a.ND + dir) * H4 + (q / HS) * H + j0 + (q % HS)] = 0.f;
+            a.gates[(((size_t)(r0 + r) * a.sb + (size_t)t * a.st) * a.ND + dir) * H4 + (q / HS) * H + j0 + (q % HS)] = 0.f;
         }
     }
 }
@@ -285,6 +288,7 @@ extern "C" int asr_lstm_layer_bwd(void* stream, const float* x, int B, int T, in
     a.len = len; a.hx = static_cast<u64*>(hx_ws); a.err = err_flag;
     a.xcc_slots = reinterpret_cast<u64*>(static_cast<char*>(hx_ws) + lstm_bwd_hx_bytes(B, H, ndir));
     a.B = B; a.T = T; a.Tout = Tout; a.ND = ndir; a.boff = 0; a.keep = keep_prob; a.seed = seed;
+    a.sb = T; a.st = 1; a.osb = Tout; a.ost = 1; a.ldo = ndir * H; a.dsb = Tout; a.dst = 1;
     const int R = asr_lstm_pick_rows(B, ndir, G);
     const int max_groups = 256 / G / ndir;
     const int rows_per_launch = max_groups > 0 ? max_groups * R : R;
@@ -338,4 +342,28 @@ extern "C" int asr_lstm_layer_bwd(void* stream, const float* x, int B, int T, in
     if (hipEventRecord(e_done, ss) != hipSuccess) return ASR_ELAUNCH;
     set_pending_join(e_done);
     return ASR_OK;
+}
+
+
+// Time-major single-direction BPTT over all T steps (the decoder's LM cell chain; see asr_lstm_rec_fwd_tm):
+// gates [T][B][4H] receives dG, act [T][B][H][8], dout rows t*B + b with leading dimension ldo.
+bool asr_lstm_tm_supported(int B, int H);
+int asr_lstm_rec_bwd_tm(hipStream_t s, float* gates, const float* act, const float* dout, int ldo, const float* kh,
+                        const int* full_len, void* hx_ws, int* err, int B, int T, int H, float keep, unsigned seed) {
+    using namespace asr;
+    if (!asr_lstm_tm_supported(B, H)) return ASR_EUNSUPPORTED;
+    if (hipMemsetAsync(hx_ws, 0, asr_lstm_bwd_ws_bytes(B, H, 1), s) != hipSuccess) return ASR_ELAUNCH;
+    LstmBwdArgs a;
+    a.gates = gates; a.act = act; a.dout = dout; a.kh[0] = kh; a.kh[1] = nullptr; a.len = full_len;
+    a.hx = static_cast<u64*>(hx_ws); a.err = err;
+    a.xcc_slots = reinterpret_cast<u64*>(static_cast<char*>(hx_ws) + lstm_bwd_hx_bytes(B, H, 1));
+    a.B = B; a.T = T; a.Tout = T; a.ND = 1; a.boff = 0; a.keep = keep; a.seed = seed;
+    a.sb = 1; a.st = B; a.osb = 1; a.ost = B; a.ldo = ldo; a.dsb = 1; a.dst = B;
+    const int R = asr_lstm_pick_rows(B, 1, H / 32);
+    switch (H) {
+        case 64: return launch_bwd_h<64>(s, a, R);
+        case 128: return launch_bwd_h<128>(s, a, R);
+        case 256: return launch_bwd_h<256>(s, a, R);
+        default: return launch_bwd_h<512>(s, a, R);
+    }
 }

@@ -345,6 +345,12 @@ def attn_decoder_fwd(wt, dec_inp, seq_len, enc, enc_len, mode=0, coin=None, samp
         ws["w2k"] = f(P_ + D + 1, 4 * H)          # W_inp.K_x [(P+D),4H] followed by the composed bias [4H]
         ws["chain_ws"] = _hx(dev, L.asr_decoder_chain_ws_bytes(B, D, A, H))
         ws["err"] = _Flag.get(dev)
+        if L.asr_decoder_lm_chain_supported(B, lmH):                     # persistent LM cell chain
+            ws["lm_act"] = f(T, B, lmH, 8)
+            ws["lm_hprev"] = f(T, B, lmH)
+            ws["lm_state"] = f(2, 2, B, lmH)
+            ws["lm_len"] = torch.full((B,), T, device=dev, dtype=torch.int32)
+            ws["lm_hx"] = _hx(dev, L.asr_lstm_ws_bytes(B, lmH, 1))
     logits = f(T * B, V)
     cw = _dec_struct(_lib.DecWeights, wt)
     cd = _lib.DecDims(B, Te, D, A, H, lmH, E, V, T)
@@ -377,6 +383,8 @@ def attn_decoder_bwd(wt, gt, ws, enc, enc_len, dlogits, denc, keep_lm=1.0, seed=
     if ws.get("err") is not None and L.asr_decoder_chain_supported(B, Te, D, A, H):   # persistent backward chain
         bw["chain_ws"] = _hx(dev, L.asr_decoder_chain_bwd_ws_bytes(B, D, A, H))
         bw["wc"] = f(D, 4 * H)
+    if ws.get("lm_act") is not None:
+        bw["lm_hx"] = _hx(dev, L.asr_lstm_bwd_ws_bytes(B, lmH, 1))
     cw = _dec_struct(_lib.DecWeights, wt)
     cg = _dec_struct(_lib.DecWeights, gt)
     cd = _lib.DecDims(B, Te, D, A, H, lmH, E, V, T)

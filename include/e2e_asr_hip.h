@@ -163,6 +163,12 @@ typedef struct {              /* activations: outputs of the forward, inputs of 
     float* w2k;               /* [(P+D+1),4H] scratch: W_inp.K_x and the composed bias (persistent chain path; NULL disables it) */
     void*  chain_ws;          /* asr_decoder_chain_ws_bytes() granule workspace (NULL disables the chain path) */
     int*   err;               /* device int set on an exchange timeout */
+    /* persistent LM cell chain (asr_decoder_lm_chain_supported; all NULL = per-step LM cells) */
+    float* lm_act;            /* [T_out,B,lmH,8] records {i,j,f,o | c, c_prev, -, -} (format of asr_lstm_layer_fwd) */
+    float* lm_hprev;          /* [T_out,B,lmH]   undropped h_{t-1} */
+    float* lm_state;          /* [2,2,B,lmH]     (h,c) hand-over between scheduled-sampling segments */
+    int*   lm_len;            /* [B] ints, each >= T_out */
+    void*  lm_hx;             /* asr_lstm_ws_bytes(B, lmH, 1) bytes */
 } asr_dec_ws;
 
 /* mode 0: teacher forcing; 1: greedy (eval, decoder.py:139-154); 2: scheduled sampling
@@ -188,6 +194,7 @@ typedef struct {              /* backward scratch (device), sized by the caller 
     float* emb_all;           /* [T_out,B,E] gathered embeddings */
     void*  chain_ws;          /* asr_decoder_chain_bwd_ws_bytes() bytes, or NULL: per-step launches */
     float* wc;                /* [D,4H] W_inp[P:] . K_x (persistent chain only, else NULL) */
+    void*  lm_hx;             /* asr_lstm_bwd_ws_bytes(B, lmH, 1) bytes (persistent LM chain only, else NULL) */
 } asr_dec_bwd_ws;
 
 /* Backward of asr_attn_decoder_fwd.  Weight gradients are ACCUMULATED into `g` (same field
@@ -207,6 +214,9 @@ int asr_side_join(void* stream);
 int asr_decoder_chain_supported(int B, int Te, int D, int A, int H);
 size_t asr_decoder_chain_ws_bytes(int B, int D, int A, int H);
 size_t asr_decoder_chain_bwd_ws_bytes(int B, int D, int A, int H);
+/* LM cell chain of the decoder through the persistent recurrent kernels of csrc/lstm.hip / lstm_bwd.hip
+ * (time-major, initial state per scheduled-sampling segment); used with the persistent decoder chain. */
+int asr_decoder_lm_chain_supported(int B, int lmH);
 int asr_zero_finished_rows(void* stream, float* logits, const int* len, int T, int B, int V);
 
 /* Optional per-kernel HIP-event timing on the launch stream (bench.py roofline leg).

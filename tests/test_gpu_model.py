@@ -452,3 +452,40 @@ def test_decoder_chain_equals_launch_path_under_scheduled_sampling(monkeypatch):
     assert (outs[0][1][1:] != np.asarray(b["char"]).T[1:outs[0][1].shape[0]]).any()   # some tokens really were sampled
     np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=0, atol=2e-5)
     np.testing.assert_allclose(outs[0][2], outs[1][2], rtol=1e-6)
+
+
+@pytest.mark.parametrize("variant", ["plain", "simple_dropout"])
+def test_persistent_lm_chain_equals_per_step_lm_cells(monkeypatch, variant):
+    """The decoder's LM cell chain through the persistent recurrent kernels (csrc/lstm.hip time-major,
+    initial state per scheduled-sampling segment; BPTT by csrc/lstm_bwd.hip) must reproduce the per-step
+    LM cells: same sampled tokens, logits, loss and every gradient -- also with SimpleProjection and
+    DropoutWrapper on the LM output (same counter-based mask in both paths)."""
+    rng = np.random.default_rng(31)
+    b = _batch(rng, 6, 24, 20, 13, 50)
+    dec = dict(hidden_size_dec=64, lm_hidden_size=64, emb_size=24, attention_vec_size=16, samp_prob=0.35)
+    if variant == "simple_dropout":
+        dec.update(lm_hidden_size=128, out_prob_dec=0.8)
+    res = []
+    for lm in ("1", "0"):
+        monkeypatch.setenv("ASR_LM_CHAIN", lm)
+        m = _model(enc_update=dict(hidden_size=64), num_layers={"char": 2}, seed=11, dec_update=dict(dec))
+        m.decoder["char"].coin_rng = np.random.default_rng(6)
+        m.global_step = 2
+        m.forward(b)
+        ws = m.decoder["char"].saved["ws"]
+        assert ws.get("chain_ws") is not None
+        assert (ws.get("lm_act") is not None) == (lm == "1")
+        if variant == "simple_dropout":
+            assert ws.get("sp") is not None and ws.get("lm_hd") is not None
+        m.backward()
+        from e2e_asr_amd import ops
+        ops.check_device_flag(torch.device(DEV))
+        grads = {n: m.variables.grad_of(n).cpu().numpy().copy() for n in m.variables.names()}
+        res.append((m.outputs["char"].cpu().numpy(), ws["tok"].cpu().numpy(), m.total_loss.item(), grads))
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+    np.testing.assert_allclose(res[0][0], res[1][0], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(res[0][2], res[1][2], rtol=1e-6)
+    for n, g1 in res[0][3].items():
+        g0 = res[1][3][n]
+        err = np.abs(g1 - g0).max() / max(1e-3, np.abs(g0).max())
+        assert err < 1e-4, (n, err)
