@@ -21,6 +21,7 @@
 // columns = 2 units x 4 gates) and each lane KG = H/32 output rows k, so the reduction over
 // columns is again 4 DPP butterflies.
 #include "common.h"
+#include <cstdlib>
 
 namespace asr {
 
@@ -234,9 +235,221 @@ __global__ __launch_bounds__(512) void lstm_rec_bwd_kernel(LstmBwdArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// All-gather formulation (default): exchange dG itself instead of partial sums of dh.
+//   step s:  gather dG of step s-1 (R x 4H values, published by their owners) -> LDS
+//            dh_rec[k] = sum_n dG[n] K_h[k][n] for this workgroup's OWN 32 units k, contraction over ALL 4H
+//            columns (K_h rows of the own units in registers: 4 units x 4H/64 columns per lane)
+//            pointwise backward for the own units -> dG_s (4 values per unit), published first
+// Same structure as the forward kernel (one exchange, two barriers per step); the reduce-scatter above needs
+// a third barrier and 4x the publishing stores.  Exchange volume per step: R*4H granules per group (4x the
+// forward's), polled by every workgroup of the group with all of a thread's loads in flight.
+template <int H, int R>
+__global__ __launch_bounds__(512) void lstm_rec_bwd_ag_kernel(LstmBwdArgs a) {
+    constexpr int HS = 32, NT = 512;
+    constexpr int G = H / HS;
+    constexpr int N = 4 * H;           // dG columns per row; position p = 4*unit + gate
+    constexpr int PC = N / 64;         // positions per lane in the matvec (64 chunks = one wave)
+    constexpr int CSB = PC + 4;        // padded LDS chunk stride
+    constexpr int NCELL = R * HS;
+    constexpr int NCW = (NCELL + 63) / 64 * 64;
+    constexpr int NPOLL = NT - NCW;
+    constexpr int NPAIR = R * N / 2;
+    constexpr int NPP = (NPAIR + NPOLL - 1) / NPOLL;   // pairs per polling thread
+    static_assert(NCW < NT && PC % 4 == 0, "mapping");
+    __shared__ __attribute__((aligned(16))) float dgl[R * 64 * CSB];
+    __shared__ __attribute__((aligned(16))) float sums[R * HS * 4];
+
+    __builtin_amdgcn_s_setprio(3);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int NG = (a.B + R - 1) / R;
+    const int ngroups = a.ND * NG;
+    int grp, mem;
+    if ((ngroups & 7) == 0) { mem = (blockIdx.x >> 3) % G; grp = (blockIdx.x & 7) + 8 * (blockIdx.x / (8 * G)); }
+    else { grp = blockIdx.x / G; mem = blockIdx.x % G; }
+    const int dir = grp / NG, bg = grp % NG;
+    const int r0 = bg * R;
+    const int H4 = 4 * H;
+    const int j0 = mem * HS;
+
+    // K_h rows of the own units (wave w: units 4w..4w+3) over this lane's PC positions -> registers
+    float w[4][PC];
+    {
+        const float* kh = a.kh[dir];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int q = 0; q < PC; ++q) {
+                const int pos = lane * PC + q;
+                w[i][q] = kh[(size_t)(j0 + 4 * wave + i) * H4 + (pos & 3) * H + (pos >> 2)];
+            }
+    }
+    int S = 0;
+    for (int r = 0; r < R; ++r) S = max(S, (r0 + r < a.B) ? min(a.len[r0 + r], a.T) : 0);
+    const bool cell = tid < NCELL;
+    const bool cell_wave = __builtin_amdgcn_readfirstlane(tid) < NCW;
+    const int cr = min(tid / HS, R - 1), cu = tid % HS;
+    const int cb = r0 + cr;
+    const int cb_safe = min(cb, a.B - 1);
+    const int clen = (cell && cb < a.B) ? min(a.len[cb], a.T) : 0;
+    const int cj = j0 + cu;
+    float dc = 0.f;
+    u64* hxg = a.hx + (size_t)grp * 2 * R * N;
+    const bool fast = group_shares_xcd(a.xcc_slots + (size_t)grp * 16, G, mem, tid, a.err);
+
+    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
+    float dout_v = 0.f;
+    auto prefetch = [&](int s) {
+        const int t = dir ? s : (clen - 1 - s);
+        const int ts = min(max(t, 0), a.T - 1);
+        const float4* rp = reinterpret_cast<const float4*>(a.act + ((((size_t)cb_safe * a.sb + (size_t)ts * a.st) * a.ND + dir) * H + cj) * 8);
+        ra = rp[0]; rb = rp[1];
+        dout_v = a.dout[((size_t)cb_safe * a.osb + (size_t)ts * a.ost) * a.ldo + dir * H + cj];
+    };
+    if (cell_wave) prefetch(0);
+
+    for (int s = 0; s < S; ++s) {
+        const bool live = cell && s < clen;
+        const int t = dir ? s : (clen - 1 - s);
+        if (s > 0) {
+            if (!cell_wave) {
+                // all of this thread's granule loads in flight, re-polled together until every tag matches
+                const u64* src = hxg + (size_t)((s - 1) & 1) * R * N;
+                bool need[NPP];
+#pragma unroll
+                for (int j = 0; j < NPP; ++j) {
+                    const int pidx = tid - NCW + NPOLL * j;
+                    need[j] = pidx < NPAIR && r0 + (2 * pidx) / N < a.B;
+                    if (pidx < NPAIR && !need[j]) {
+                        const int idx = 2 * pidx, r = idx / N, pos = idx % N;
+                        *reinterpret_cast<float2*>(dgl + (r * 64 + pos / PC) * CSB + (pos % PC)) = make_float2(0.f, 0.f);
+                    }
+                }
+                long long t0w = 0;
+                for (uint32_t spins = 0;; ++spins) {
+                    u64 x[NPP][2];
+#pragma unroll
+                    for (int j = 0; j < NPP; ++j) {
+                        const int pidx = min(tid - NCW + NPOLL * j, NPAIR - 1);
+                        x[j][0] = __hip_atomic_load(src + 2 * pidx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        x[j][1] = __hip_atomic_load(src + 2 * pidx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    bool pending = false;
+#pragma unroll
+                    for (int j = 0; j < NPP; ++j) {
+                        if (!need[j]) continue;
+                        if ((uint32_t)(x[j][0] >> 32) == (uint32_t)s && (uint32_t)(x[j][1] >> 32) == (uint32_t)s) {
+                            const int idx = 2 * (tid - NCW + NPOLL * j), r = idx / N, pos = idx % N;
+                            *reinterpret_cast<float2*>(dgl + (r * 64 + pos / PC) * CSB + (pos % PC)) =
+                                make_float2(__uint_as_float((uint32_t)x[j][0]), __uint_as_float((uint32_t)x[j][1]));
+                            need[j] = false;
+                        } else pending = true;
+                    }
+                    if (!pending) break;
+                    if ((spins & 1023) == 1023) {
+                        const long long now = wall_clock64();
+                        if (t0w == 0) t0w = now;
+                        else if (now - t0w > 200000000LL) { *a.err = 1; break; }
+                        if (__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                    }
+                }
+            }
+            __syncthreads();
+            // dh_rec for the own units: 4 units x R rows per lane, contraction over this lane's PC positions
+            float acc[R][4];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                acc[r][0] = acc[r][1] = acc[r][2] = acc[r][3] = 0.f;
+                const float4* dp = reinterpret_cast<const float4*>(dgl + (r * 64 + lane) * CSB);
+#pragma unroll
+                for (int q4 = 0; q4 < PC / 4; ++q4) {
+                    const float4 dv = dp[q4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        acc[r][i] = fmaf(dv.x, w[i][4 * q4 + 0], acc[r][i]);
+                        acc[r][i] = fmaf(dv.y, w[i][4 * q4 + 1], acc[r][i]);
+                        acc[r][i] = fmaf(dv.z, w[i][4 * q4 + 2], acc[r][i]);
+                        acc[r][i] = fmaf(dv.w, w[i][4 * q4 + 3], acc[r][i]);
+                    }
+                }
+            }
+            // 16 lanes of a DPP row by butterflies; the 4 rows of the wave meet in LDS (fixed order in the cell)
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[r][i] = row16_allreduce_sum(acc[r][i]);
+            if ((lane & 15) == 0) {
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) sums[(r * HS + 4 * wave + i) * 4 + (lane >> 4)] = acc[r][i];
+            }
+            __syncthreads();
+        }
+        if (cell_wave && cell) {
+            float dh = dout_v;
+            if (a.keep < 1.0f)
+                dh *= keep_scale(a.seed, (uint32_t)((a.boff + cb) * a.dsb + t * a.dst), (uint32_t)(dir * H + cj), a.keep);
+            if (s > 0) {
+                const float4 v = *reinterpret_cast<const float4*>(sums + (cr * HS + cu) * 4);
+                dh += (v.x + v.y) + (v.z + v.w);
+            }
+            float4 dg = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (live) {
+                const float gi = ra.x, gj = ra.y, gf = ra.z, go = ra.w, cc = rb.x, cp = rb.y;
+                const float tc = fast_tanh(cc);
+                const float dct = dc + dh * go * (1.f - tc * tc);
+                dg.x = dct * gj * gi * (1.f - gi);
+                dg.y = dct * gi * (1.f - gj * gj);
+                dg.z = dct * cp * gf * (1.f - gf);
+                dg.w = dh * tc * go * (1.f - go);
+                dc = dct * gf;
+            }
+            // publish dG_s of this unit FIRST (zeros for rows past their length): 4 adjacent granules
+            if (cb < a.B && s + 1 < S) {
+                u64* dst = hxg + ((size_t)(s & 1) * R + cr) * N + 4 * cj;
+                const uint32_t tg = (uint32_t)(s + 1);
+                if (fast) {
+                    typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
+                    const u32x4s g0 = {__float_as_uint(dg.x), tg, __float_as_uint(dg.y), tg};
+                    const u32x4s g1 = {__float_as_uint(dg.z), tg, __float_as_uint(dg.w), tg};
+                    asm volatile("global_store_dwordx4 %0, %1, off\n\tglobal_store_dwordx4 %0, %2, off offset:16"
+                                 :: "v"(dst), "v"(g0), "v"(g1) : "memory");
+                } else {
+                    __hip_atomic_store(dst + 0, ((u64)tg << 32) | __float_as_uint(dg.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(dst + 1, ((u64)tg << 32) | __float_as_uint(dg.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(dst + 2, ((u64)tg << 32) | __float_as_uint(dg.z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(dst + 3, ((u64)tg << 32) | __float_as_uint(dg.w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            if (live) {       // bookkeeping, off the critical path
+                float* gp = a.gates + (((size_t)cb * a.sb + (size_t)t * a.st) * a.ND + dir) * H4 + cj;
+                gp[0] = dg.x; gp[H] = dg.y; gp[2 * H] = dg.z; gp[3 * H] = dg.w;
+            }
+            if (s + 1 < S) prefetch(s + 1);
+        }
+    }
+    // dG = 0 past each row's length (the weight/input GEMMs read every row)
+    for (int r = 0; r < R; ++r) {
+        if (r0 + r >= a.B) break;
+        const int l = min(a.len[r0 + r], a.T);
+        const int nz = a.T - l;
+        for (int idx = tid; idx < nz * 4 * HS; idx += NT) {
+            const int t = l + idx / (4 * HS), q = idx % (4 * HS);
+            a.gates[(((size_t)(r0 + r) * a.sb + (size_t)t * a.st) * a.ND + dir) * H4 + (q / HS) * H + j0 + (q % HS)] = 0.f;
+        }
+    }
+}
+
 template <int H>
 static int launch_bwd_h(hipStream_t s, const LstmBwdArgs& a, int R) {
     const int grid = a.ND * ((a.B + R - 1) / R) * (H / 32);
+    static const bool allgather = [] { const char* e = getenv("ASR_BPTT_AG"); return !(e && e[0] == '0'); }();
+    if (allgather && R <= 2) {     // more rows per group: too many granule loads per polling thread -> reduce-scatter kernel
+        if (R == 1) hipLaunchKernelGGL((lstm_rec_bwd_ag_kernel<H, 1>), dim3(grid), dim3(512), 0, s, a);
+        else hipLaunchKernelGGL((lstm_rec_bwd_ag_kernel<H, 2>), dim3(grid), dim3(512), 0, s, a);
+        return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
+    }
     switch (R) {
         case 1: hipLaunchKernelGGL((lstm_rec_bwd_kernel<H, 1>), dim3(grid), dim3(512), 0, s, a); break;
         case 2: hipLaunchKernelGGL((lstm_rec_bwd_kernel<H, 2>), dim3(grid), dim3(512), 0, s, a); break;
@@ -255,7 +468,7 @@ extern "C" int asr_colsum_f32(void* stream, const float* x, int ldx, int M, int 
 int asr_lstm_pick_rows(int B, int ND, int G);
 
 static size_t lstm_bwd_hx_bytes(int B, int H, int ndir) {
-    const size_t G = H / 32;
+    const size_t G = H / 32 < 4 ? 4 : H / 32;    // reduce-scatter: 2*G*H granules per row; all-gather: 2*4H
     return (size_t)ndir * (size_t)((B + 7) / 8 * 8) * 2 * G * H * sizeof(u64);
 }
 extern "C" size_t asr_lstm_bwd_ws_bytes(int B, int H, int ndir) {
