@@ -53,6 +53,20 @@ template <bool KMAJOR, int BT>
 struct Stager {
     static constexpr int LDT = BT + 4;   // padded k-row (16-B aligned)
     float4 r0, r1;
+    // FULL: the whole tile is in range and 16-B aligned -> unconditional vector loads
+    __device__ __forceinline__ void load_full(const float* P, int ld, int m0, int k0, int tid) {
+        if (KMAJOR) {
+            const float* p = P + (size_t)(k0 + (tid >> 4)) * ld + m0 + (tid & 15) * 4;
+            r0 = *reinterpret_cast<const float4*>(p);
+            if (BT == 128) r1 = *reinterpret_cast<const float4*>(p + 64);
+        } else if (BT == 128) {
+            const float* p = P + (size_t)(m0 + (tid >> 1)) * ld + k0 + (tid & 1) * 8;
+            r0 = *reinterpret_cast<const float4*>(p);
+            r1 = *reinterpret_cast<const float4*>(p + 4);
+        } else {
+            r0 = *reinterpret_cast<const float4*>(P + (size_t)(m0 + (tid >> 2)) * ld + k0 + (tid & 3) * 4);
+        }
+    }
     __device__ __forceinline__ void load(const float* P, int ld, int m0, int k0, int Mdim, int Kdim,
                                          bool vec, int tid) {
         r0 = r1 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -92,11 +106,11 @@ struct Stager {
 };
 
 // TA: A is given transposed ([K,M] row-major).  TB: B is given transposed ([N,K] row-major).
-template <bool TA, bool TB, int BT = 128>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
+template <bool TA, bool TB, int BT = 128, bool FULL = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void gemm_f32_kernel(GemmArgs a) {
     constexpr int BM = BT, BN = BT, LDT = BT + 4, WT = BT / 2, MI = BT / 64;   // wave tile WT x WT = MI x MI MFMA tiles
-    __shared__ __attribute__((aligned(16))) float As[BK * LDT];
-    __shared__ __attribute__((aligned(16))) float Bs[BK * LDT];
+    __shared__ __attribute__((aligned(16))) float As[2 * BK * LDT];
+    __shared__ __attribute__((aligned(16))) float Bs[2 * BK * LDT];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid >> 1, wc = wid & 1;
     a.A += (size_t)blockIdx.z * a.sA; a.B += (size_t)blockIdx.z * a.sB; a.C += (size_t)blockIdx.z * a.sC;
@@ -127,20 +141,20 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
     const int per = (nk_all + a.splits - 1) / a.splits;
     const int kt0 = blockIdx.y * per, kt1 = min(nk_all, kt0 + per);
     if (kt0 >= kt1) return;
-    sa.load(a.A, a.lda, m0, kt0 * BK, a.M, a.K, a.vecA, tid);
-    sb.load(a.B, a.ldb, n0, kt0 * BK, a.N, a.K, a.vecB, tid);
+    if (FULL) { sa.load_full(a.A, a.lda, m0, kt0 * BK, tid); sb.load_full(a.B, a.ldb, n0, kt0 * BK, tid); }
+    else {
+        sa.load(a.A, a.lda, m0, kt0 * BK, a.M, a.K, a.vecA, tid);
+        sb.load(a.B, a.ldb, n0, kt0 * BK, a.N, a.K, a.vecB, tid);
+    }
     const int nk = kt1;
-    for (int kt = kt0; kt < nk; ++kt) {
-        __syncthreads();               // previous tile's reads are done
-        sa.store(As, tid);
-        sb.store(Bs, tid);
-        __syncthreads();
-        if (kt + 1 < nk) {             // prefetch next tile under this tile's MFMAs
-            sa.load(a.A, a.lda, m0, (kt + 1) * BK, a.M, a.K, a.vecA, tid);
-            sb.load(a.B, a.ldb, n0, (kt + 1) * BK, a.N, a.K, a.vecB, tid);
-        }
-        const float* ap = As + (lane >> 5) * LDT + wr * WT + (lane & 31);
-        const float* bp = Bs + (lane >> 5) * LDT + wc * WT + (lane & 31);
+    // double-buffered LDS: tile kt is read from buffer (kt-kt0)&1 while tile kt+1 goes global -> registers
+    // (issued before the MFMAs) -> the other buffer (after them): ONE barrier per k-tile
+    sa.store(As, tid);
+    sb.store(Bs, tid);
+    __syncthreads();
+    auto compute = [&](int cur) {
+        const float* ap = As + cur * (BK * LDT) + (lane >> 5) * LDT + wr * WT + (lane & 31);
+        const float* bp = Bs + cur * (BK * LDT) + (lane >> 5) * LDT + wc * WT + (lane & 31);
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
             float av[MI], bv[MI];
@@ -152,19 +166,33 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
                 for (int j = 0; j < MI; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
         }
+    };
+    // steady state (no conditionals around the prefetch: its registers go straight from the load to the LDS store)
+    for (int kt = kt0; kt + 1 < nk; ++kt) {
+        const int cur = (kt - kt0) & 1;
+        if (FULL) { sa.load_full(a.A, a.lda, m0, (kt + 1) * BK, tid); sb.load_full(a.B, a.ldb, n0, (kt + 1) * BK, tid); }
+        else {
+            sa.load(a.A, a.lda, m0, (kt + 1) * BK, a.M, a.K, a.vecA, tid);
+            sb.load(a.B, a.ldb, n0, (kt + 1) * BK, a.N, a.K, a.vecB, tid);
+        }
+        compute(cur);
+        sa.store(As + (cur ^ 1) * (BK * LDT), tid);
+        sb.store(Bs + (cur ^ 1) * (BK * LDT), tid);
+        __syncthreads();
     }
+    compute((nk - 1 - kt0) & 1);
     // Epilogue.  C/D map of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < MI; ++ni) {
             const int n = n0 + wc * WT + ni * 32 + (lane & 31);
-            if (n >= a.N) continue;
+            if (!FULL && n >= a.N) continue;
             const float bv = (a.bias && blockIdx.y == 0) ? a.bias[n] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wr * WT + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (m < a.M) {
+                if (FULL || m < a.M) {
                     float* cp = a.C + (size_t)m * a.ldc + n;
                     float v = acc[mi][ni][r] + bv;
                     if (a.splits > 1) { atomicAdd(cp, v); }      // 32 lanes x 4 B = one 128-B segment per row
@@ -227,6 +255,14 @@ extern "C" int asr_gemm_f32_batched(void* stream, int transA, int transB, int M,
         else if (transA)            hipLaunchKernelGGL((gemm_f32_kernel<true, false, 64>), dim3(nwg, 1, batch), dim3(256), 0, s, g);
         else if (transB)            hipLaunchKernelGGL((gemm_f32_kernel<false, true, 64>), dim3(nwg, 1, batch), dim3(256), 0, s, g);
         else                        hipLaunchKernelGGL((gemm_f32_kernel<false, false, 64>), dim3(nwg, 1, batch), dim3(256), 0, s, g);
+        ASR_CHECK_LAUNCH();
+        return ASR_OK;
+    }
+    // whole tiles, aligned operands: the variant without bounds checks (all large encoder products)
+    if (M % 128 == 0 && N % 128 == 0 && K % BK == 0 && g.vecA && g.vecB && (!transA || !transB)) {
+        if (transA)       hipLaunchKernelGGL((gemm_f32_kernel<true, false, 128, true>), dim3(nwg, splits, batch), dim3(256), 0, s, g);
+        else if (transB)  hipLaunchKernelGGL((gemm_f32_kernel<false, true, 128, true>), dim3(nwg, splits, batch), dim3(256), 0, s, g);
+        else              hipLaunchKernelGGL((gemm_f32_kernel<false, false, 128, true>), dim3(nwg, splits, batch), dim3(256), 0, s, g);
         ASR_CHECK_LAUNCH();
         return ASR_OK;
     }
