@@ -43,6 +43,29 @@ def build_model(dev, training=True):
     return Seq2SeqModel(None, isTraining=training, params=p, device=dev, feat_length=F, seed=10)
 
 
+def gemm_roofline(dev):
+    """Second roofline line, for the throughput-bound kernel family (all GEMMs together are ~30 % of the GPU time):
+    the layer-2 input projection [B*T/2, 1024] x [1024, 4H] of config 2, alone on the chip, HIP events on the
+    current stream (the stream the kernel is launched on)."""
+    import torch
+    from e2e_asr_amd import ops
+    M, N, K = B * ENC_LAYER_T[1], 4 * H, ENC_LAYER_IN[1]
+    a = torch.randn(M, K, device=dev); b = torch.randn(K, N, device=dev); c = torch.empty(M, N, device=dev)
+    for _ in range(3):
+        ops.gemm(a, b, None, False, False, out=c)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = 10
+    e0.record()
+    for _ in range(n):
+        ops.gemm(a, b, None, False, False, out=c)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    tf = 2.0 * M * N * K / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "gemm_f32_kernel<NN,128,full> layer-2 input projection %dx%dx%d" % (M, N, K),
+            "achieved": tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_F32_MFMA_TFLOPS,
+            "avg_launch_ms": ms}
+
+
 def cpu_baseline():
     """CPU 'port' baseline: the torch twin of the oracle (oracle/torch_ref.py: per-timestep
     BasicLSTMCell loops with masking exactly as dynamic_rnn/raw_rnn run them, float32, autograd
@@ -162,7 +185,7 @@ def main():
     recb_per_step_ms = recb_ms / args.steps
     use_bwd = mode == "train" and recb_per_step_ms > rec_per_step_ms
     dom_ms = recb_per_step_ms if use_bwd else rec_per_step_ms
-    dom_name = "lstm_rec_bwd_kernel<256,2> (persistent BPTT)" if use_bwd else "lstm_rec_fwd_kernel<256,32,2> (persistent recurrent LSTM)"
+    dom_name = "lstm_rec_bwd_ag_kernel<256,2> (persistent BPTT)" if use_bwd else "lstm_rec_fwd_kernel<256,32,2> (persistent recurrent LSTM)"
     achieved = REC_FLOP_FWD / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else None
     traffic = None
     tp = os.path.join(ROOT, "profiles", "traffic_r01.json")
@@ -191,6 +214,7 @@ def main():
         "phases_ms_per_step": {"lstm_rec_fwd": rec_per_step_ms, "lstm_rec_bwd": recb_ms / args.steps,
                                "decoder_fwd": decf_ms / args.steps},
     }
+    out["roofline_gemm"] = gemm_roofline(dev)
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     print(json.dumps(out))

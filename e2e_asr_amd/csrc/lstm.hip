@@ -311,10 +311,15 @@ extern "C" int asr_gemm_f32(void*, int, int, int, int, int, const float*, int, c
                             float*, int, const float*, int);
 
 // rows per group: smallest R whose grid fits one workgroup per CU (256 CUs); override for tuning
+// resident-workgroup budget of one recurrent launch (tuning knob; default one workgroup per CU)
+int asr_lstm_max_wgs() {
+    static const int v = [] { const char* e = getenv("ASR_LSTM_MAXWG"); const int x = e ? atoi(e) : 256; return x >= 64 ? x : 256; }();
+    return v;
+}
 int asr_lstm_pick_rows(int B, int ND, int G) {
     if (const char* e = getenv("ASR_LSTM_R")) { int r = atoi(e); if (r == 1 || r == 2 || r == 4 || r == 8) return r; }
     for (int R : {1, 2, 4, 8})
-        if (ND * ((B + R - 1) / R) * G <= 256) return R;
+        if (ND * ((B + R - 1) / R) * G <= asr_lstm_max_wgs()) return R;
     return 8;
 }
 
@@ -360,7 +365,7 @@ extern "C" int asr_lstm_layer_fwd(void* stream, const float* x, int B, int T, in
     a.h0 = a.c0 = nullptr; a.h_last = a.c_last = nullptr;
     const int R = asr_lstm_pick_rows(B, ndir, H / 32);
     // batches too large for one resident grid run as consecutive launches over row ranges
-    const int max_groups = 256 / (H / 32) / ndir;
+    const int max_groups = asr_lstm_max_wgs() / (H / 32) / ndir;
     const int rows_per_launch = max_groups > 0 ? max_groups * R : R;
     for (int b0 = 0; b0 < B; b0 += rows_per_launch) {
         LstmRecArgs c = a;
@@ -397,7 +402,7 @@ bool asr_lstm_tm_supported(int B, int H) {
     if (H != 64 && H != 128 && H != 256 && H != 512) return false;
     const int G = H / 32;
     const int R = asr_lstm_pick_rows(B, 1, G);
-    return ((B + R - 1) / R) * G <= 256;
+    return ((B + R - 1) / R) * G <= asr_lstm_max_wgs();
 }
 int asr_lstm_rec_fwd_tm(hipStream_t s, const float* gates, const float* kh, const int* full_len, float* out, int ldo,
                         float* act, float* hprev, const float* h0, const float* c0, float* h_last, float* c_last,

@@ -466,6 +466,7 @@ extern "C" int asr_gemm_f32(void*, int, int, int, int, int, const float*, int, c
                             float*, int, const float*, int);
 extern "C" int asr_colsum_f32(void* stream, const float* x, int ldx, int M, int N, float* out, int accumulate);
 int asr_lstm_pick_rows(int B, int ND, int G);
+int asr_lstm_max_wgs();
 
 static size_t lstm_bwd_hx_bytes(int B, int H, int ndir) {
     const size_t G = H / 32 < 4 ? 4 : H / 32;    // reduce-scatter: 2*G*H granules per row; all-gather: 2*4H
@@ -503,7 +504,7 @@ extern "C" int asr_lstm_layer_bwd(void* stream, const float* x, int B, int T, in
     a.B = B; a.T = T; a.Tout = Tout; a.ND = ndir; a.boff = 0; a.keep = keep_prob; a.seed = seed;
     a.sb = T; a.st = 1; a.osb = Tout; a.ost = 1; a.ldo = ndir * H; a.dsb = Tout; a.dst = 1;
     const int R = asr_lstm_pick_rows(B, ndir, G);
-    const int max_groups = 256 / G / ndir;
+    const int max_groups = asr_lstm_max_wgs() / G / ndir;
     const int rows_per_launch = max_groups > 0 ? max_groups * R : R;
     for (int b0 = 0; b0 < B; b0 += rows_per_launch) {
         if (hipMemsetAsync(hx_ws, 0, asr_lstm_bwd_ws_bytes(B, H, ndir), s) != hipSuccess) return ASR_ELAUNCH;

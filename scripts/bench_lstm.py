@@ -1,0 +1,29 @@
+"""Recurrent kernels alone (no co-running side-stream GEMMs): us per step of one BiLSTM layer, B=32, H=256.
+Diagnostic only; the bench line's numbers come from bench.py."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from e2e_asr_amd import ops
+dev = torch.device("cuda:0")
+B, H = 32, 256
+for T, IN in ((800, 80), (400, 1024), (100, 1024)):
+    x = torch.randn(B, T, IN, device=dev) * 0.3
+    ln = torch.full((B,), T, dtype=torch.int32, device=dev)
+    k = [torch.randn(IN + H, 4 * H, device=dev) * 0.05 for _ in range(2)]
+    bz = [torch.zeros(4 * H, device=dev) for _ in range(2)]
+    dk = [torch.zeros_like(k[0]) for _ in range(2)]
+    db = [torch.zeros_like(bz[0]) for _ in range(2)]
+    ops.prof_enable(True)
+    n = 6
+    for it in range(n + 2):
+        if it == 2:
+            torch.cuda.synchronize(); ops.prof_enable(False); ops.prof_enable(True)
+        out, gates, act, hp = ops.lstm_layer_fwd(x, ln, k[0], bz[0], k[1], bz[1], save=True)
+        dout = torch.ones_like(out)
+        torch.cuda.synchronize()
+        ops.lstm_layer_bwd(x, ln, k[0], k[1], dout, gates, act, hp, dk[0], db[0], dk[1], db[1], need_dx=True, join=True)
+        torch.cuda.synchronize()
+    f_ms, f_n = ops.prof_read("lstm_rec_fwd")
+    b_ms, b_n = ops.prof_read("lstm_rec_bwd")
+    print("T=%4d in=%4d  fwd %.3f us/step (%d launches)   bwd %.3f us/step (%d launches)" % (
+        T, IN, f_ms / f_n / T * 1e3, f_n, b_ms / b_n / T * 1e3, b_n))
