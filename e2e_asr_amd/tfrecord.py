@@ -1,0 +1,211 @@
+"""TFRecord files of `tf.train.SequenceExample` protos, without TensorFlow.
+
+The reference reads its data with `tf.data.TFRecordDataset` + `tf.parse_single_sequence_example`
+(speech_dataset.py:15-45, lm_dataset.py:12-31).  This module restates the two public formats involved:
+
+* TFRecord framing: `uint64 length | uint32 masked_crc32c(length) | data | uint32 masked_crc32c(data)`, little
+  endian, mask = rotr15(crc) + 0xa282ead8 (tensorflow/core/lib/io/record_writer.h, public format).
+* protobuf wire format of SequenceExample (tensorflow/core/example/{example,feature}.proto):
+    SequenceExample { Features context = 1; FeatureLists feature_lists = 2; }
+    Features     { map<string, Feature> feature = 1; }          FeatureLists { map<string, FeatureList> feature_list = 1; }
+    FeatureList  { repeated Feature feature = 1; }
+    Feature      { oneof kind { BytesList bytes_list = 1; FloatList float_list = 2; Int64List int64_list = 3; } }
+    BytesList { repeated bytes value = 1; }  FloatList { repeated float value = 1 [packed]; }  Int64List { repeated int64 value = 1 [packed]; }
+
+Both a reader and a writer are provided (the writer makes synthetic corpora and the test fixtures).
+"""
+import struct
+
+import numpy as np
+
+_CRC_TABLE = None
+
+
+def _crc_table():
+    global _CRC_TABLE
+    if _CRC_TABLE is None:
+        poly = 0x82F63B78            # CRC-32C (Castagnoli), reflected
+        tab = []
+        for i in range(256):
+            c = i
+            for _ in range(8):
+                c = (c >> 1) ^ poly if c & 1 else c >> 1
+            tab.append(c)
+        _CRC_TABLE = tab
+    return _CRC_TABLE
+
+
+def crc32c(data):
+    """CRC-32C of a bytes-like object (pure Python; records' payload CRCs are only checked on request)."""
+    tab = _crc_table()
+    c = 0xFFFFFFFF
+    for b in bytes(data):
+        c = tab[(c ^ b) & 0xFF] ^ (c >> 8)
+    return c ^ 0xFFFFFFFF
+
+
+def masked_crc32c(data):
+    c = crc32c(data)
+    return (((c >> 15) | (c << 17)) + 0xA282EAD8) & 0xFFFFFFFF
+
+
+# ---------------------------------------------------------------------------------- record framing
+def write_records(path, records):
+    with open(path, "wb") as f:
+        for rec in records:
+            hdr = struct.pack("<Q", len(rec))
+            f.write(hdr)
+            f.write(struct.pack("<I", masked_crc32c(hdr)))
+            f.write(rec)
+            f.write(struct.pack("<I", masked_crc32c(rec)))
+
+
+def read_records(path, verify_payload=False):
+    """Yield the raw record payloads of one TFRecord file.  The length CRC is always checked (it guards the
+    framing); the payload CRC only when `verify_payload` (pure-Python CRC over ~256 KB utterances is slow)."""
+    with open(path, "rb") as f:
+        while True:
+            hdr = f.read(8)
+            if not hdr:
+                return
+            if len(hdr) != 8:
+                raise ValueError("%s: truncated record header" % path)
+            (crc,) = struct.unpack("<I", f.read(4))
+            if crc != masked_crc32c(hdr):
+                raise ValueError("%s: corrupt record length" % path)
+            (n,) = struct.unpack("<Q", hdr)
+            data = f.read(n)
+            tail = f.read(4)
+            if len(data) != n or len(tail) != 4:
+                raise ValueError("%s: truncated record" % path)
+            if verify_payload and struct.unpack("<I", tail)[0] != masked_crc32c(data):
+                raise ValueError("%s: corrupt record payload" % path)
+            yield data
+
+
+# ---------------------------------------------------------------------------------- protobuf wire format
+def _varint(buf, pos):
+    res, shift = 0, 0
+    while True:
+        b = buf[pos]
+        pos += 1
+        res |= (b & 0x7F) << shift
+        if not b & 0x80:
+            return res, pos
+        shift += 7
+
+
+def _enc_varint(v):
+    v &= (1 << 64) - 1
+    out = bytearray()
+    while True:
+        b = v & 0x7F
+        v >>= 7
+        if v:
+            out.append(b | 0x80)
+        else:
+            out.append(b)
+            return bytes(out)
+
+
+def _fields(buf):
+    """(field number, wire type, value) triples of one message; value is an int (varint/fixed) or a memoryview."""
+    buf = memoryview(buf)
+    pos, n = 0, len(buf)
+    while pos < n:
+        key, pos = _varint(buf, pos)
+        fn, wt = key >> 3, key & 7
+        if wt == 0:
+            v, pos = _varint(buf, pos)
+        elif wt == 1:
+            v = bytes(buf[pos:pos + 8]); pos += 8
+        elif wt == 2:
+            ln, pos = _varint(buf, pos)
+            v = buf[pos:pos + ln]; pos += ln
+        elif wt == 5:
+            v = bytes(buf[pos:pos + 4]); pos += 4
+        else:
+            raise ValueError("unsupported protobuf wire type %d" % wt)
+        yield fn, wt, v
+
+
+def _ld(fn, payload):
+    return _enc_varint((fn << 3) | 2) + _enc_varint(len(payload)) + payload
+
+
+def _to_i64(v):
+    return v - (1 << 64) if v >= (1 << 63) else v
+
+
+def _parse_feature(buf):
+    """Feature -> numpy array (float32 / int64) or list of bytes."""
+    for fn, wt, v in _fields(buf):
+        if fn == 1:                                           # BytesList
+            return [bytes(x) for f2, _, x in _fields(v) if f2 == 1]
+        if fn == 2:                                           # FloatList (packed, or one fixed32 per value)
+            parts = []
+            for f2, w2, x in _fields(v):
+                if f2 == 1:
+                    parts.append(np.frombuffer(bytes(x), dtype="<f4"))
+            return np.concatenate(parts) if len(parts) != 1 else parts[0]
+        if fn == 3:                                           # Int64List (packed varints, or one varint per value)
+            vals = []
+            for f2, w2, x in _fields(v):
+                if f2 != 1:
+                    continue
+                if w2 == 0:
+                    vals.append(_to_i64(x))
+                else:
+                    p, xb = 0, x
+                    while p < len(xb):
+                        y, p = _varint(xb, p)
+                        vals.append(_to_i64(y))
+            return np.asarray(vals, dtype=np.int64)
+    return np.zeros((0,), np.float32)
+
+
+def _parse_map(buf, value_parser):
+    out = {}
+    for fn, wt, entry in _fields(buf):
+        if fn != 1:
+            continue
+        key, val = None, None
+        for f2, _, x in _fields(entry):
+            if f2 == 1:
+                key = bytes(x).decode("utf-8")
+            elif f2 == 2:
+                val = value_parser(x)
+        out[key] = val
+    return out
+
+
+def parse_sequence_example(record):
+    """-> (context: {name: array|[bytes]}, feature_lists: {name: [array|[bytes] per step]})."""
+    context, lists = {}, {}
+    for fn, wt, v in _fields(record):
+        if fn == 1:
+            context = _parse_map(v, _parse_feature)
+        elif fn == 2:
+            lists = _parse_map(v, lambda fl: [_parse_feature(x) for f2, _, x in _fields(fl) if f2 == 1])
+    return context, lists
+
+
+def _enc_feature(value):
+    if isinstance(value, (bytes, str)):
+        value = [value]
+    if isinstance(value, (list, tuple)) and value and isinstance(value[0], (bytes, str)):
+        body = b"".join(_ld(1, v.encode("utf-8") if isinstance(v, str) else v) for v in value)
+        return _ld(1, body)
+    arr = np.asarray(value)
+    if arr.dtype.kind == "f":
+        return _ld(2, _ld(1, arr.astype("<f4").tobytes()))
+    return _ld(3, _ld(1, b"".join(_enc_varint(int(x)) for x in arr.reshape(-1))))
+
+
+def make_sequence_example(context, feature_lists):
+    """Serialise {name: scalar/array/bytes} context features and {name: [per-step value]} feature lists."""
+    def enc_map(d, enc_value):
+        return b"".join(_ld(1, _ld(1, k.encode("utf-8")) + _ld(2, enc_value(v))) for k, v in d.items())
+    ctx = enc_map(context, lambda v: _enc_feature(np.asarray([v]) if np.isscalar(v) and not isinstance(v, (bytes, str)) else v))
+    fl = enc_map(feature_lists, lambda steps: b"".join(_ld(1, _enc_feature(s)) for s in steps))
+    return _ld(1, ctx) + _ld(2, fl)

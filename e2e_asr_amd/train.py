@@ -6,9 +6,11 @@ LM steps with probability lm_prob (269-291), every `steps_per_checkpoint` steps 
 decode (322), LR halving when the dev error is no better than the worst of the last three after
 `min_steps` while lr > 1e-4 (334-343), stop after 10 non-improving checkpoints at floor LR
 (346-349, check_progess 153-158), `best.txt` / `asr_err.txt` / keep-all + best checkpoints
-(353-371).  TFRecord reading is out of scope: datasets are injected as lists of
-re-iterable batch sources (anything yielding the speech_dataset.py:43-45 dict)."""
+(353-371).  Data sets are re-iterable batch sources yielding the speech_dataset.py:43-45 dict: `get_data_sets()`
+builds them from the TFRecord buckets `train_1k.<bucket>.*` / `dev*` of `data_dir` (94-131); `train()` also takes
+injected ones (tests, synthetic corpora)."""
 import copy
+import glob
 import math
 import os
 import random
@@ -19,8 +21,10 @@ from . import checkpoint, ops
 from .base_params import BaseParams, Bunch
 from .eval_model import Eval
 from .lm_encoder import LMEncoder
+from .lm_dataset import LMDataset
 from .lm_model import LMModel
 from .seq2seq_model import Seq2SeqModel
+from .speech_dataset import SpeechDataset
 
 
 class Train(BaseParams):
@@ -38,6 +42,44 @@ class Train(BaseParams):
         self.seq2seq_params = model_params
         self.eval_model = None
         self.device = device
+
+    @staticmethod
+    def load_train_subset_file(subset_file):
+        """train.py:83-92: file names (one per line) the training buckets are restricted to."""
+        try:
+            with open(subset_file) as f:
+                return dict((line.strip(), 0) for line in f.readlines())
+        except (IOError, OSError):
+            return {}
+
+    def get_data_sets(self, logging=True):
+        """train.py:94-131: one training set per length bucket (batch sizes buck_batch_size, files
+        data_dir/train_1k.<bucket>.*, shuffled file order, optional subset file) and the dev set (data_dir/dev*)."""
+        params = self.params
+        subset = self.load_train_subset_file(params.subset_file) if params.subset_file else None
+        buck_train_sets, total = [], 0
+        for batch_id, batch_size in enumerate(params.buck_batch_size):
+            files = sorted(glob.glob(os.path.join(params.data_dir, "train_1k." + str(batch_id) + ".*")))
+            if subset:
+                files = [f for f in files if os.path.basename(f) in subset]
+            random.shuffle(files)
+            total += len(files)
+            buck_train_sets.append(SpeechDataset(Bunch(batch_size=batch_size, feat_length=params.feat_length), files,
+                                                 isTraining=True))
+        dev_files = sorted(glob.glob(os.path.join(params.data_dir, "dev*")))
+        if logging:
+            print("Total train files: %d" % total)
+            print("Total dev files: %d" % len(dev_files))
+        dev_set = SpeechDataset(Bunch(batch_size=params.batch_size, feat_length=params.feat_length), dev_files,
+                                isTraining=False)
+        return buck_train_sets, dev_set
+
+    def get_lm_files(self):
+        return sorted(glob.glob(os.path.join(self.params.lm_data_dir, "lm*")))          # train.py:134-137
+
+    def get_lm_set(self):
+        """The LM corpus as a batch source (train.py:197-200: LMDataset(lm_files, lm_params.batch_size))."""
+        return LMDataset(self.get_lm_files(), self.params.lm_params.lm_batch_size)
 
     @staticmethod
     def check_progess(previous_errs, num=10):
@@ -64,10 +106,15 @@ class Train(BaseParams):
         self.eval_model = Eval(model_dev, params=Bunch(best_model_dir=self.params.best_model_dir, vocab_dir=self.params.vocab_dir))
         return model_dev
 
-    def train(self, buck_train_sets, dev_set, lm_set=None, max_steps=None):
+    def train(self, buck_train_sets=None, dev_set=None, lm_set=None, max_steps=None):
         """buck_train_sets: list (shortest bucket first) of re-iterable batch sources; dev_set: a
-        re-iterable of dev batches; lm_set: re-iterable of LM batches (needed when lm_prob > 0)."""
+        re-iterable of dev batches; lm_set: re-iterable of LM batches (needed when lm_prob > 0).  Left out, they are
+        read from params.data_dir / params.lm_data_dir like the reference does."""
         params = self.params
+        if buck_train_sets is None or dev_set is None:
+            buck_train_sets, dev_set = self.get_data_sets()
+        if lm_set is None and params.lm_prob > 0:
+            lm_set = self.get_lm_set()
         random.seed(int(time.time()) if params.chaos else 10)                       # train.py:167-174
         os.makedirs(params.train_dir, exist_ok=True)
         os.makedirs(params.best_model_dir, exist_ok=True)
