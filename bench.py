@@ -61,9 +61,12 @@ def gemm_roofline(dev):
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / n
     tf = 2.0 * M * N * K / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "gemm_f32_kernel<NN,128,full> layer-2 input projection %dx%dx%d" % (M, N, K),
-            "achieved": tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_F32_MFMA_TFLOPS,
-            "avg_launch_ms": ms}
+    bf16 = ops.get_gemm_precision() == "bf16"
+    peak = 2500.0 if bf16 else PEAK_F32_MFMA_TFLOPS            # dense bf16 MFMA peak ~2.5 PFLOP/s (MI355X_MICROARCH.md)
+    return {"bound": "mfma", "kernel": "%s layer-2 input projection %dx%dx%d" % (
+                "gemm_bf16_kernel<NN> (fp32 operands rounded on the way into LDS: bound by reading them)" if bf16
+                else "gemm_f32_kernel<NN,128,full>", M, N, K),
+            "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak, "avg_launch_ms": ms}
 
 
 def cpu_baseline():
@@ -104,6 +107,9 @@ def main():
     ap.add_argument("--mode", default="auto", choices=["auto", "train", "fwd"])
     ap.add_argument("--variable-len", action="store_true", help="lengths U[400,800] (masking run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="bf16 = BASELINE config 3's per-GPU workload: bf16 MFMA operands in the GEMMs (fp32 accumulate, state, "
+                         "recurrences); the default line is the fp32 config 2")
     ap.add_argument("--graph", action="store_true", help="EXPERIMENT: replay one captured step as a hipGraph (step-varying scalars frozen)")
     args = ap.parse_args()
 
@@ -119,6 +125,7 @@ def main():
 
     from e2e_asr_amd import ops
     from e2e_asr_amd.weights import synthetic_batch
+    ops.set_gemm_precision(args.dtype)
     model = build_model(dev, training=True)
     has_train = hasattr(model, "step")
     mode = args.mode if args.mode != "auto" else ("train" if has_train else "fwd")
@@ -197,8 +204,10 @@ def main():
     out = {
         "metric": "encoder+decoder frames/sec at batch32x800frx80mel", "value": value, "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "config2: 4-layer pyramidal BiLSTM(256)+attn decoder(256), V=1000, per-GPU batch "
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if args.dtype == "f32" else "bf16 MFMA operands in the GEMMs; fp32 accumulate, recurrences, attention, loss, Adam",
+        "data": "synthetic",
+        "config": {"workload": ("config2" if args.dtype == "f32" else "config3 (per-GPU)") + ": 4-layer pyramidal BiLSTM(256)+attn decoder(256), V=1000, per-GPU batch "
                                "32x800x80, %s step%s" % (
                                    "full train (fwd+bwd+clip+Adam%s)" % ("+RCCL all-reduce" if world > 1 else "")
                                    if mode == "train" else "forward-only (training graph incl. loss)",

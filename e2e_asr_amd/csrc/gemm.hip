@@ -202,6 +202,130 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// bf16 variant (BASELINE config 3): SAME interface -- fp32 operands in memory, fp32 accumulation and
+// output -- but the operands are rounded to bf16 (v_cvt_pk_bf16_f32, round-to-nearest-even) while they are
+// staged into LDS, and the contraction runs on v_mfma_f32_32x32x16_bf16 (16x the fp32 matrix rate).  No
+// separate cast kernels and no bf16 copies in HBM: the kernel is bound by reading the fp32 operands.
+// 128x128 block tile, BK = 32 (two MFMA k-steps), 4 waves x 64x64.  LDS image [row][k] bf16 with an 80-byte
+// row pitch: a lane's operand fragment (8 consecutive k of one row, guide: A[row l&31][k = 8(l>>5)+j], B alike)
+// is one conflict-free ds_read_b128.  Whole tiles only (M,N % 128 == 0, K % 32 == 0); other shapes use the fp32 kernel.
+constexpr int BKB = 32, PITCHB = 40;       // k-tile and LDS row pitch in bf16 elements
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+
+// One thread stages 16 consecutive k of one tile row.  KMAJOR (memory is [k][m], m contiguous): thread ->
+// (row = tid & 127, k-half = tid >> 7), 16 coalesced scalar loads.  Otherwise ([m][k], k contiguous): thread ->
+// (row = tid >> 1, k-half = tid & 1), four 16-byte loads.
+template <bool KMAJOR>
+struct StagerB16 {
+    float v[16];
+    __device__ __forceinline__ void load(const float* P, int ld, int m0, int k0, int tid) {
+        if (KMAJOR) {
+            const float* p = P + (size_t)(k0 + (tid >> 7) * 16) * ld + m0 + (tid & 127);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = p[(size_t)j * ld];
+        } else {
+            const float4* p = reinterpret_cast<const float4*>(P + (size_t)(m0 + (tid >> 1)) * ld + k0 + (tid & 1) * 16);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float4 x = p[j]; v[4 * j] = x.x; v[4 * j + 1] = x.y; v[4 * j + 2] = x.z; v[4 * j + 3] = x.w; }
+        }
+    }
+    __device__ __forceinline__ void store(unsigned short* S, int tid) const {
+        const int row = KMAJOR ? (tid & 127) : (tid >> 1), kh = KMAJOR ? (tid >> 7) : (tid & 1);
+        uint4* d = reinterpret_cast<uint4*>(S + row * PITCHB + kh * 16);
+        d[0] = make_uint4(cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3]), cvt_pk_bf16(v[4], v[5]), cvt_pk_bf16(v[6], v[7]));
+        d[1] = make_uint4(cvt_pk_bf16(v[8], v[9]), cvt_pk_bf16(v[10], v[11]), cvt_pk_bf16(v[12], v[13]), cvt_pk_bf16(v[14], v[15]));
+    }
+};
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
+    constexpr int BM = 128, BN = 128;
+    __shared__ __attribute__((aligned(16))) unsigned short As[2 * BM * PITCHB];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[2 * BN * PITCHB];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1;
+    a.A += (size_t)blockIdx.z * a.sA; a.B += (size_t)blockIdx.z * a.sB; a.C += (size_t)blockIdx.z * a.sC;
+    const int ntn = a.N / BN, ntm = a.M / BM;
+    const int nwg = ntn * ntm;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+    }
+    const int m0 = (bid / ntn) * BM, n0 = (bid % ntn) * BN;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    StagerB16<TA> sa;      // A natural [M,K]: k contiguous unless transposed
+    StagerB16<!TB> sb;     // B natural [K,N]: n contiguous unless transposed
+    const int nk_all = a.K / BKB;
+    const int per = (nk_all + a.splits - 1) / a.splits;
+    const int kt0 = blockIdx.y * per, nk = min(nk_all, kt0 + per);
+    if (kt0 >= nk) return;
+    sa.load(a.A, a.lda, m0, kt0 * BKB, tid);
+    sb.load(a.B, a.ldb, n0, kt0 * BKB, tid);
+    sa.store(As, tid);
+    sb.store(Bs, tid);
+    __syncthreads();
+    auto compute = [&](int cur) {
+        const unsigned short* ap = As + cur * (BM * PITCHB) + (wr * 64 + (lane & 31)) * PITCHB + 8 * (lane >> 5);
+        const unsigned short* bp = Bs + cur * (BN * PITCHB) + (wc * 64 + (lane & 31)) * PITCHB + 8 * (lane >> 5);
+#pragma unroll
+        for (int ks = 0; ks < BKB / 16; ++ks) {
+            bf16x8 af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                af[i] = *reinterpret_cast<const bf16x8*>(ap + i * 32 * PITCHB + ks * 16);
+                bf[i] = *reinterpret_cast<const bf16x8*>(bp + i * 32 * PITCHB + ks * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    for (int kt = kt0; kt + 1 < nk; ++kt) {
+        const int cur = (kt - kt0) & 1;
+        sa.load(a.A, a.lda, m0, (kt + 1) * BKB, tid);
+        sb.load(a.B, a.ldb, n0, (kt + 1) * BKB, tid);
+        compute(cur);
+        sa.store(As + (cur ^ 1) * (BM * PITCHB), tid);
+        sb.store(Bs + (cur ^ 1) * (BN * PITCHB), tid);
+        __syncthreads();
+    }
+    compute((nk - 1 - kt0) & 1);
+    // C/D map identical to the fp32 32x32 tile (dtype-independent on gfx950)
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int n = n0 + wc * 64 + ni * 32 + (lane & 31);
+            const float bv = (a.bias && blockIdx.y == 0) ? a.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                float* cp = a.C + (size_t)m * a.ldc + n;
+                float v = acc[mi][ni][r] + bv;
+                if (a.splits > 1) { atomicAdd(cp, v); }
+                else { if (a.accumulate) v += *cp; *cp = v; }
+            }
+        }
+}
+
+static int g_gemm_bf16 = 0;
 }  // namespace asr
 
 // ---------------------------------------------------------------------------------
@@ -210,6 +334,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
 extern "C" int asr_gemm_f32_batched(void* stream, int transA, int transB, int M, int N, int K,
                                     const float* A, int lda, long long strideA, const float* B, int ldb, long long strideB,
                                     float* C, int ldc, long long strideC, const float* bias, int accumulate, int batch);
+
+// 0: exact fp32 MFMA everywhere (default).  1: products made of whole 128x128x32 tiles round their operands to
+// bf16 on the way into LDS and run on the bf16 matrix cores (fp32 accumulate/output); all others stay fp32.
+extern "C" int asr_set_gemm_precision(int mode) {
+    if (mode != 0 && mode != 1) return ASR_EINVAL;
+    asr::g_gemm_bf16 = mode;
+    return ASR_OK;
+}
+extern "C" int asr_get_gemm_precision(void) { return asr::g_gemm_bf16; }
 
 extern "C" int asr_gemm_f32(void* stream, int transA, int transB, int M, int N, int K,
                             const float* A, int lda, const float* B, int ldb,
@@ -246,6 +379,20 @@ extern "C" int asr_gemm_f32_batched(void* stream, int transA, int transB, int M,
     g.splits = splits;
     if (splits > 1 && !accumulate) {
         if (hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, s) != hipSuccess) return ASR_ELAUNCH;
+    }
+    if (g_gemm_bf16 && M % 128 == 0 && N % 128 == 0 && K % BKB == 0 && g.vecA && g.vecB && !(transA && transB)) {
+        int sp = 1;
+        const int nkb = K / BKB;
+        if (transA && batch == 1 && nwg < 192 && nkb >= 32) sp = std::min((768 + nwg - 1) / nwg, nkb / 8);
+        g.splits = sp;
+        if (sp > 1 && !accumulate &&
+            hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, s) != hipSuccess) return ASR_ELAUNCH;
+        if (sp == 1 && splits > 1 && !accumulate) { /* C was zeroed above for the fp32 split: harmless, the kernel overwrites */ }
+        if (transA)       hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), dim3(nwg, sp, batch), dim3(256), 0, s, g);
+        else if (transB)  hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), dim3(nwg, sp, batch), dim3(256), 0, s, g);
+        else              hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), dim3(nwg, sp, batch), dim3(256), 0, s, g);
+        ASR_CHECK_LAUNCH();
+        return ASR_OK;
     }
     // few output tiles and no split-K: 64x64 block tiles fill the chip 4x better (still reproducible)
     static const int small_thr = [] { const char* e = getenv("ASR_GEMM_SMALL"); return e ? atoi(e) : 160; }();

@@ -273,6 +273,10 @@ __global__ __launch_bounds__(16 * HS) void lstm_rec_fwd_kernel(LstmRecArgs a) {
         for (int idx = tid; idx < nz * HS; idx += NT) {
             const int t = l + idx / HS, uu = idx % HS;
             a.out[((size_t)(r0 + r) * a.osb + (size_t)t * a.ost) * a.ldo + dir * H + mem * HS + uu] = 0.f;
+            // hprev feeds dK_h = Hprev^T.dG over ALL rows: past the length dG is zero, so the value must merely
+            // be finite (uninitialised memory may hold NaN bit patterns)
+            if (a.hprev && t < a.T)
+                a.hprev[(((size_t)(r0 + r) * a.sb + (size_t)t * a.st) * a.ND + dir) * H + mem * HS + uu] = 0.f;
         }
     }
 }

@@ -398,6 +398,17 @@ def attn_decoder_bwd(wt, gt, ws, enc, enc_len, dlogits, denc, keep_lm=1.0, seed=
     return bw
 
 
+def set_gemm_precision(dtype):
+    """"f32" (default, exact) or "bf16": bf16 MFMA operands with fp32 accumulation for the whole-tile GEMMs
+    (BASELINE config 3).  Process-wide."""
+    mode = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}[str(dtype)]
+    _check(_lib.lib().asr_set_gemm_precision(mode), "asr_set_gemm_precision")
+
+
+def get_gemm_precision():
+    return "bf16" if _lib.lib().asr_get_gemm_precision() else "f32"
+
+
 PROF_TAGS = {"lstm_rec_fwd": 0, "lstm_rec_bwd": 1, "gemm": 2, "decoder_fwd": 3, "decoder_bwd": 4, "optim": 5}
 
 

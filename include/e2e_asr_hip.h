@@ -32,6 +32,13 @@ int asr_gemm_f32_batched(void* stream, int transA, int transB, int M, int N, int
                          const float* A, int lda, long long strideA, const float* B, int ldb, long long strideB,
                          float* C, int ldc, long long strideC, const float* bias, int accumulate, int batch);
 
+/* Precision of the MFMA GEMMs (BASELINE config 3, "same model bf16").  0 (default): exact fp32 everywhere.
+ * 1: products made of whole 128x128x32 tiles (all large encoder / decoder products) round their fp32 operands to
+ * bf16 (round-to-nearest-even) while staging them into LDS and run on v_mfma_f32_32x32x16_bf16; accumulation, outputs,
+ * recurrent state, attention, loss and the optimizer stay fp32.  Process-wide; set between steps. */
+int asr_set_gemm_precision(int mode);
+int asr_get_gemm_precision(void);
+
 /* One (Bi)LSTM encoder layer over a whole padded batch -- encoder.py:55-91
  * (bidirectional_dynamic_rnn / dynamic_rnn over BasicLSTMCell with sequence_length).
  * x [B,T,in] batch-major (row stride ldx); out [B,Tout,ndir*H] with fw in [:H], bw in

@@ -1,0 +1,92 @@
+"""BASELINE config 3 ("same model bf16"): GEMMs with bf16 MFMA operands (csrc/gemm.hip gemm_bf16_kernel), fp32
+accumulation and fp32 everything else.  Tolerances are stated here: the kernel itself must equal an fp64 product of
+the bf16-ROUNDED operands to fp32 accumulation error; the model's logits may move by the operand rounding
+(2^-9 relative per operand), bounded below against the float64 oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(autouse=True)
+def _restore_precision():
+    from e2e_asr_amd import ops
+    yield
+    ops.set_gemm_precision("f32")
+
+
+def _bf16_round(x):
+    return x.to(torch.bfloat16).to(torch.float64)       # round-to-nearest-even, like v_cvt_pk_bf16_f32
+
+
+@pytest.mark.parametrize("ta,tb,M,N,K,acc", [(0, 0, 256, 128, 96, 0), (0, 1, 128, 256, 64, 0), (1, 0, 128, 128, 4096, 0),
+                                             (1, 0, 256, 256, 8192, 1), (0, 0, 384, 1024, 1024, 1)])
+def test_gemm_bf16_equals_product_of_rounded_operands(ta, tb, M, N, K, acc):
+    from e2e_asr_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    a = torch.randn((K, M) if ta else (M, K), generator=g).to(DEV)
+    b = torch.randn((N, K) if tb else (K, N), generator=g).to(DEV)
+    bias = None if ta else torch.randn(N, generator=g).to(DEV)
+    c0 = torch.randn(M, N, generator=g).to(DEV)
+    ops.set_gemm_precision("bf16")
+    assert ops.get_gemm_precision() == "bf16"
+    out = ops.gemm(a, b, bias, bool(ta), bool(tb), out=c0.clone(), accumulate=bool(acc))
+    ra, rb = _bf16_round(a), _bf16_round(b)
+    ref = (ra.t() if ta else ra) @ (rb.t() if tb else rb)
+    if bias is not None:
+        ref = ref + bias.double()
+    if acc:
+        ref = ref + c0.double()
+    err = (out.double() - ref).abs().max().item()
+    assert err <= 2e-6 * K ** 0.5 * 4 + 1e-5, err            # fp32 accumulation of K products of magnitude ~1
+    # ... and it really is the bf16 path: the exact fp32 kernel gives a visibly different (more accurate) result
+    ops.set_gemm_precision("f32")
+    exact = ops.gemm(a, b, bias, bool(ta), bool(tb), out=c0.clone(), accumulate=bool(acc))
+    assert (exact - out).abs().max().item() > 1e-3
+
+
+def test_partial_tiles_fall_back_to_exact_fp32():
+    from e2e_asr_amd import ops
+    a = torch.randn(100, 80, device=DEV); b = torch.randn(80, 1000, device=DEV)
+    ops.set_gemm_precision("bf16")
+    out = ops.gemm(a, b)
+    ref = a.double() @ b.double()
+    assert (out.double() - ref).abs().max().item() < 1e-4
+
+
+def test_model_bf16_logits_and_gradients_close_to_fp64_oracle():
+    """Config-2 architecture at reduced time extent (H=256 so that the products are whole tiles and take the bf16
+    path): logits within 5e-2 absolute (fp32 path: 2e-7) and loss within 1e-2 relative of the float64 oracle; every
+    gradient has cosine similarity >= 0.995 with the fp32 path's gradient."""
+    from tests.test_gpu_model import _model, _batch, _f64
+    from oracle import asr_oracle as O
+    from e2e_asr_amd import ops
+    rng = np.random.default_rng(41)
+    kw = dict(enc_update=dict(hidden_size=256), num_layers={"char": 3}, seed=5,
+              dec_update=dict(hidden_size_dec=256, lm_hidden_size=256, emb_size=256, attention_vec_size=128))
+    b = _batch(rng, 8, 64, 20, 12, 50)
+    res = {}
+    for prec in ("f32", "bf16"):
+        ops.set_gemm_precision(prec)
+        m = _model(**kw)
+        m.forward(b)
+        out = m.outputs["char"].cpu().numpy().copy()
+        loss = m.total_loss.item()
+        m.backward()
+        ops.check_device_flag(torch.device(DEV))
+        res[prec] = (out, loss, {n: m.variables.grad_of(n).cpu().numpy().copy() for n in m.variables.names()}, m)
+    m = res["f32"][3]
+    w = _f64(m.variables.to_arrays())
+    b64 = dict(b); b64["logmel"] = b["logmel"].astype(np.float64)
+    r = O.seq2seq_forward(b64, w, num_layers={"char": 3}, is_training=True)
+    ref = r["outputs"]["char"]
+    assert np.abs(res["f32"][0] - ref).max() < 1e-4
+    d = np.abs(res["bf16"][0] - ref).max()
+    assert 1e-5 < d < 5e-2, d                                  # moved by the operand rounding, but bounded
+    assert abs(res["bf16"][1] - r["total_loss"]) < 1e-2 * abs(r["total_loss"])
+    for n, g32 in res["f32"][2].items():
+        g16 = res["bf16"][2][n]
+        cos = float((g32 * g16).sum() / (np.linalg.norm(g32) * np.linalg.norm(g16) + 1e-30))
+        assert cos > 0.995, (n, cos)

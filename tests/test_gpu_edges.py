@@ -98,3 +98,22 @@ def test_argument_validation_raises_valueerror():
         ops.linear(torch.zeros(2, 6, device=DEV), torch.zeros(6, 8, device=DEV))
     with pytest.raises(ValueError, match="contiguous float32"):
         ops.gemm(torch.zeros(4, 4, device=DEV).t(), torch.zeros(4, 4, device=DEV))
+
+
+def test_gradients_finite_when_recycled_memory_holds_nan():
+    """Workspaces come from torch.empty: rows past an utterance's length that a kernel does not write must never
+    reach a product (found by the bf16 test: hprev rows past the length held NaN bit patterns from a freed tensor and
+    poisoned dK_h = Hprev^T.dG although dG is zero there).  Poison the allocator's free blocks, then take a ragged step."""
+    from tests.test_gpu_model import _model, _batch
+    rng = np.random.default_rng(77)
+    for _ in range(2):
+        junk = [torch.full((n,), float("nan"), device=DEV) for n in (1 << 22, 1 << 20, 1 << 18, 1 << 16, 3 << 14)]
+        del junk
+        m = _model(enc_update=dict(hidden_size=64), num_layers={"char": 3}, seed=9,
+                   dec_update=dict(hidden_size_dec=64, lm_hidden_size=64, emb_size=24, attention_vec_size=16))
+        b = _batch(rng, 6, 29, 20, 11, 50, lens=[29, 3, 17, 1, 22, 8])
+        m.forward(b)
+        assert np.isfinite(m.total_loss.item())
+        m.backward()
+        for n in m.variables.names():
+            assert torch.isfinite(m.variables.grad_of(n)).all(), n
