@@ -96,6 +96,30 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(float* p, float* m, floa
         }
 }
 
+// num_utils.py:6-14 of the reference: elementwise logistic; softmax over a 1-D vector (axis 0), max-shifted.
+__global__ __launch_bounds__(256) void sigmoid_kernel(const float* x, float* y, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) y[i] = 1.0f / (1.0f + expf(-x[i]));
+}
+__global__ __launch_bounds__(256) void softmax1d_kernel(const float* x, float* y, int n) {
+    __shared__ float red[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float m = -INFINITY;
+    for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, x[i]);
+    m = wave_allreduce_max(m);
+    if (lane == 0) red[w] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += expf(x[i] - m);
+    s = wave_allreduce_sum(s);
+    if (lane == 0) red[w] = s;
+    __syncthreads();
+    s = (red[0] + red[1]) + (red[2] + red[3]);
+    for (int i = threadIdx.x; i < n; i += 256) y[i] = expf(x[i] - m) / s;
+}
+
 }  // namespace asr
 
 extern "C" int asr_colsum_f32(void* stream, const float* x, int ldx, int M, int N, float* out, int accumulate) {
@@ -149,6 +173,22 @@ extern "C" int asr_clip_adam_f32(void* stream, float* p, float* m, float* v, con
     hipLaunchKernelGGL(asr::clip_adam_kernel, dim3(nb), dim3(256), 0, static_cast<hipStream_t>(stream), p, m, v, g, n,
                        sumsq, grad_scale, clip_norm, lr_t, beta1, beta2, eps);
     asr::prof_end(ASR_PROF_OPTIM, static_cast<hipStream_t>(stream));
+    ASR_CHECK_LAUNCH();
+    return ASR_OK;
+}
+
+
+extern "C" int asr_sigmoid_f32(void* stream, const float* x, float* y, size_t n) {
+    if (!x || !y) return ASR_EINVAL;
+    if (n == 0) return ASR_OK;
+    hipLaunchKernelGGL(asr::sigmoid_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), x, y, n);
+    ASR_CHECK_LAUNCH();
+    return ASR_OK;
+}
+
+extern "C" int asr_softmax_f32(void* stream, const float* x, float* y, int n) {
+    if (!x || !y || n <= 0) return ASR_EINVAL;
+    hipLaunchKernelGGL(asr::softmax1d_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), x, y, n);
     ASR_CHECK_LAUNCH();
     return ASR_OK;
 }

@@ -25,6 +25,14 @@ def _p(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+def default_device():
+    """Device of the module-level helpers that take NumPy arrays (num_utils, BasicLSTM): the current CUDA device.
+    There is no CPU path."""
+    if not torch.cuda.is_available():
+        raise RuntimeError("e2e_asr_amd: no GPU visible; the HIP path has no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 

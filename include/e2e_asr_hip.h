@@ -74,6 +74,9 @@ int asr_linear_wt_fwd(void* stream, const float* x, int ldx, int K, const float*
                       float* out, int ldo, int M, int N, int accumulate);
 
 /* out[N] (+)= column sums of x[M,N] (bias gradients); fixed-order, reproducible. */
+/* num_utils.py:6-14: y = 1/(1+exp(-x)) elementwise; y = softmax(x) over a 1-D vector (max-shifted). */
+int asr_sigmoid_f32(void* stream, const float* x, float* y, size_t n);
+int asr_softmax_f32(void* stream, const float* x, float* y, int n);
 int asr_colsum_f32(void* stream, const float* x, int ldx, int M, int N, float* out, int accumulate);
 /* out[r,:] = table[idx[r],:] (embedding_lookup) and table_grad[idx[r],:] += g[r,:] (its gradient). */
 int asr_gather_rows(void* stream, const float* table, const int* idx, float* out, int rows, int width);

@@ -307,3 +307,31 @@ def test_colsum_gather_scatter_optimizer(dev):
             np.testing.assert_allclose(np.sqrt(ss.item()), gn, rtol=1e-5)
             rp, rm, rv = O.adam_step(rp, rm, rv, cg, step, 1e-3)
         np.testing.assert_allclose(p.cpu().numpy(), rp, rtol=0, atol=2e-6)
+
+
+def test_num_utils_and_basic_lstm_dropins_vs_reference_golden(golden_dir):
+    """num_utils.sigmoid / softmax and BasicLSTM(weight, bias)(x, (c, h)) with the reference's NumPy-in/NumPy-out
+    signatures, against vectors generated by the reference's own num_utils.py / basic_lstm.py (oracle/gen_golden.py)."""
+    import os
+    from e2e_asr_amd import num_utils
+    from e2e_asr_amd.basic_lstm import BasicLSTM
+    g = np.load(os.path.join(golden_dir, "num_utils.npz"))
+    y = num_utils.sigmoid(g["sig_x"])
+    assert y.shape == g["sig_x"].shape and y.dtype == np.float64
+    np.testing.assert_allclose(y, g["sig_y"], rtol=0, atol=2e-7)
+    assert np.isfinite(y).all()                                    # the large-|x| edge cases saturate, no NaN
+    for i in range(4):
+        y = num_utils.softmax(g["sm_x%d" % i])
+        np.testing.assert_allclose(y, g["sm_y%d" % i], rtol=0, atol=2e-7)
+        assert abs(y.sum() - 1.0) < 1e-5
+    with pytest.raises(ValueError):
+        num_utils.softmax(np.zeros((2, 3)))
+    g = np.load(os.path.join(golden_dir, "basic_lstm.npz"))
+    for tag in ("e40h128_float64", "e40h128_float32", "e256h256_float32"):
+        cell = BasicLSTM(g[tag + "_w"], g[tag + "_b"])
+        c, h = cell(g[tag + "_x"], (g[tag + "_c"], g[tag + "_h"]))
+        assert c.shape == g[tag + "_new_c"].shape and c.dtype == g[tag + "_x"].dtype
+        np.testing.assert_allclose(c, g[tag + "_new_c"], rtol=0, atol=3e-6)
+        np.testing.assert_allclose(h, g[tag + "_new_h"], rtol=0, atol=3e-6)
+    with pytest.raises(ValueError):
+        cell(np.zeros(7, np.float32), (g[tag + "_c"], g[tag + "_h"]))
