@@ -120,6 +120,33 @@ __global__ __launch_bounds__(256) void softmax1d_kernel(const float* x, float* y
     for (int i = threadIdx.x; i < n; i += 256) y[i] = expf(x[i] - m) / s;
 }
 
+// Pyramid time reduction (encoder.py:94-119) as a standalone copy for callers whose layer output is NOT already
+// laid out [B, T_pad, F] with T_pad divisible by skip (inside Encoder it is a view: the recurrent kernel writes the
+// zero pad frame itself).  y[b, t', s*F + f] = x[b, t'*skip + s, f], zero where t'*skip + s >= T.  Row-contiguous in
+// both directions: each thread moves one float4 (or one float when F % 4 != 0), consecutive lanes consecutive addresses.
+template <int VEC>
+__global__ __launch_bounds__(256) void pyramid_kernel(const float* x, float* y, int B, int T, int F, int skip, int Tp, int bwd) {
+    const size_t rowlen = (size_t)F / VEC;                         // elements (of VEC floats) per input frame
+    const size_t total = (size_t)B * Tp * skip * rowlen;           // over the PADDED frames
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const size_t e = i % rowlen, frame = i / rowlen;               // frame index in [B][Tp*skip]
+    const size_t b = frame / ((size_t)Tp * skip), t = frame % ((size_t)Tp * skip);
+    const size_t yi = (frame * rowlen + e) * VEC;                   // y is [B][Tp][skip*F] == [B][Tp*skip][F] flat
+    const size_t xi = ((b * T + t) * rowlen + e) * VEC;
+    if (VEC == 4) {
+        if (!bwd) *reinterpret_cast<float4*>(y + yi) = t < (size_t)T ? *reinterpret_cast<const float4*>(x + xi) : make_float4(0.f, 0.f, 0.f, 0.f);
+        else if (t < (size_t)T) *reinterpret_cast<float4*>(y + xi) = *reinterpret_cast<const float4*>(x + yi);
+    } else {
+        if (!bwd) y[yi] = t < (size_t)T ? x[xi] : 0.f;
+        else if (t < (size_t)T) y[xi] = x[yi];
+    }
+}
+__global__ __launch_bounds__(256) void ceil_div_len_kernel(const int* len_in, int* len_out, int B, int skip) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b < B) len_out[b] = (len_in[b] + skip - 1) / skip;         // ceil (encoder.py:117-118)
+}
+
 }  // namespace asr
 
 extern "C" int asr_colsum_f32(void* stream, const float* x, int ldx, int M, int N, float* out, int accumulate) {
@@ -189,6 +216,37 @@ extern "C" int asr_sigmoid_f32(void* stream, const float* x, float* y, size_t n)
 extern "C" int asr_softmax_f32(void* stream, const float* x, float* y, int n) {
     if (!x || !y || n <= 0) return ASR_EINVAL;
     hipLaunchKernelGGL(asr::softmax1d_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), x, y, n);
+    ASR_CHECK_LAUNCH();
+    return ASR_OK;
+}
+
+
+// y [B, Tp, skip*F] with Tp = ceil(T / skip); len_out[b] = ceil(len_in[b] / skip) (either may be NULL).
+extern "C" int asr_pyramid_reduce_fwd(void* stream, const float* x, const int* len_in, float* y, int* len_out,
+                                      int B, int T, int F, int skip) {
+    if (!x || !y || B <= 0 || T <= 0 || F <= 0 || skip <= 0) return ASR_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int Tp = (T + skip - 1) / skip;
+    const bool v4 = F % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
+    const size_t total = (size_t)B * Tp * skip * (v4 ? F / 4 : F);
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    if (v4) hipLaunchKernelGGL(asr::pyramid_kernel<4>, dim3(grid), dim3(256), 0, s, x, y, B, T, F, skip, Tp, 0);
+    else hipLaunchKernelGGL(asr::pyramid_kernel<1>, dim3(grid), dim3(256), 0, s, x, y, B, T, F, skip, Tp, 0);
+    if (len_in && len_out) hipLaunchKernelGGL(asr::ceil_div_len_kernel, dim3((B + 255) / 256), dim3(256), 0, s, len_in, len_out, B, skip);
+    ASR_CHECK_LAUNCH();
+    return ASR_OK;
+}
+
+// dx [B, T, F] = the un-padded frames of dy [B, Tp, skip*F] (the gradient of the zero pad is dropped).
+extern "C" int asr_pyramid_reduce_bwd(void* stream, const float* dy, float* dx, int B, int T, int F, int skip) {
+    if (!dy || !dx || B <= 0 || T <= 0 || F <= 0 || skip <= 0) return ASR_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int Tp = (T + skip - 1) / skip;
+    const bool v4 = F % 4 == 0 && ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0;
+    const size_t total = (size_t)B * Tp * skip * (v4 ? F / 4 : F);
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    if (v4) hipLaunchKernelGGL(asr::pyramid_kernel<4>, dim3(grid), dim3(256), 0, s, dy, dx, B, T, F, skip, Tp, 1);
+    else hipLaunchKernelGGL(asr::pyramid_kernel<1>, dim3(grid), dim3(256), 0, s, dy, dx, B, T, F, skip, Tp, 1);
     ASR_CHECK_LAUNCH();
     return ASR_OK;
 }

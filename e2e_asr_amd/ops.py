@@ -406,6 +406,31 @@ def attn_decoder_bwd(wt, gt, ws, enc, enc_len, dlogits, denc, keep_lm=1.0, seed=
     return bw
 
 
+def pyramid_reduce(x, seq_len=None, skip=2):
+    """encoder.py:94-119 as a standalone kernel: x [B,T,F] -> ([B,ceil(T/skip),skip*F], ceil(len/skip)); frames past T
+    are zeros.  (Encoder itself never copies: its layer outputs are already in this layout.)"""
+    _f32(x, "x")
+    B, T, F = x.shape
+    Tp = (T + skip - 1) // skip
+    y = torch.empty((B, Tp, skip * F), device=x.device, dtype=torch.float32)
+    lo = None
+    if seq_len is not None:
+        _i32(seq_len, "seq_len")
+        lo = torch.empty_like(seq_len)
+    _check(_lib.lib().asr_pyramid_reduce_fwd(_stream(), _p(x), _p(seq_len), _p(y), _p(lo), B, T, F, skip), "asr_pyramid_reduce_fwd")
+    return (y, lo) if seq_len is not None else y
+
+
+def pyramid_reduce_bwd(dy, T, skip=2):
+    """Gradient of pyramid_reduce w.r.t. x: dy [B,Tp,skip*F] -> dx [B,T,F]."""
+    _f32(dy, "dy")
+    B, Tp, SF = dy.shape
+    F = SF // skip
+    dx = torch.empty((B, T, F), device=dy.device, dtype=torch.float32)
+    _check(_lib.lib().asr_pyramid_reduce_bwd(_stream(), _p(dy), _p(dx), B, T, F, skip), "asr_pyramid_reduce_bwd")
+    return dx
+
+
 def set_gemm_precision(dtype):
     """"f32" (default, exact) or "bf16": bf16 MFMA operands with fp32 accumulation for the whole-tile GEMMs
     (BASELINE config 3).  Process-wide."""

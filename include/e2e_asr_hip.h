@@ -74,6 +74,13 @@ int asr_linear_wt_fwd(void* stream, const float* x, int ldx, int K, const float*
                       float* out, int ldo, int M, int N, int accumulate);
 
 /* out[N] (+)= column sums of x[M,N] (bias gradients); fixed-order, reproducible. */
+/* Pyramid time reduction, encoder.py:94-119 (_get_pyramid_input): x [B,T,F] -> y [B,ceil(T/skip),skip*F], frames past T
+ * are zeros (the reference pads when max(len) % skip != 0: pass T = max(len)); len_out = ceil(len_in / skip).  Inside
+ * Encoder this is a view (the recurrent kernel writes fw|bw and the zero pad frame into the fused layout); the
+ * standalone coalesced copy serves callers with their own layouts.  _bwd scatters dy back to the T un-padded frames. */
+int asr_pyramid_reduce_fwd(void* stream, const float* x, const int* len_in, float* y, int* len_out,
+                           int B, int T, int F, int skip);
+int asr_pyramid_reduce_bwd(void* stream, const float* dy, float* dx, int B, int T, int F, int skip);
 /* num_utils.py:6-14: y = 1/(1+exp(-x)) elementwise; y = softmax(x) over a 1-D vector (max-shifted). */
 int asr_sigmoid_f32(void* stream, const float* x, float* y, size_t n);
 int asr_softmax_f32(void* stream, const float* x, float* y, int n);

@@ -335,3 +335,21 @@ def test_num_utils_and_basic_lstm_dropins_vs_reference_golden(golden_dir):
         np.testing.assert_allclose(h, g[tag + "_new_h"], rtol=0, atol=3e-6)
     with pytest.raises(ValueError):
         cell(np.zeros(7, np.float32), (g[tag + "_c"], g[tag + "_h"]))
+
+
+@pytest.mark.parametrize("B,T,F,skip", [(3, 7, 8, 2), (2, 8, 6, 2), (4, 37, 512, 2), (2, 10, 5, 3), (1, 1, 4, 2)])
+def test_pyramid_reduce_kernel_vs_oracle(B, T, F, skip):
+    """Standalone pyramid time reduction (encoder.py:94-119): odd and even T (zero pad frame), F % 4 != 0 (scalar
+    path), skip 3, and its gradient (adjoint identity <y, P x> = <P^T y, x>)."""
+    from e2e_asr_amd import ops
+    rng = np.random.default_rng(B * 100 + T)
+    x = rng.standard_normal((B, T, F)).astype(np.float32)
+    lens = rng.integers(1, T + 1, B); lens[0] = T
+    y, lo = ops.pyramid_reduce(torch.tensor(x, device="cuda:0"), torch.tensor(lens, dtype=torch.int32, device="cuda:0"), skip)
+    ref, ref_len = O.pyramid(x, lens, skip)
+    np.testing.assert_array_equal(y.cpu().numpy(), ref)
+    np.testing.assert_array_equal(lo.cpu().numpy(), ref_len)
+    dy = rng.standard_normal(ref.shape).astype(np.float32)
+    dx = ops.pyramid_reduce_bwd(torch.tensor(dy, device="cuda:0"), T, skip).cpu().numpy()
+    np.testing.assert_array_equal(dx, dy.reshape(B, -1, F)[:, :T])
+    assert abs(float((dy * ref).sum()) - float((dx * x).sum())) < 1e-3 * (1 + abs(float((dy * ref).sum())))
