@@ -76,19 +76,22 @@ __device__ __forceinline__ float wave_allreduce_max(float v) {
 // protocol; if all G ids are equal the group's granules may be published with PLAIN stores: the line
 // then stays in that XCD's L2, where the peers' L1-bypassing sc1 loads find it (measured -12 % per
 // recurrent step), instead of being written through to the fabric.  Any other placement keeps sc1.
-__device__ __forceinline__ bool group_shares_xcd(u64* slots, int G, int mem, int tid, int* err, int* lds_flag = nullptr) {
+__device__ __forceinline__ bool group_shares_xcd(u64* slots, int G, int mem, int tid, int* err, int* lds_flag = nullptr,
+                                                 uint32_t epoch = 0) {
+    // epoch: launches that share zeroed-once slots (segments of one decoder call) use distinct tags
+    const u64 tagv = 0xA5A50000ull + (epoch & 0xFFFFu);
     __shared__ int s_same_static;
     int* s_same_p = lds_flag ? lds_flag : &s_same_static;   // kernels with dynamic LDS pass their own word (G17)
 #define s_same (*s_same_p)
     if (tid == 0) {
         const uint32_t xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 0xF;   // HW_REG_XCC_ID[3:0]
-        __hip_atomic_store(slots + mem, (0xA5A50000ull << 32) | xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(slots + mem, (tagv << 32) | xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         bool same = true;
         long long t0 = wall_clock64();
         for (int m = 0; m < G && same; ++m) {
             for (;;) {
                 const u64 x = __hip_atomic_load(slots + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((x >> 32) == 0xA5A50000ull) { same = ((uint32_t)x == xcc); break; }
+                if ((x >> 32) == tagv) { same = ((uint32_t)x == xcc); break; }
                 if (wall_clock64() - t0 > 200000000LL) { *err = 1; same = false; break; }
             }
         }

@@ -101,15 +101,21 @@ extern "C" int asr_attn_decoder_fwd(void* stream, const asr_dec_weights* w, cons
             while (t1 < T && !feedback(t1)) ++t1;
             t1 = t1 < T ? t1 + 1 : T;                       // the feedback step closes the segment
             // side stream: LM cells of the segment (they need the token produced by the previous segment)
-            if (feedback(t0 - 1) && hipStreamWaitEvent(ss, e_tok, 0) != hipSuccess) return ASR_ELAUNCH;
             if (lm_chain) {
+                // one recurrent launch per segment, on the MAIN stream: the segment's LM needs the token the previous
+                // segment produced and its attention chain needs this LM output, so a second stream would only add two
+                // cross-queue hand-overs (~14 us each) per segment; only the hoisted x.K_x product ran on the side stream
                 const size_t o0 = (size_t)t0 * B;
+                if (t0 == 0) {
+                    hipEvent_t e_pre = asr::next_event();
+                    if (hipEventRecord(e_pre, ss) != hipSuccess || hipStreamWaitEvent(ms, e_pre, 0) != hipSuccess) return ASR_ELAUNCH;
+                }
                 if (feedback(t0 - 1) &&       // the sampled token of step t0: redo its rows of x.K_x + b
-                    (rc = asr_linear_fwd(side, w->embedding, E, E, ws->tok + o0, nullptr, 0, 0, w->lm_kernel, 4 * lmH, w->lm_bias,
+                    (rc = asr_linear_fwd(stream, w->embedding, E, E, ws->tok + o0, nullptr, 0, 0, w->lm_kernel, 4 * lmH, w->lm_bias,
                                          ws->lm_gates + o0 * 4 * lmH, 4 * lmH, B, 4 * lmH, nullptr, 0))) return rc;
                 float* st_in = ws->lm_state + (size_t)((seg + 1) & 1) * 2 * B * lmH;
                 float* st_out = ws->lm_state + (size_t)(seg & 1) * 2 * B * lmH;
-                if ((rc = asr_lstm_rec_fwd_tm(ss, ws->lm_gates + o0 * 4 * lmH, w->lm_kernel + (size_t)E * 4 * lmH, ws->lm_len,
+                if ((rc = asr_lstm_rec_fwd_tm(ms, ws->lm_gates + o0 * 4 * lmH, w->lm_kernel + (size_t)E * 4 * lmH, ws->lm_len,
                                               lm_out_buf + o0 * lmH, lmH, ws->lm_act + o0 * lmH * 8, ws->lm_hprev + o0 * lmH,
                                               t0 ? st_in : nullptr, t0 ? st_in + (size_t)B * lmH : nullptr, st_out,
                                               st_out + (size_t)B * lmH, ws->lm_hx, ws->err, B, t1 - t0, lmH, t0, keep_lm, seed)))
@@ -117,13 +123,13 @@ extern "C" int asr_attn_decoder_fwd(void* stream, const asr_dec_weights* w, cons
                 if (w->simple_w) {
                     const int rows = (t1 - t0) * B;
                     if (rows <= 512) {
-                        if ((rc = asr_linear_fwd(side, lm_out_buf + o0 * lmH, lmH, lmH, nullptr, nullptr, 0, 0, w->simple_w, H,
+                        if ((rc = asr_linear_fwd(stream, lm_out_buf + o0 * lmH, lmH, lmH, nullptr, nullptr, 0, 0, w->simple_w, H,
                                                  w->simple_b, ws->sp + o0 * H, H, rows, H, nullptr, 0))) return rc;
-                    } else if ((rc = asr_gemm_f32(side, 0, 0, rows, H, lmH, lm_out_buf + o0 * lmH, lmH, w->simple_w, H,
+                    } else if ((rc = asr_gemm_f32(stream, 0, 0, rows, H, lmH, lm_out_buf + o0 * lmH, lmH, w->simple_w, H,
                                                   ws->sp + o0 * H, H, w->simple_b, 0))) return rc;
                 }
                 ++seg;
-            }
+            } else if (feedback(t0 - 1) && hipStreamWaitEvent(ss, e_tok, 0) != hipSuccess) return ASR_ELAUNCH;
             for (int i = t0; i < t1 && !lm_chain; ++i) {
                 const size_t o = (size_t)i * B;
                 const float* lm_hp = i ? ws->lm_h + (o - B) * lmH : ws->zeros;
@@ -140,8 +146,10 @@ extern "C" int asr_attn_decoder_fwd(void* stream, const asr_dec_weights* w, cons
                         return rc;
                 }
             }
-            hipEvent_t e_lm = asr::next_event();
-            if (hipEventRecord(e_lm, ss) != hipSuccess || hipStreamWaitEvent(ms, e_lm, 0) != hipSuccess) return ASR_ELAUNCH;
+            if (!lm_chain) {
+                hipEvent_t e_lm = asr::next_event();
+                if (hipEventRecord(e_lm, ss) != hipSuccess || hipStreamWaitEvent(ms, e_lm, 0) != hipSuccess) return ASR_ELAUNCH;
+            }
             const int rows = (t1 - t0) * B;
             const size_t o0 = (size_t)t0 * B;
             // preG = lm_out . WK[:P] + b'  -> the gates buffer (the chain kernel overwrites it with the

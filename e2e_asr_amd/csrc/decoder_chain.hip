@@ -122,7 +122,7 @@ __global__ __launch_bounds__(512) void decoder_chain_fwd_kernel(ChainArgs a) {
     constexpr int NS = R * KS, NQ = R * H, NY = R * A, NE = R * G * MAXTS;
     constexpr int NPAR = NS + NQ + NY + NE;
     u64* gbase = a.gx + (size_t)grp * 2 * NPAR;
-    const bool fast = group_shares_xcd(a.xcc_slots + (size_t)grp * 16, G, mem, tid, a.err, lds_flag);
+    const bool fast = group_shares_xcd(a.xcc_slots + (size_t)grp * 16, G, mem, tid, a.err, lds_flag, (uint32_t)a.t0);
 
     // ---- resident operands -----------------------------------------------------------------
     // cell matvec: DPP row -> (unit u = row % HS..., part): rows [0,16) take chunks 0..15, rows [16,32) chunks 16..31
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(512) void decoder_chain_fwd_kernel(ChainArgs a) {
     const int nsteps = a.t1 - a.t0;
     for (int s = 0; s < nsteps; ++s) {
         const int i = a.t0 + s;
-        const uint32_t ep = (uint32_t)(s + 1);
+        const uint32_t ep = (uint32_t)(a.t0 + s + 1);      // tags unique over the segments of one call (workspace zeroed once)
         u64* gpar = gbase + (size_t)(s & 1) * NPAR;
         u64* gS = gpar; u64* gQ = gpar + NS; u64* gY = gQ + NQ; u64* gE = gY + NY;
         if (wave7) {
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(512) void decoder_chain_fwd_kernel(ChainArgs a) {
                 for (int p = tid - 64; p < NS / 2; p += NPOLL) {
                     const int idx = 2 * p, r = idx / KS, k = idx % KS;
                     float v0 = 0.f, v1 = 0.f;
-                    if (r0 + r < a.B) chain_poll2(src + idx, (uint32_t)s, v0, v1, a.err);
+                    if (r0 + r < a.B) chain_poll2(src + idx, (uint32_t)(a.t0 + s), v0, v1, a.err);
                     *reinterpret_cast<float2*>(sl + (r * 32 + k / KC) * KCP + (k % KC)) = make_float2(v0, v1);
                 }
             }
@@ -458,7 +458,7 @@ int asr_decoder_chain_fwd(void* stream, float* gates, const float* wh, const flo
     // NOTE: all batch rows of a launch share the [T][B][.] row stride B, so chunking is by group range only
     if (B > 32) return ASR_EUNSUPPORTED;
     const size_t bytes = asr_decoder_chain_ws_bytes(B, D, A, H);
-    if (hipMemsetAsync(ws, 0, bytes, s) != hipSuccess) return ASR_ELAUNCH;
+    if (t0 == 0 && hipMemsetAsync(ws, 0, bytes, s) != hipSuccess) return ASR_ELAUNCH;     // once per sequence
     ChainArgs a;
     a.gates = gates; a.wh = wh; a.wc = wc; a.w_att = w_att; a.b_att = b_att; a.v = v; a.hf = hf; a.enc = enc;
     a.enc_len = enc_len; a.dec_c = dec_c; a.dec_h = dec_h; a.alpha = alpha; a.ctx = ctx; a.y = y;

@@ -47,6 +47,7 @@ struct LstmRecArgs {
     // dropout counter = (boff+b)*dsb + (toff+t)*dst.  Batch-major encoder layer: sb = T, st = 1, osb = Tout,
     // ost = 1, ldo = ND*H, dsb = Tout, dst = 1.  Time-major (decoder LM chain): sb = 1, st = B, ...
     int sb, st, osb, ost, ldo, dsb, dst, toff;
+    int ep0;               // granule tag base: tags are ep0 + step + 1 (segments of one call share a workspace zeroed once)
     const float* h0; const float* c0;      // [B][H] initial state (ND = 1) or nullptr = zeros
     float* h_last; float* c_last;          // [B][H] final state (ND = 1) or nullptr
 };
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(16 * HS) void lstm_rec_fwd_kernel(LstmRecArgs a) {
     const bool has_init = a.h0 != nullptr;           // uniform
     if (has_init && cell && cb < a.B) { h = a.h0[(size_t)cb * H + cj]; c = a.c0[(size_t)cb * H + cj]; }
     u64* hxg = a.hx + (size_t)grp * 2 * R * H;
-    const bool fast = group_shares_xcd(a.xcc_slots + (size_t)grp * 16, G, mem, tid, a.err);
+    const bool fast = group_shares_xcd(a.xcc_slots + (size_t)grp * 16, G, mem, tid, a.err, nullptr, (uint32_t)a.ep0);
     // x.Kx+b of the NEXT step is loaded at the end of each cell phase (software pipelining): the
     // registers are loop-carried, never re-initialised, so the loop head needs no vmcnt wait and the
     // load latency hides under the next step's exchange.
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(16 * HS) void lstm_rec_fwd_kernel(LstmRecArgs a) {
                     const int r = idx / H, k = idx % H;
                     float v0 = 0.f, v1 = 0.f;
                     if (r0 + r < a.B) {
-                        if (s > 0) poll_granule2(src + idx, (uint32_t)s, v0, v1, a.err);
+                        if (s > 0) poll_granule2(src + idx, (uint32_t)(a.ep0 + s), v0, v1, a.err);
                         else { v0 = a.h0[(size_t)(r0 + r) * H + k]; v1 = a.h0[(size_t)(r0 + r) * H + k + 1]; }
                     }
                     *reinterpret_cast<float2*>(hl + (r * 16 + k / KPT) * CS + (k % KPT)) = make_float2(v0, v1);
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(16 * HS) void lstm_rec_fwd_kernel(LstmRecArgs a) {
             // every other workgroup of the group.  ONE 8-byte sc1 store.
             if (cb < a.B && s + 1 < S) {
                 u64* dst = hxg + ((size_t)(s & 1) * R + cr) * H + cj;
-                const u64 gv = ((u64)(uint32_t)(s + 1) << 32) | __float_as_uint(h);
+                const u64 gv = ((u64)(uint32_t)(a.ep0 + s + 1) << 32) | __float_as_uint(h);
                 if (fast) asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(dst), "v"(gv) : "memory");   // stays in this XCD's L2
                 else __hip_atomic_store(dst, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                 // write-through (sc1)
             }
@@ -366,7 +367,7 @@ extern "C" int asr_lstm_layer_fwd(void* stream, const float* x, int B, int T, in
     a.xcc_slots = reinterpret_cast<u64*>(static_cast<char*>(hx_ws) + lstm_hx_bytes(B, H, ndir));
     a.B = B; a.T = T; a.Tout = Tout; a.ND = ndir; a.keep = keep_prob; a.seed = seed;
     a.sb = T; a.st = 1; a.osb = Tout; a.ost = 1; a.ldo = ndir * H; a.dsb = Tout; a.dst = 1; a.toff = 0;
-    a.h0 = a.c0 = nullptr; a.h_last = a.c_last = nullptr;
+    a.h0 = a.c0 = nullptr; a.h_last = a.c_last = nullptr; a.ep0 = 0;
     const int R = asr_lstm_pick_rows(B, ndir, H / 32);
     // batches too large for one resident grid run as consecutive launches over row ranges
     const int max_groups = asr_lstm_max_wgs() / (H / 32) / ndir;
@@ -413,14 +414,15 @@ int asr_lstm_rec_fwd_tm(hipStream_t s, const float* gates, const float* kh, cons
                         void* hx_ws, int* err, int B, int T, int H, int toff, float keep, unsigned seed) {
     using namespace asr;
     if (!asr_lstm_tm_supported(B, H)) return ASR_EUNSUPPORTED;
-    if (hipMemsetAsync(hx_ws, 0, asr_lstm_ws_bytes(B, H, 1), s) != hipSuccess) return ASR_ELAUNCH;
+    // the workspace is zeroed once per sequence (first segment); later segments use fresh granule tags (ep0 = toff)
+    if (toff == 0 && hipMemsetAsync(hx_ws, 0, asr_lstm_ws_bytes(B, H, 1), s) != hipSuccess) return ASR_ELAUNCH;
     LstmRecArgs a;
     a.gates = gates; a.act = act; a.kh[0] = kh; a.kh[1] = nullptr; a.len = full_len; a.out = out; a.dbg = nullptr;
     a.hprev = hprev; a.hx = static_cast<u64*>(hx_ws); a.err = err;
     a.xcc_slots = reinterpret_cast<u64*>(static_cast<char*>(hx_ws) + lstm_hx_bytes(B, H, 1));
     a.B = B; a.T = T; a.Tout = T; a.ND = 1; a.boff = 0; a.keep = keep; a.seed = seed;
     a.sb = 1; a.st = B; a.osb = 1; a.ost = B; a.ldo = ldo; a.dsb = 1; a.dst = B; a.toff = toff;
-    a.h0 = h0; a.c0 = c0; a.h_last = h_last; a.c_last = c_last;
+    a.h0 = h0; a.c0 = c0; a.h_last = h_last; a.c_last = c_last; a.ep0 = toff;
     const int R = asr_lstm_pick_rows(B, 1, H / 32);
     switch (H) {
         case 64: return launch_rec_h<64>(s, a, R);
