@@ -353,6 +353,20 @@ extern "C" int asr_attn_decoder_bwd(void* stream, const asr_dec_weights* w, cons
     // ---- hoisted data gradients: dP = dLogits.W_out^T ; dQC = dP.W_ap^T
     if ((rc = asr_gemm_f32(stream, 0, 1, TB, H, V, dlogits, V, w->out_w, V, bw->dP, H, nullptr, 0))) return rc;
     if ((rc = asr_gemm_f32(stream, 0, 1, TB, H + D, H, bw->dP, H, w->ap_w, H, bw->dQC, H + D, nullptr, 0))) return rc;
+    {   // the weight gradients that need only dLogits / dP run on the side stream UNDER the (latency-bound) chain below
+        hipEvent_t e_pre = next_event();
+        if (hipEventRecord(e_pre, s) != hipSuccess || hipStreamWaitEvent(ss, e_pre, 0) != hipSuccess) return ASR_ELAUNCH;
+        auto wg0 = [&](int M, int N, int K, const float* Ap, int lda, const float* Bp, int ldb, float* C) {
+            return asr_gemm_f32(side, 1, 0, M, N, K, Ap, lda, Bp, ldb, C, N, nullptr, 1);
+        };
+        float* gw0 = const_cast<float*>(g->out_w);                       // OutputProjection
+        if ((rc = wg0(H, V, TB, ws->p, H, dlogits, V, gw0))) return rc;
+        if ((rc = asr_colsum_f32(side, dlogits, V, TB, V, const_cast<float*>(g->out_b), 1))) return rc;
+        gw0 = const_cast<float*>(g->ap_w);                               // AttnProjection: rows [q | ctx]
+        if ((rc = wg0(H, H, TB, ws->dec_c, H, bw->dP, H, gw0))) return rc;
+        if ((rc = wg0(D, H, TB, ws->ctx, D, bw->dP, H, gw0 + (size_t)H * H))) return rc;
+        if ((rc = asr_colsum_f32(side, bw->dP, H, TB, H, const_cast<float*>(g->ap_b), 1))) return rc;
+    }
     if (hipMemsetAsync(bw->dc_dec, 0, sizeof(float) * B * H, s) != hipSuccess) return ASR_ELAUNCH;
     if (hipMemsetAsync(bw->dhf, 0, sizeof(float) * (size_t)B * Te * A, s) != hipSuccess) return ASR_ELAUNCH;
     if (hipMemsetAsync(bw->dv_part, 0, sizeof(float) * B * A, s) != hipSuccess) return ASR_ELAUNCH;
@@ -464,15 +478,7 @@ extern "C" int asr_attn_decoder_bwd(void* stream, const asr_dec_weights* w, cons
         return asr_gemm_f32(stream_w, 1, 0, M, N, K, Ap, lda, Bp, ldb, C, N, nullptr, 1);
     };
     float* gw = nullptr;
-    // OutputProjection
-    gw = const_cast<float*>(g->out_w);
-    if ((rc = wgrad(H, V, TB, ws->p, H, dlogits, V, gw))) return rc;
-    if ((rc = asr_colsum_f32(stream_w, dlogits, V, TB, V, const_cast<float*>(g->out_b), 1))) return rc;
-    // AttnProjection: rows [q | ctx]
-    gw = const_cast<float*>(g->ap_w);
-    if ((rc = wgrad(H, H, TB, ws->dec_c, H, bw->dP, H, gw))) return rc;
-    if ((rc = wgrad(D, H, TB, ws->ctx, D, bw->dP, H, gw + (size_t)H * H))) return rc;
-    if ((rc = asr_colsum_f32(stream_w, bw->dP, H, TB, H, const_cast<float*>(g->ap_b), 1))) return rc;
+    // (OutputProjection / AttnProjection gradients were issued before the chain, see above)
     // Attention query projection, AttnV
     if ((rc = wgrad(H, A, TB, ws->dec_c, H, bw->dY, A, const_cast<float*>(g->attn_w)))) return rc;
     if ((rc = asr_colsum_f32(stream_w, bw->dY, A, TB, A, const_cast<float*>(g->attn_b), 1))) return rc;
