@@ -73,7 +73,7 @@ extern "C" int asr_attn_decoder_fwd(void* stream, const asr_dec_weights* w, cons
     // ---- persistent chain path: the per-step attention chain of a whole SEGMENT (steps up to and
     // including the next feedback step) runs in one launch of csrc/decoder_chain.hip
     const bool use_chain = mode != 1 && ws->chain_ws && ws->w2k && ws->err && ws->y && ws->dec_gates &&
-                           asr_decoder_chain_supported(B, Te, D, A, H) && B <= 32;
+                           asr_decoder_chain_supported(B, Te, D, A, H);
     if (use_chain) {
         // WK = W_inp . K_x  ([P+D,E].[E,4H]) and b' = b_inp . K_x + b_dec: InputProjection folded into the
         // outer cell, so that gates_i = lm_out_i . WK[:P] + ctx_{i-1} . WK[P:] + h_{i-1} . K_h + b'

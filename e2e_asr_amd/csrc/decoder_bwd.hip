@@ -372,7 +372,7 @@ extern "C" int asr_attn_decoder_bwd(void* stream, const asr_dec_weights* w, cons
     if (hipMemsetAsync(bw->dv_part, 0, sizeof(float) * B * A, s) != hipSuccess) return ASR_ELAUNCH;
     const int ldXH = E + H, ldLC = P + D, ldEH = E + lmH;
     // ---- persistent chain (csrc/decoder_chain_bwd.hip): the whole reverse-time recursion in one launch
-    const bool use_chain = bw->chain_ws && bw->wc && ws->y && ws->err && B <= 32 &&
+    const bool use_chain = bw->chain_ws && bw->wc && ws->y && ws->err &&
                            asr_decoder_chain_supported(B, Te, D, A, H);
     int dv_rows = B;
     if (use_chain) {
@@ -420,7 +420,7 @@ extern "C" int asr_attn_decoder_bwd(void* stream, const asr_dec_weights* w, cons
     if (hipMemsetAsync(bw->dc_lm, 0, sizeof(float) * B * lmH, ss) != hipSuccess) return ASR_ELAUNCH;
     // persistent LM chain (the forward ran csrc/lstm.hip time-major under the same predicate): one BPTT launch
     // over all steps (dG overwrites lm_gates), then demb = dG . K_x^T for all steps as one GEMM
-    const bool lm_chain = ws->chain_ws && ws->w2k && ws->err && ws->y && B <= 32 && asr_decoder_chain_supported(B, Te, D, A, H) &&
+    const bool lm_chain = ws->chain_ws && ws->w2k && ws->err && ws->y && asr_decoder_chain_supported(B, Te, D, A, H) &&
                           ws->lm_act && ws->lm_hprev && ws->lm_state && ws->lm_len && ws->lm_hx && bw->lm_hx &&
                           asr_decoder_lm_chain_supported(B, lmH);
     if (lm_chain) {

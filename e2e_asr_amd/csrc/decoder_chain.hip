@@ -19,6 +19,7 @@
 // wave 0 is the cell/publisher wave (owns every global store, never polls), waves 1-7 poll.
 // The same-XCD plain-store fast path is used when the group's XCC ids agree.
 #include "common.h"
+#include <algorithm>
 #include <cstdlib>
 
 extern "C" int asr_decoder_chain_supported(int B, int Te, int D, int A, int H);
@@ -39,6 +40,7 @@ struct ChainArgs {
     u64* xcc_slots;          // [groups][16]
     int* err;
     int B, Te, t0, t1;
+    int g0, ng;              // this launch covers groups [g0, g0 + ng) of the batch (<= 16 groups = 256 workgroups)
 };
 
 typedef unsigned int u32x4c __attribute__((ext_vector_type(4)));
@@ -103,10 +105,11 @@ __global__ __launch_bounds__(512) void decoder_chain_fwd_kernel(ChainArgs a) {
     __builtin_amdgcn_s_setprio(3);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kq = lane & 15, row = tid >> 4;       // 32 DPP rows
-    const int NG = (a.B + R - 1) / R;
+    const int NG = a.ng;
     int grp, mem;
     if ((NG & 7) == 0) { mem = (blockIdx.x >> 3) % G; grp = (blockIdx.x & 7) + 8 * (blockIdx.x / (8 * G)); }
     else { grp = blockIdx.x / G; mem = blockIdx.x % G; }
+    grp += a.g0;
     const int r0 = grp * R;
     const bool wave0 = __builtin_amdgcn_readfirstlane(tid) < 64;
     // wave 7 neither polls nor stores: it fetches the next step's preG one step ahead (its loads never wait
@@ -435,7 +438,7 @@ extern "C" size_t asr_decoder_chain_ws_bytes(int B, int D, int A, int H) {
 template <int H, int D, int A>
 static int chain_launch(hipStream_t s, asr::ChainArgs& a, int Te) {
     constexpr int R = 2, G = 16;
-    const int groups = (a.B + R - 1) / R;
+    const int groups = a.ng;
     constexpr int KSP = (H + D + 127) / 128 * 128, KCP = KSP / 32 + 4, QP = (H + 127) / 128 * 128;
     const size_t lds = sizeof(float) * (4 + (size_t)R * 32 * KCP + 2 * (H / G) * R * 4 + R * QP + 2 * (A / G) * R + 4 + R * A +
                                         R * G * 16 + 32 + 8 * R * (D / G) + R * (H / G) * 4 + A + R * 16 * A + (size_t)R * Te * (D / G));
@@ -446,7 +449,8 @@ static int chain_launch(hipStream_t s, asr::ChainArgs& a, int Te) {
     return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
 }
 
-// Steps [t0,t1) of the decoder chain for B <= 32 utterances per launch (larger batches: chunks).
+// Steps [t0,t1) of the decoder chain; 16 groups (32 utterances) per launch, larger batches run as consecutive
+// launches over group ranges (each range has its own granule area, so no re-zeroing in between).
 // gates holds preG for those steps on entry.  ws: asr_decoder_chain_ws_bytes().
 int asr_decoder_chain_fwd(void* stream, float* gates, const float* wh, const float* wc, const float* w_att,
                           const float* b_att, const float* v, const float* hf, const float* enc, const int* enc_len,
@@ -456,7 +460,6 @@ int asr_decoder_chain_fwd(void* stream, float* gates, const float* wh, const flo
     if (!asr_decoder_chain_supported(B, Te, D, A, H) || t1 <= t0) return ASR_EUNSUPPORTED;
     hipStream_t s = static_cast<hipStream_t>(stream);
     // NOTE: all batch rows of a launch share the [T][B][.] row stride B, so chunking is by group range only
-    if (B > 32) return ASR_EUNSUPPORTED;
     const size_t bytes = asr_decoder_chain_ws_bytes(B, D, A, H);
     if (t0 == 0 && hipMemsetAsync(ws, 0, bytes, s) != hipSuccess) return ASR_ELAUNCH;     // once per sequence
     ChainArgs a;
@@ -467,6 +470,10 @@ int asr_decoder_chain_fwd(void* stream, float* gates, const float* wh, const flo
     const size_t npar = 2 * (size_t)(H + D) + 2 * (size_t)H + 2 * (size_t)A + 2 * 16 * 16;
     a.xcc_slots = a.gx + groups * 2 * npar;
     a.err = err; a.B = B; a.Te = Te; a.t0 = t0; a.t1 = t1;
-    if (H == 256) return chain_launch<256, 512, 128>(s, a, Te);
-    return chain_launch<64, 128, 16>(s, a, Te);
+    for (int g0 = 0; g0 < (int)groups; g0 += 16) {
+        a.g0 = g0; a.ng = std::min<int>(16, (int)groups - g0);
+        const int rc = (H == 256) ? chain_launch<256, 512, 128>(s, a, Te) : chain_launch<64, 128, 16>(s, a, Te);
+        if (rc) return rc;
+    }
+    return ASR_OK;
 }

@@ -45,6 +45,7 @@ struct ChainBwdArgs {
     float* dv_part;            // [groups*16][A]
     u64* gx; u64* xcc_slots; int* err;
     int B, Te, T;
+    int g0, ng;                // groups [g0, g0 + ng) of the batch in this launch
 };
 
 typedef unsigned int u32x4d __attribute__((ext_vector_type(4)));
@@ -140,10 +141,11 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
     __builtin_amdgcn_s_setprio(3);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kq = lane & 15, row = tid >> 4;
-    const int NG = (a.B + R - 1) / R;
+    const int NG = a.ng;
     int grp, mem;
     if ((NG & 7) == 0) { mem = (blockIdx.x >> 3) % G; grp = (blockIdx.x & 7) + 8 * (blockIdx.x / (8 * G)); }
     else { grp = blockIdx.x / G; mem = blockIdx.x % G; }
+    grp += a.g0;
     const int r0 = grp * R;
     const bool wave0 = __builtin_amdgcn_readfirstlane(tid) < 64;
     const bool wave1 = !wave0 && __builtin_amdgcn_readfirstlane(tid) < 128;     // the gathering wave
@@ -450,7 +452,7 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
     for (int aa = tid; aa < A; aa += NT) {
         float x = 0.f;
         for (int t = 0; t < 32; ++t) x += dyrow[t * A + aa];
-        a.dv_part[(size_t)blockIdx.x * A + aa] = x;
+        a.dv_part[((size_t)grp * G + mem) * A + aa] = x;
     }
 }
 
@@ -465,7 +467,7 @@ extern "C" size_t asr_decoder_chain_bwd_ws_bytes(int B, int D, int A, int H) {
 template <int H, int D, int A>
 static int chain_bwd_launch(hipStream_t s, asr::ChainBwdArgs& a) {
     constexpr int R = 2, G = 16, HS = H / G, AS = A / G, DS = D / G, HS2 = (HS + 1) & ~1, AS2 = (AS + 1) & ~1;
-    const int groups = (a.B + R - 1) / R;
+    const int groups = a.ng;
     const size_t lds = sizeof(float) * (4 + R * DS + R * HS2 + R * G * 16 + 4 + R * 16 + R * A + 32 * A + R * A + R * AS2 +
                                         R * H + R * HS2 + R * 4 * HS + R * (H + D) + 2 * R * 16 * A + H * AS + A + (size_t)R * a.Te * DS +
                                         (size_t)R * (a.Te + 1) + 2 * R * DS + 7 * R * HS + 16);
@@ -482,7 +484,7 @@ int asr_decoder_chain_bwd(void* stream, float* gates, const float* dec_c, const 
                           const float* v, const float* hf, const float* enc, const int* enc_len, float* dY, float* dctx,
                           float* dhf, float* dv_part, void* ws, int* err, int B, int Te, int D, int A, int H, int T) {
     using namespace asr;
-    if (!asr_decoder_chain_supported(B, Te, D, A, H) || B > 32 || T <= 0) return ASR_EUNSUPPORTED;
+    if (!asr_decoder_chain_supported(B, Te, D, A, H) || T <= 0) return ASR_EUNSUPPORTED;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t bytes = asr_decoder_chain_bwd_ws_bytes(B, D, A, H);
     if (hipMemsetAsync(ws, 0, bytes, s) != hipSuccess) return ASR_ELAUNCH;
@@ -492,6 +494,11 @@ int asr_decoder_chain_bwd(void* stream, float* gates, const float* dec_c, const 
     a.dv_part = dv_part; a.gx = static_cast<u64*>(ws);
     a.xcc_slots = reinterpret_cast<u64*>(static_cast<char*>(ws) + bytes) - ((size_t)((B + 1) / 2) * 16);
     a.err = err; a.B = B; a.Te = Te; a.T = T;
-    if (H == 256) return chain_bwd_launch<256, 512, 128>(s, a);
-    return chain_bwd_launch<64, 128, 16>(s, a);
+    const int groups = (B + 1) / 2;
+    for (int g0 = 0; g0 < groups; g0 += 16) {          // 16 groups = 256 workgroups per launch
+        a.g0 = g0; a.ng = groups - g0 < 16 ? groups - g0 : 16;
+        const int rc = (H == 256) ? chain_bwd_launch<256, 512, 128>(s, a) : chain_bwd_launch<64, 128, 16>(s, a);
+        if (rc) return rc;
+    }
+    return ASR_OK;
 }

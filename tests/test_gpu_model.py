@@ -425,12 +425,13 @@ def test_decoder_chain_path_vs_oracle_and_autograd():
         assert err < 2e-3, (name, err)
 
 
-def test_decoder_chain_equals_launch_path_under_scheduled_sampling(monkeypatch):
+@pytest.mark.parametrize("nb", [6, 37])
+def test_decoder_chain_equals_launch_path_under_scheduled_sampling(monkeypatch, nb):
     """Scheduled sampling cuts the sequence into segments (one persistent launch each); the result
     must equal the per-step launch path: same sampled tokens, same logits, and the persistent backward
     chain (csrc/decoder_chain_bwd.hip) must give the per-step backward's gradients."""
     rng = np.random.default_rng(22)
-    b = _batch(rng, 6, 24, 20, 13, 50)
+    b = _batch(rng, nb, 24, 20, 13, 50)      # 37 utterances = 19 groups: two launches of the chain kernels (16 + 3 groups)
     outs = []
     for chain in ("1", "0"):
         monkeypatch.setenv("ASR_DEC_CHAIN", chain)
