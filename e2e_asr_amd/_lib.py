@@ -38,6 +38,15 @@ class DecBwdWs(C.Structure):
                                   "dv_part", "dctx", "emb_all", "chain_ws", "wc", "lm_hx")]
 
 
+class LmWeights(C.Structure):
+    _fields_ = [(n, vp) for n in ("embedding", "lstm_kernel", "lstm_bias", "simple_w", "simple_b", "out_w", "out_b")] + \
+               [(n, C.c_int) for n in ("E", "H", "P", "V")]
+
+
+class BeamState(C.Structure):
+    _fields_ = [(n, vp) for n in ("dc", "dh", "dlc", "dlh", "lc", "lh", "ctx")]
+
+
 class DecGrads(C.Structure):
     _fields_ = [(n, vp) for n in (
         "embedding", "attn_enc_w", "attn_v", "attn_w", "attn_b", "lm_kernel", "lm_bias",
@@ -84,6 +93,9 @@ SIGNATURES = {
     "asr_pyramid_reduce_bwd": (C.c_int, [vp, vp, vp] + [C.c_int] * 4),
     "asr_sigmoid_f32": (C.c_int, [vp, vp, vp, C.c_size_t]),
     "asr_softmax_f32": (C.c_int, [vp, vp, vp, C.c_int]),
+    "asr_beam_scratch_floats": (C.c_size_t, [C.c_int] * 5),
+    "asr_beam_step": (C.c_int, [vp] * 13),
+    "asr_beam_gather": (C.c_int, [vp, vp, C.c_int, vp, vp] + [C.c_int] * 4),
     "asr_set_gemm_precision": (C.c_int, [C.c_int]),
     "asr_get_gemm_precision": (C.c_int, []),
     "asr_decoder_chain_ws_bytes": (C.c_size_t, [C.c_int] * 4),

@@ -11,10 +11,12 @@ device logits, `np.argpartition` top-k per hypothesis and over the k*k continuat
 selection of the result (:336).  Token indices therefore equal the float64 oracle's unless two
 candidates tie within float32 logit resolution (~1e-6).
 """
+import ctypes as C
+
 import numpy as np
 import torch
 
-from . import data_utils, ops
+from . import _lib, data_utils, ops
 from .base_params import BaseParams, Bunch
 from .beam_entry import BeamEntry
 
@@ -107,36 +109,70 @@ class BeamSearch(BaseParams):
         return attention
 
     def top_k_setup_with_lm(self, encoder_hidden_states):
-        """beam_search.py:163-221, batched over hypotheses.  state = dict of device tensors with one
-        row per hypothesis: dec (c,h), dec_lm (c,h), lm (c,h), ctx."""
+        """beam_search.py:163-221, batched over the live hypotheses of the utterance: ONE library call per step
+        (`asr_beam_step`: ten stream-ordered launches) on pre-allocated state buffers, one H2D copy (tokens + parent
+        rows) and one D2H copy (both logit vectors) per step; scoring in float64 on the host as the reference does."""
         p, lp, sp = self.dec_params, self.lm_params, self.search_params
         attention = self.calc_attention(encoder_hidden_states)
+        enc = attention.enc
+        dev = self.device
+        L = _lib.lib()
+        kmax = max(1, int(sp.beam_size))
+        Te, D = enc.shape
+        H, A = p.attn_dec_w.shape
+        lmH, E, V = p.lm_lstm_w.shape[1] // 4, p.embedding.shape[1], p.out_w.shape[1]
+        extE, extH = lp.embedding.shape[1], lp.lstm_w.shape[1] // 4
+        extP = lp.simple_w.shape[1] if lp.simple_w is not None else extH
+        extV = lp.out_w.shape[1]
+        if extV != V:
+            raise ValueError("LM vocabulary (%d) differs from the decoder's (%d)" % (extV, V))
+        f = lambda *shape: torch.zeros(shape, device=dev, dtype=torch.float32)
+        widths = dict(dc=H, dh=H, dlc=lmH, dlh=lmH, lc=extH, lh=extH, ctx=D)
+        sets = [dict((n, f(kmax, w)) for n, w in widths.items()) for _ in range(2)]      # [0]: step input, [1]: step output
+        cst = [ops._dec_struct(_lib.BeamState, st) for st in sets]
+        cw = ops._dec_struct(_lib.DecWeights, dict(
+            embedding=p.embedding, attn_enc_w=p.attn_enc_w, attn_v=p.attn_v, attn_w=p.attn_dec_w, attn_b=p.attn_dec_b,
+            lm_kernel=p.lm_lstm_w, lm_bias=p.lm_lstm_b, dec_kernel=p.dec_lstm_w, dec_bias=p.dec_lstm_b,
+            inp_w=p.inp_w, inp_b=p.inp_b, ap_w=p.attn_proj_w, ap_b=p.attn_proj_b, out_w=p.out_w, out_b=p.out_b,
+            simple_w=p.simple_w, simple_b=p.simple_b))
+        clm = ops._dec_struct(_lib.LmWeights, dict(embedding=lp.embedding, lstm_kernel=lp.lstm_w, lstm_bias=lp.lstm_b,
+                                                  simple_w=lp.simple_w, simple_b=lp.simple_b, out_w=lp.out_w, out_b=lp.out_b))
+        clm.E, clm.H, clm.P, clm.V = extE, extH, extP, extV
+        hf = ops.gemm(enc, p.attn_enc_w)
+        ln = torch.tensor([Te], dtype=torch.int32, device=dev)
+        scratch = torch.empty(L.asr_beam_scratch_floats(kmax, Te, H, E, extP), device=dev, dtype=torch.float32)
+        logits = torch.empty((2, kmax, V), device=dev, dtype=torch.float32)
+        ints = torch.zeros(2 * kmax, dtype=torch.int32, device=dev)                     # [tokens | parent rows]
+        keep = (sets, hf, ln, scratch, logits, ints, enc)                                # owned by the closure
 
-        def get_top_k(tokens, state, beam_size=sp.beam_size):
-            tok = torch.as_tensor(np.asarray(tokens, dtype=np.int32)).to(self.device)
-            dlc, dlh = ops.lstm_cell(p.embedding, state["dlh"], state["dlc"], p.lm_lstm_w, p.lm_lstm_b, gather=tok)
-            o = dlh
-            if p.simple_w is not None:
-                o = ops.linear(o, p.simple_w, p.simple_b)
-            x_dec = ops.linear(o, p.inp_w, p.inp_b, x2=state["ctx"])                       # :188-189
-            dc, dh = ops.lstm_cell(x_dec, state["dh"], state["dc"], p.dec_lstm_w, p.dec_lstm_b)
-            ctx, _ = attention(dc)                                                        # :193 (query = c)
-            proj = ops.linear(dc, p.attn_proj_w, p.attn_proj_b, x2=ctx)
-            logits = ops.linear(proj, p.out_w, p.out_b)
-            lc, lh = ops.lstm_cell(lp.embedding, state["lh"], state["lc"], lp.lstm_w, lp.lstm_b, gather=tok)  # :200
-            lo = lh
-            if lp.simple_w is not None:
-                lo = ops.linear(lo, lp.simple_w, lp.simple_b)
-            logits_lm = ops.linear(lo, lp.out_w, lp.out_b)
-            both = torch.stack((logits, logits_lm)).cpu().numpy()                         # one D2H copy per step
+        def get_top_k(tokens, rows, beam_size=sp.beam_size):
+            """tokens: last token of each live hypothesis; rows: its parent's row in the previous step's output
+            (None at step 0: zero states).  -> per hypothesis (indices, model scores, scores)."""
+            k = len(tokens)
+            host = np.zeros(2 * kmax, np.int32)
+            host[:k] = tokens
+            if rows is not None:
+                host[kmax:kmax + k] = rows
+            ints.copy_(torch.from_numpy(host))
+            if rows is None:
+                for t in sets[0].values():
+                    t.zero_()
+            else:
+                ops._check(L.asr_beam_gather(ops._stream(), ops._p(ints[kmax:]), k, C.byref(cst[1]), C.byref(cst[0]),
+                                             H, lmH, extH, D), "asr_beam_gather")
+            cd = _lib.DecDims(k, Te, D, A, H, lmH, E, V, 1)
+            ops._check(L.asr_beam_step(ops._stream(), C.byref(cw), C.byref(clm), C.byref(cd), ops._p(hf), ops._p(enc), ops._p(ln),
+                                       ops._p(ints), C.byref(cst[0]), C.byref(cst[1]), ops._p(scratch),
+                                       ops._p(logits[0]), ops._p(logits[1])), "asr_beam_step")
+            both = logits[:, :k].cpu().numpy()                                            # one D2H copy per step
             comb = _log_softmax64(both[0]) + sp.lm_weight * _log_softmax64(both[1])       # :208
             score = comb + 0.0                                                            # :210-212
-            new_state = dict(dc=dc, dh=dh, dlc=dlc, dlh=dlh, lc=lc, lh=lh, ctx=ctx)
             out = []
-            for r in range(comb.shape[0]):
+            for r in range(k):
                 idx = np.argpartition(score[r], -beam_size)[-beam_size:]                  # :214
                 out.append((idx, comb[r][idx], score[r][idx]))
-            return out, new_state
+            return out
+        get_top_k.keep = keep
         return get_top_k
 
     def _zero_state(self, k, D):
@@ -154,7 +190,7 @@ class BeamSearch(BaseParams):
         k = sp.beam_size
         output_list, final_output_list = [], []
         # step 0 from the GO symbol and zero states (:232-266)
-        res, state = get_top_k([data_utils.GO_ID], self._zero_state(1, D), beam_size=k)
+        res = get_top_k([data_utils.GO_ID], None, beam_size=k)
         idx, mscore, _ = res[0]
         rows = []
         for i in range(idx.shape[0]):
@@ -165,9 +201,7 @@ class BeamSearch(BaseParams):
                 output_list.append(tup); rows.append(0)
         step_count = 1
         while step_count < 120 and k > 0:                                                   # :269
-            sel = torch.as_tensor(np.asarray(rows, dtype=np.int64)).to(self.device)
-            cur = {n: t.index_select(0, sel) for n, t in state.items()}                      # one row per live hypothesis
-            res, state = get_top_k([c.get_last_output() for c, _ in output_list], cur, beam_size=k)
+            res = get_top_k([c.get_last_output() for c, _ in output_list], rows, beam_size=k)   # one row per live hypothesis
             score_list = [r[2] + cs for r, (_, cs) in zip(res, output_list)]                 # :290
             model_score_list = [r[1] + cs for r, (_, cs) in zip(res, output_list)]
             all_scores = np.concatenate(score_list); all_model = np.concatenate(model_score_list)

@@ -317,7 +317,9 @@ DEC_WEIGHT_LEAVES = {   # struct field -> variable leaf under model/rnn_decoder_
 
 def _dec_struct(cls, tensors):
     s = cls()
-    for f, _ in cls._fields_:
+    for f, ft in cls._fields_:
+        if ft is not _lib.vp:
+            continue                       # scalar members are set by the caller
         t = tensors.get(f)
         setattr(s, f, None if t is None else t.data_ptr())
     return s

@@ -223,6 +223,31 @@ int asr_attn_decoder_bwd(void* stream, const asr_dec_weights* w, const asr_dec_w
                          float* denc, float keep_lm, unsigned seed);
 int asr_scatter_add_rows_ld(void* stream, float* table_grad, const int* idx, const float* g, int rows, int width, int ldg);
 
+/* One beam-search step for the k live hypotheses of one utterance: BeamSearch.get_top_k (beam_search.py:163-221) up
+ * to the two logit vectors (decoder and external LM); the float64 scoring / argpartition stays on the host.
+ * d->B = k rows; hf [Te,A] = enc . AttnW (asr_gemm_f32), enc [Te,D], enc_len[0] = Te.  State rows are per hypothesis
+ * ([k, .]); `in` and `out` must not alias.  scratch: asr_beam_scratch_floats(k, Te, H, E, lm->P) floats. */
+typedef struct {              /* the external LM of shallow fusion (beam_search.py:100-134, map_lm_variables) */
+    const float* embedding;   /* [V,E] */
+    const float* lstm_kernel; /* [E+H,4H] */
+    const float* lstm_bias;
+    const float* simple_w;    /* [H,P] or NULL */
+    const float* simple_b;
+    const float* out_w;       /* [P or H, V] */
+    const float* out_b;
+    int E, H, P, V;
+} asr_lm_weights;
+typedef struct { float* dc; float* dh; float* dlc; float* dlh; float* lc; float* lh; float* ctx; } asr_beam_state;
+size_t asr_beam_scratch_floats(int k, int Te, int H, int E, int lmP);
+/* out row r = in row sel[r] for all seven state fields (parents of the surviving hypotheses, beam_search.py:306-318);
+ * widths: dc,dh [H]; dlc,dlh [lmH]; lc,lh [extH]; ctx [D]. */
+int asr_beam_gather(void* stream, const int* sel, int k, const asr_beam_state* in, const asr_beam_state* out,
+                    int H, int lmH, int extH, int D);
+int asr_beam_step(void* stream, const asr_dec_weights* w, const asr_lm_weights* lm, const asr_dec_dims* d,
+                  const float* hf, const float* enc, const int* enc_len, const int* tokens,
+                  const asr_beam_state* in, const asr_beam_state* out, float* scratch,
+                  float* logits, float* logits_lm);
+
 /* The decoder entry points run the LM cell chain on a library-owned side stream (forked from and
  * ordered against `stream` with events; legal under hipGraph capture).  asr_attn_decoder_bwd leaves
  * LM-chain gradient work in flight on it: call asr_side_join(stream) before reading the gradients. */
