@@ -235,7 +235,10 @@ def test_next_token_argmax_first_max(dev):
     (5, 17, 24, 64, True, [17, 16, 1, 2, 9], 1.0),
     (32, 24, 80, 256, True, None, 1.0),
     (6, 12, 16, 64, True, [12, 5, 12, 3, 8, 1], 0.9),        # with output dropout
-    (70, 6, 16, 256, True, None, 1.0),                        # multi-launch batch split
+    (70, 6, 16, 256, True, None, 1.0),                        # multi-launch batch split (R = 8: reduce-scatter kernel)
+    (9, 10, 32, 512, True, None, 1.0),                        # H = 512, R = 2 (all-gather kernel, 32 positions per lane)
+    (40, 9, 16, 128, True, None, 0.9),                        # H = 128, R = 2, dropout
+    (20, 7, 16, 256, False, None, 1.0),                       # uni-directional, R = 1
 ])
 def test_lstm_layer_bwd_vs_autograd(dev, B, Tn, IN, H, bi, lens, keep):
     """BPTT kernel + dX/dK/db GEMMs against torch autograd (float64) on the oracle twin."""
