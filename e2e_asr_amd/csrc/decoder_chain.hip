@@ -330,10 +330,22 @@ __global__ __launch_bounds__(512) void decoder_chain_fwd_kernel(ChainArgs a) {
             float sc = 0.f;
             if (tl < TS) {
                 constexpr int AL = A / 16;
-                const float* hp = hfl + (r * MAXTS + tl) * A + kq * AL;
-                const float* yp = yl + r * A + kq * AL;
+                const float* hrow = hfl + (r * MAXTS + tl) * A;
+                const float* yrow = yl + r * A;
+                if (AL % 4 == 0) {       // float4 chunks 64 columns apart: conflict-free across the 16 lanes of the DPP row
 #pragma unroll
-                for (int q4 = 0; q4 < AL; ++q4) sc = fmaf(vl[kq * AL + q4], fast_tanh(hp[q4] + yp[q4]), sc);
+                    for (int c = 0; c < AL / 4; ++c) {
+                        const int a0 = c * 64 + kq * 4;
+                        const float4 h4 = *reinterpret_cast<const float4*>(hrow + a0);
+                        const float4 y4 = *reinterpret_cast<const float4*>(yrow + a0);
+                        const float4 v4 = *reinterpret_cast<const float4*>(vl + a0);
+                        sc = fmaf(v4.x, fast_tanh(h4.x + y4.x), sc); sc = fmaf(v4.y, fast_tanh(h4.y + y4.y), sc);
+                        sc = fmaf(v4.z, fast_tanh(h4.z + y4.z), sc); sc = fmaf(v4.w, fast_tanh(h4.w + y4.w), sc);
+                    }
+                } else {
+#pragma unroll
+                    for (int q4 = 0; q4 < AL; ++q4) sc = fmaf(vl[kq * AL + q4], fast_tanh(hrow[kq * AL + q4] + yrow[kq * AL + q4]), sc);
+                }
             }
             sc = row16_allreduce_sum(sc);
             if (kq == 0) eout[row] = sc;

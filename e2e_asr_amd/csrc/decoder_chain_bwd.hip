@@ -23,6 +23,7 @@
 #include <cstdlib>
 
 extern "C" int asr_decoder_chain_supported(int B, int Te, int D, int A, int H);
+namespace asr { extern unsigned long long* g_lstm_dbg; }
 
 namespace asr {
 
@@ -45,6 +46,7 @@ struct ChainBwdArgs {
     float* dv_part;            // [groups*16][A]
     u64* gx; u64* xcc_slots; int* err;
     int B, Te, T;
+    unsigned long long* dbg;   // STAMP build only
     int g0, ng;                // groups [g0, g0 + ng) of the batch in this launch
 };
 
@@ -83,8 +85,14 @@ __device__ __forceinline__ void pubg(u64* dst, uint32_t epoch, float v, bool fas
     else __hip_atomic_store(dst, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <int H, int D, int A>
+// STAMP: diagnostic instantiation (ASR_CHAIN_STAMP=1 + asr_debug_set_buffer): per-phase s_memtime totals of wave 0 of
+// workgroup 0 (phase = code between two consecutive barriers of a step); never used for timing claims.
+template <int H, int D, int A, bool STAMP = false>
 __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) {
+    unsigned int stamp[16] = {0};
+    unsigned long long tlast = 0;
+    int sph = 0;
+#define CHAIN_STAMP() if (STAMP) { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); stamp[sph & 15] += (unsigned int)(t__ - tlast); tlast = t__; ++sph; }
     constexpr int R = 2, G = 16, NT = 512;
     constexpr int HS = H / G, AS = A / G, DS = D / G;
     constexpr int KS = H + D;
@@ -233,7 +241,9 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
     }
     __syncthreads();
 
+    if (STAMP) tlast = __builtin_amdgcn_s_memtime();
     for (int s = 0; s < a.T; ++s) {
+        sph = 0;
         const int i = a.T - 1 - s;
         const uint32_t ep = (uint32_t)(s + 1);
         u64* gpar = gbase + (size_t)(s & 1) * NPAR;
@@ -265,6 +275,7 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
             if (q < HS) dhl[r * HS2 + q] = v0; else dctl[r * DS + (q - HS)] = v0;
         }
         __syncthreads();
+        CHAIN_STAMP()
         // dctx_tot = dctx_ap + carry (D-slice), saved for the denc GEMM; partial S = dctx_tot . ctx_i
         if (wave0) {
             float sprt = 0.f;
@@ -284,6 +295,7 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
             if (dd0 == 0) sp[r] = sprt;
         }
         __syncthreads();
+        CHAIN_STAMP()
         // ---- (b) partial dalpha over my D-slice, all positions: thread -> (r, tau)
         for (int idx = tid; idx < R * G * MAXTS; idx += NT) {
             const int r = idx / (G * MAXTS), slot = idx % (G * MAXTS), tau = (slot / MAXTS) * TS + (slot % MAXTS);
@@ -297,6 +309,7 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
             dal[idx] = x;
         }
         __syncthreads();
+        CHAIN_STAMP()
         if (wave0) {     // X1 publish: to the owner of each position slice, plus my S partial to everyone
             for (int idx = lane; idx < R * G * MAXTS; idx += 64) {
                 const int r = idx / (G * MAXTS), slot = idx % (G * MAXTS), md = slot / MAXTS, tl = slot % MAXTS;
@@ -318,24 +331,47 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
             else if (q < MAXTS) del[r * MAXTS + q] = v0;
         }
         __syncthreads();
+        CHAIN_STAMP()
         // ---- (d) tanh backward on my positions
         {
             const int r = trow_r, tl = trow_tl, tau = tau0 + tl;
             float de = 0.f;
             if (tl < TS && tau < blenf(r)) de = alf[r * TeP + tau] * (del[r * MAXTS + tl] - sp[2 + r]);
-            float* hp = hfl + (r * MAXTS + tl) * A + kq * AL;
-            float* gp = dhfl + (r * MAXTS + tl) * A + kq * AL;
-            const float* yp = yl + r * A + kq * AL;
+            // element q of lane kq is column acol(q): float4 chunks 64 columns apart, so that the 16 lanes of a DPP row
+            // touch 16 consecutive 16-byte words (the strided kq*AL+q map was a 4-way LDS bank conflict on every access)
+            float* hrow = hfl + (r * MAXTS + tl) * A;
+            float* grow = dhfl + (r * MAXTS + tl) * A;
+            const float* yrow = yl + r * A;
+            if (AL % 4 == 0) {
 #pragma unroll
-            for (int q = 0; q < AL; ++q) {
-                const float th = fast_tanh(hp[q] + yp[q]);
-                const float ds = de * vl[kq * AL + q] * (1.f - th * th);
-                gp[q] += ds;
-                dvacc[q] = fmaf(de, th, dvacc[q]);
-                dyrow[row * A + kq * AL + q] = ds;
+                for (int c = 0; c < AL / 4; ++c) {
+                    const int a0 = c * 64 + kq * 4;
+                    const float4 h4 = *reinterpret_cast<const float4*>(hrow + a0);
+                    const float4 y4 = *reinterpret_cast<const float4*>(yrow + a0);
+                    const float4 v4 = *reinterpret_cast<const float4*>(vl + a0);
+                    float4 g4 = *reinterpret_cast<float4*>(grow + a0);
+                    float4 d4;
+                    float th;
+#define ASR_TBW(f, j) th = fast_tanh(h4.f + y4.f); d4.f = de * v4.f * (1.f - th * th); g4.f += d4.f; dvacc[4 * c + j] = fmaf(de, th, dvacc[4 * c + j]);
+                    ASR_TBW(x, 0) ASR_TBW(y, 1) ASR_TBW(z, 2) ASR_TBW(w, 3)
+#undef ASR_TBW
+                    *reinterpret_cast<float4*>(grow + a0) = g4;
+                    *reinterpret_cast<float4*>(dyrow + row * A + a0) = d4;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < AL; ++q) {
+                    const int a0 = kq * AL + q;
+                    const float th = fast_tanh(hrow[a0] + yrow[a0]);
+                    const float ds = de * vl[a0] * (1.f - th * th);
+                    grow[a0] += ds;
+                    dvacc[q] = fmaf(de, th, dvacc[q]);
+                    dyrow[row * A + a0] = ds;
+                }
             }
         }
         __syncthreads();
+        CHAIN_STAMP()
         for (int idx = tid; idx < R * A; idx += NT) {        // partial dy[r][a] = sum over my positions (16 DPP rows)
             const int r = idx / A, aa = idx % A;
             float x = 0.f;
@@ -344,6 +380,7 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
             dyp[idx] = x;
         }
         __syncthreads();
+        CHAIN_STAMP()
         if (wave0) {     // X2 publish: to the owner of each A-slice
             for (int idx = lane; idx < R * A; idx += 64) {
                 const int r = idx / A, aa = idx % A, md = aa / AS, al = aa % AS;
@@ -358,6 +395,7 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
             dys[r * AS2 + q] = v0;
         }
         __syncthreads();
+        CHAIN_STAMP()
         if (wave0 && tid < R * AS) {      // save dy (dW_att = q^T . dy after the loop)
             const int r = tid / AS, al = tid % AS;
             if (rok(r)) a.dY[((size_t)i * a.B + r0 + r) * A + mem * AS + al] = dys[r * AS2 + al];
@@ -370,6 +408,7 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
             dqp[tid] = x;
         }
         __syncthreads();
+        CHAIN_STAMP()
         if (wave0) {     // X3 publish: to the owner of each unit slice
             for (int idx = lane; idx < R * H; idx += 64) {
                 const int r = idx / H, k = idx % H, md = k / HS, u = k % HS;
@@ -384,6 +423,7 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
             dql[r * HS2 + q] = v0;
         }
         __syncthreads();
+        CHAIN_STAMP()
         // ---- cell pointwise backward (wave 0) -> dG slice
         if (wave0 && cell) {
             float4 dg = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -408,6 +448,7 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
             *reinterpret_cast<float4*>(dgl + cr * NCOL + 4 * cuu) = dg;
         }
         __syncthreads();
+        CHAIN_STAMP()
         // ---- (f) partial [dh_{i-1} | dctx_{i-1}] over my gate columns, for all KS outputs
         if (s + 1 < a.T) {
 #pragma unroll
@@ -427,6 +468,7 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
                 if (!(it & 1) && k < KS) { outp[k] = o0; outp[KS + k] = o1; }
             }
             __syncthreads();
+        CHAIN_STAMP()
             if (wave0) {     // X4 publish: dh part to the unit owner, dctx part to the D-slice owner
                 for (int idx = lane; idx < R * KS; idx += 64) {
                     const int r = idx / KS, k = idx % KS;
@@ -437,8 +479,11 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
                 }
             }
         }
+        CHAIN_STAMP()
         // (LDS buffers written by wave 1 / the compute phases are rewritten only after later barriers)
     }
+    if (STAMP && a.dbg && blockIdx.x == 0 && threadIdx.x == 0) { for (int i = 0; i < 16; ++i) a.dbg[i] = stamp[i]; }
+#undef CHAIN_STAMP
     // ---- epilogue: dhf slice and dv partial
     __syncthreads();
     for (int idx = tid; idx < R * MAXTS * A; idx += NT) {
@@ -447,7 +492,7 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
         if (rok(r) && tl < TS && tau < Te) a.dhf[((size_t)(r0 + r) * Te + tau) * A + aa] = dhfl[idx];
     }
 #pragma unroll
-    for (int q = 0; q < AL; ++q) dyrow[row * A + kq * AL + q] = dvacc[q];
+    for (int q = 0; q < AL; ++q) dyrow[row * A + (AL % 4 == 0 ? (q / 4) * 64 + kq * 4 + (q & 3) : kq * AL + q)] = dvacc[q];
     __syncthreads();
     for (int aa = tid; aa < A; aa += NT) {
         float x = 0.f;
@@ -474,6 +519,12 @@ static int chain_bwd_launch(hipStream_t s, asr::ChainBwdArgs& a) {
     if (lds > 150 * 1024) return ASR_EUNSUPPORTED;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asr::decoder_chain_bwd_kernel<H, D, A>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (H == 256 && a.dbg) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asr::decoder_chain_bwd_kernel<256, 512, 128, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((asr::decoder_chain_bwd_kernel<256, 512, 128, true>), dim3(groups * G), dim3(512), lds, s, a);
+        return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
+    }
     hipLaunchKernelGGL((asr::decoder_chain_bwd_kernel<H, D, A>), dim3(groups * G), dim3(512), lds, s, a);
     return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
 }
@@ -494,6 +545,7 @@ int asr_decoder_chain_bwd(void* stream, float* gates, const float* dec_c, const 
     a.dv_part = dv_part; a.gx = static_cast<u64*>(ws);
     a.xcc_slots = reinterpret_cast<u64*>(static_cast<char*>(ws) + bytes) - ((size_t)((B + 1) / 2) * 16);
     a.err = err; a.B = B; a.Te = Te; a.T = T;
+    a.dbg = getenv("ASR_CHAIN_STAMP") ? asr::g_lstm_dbg : nullptr;
     const int groups = (B + 1) / 2;
     for (int g0 = 0; g0 < groups; g0 += 16) {          // 16 groups = 256 workgroups per launch
         a.g0 = g0; a.ng = groups - g0 < 16 ? groups - g0 : 16;

@@ -282,7 +282,7 @@ __global__ __launch_bounds__(16 * HS) void lstm_rec_fwd_kernel(LstmRecArgs a) {
     }
 }
 
-static unsigned long long* g_lstm_dbg = nullptr;
+unsigned long long* g_lstm_dbg = nullptr;      // diagnostic stamp buffer (also read by decoder_chain_bwd.hip)
 extern "C" int asr_debug_set_buffer(void* p) { g_lstm_dbg = static_cast<unsigned long long*>(p); return ASR_OK; }
 
 template <int H, int R>

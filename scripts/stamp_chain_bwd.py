@@ -1,0 +1,26 @@
+"""Per-phase s_memtime shares of one step of the persistent decoder backward chain (diagnostic build: ASR_CHAIN_STAMP=1;
+wave 0 of workgroup 0).  Phases = code between consecutive barriers of a step, in program order."""
+import os, sys
+os.environ["ASR_CHAIN_STAMP"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from e2e_asr_amd import _lib, ops
+from e2e_asr_amd.weights import synthetic_batch
+dev = torch.device("cuda:0")
+dbg = torch.zeros(16, dtype=torch.int64, device=dev)
+_lib.lib().asr_debug_set_buffer(dbg.data_ptr())
+model = bench.build_model(dev, training=True)
+batch = synthetic_batch(B=32, T=800, F=80, t_dec=121, vocab=1000, variable_len=False, seed=1)
+for _ in range(3):
+    model.step(batch)
+torch.cuda.synchronize()
+d = dbg.cpu().numpy()
+names = ["X4 gather + prefetch hand-over", "dctx_tot, S partial (wave 0)", "(b) dalpha partials", "X1 publish + gather", "(d) tanh backward",
+         "dy row reduce", "X2 publish + gather", "(e) dq partials", "X3 publish + gather", "cell pointwise", "(f) [dh|dctx] partials",
+         "X4 publish"]
+tot = float(d[:12].sum())
+steps = 120
+print("cycles per step: %.0f  (%.2f us at 100 MHz s_memtime clock)" % (tot / steps, tot / steps / 100.0))
+for n, v in zip(names, d[:12]):
+    print("  %-34s %6.1f %%  %7.0f ticks/step" % (n, 100.0 * v / tot, v / steps))
