@@ -4,7 +4,10 @@
 //
 // Per step i (T-1 .. 0), for a group of R = 2 utterances over G = 16 workgroups (same ownership as the
 // forward: H/16 units, A/16 attention columns, ceil(Te/16) positions, D/16 context columns each):
-//   X4  gather  [dh_i | dctx_carry] for my units / my D-slice = sum of the 16 partials of step i+1
+//   AG  gather dG of step i+1 (all 4H positions of both rows; all-gather, published by the owners of the units)
+//       [dh_i | dctx_carry] for my units / my D-slice = dG_{i+1} . [K_h ; W_inp[P:].K_x]^T over ALL gate columns, with the
+//       rows of my own H/16 + D/16 outputs resident in registers (the forward's structure; the first version scattered
+//       partial sums of all H + D outputs: 1536 publishing stores per workgroup and step, 27 % of the step)
 //       dctx_tot = dctx_ap[i] + dctx_carry   (saved: the caller turns sum_i alpha_i^T.dctx_i into denc)
 //   (b) partial dalpha[tau] over my D-slice for ALL positions, and the partial of the softmax scalar
 //       S = sum_tau alpha.dalpha = dctx_tot . ctx_i  (identity: ctx = sum alpha.enc)     -> X1 publish
@@ -13,12 +16,11 @@
 //       end); dv += de th (registers); partial dy[a] over my positions               -> X2 publish
 //   X2  gather dy for my A-slice (saved: dW_att = q^T.dy after the loop); partial dq[k] = dy.W_att[k, slice]
 //                                                                                    -> X3 publish
-//   X3  gather dq_att for my units; cell pointwise backward -> dG (in place over the saved gates), dc carry
-//   (f) partial [dh_{i-1} | dctx_{i-1}] = dG_slice . [K_h ; W_inp[P:].K_x]^T over my 4*H/16 gate columns,
-//       for all H + D outputs                                                        -> X4 publish
-// Every exchange is a reduce-scatter of tagged granules: destination-major [dst][src][slot]; ONE wave
-// gathers, each lane issuing its 16 source loads together and summing in fixed order (reproducible).
-// Wave 0 owns every global store.  dx = dG.K_x^T and dlm_out = dx.W_inp[:P]^T are GEMMs after the loop.
+//   X3  gather dq_att for my units; cell pointwise backward -> dG (in place over the saved gates), dc carry;
+//       the 4 dG values of each unit are published first (AG of the next step)
+// X1-X3 are reduce-scatters of tagged granules: destination-major [dst][src][slot]; ONE wave gathers, each lane
+// issuing its 16 source loads together and summing in fixed order (reproducible).  Wave 0 owns every global store.
+// dx = dG.K_x^T and dlm_out = dx.W_inp[:P]^T are GEMMs after the loop.
 #include "common.h"
 #include <cstdlib>
 
@@ -96,20 +98,24 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
     constexpr int R = 2, G = 16, NT = 512;
     constexpr int HS = H / G, AS = A / G, DS = D / G;
     constexpr int KS = H + D;
-    constexpr int NCOL = 4 * HS;                      // gate columns owned by this workgroup
-    constexpr int CP = NCOL / 2;                      // phase (f): a thread covers half of the gate columns of an output k
-    constexpr int KPT = (2 * KS + NT - 1) / NT;       // (k, half) items per thread
+    constexpr int N4 = 4 * H;                         // dG positions per row: p = 4*unit + gate
+    constexpr int PC = N4 / 64;                       // positions per lane in the [dh|dctx] contraction (64 chunks = one wave)
+    constexpr int CSB = PC + 4;                       // padded LDS chunk stride
+    constexpr int NOUT = HS + DS;                     // outputs owned by this workgroup: dh of my units | dctx of my columns
+    constexpr int OPW = (NOUT + 7) / 8;               // outputs per wave
+    constexpr int NPAIR4 = R * N4 / 2;                // granule pairs gathered per step
+    constexpr int NGT = 192;                          // gathering threads of the dG all-gather: waves 1-3
+    constexpr int NPP4 = (NPAIR4 + NGT - 1) / NGT;    // ... pairs per gathering thread
     constexpr int MAXTS = 16;
     constexpr int AL = A / 16;                        // a values per lane in the tanh phase
     constexpr int H4 = 4 * H;
     // slots per (dst, src): even counts so that pairs never straddle
-    constexpr int S4 = R * (HS + DS);                 // X4: [r][dh units | dctx cols]
     constexpr int S1 = R * (MAXTS + 2);               // X1: [r][dalpha positions | S | pad]
     constexpr int S2 = R * ((AS + 1) & ~1);           // X2: [r][dy a-slice]
     constexpr int S3 = R * ((HS + 1) & ~1);           // X3: [r][dq units]
     constexpr int AS2 = (AS + 1) & ~1, HS2 = (HS + 1) & ~1;
-    static_assert((HS + DS) % 2 == 0 && HS * G == H && AS * G == A && DS * G == D, "sizes");
-    constexpr int NPAR = G * G * (S4 + S1 + S2 + S3);  // granules per parity per group
+    static_assert(HS * G == H && AS * G == A && DS * G == D && PC % 4 == 0, "sizes");
+    constexpr int NPAR = G * G * (S1 + S2 + S3) + R * N4;  // granules per parity per group (X1, X2, X3 reduce-scatters + dG all-gather)
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int* lds_flag = reinterpret_cast<int*>(smem);
@@ -123,9 +129,9 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
     float* dys = dyp + R * A;                         // dy for my a-slice [R][AS2]
     float* dqp = dys + R * AS2;                       // partial dq [R][H]                            -> X3 publish
     float* dql = dqp + R * H;                         // gathered dq_att for my units [R][HS2]
-    float* dgl = dql + R * HS2;                       // dG slice [R][NCOL]
-    float* outp = dgl + R * NCOL;                     // partial [dh|dctx] [R][KS]                    -> X4 publish
-    float* hfl = outp + R * KS;                       // hf slice [R][MAXTS][A]
+    float* dga = dql + R * HS2;                       // gathered dG of the later step [R][64 chunks][CSB]
+    float* fpart = dga + R * 64 * CSB;                // [dh|dctx] partial sums [NOUT][R][4 DPP rows]
+    float* hfl = fpart + ((NOUT * R * 4 + 3) & ~3);   // hf slice [R][MAXTS][A]
     float* dhfl = hfl + R * MAXTS * A;                // dhf accumulator [R][MAXTS][A]
     const int Te = a.Te;
     const int TS = (Te + G - 1) / G;
@@ -133,7 +139,7 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
     float* vl = wal + H * AS;                         // v [A]
     float* encl = vl + A;                             // enc slice [R][Te][DS]
     // operands of the CURRENT step that depend on no exchange: fetched one step ahead by the prefetch waves
-    // (threads >= 192, which neither poll nor store) -- item order below = LDS order
+    // (threads >= 256, which neither poll nor store) -- item order below = LDS order
     const int TeP = (Te + 1) & ~1;
     float* pfl = encl + R * Te * DS;
     float* yl = pfl;                                  // y_i [R][A]
@@ -167,16 +173,19 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
     const bool fast = group_shares_xcd(a.xcc_slots + (size_t)grp * 16, G, mem, tid, a.err, lds_flag);
 
     // ---- resident operands
-    // phase (f): item = tid + 512*p -> (k = item / 2, column half = item % 2): adjacent lanes share k and add
-    // their halves through DPP; weights over my gate columns n = 4*unit + gate, n in [half*CP, half*CP + CP)
-    float wf[KPT][CP];
+    // [dh|dctx] of the EARLIER step = dG . [K_h ; WK_c]^T for my own outputs: wave w owns outputs w*OPW .. +OPW-1 (unit
+    // rows of K_h, then context rows of WK_c), lane l the positions [l*PC, l*PC + PC) of all 4H gate columns
+    float wo[OPW][PC];
 #pragma unroll
-    for (int p = 0; p < KPT; ++p) {
-        const int it = tid + NT * p, k = it >> 1, n0 = (it & 1) * CP;
-        const bool kok = k < KS;
-        const float* wr = (k < H) ? a.wh + (size_t)(kok ? k : 0) * H4 : a.wc + (size_t)(kok ? k - H : 0) * H4;
+    for (int i = 0; i < OPW; ++i) {
+        const int o = wave * OPW + i;
+        const bool ook = o < NOUT;
+        const float* wr = (o < HS) ? a.wh + (size_t)(mem * HS + (ook ? o : 0)) * H4 : a.wc + (size_t)(mem * DS + (ook ? o - HS : 0)) * H4;
 #pragma unroll
-        for (int n = 0; n < CP; ++n) wf[p][n] = kok ? wr[((n0 + n) & 3) * H + mem * HS + ((n0 + n) >> 2)] : 0.f;
+        for (int q = 0; q < PC; ++q) {
+            const int pos = lane * PC + q;
+            wo[i][q] = ook ? wr[(pos & 3) * H + (pos >> 2)] : 0.f;
+        }
     }
     // phase (e): thread -> (r = tid / H, k = tid % H) (R*H <= 512): W_att[k][my a-slice]
     const int ek = tid % H, er = tid / H;
@@ -207,7 +216,7 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
     const int cb = r0 + cr;
     const bool cb_ok = cell && cb < a.B;
     float dc = 0.f;
-    constexpr int NPF = 4, PF0 = 192, PFN = NT - PF0;
+    constexpr int NPF = 5, PF0 = 256, PFN = NT - PF0;      // waves 4-7 prefetch
     const bool pfw = __builtin_amdgcn_readfirstlane(tid) >= PF0;
     auto pf_fetch = [&](int i, int idx) -> float {
         if (idx < R * A) { const int r = idx / A; return rok(r) ? a.y[((size_t)i * a.B + browf(r)) * A + idx % A] : 0.f; }
@@ -247,8 +256,8 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
         const int i = a.T - 1 - s;
         const uint32_t ep = (uint32_t)(s + 1);
         u64* gpar = gbase + (size_t)(s & 1) * NPAR;
-        u64* g4 = gpar; u64* g1 = g4 + G * G * S4; u64* g2 = g1 + G * G * S1; u64* g3 = g2 + G * G * S2;
-        const u64* g4prev = gbase + (size_t)((s - 1) & 1) * NPAR;     // X4 of the previous (later-time) step
+        u64* g1 = gpar; u64* g2 = g1 + G * G * S1; u64* g3 = g2 + G * G * S2; u64* g4 = g3 + G * G * S3;
+        const u64* g4prev = gbase + (size_t)((s - 1) & 1) * NPAR + G * G * (S1 + S2 + S3);     // dG of the previous (later-time) step
         // ---- operands of this step that do not depend on any exchange (waves >= 2 fetch them)
         if (pfw) {
 #pragma unroll
@@ -267,21 +276,99 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
                 }
             }
         }
-        // ---- X4 gather: [dh | dctx_carry] for my slices, summed over the 16 sources (one lane per slot)
-        if (tid >= 64 && tid < 64 + S4) {
-            const int slot = tid - 64, r = slot / (HS + DS), q = slot % (HS + DS);
-            float v0 = 0.f;
-            if (s > 0 && rok(r)) gather16_one<S4>(g4prev + ((size_t)mem * G) * S4 + slot, (uint32_t)s, v0, a.err);
-            if (q < HS) dhl[r * HS2 + q] = v0; else dctl[r * DS + (q - HS)] = v0;
+        // ---- gather dG of the later step (all 4H positions of both rows; published by their owners), waves 1-2:
+        // all of a thread's granule loads in flight, re-polled together until every tag matches
+        if (s > 0 && tid >= 64 && tid < 64 + NGT) {
+            bool need[NPP4];
+#pragma unroll
+            for (int j = 0; j < NPP4; ++j) {
+                const int pidx = tid - 64 + NGT * j;
+                need[j] = pidx < NPAIR4 && rok((2 * pidx) / N4);
+                if (pidx < NPAIR4 && !need[j]) {
+                    const int idx = 2 * pidx, r = idx / N4, pos = idx % N4;
+                    *reinterpret_cast<float2*>(dga + (r * 64 + pos / PC) * CSB + (pos % PC)) = make_float2(0.f, 0.f);
+                }
+            }
+            long long t0w = 0;
+            for (uint32_t spins = 0;; ++spins) {
+                u64 x[NPP4][2];
+#pragma unroll
+                for (int j = 0; j < NPP4; ++j) {
+                    const int pidx = min(tid - 64 + NGT * j, NPAIR4 - 1);
+                    x[j][0] = __hip_atomic_load(g4prev + 2 * pidx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    x[j][1] = __hip_atomic_load(g4prev + 2 * pidx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                bool pending = false;
+#pragma unroll
+                for (int j = 0; j < NPP4; ++j) {
+                    if (!need[j]) continue;
+                    if ((uint32_t)(x[j][0] >> 32) == (uint32_t)s && (uint32_t)(x[j][1] >> 32) == (uint32_t)s) {
+                        const int idx = 2 * (tid - 64 + NGT * j), r = idx / N4, pos = idx % N4;
+                        *reinterpret_cast<float2*>(dga + (r * 64 + pos / PC) * CSB + (pos % PC)) =
+                            make_float2(__uint_as_float((uint32_t)x[j][0]), __uint_as_float((uint32_t)x[j][1]));
+                        need[j] = false;
+                    } else pending = true;
+                }
+                if (!pending) break;
+                if ((spins & 1023) == 1023) {
+                    const long long now = wall_clock64();
+                    if (t0w == 0) t0w = now;
+                    else if (now - t0w > 200000000LL) { *a.err = 1; break; }
+                    if (__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                }
+            }
         }
         __syncthreads();
         CHAIN_STAMP()
-        // dctx_tot = dctx_ap + carry (D-slice), saved for the denc GEMM; partial S = dctx_tot . ctx_i
+        // ---- [dh_i | dctx_carry_i] for my outputs = dG_{i+1} . [K_h ; WK_c]^T: 64 position chunks per wave, DPP-row
+        // butterflies, the 4 rows of the wave meet in LDS (summed in fixed order by the consumers below)
+        if (s > 0) {
+            float acc[R][OPW];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+#pragma unroll
+                for (int i = 0; i < OPW; ++i) acc[r][i] = 0.f;
+                const float4* dp = reinterpret_cast<const float4*>(dga + (r * 64 + lane) * CSB);
+#pragma unroll
+                for (int q4 = 0; q4 < PC / 4; ++q4) {
+                    const float4 dv = dp[q4];
+#pragma unroll
+                    for (int i = 0; i < OPW; ++i) {
+                        acc[r][i] = fmaf(dv.x, wo[i][4 * q4 + 0], acc[r][i]);
+                        acc[r][i] = fmaf(dv.y, wo[i][4 * q4 + 1], acc[r][i]);
+                        acc[r][i] = fmaf(dv.z, wo[i][4 * q4 + 2], acc[r][i]);
+                        acc[r][i] = fmaf(dv.w, wo[i][4 * q4 + 3], acc[r][i]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int i = 0; i < OPW; ++i) acc[r][i] = row16_allreduce_sum(acc[r][i]);
+            if ((lane & 15) == 0) {
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int i = 0; i < OPW; ++i)
+                        if (wave * OPW + i < NOUT) fpart[((wave * OPW + i) * R + r) * 4 + (lane >> 4)] = acc[r][i];
+            }
+        }
+        __syncthreads();
+        CHAIN_STAMP()
+        // dh for my units (threads 64 ..) and dctx_tot = dctx_ap + carry (D-slice; wave 0), saved for the denc GEMM;
+        // partial S = dctx_tot . ctx_i
+        if (tid >= 64 && tid < 64 + R * HS) {
+            const int r = (tid - 64) / HS, u = (tid - 64) % HS;
+            float x = 0.f;
+            if (s > 0) { const float4 v = *reinterpret_cast<const float4*>(fpart + (u * R + r) * 4); x = (v.x + v.y) + (v.z + v.w); }
+            dhl[r * HS2 + u] = x;
+        }
         if (wave0) {
             float sprt = 0.f;
             const int r = lane / 32, dd0 = lane % 32;      // 2 rows x 32 lanes
             for (int dd = dd0; dd < DS; dd += 32) {
-                float x = dctl[r * DS + dd];
+                float x = 0.f;
+                if (s > 0) { const float4 v = *reinterpret_cast<const float4*>(fpart + ((HS + dd) * R + r) * 4); x = (v.x + v.y) + (v.z + v.w); }
                 if (rok(r)) {
                     const size_t rowi = (size_t)i * a.B + r0 + r;
                     x += dqcx[r * DS + dd];
@@ -443,40 +530,21 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
                 dg.z = dct * cp * gf * (1.f - gf);
                 dg.w = dh * tc * go * (1.f - go);
                 dc = dct * gf;
+                // publish dG_i of this unit FIRST: 4 adjacent granules (all-gather; the peers contract it with their rows)
+                if (s + 1 < a.T) {
+                    u64* dst = g4 + (size_t)cr * N4 + 4 * cj;
+                    if (fast) {
+                        typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
+                        const u32x4s q0 = {__float_as_uint(dg.x), ep, __float_as_uint(dg.y), ep};
+                        const u32x4s q1 = {__float_as_uint(dg.z), ep, __float_as_uint(dg.w), ep};
+                        asm volatile("global_store_dwordx4 %0, %1, off\n\tglobal_store_dwordx4 %0, %2, off offset:16"
+                                     :: "v"(dst), "v"(q0), "v"(q1) : "memory");
+                    } else {
+                        pubg(dst + 0, ep, dg.x, false); pubg(dst + 1, ep, dg.y, false);
+                        pubg(dst + 2, ep, dg.z, false); pubg(dst + 3, ep, dg.w, false);
+                    }
+                }
                 gp[0] = dg.x; gp[H] = dg.y; gp[2 * H] = dg.z; gp[3 * H] = dg.w;
-            }
-            *reinterpret_cast<float4*>(dgl + cr * NCOL + 4 * cuu) = dg;
-        }
-        __syncthreads();
-        CHAIN_STAMP()
-        // ---- (f) partial [dh_{i-1} | dctx_{i-1}] over my gate columns, for all KS outputs
-        if (s + 1 < a.T) {
-#pragma unroll
-            for (int p = 0; p < KPT; ++p) {
-                const int it = tid + NT * p, k = it >> 1, n0 = (it & 1) * CP;
-                float o0 = 0.f, o1 = 0.f;
-#pragma unroll
-                for (int n4 = 0; n4 < CP / 4; ++n4) {
-                    const float4 d0 = *reinterpret_cast<const float4*>(dgl + n0 + 4 * n4);
-                    const float4 d1 = *reinterpret_cast<const float4*>(dgl + NCOL + n0 + 4 * n4);
-                    o0 = fmaf(d0.x, wf[p][4 * n4], o0); o0 = fmaf(d0.y, wf[p][4 * n4 + 1], o0);
-                    o0 = fmaf(d0.z, wf[p][4 * n4 + 2], o0); o0 = fmaf(d0.w, wf[p][4 * n4 + 3], o0);
-                    o1 = fmaf(d1.x, wf[p][4 * n4], o1); o1 = fmaf(d1.y, wf[p][4 * n4 + 1], o1);
-                    o1 = fmaf(d1.z, wf[p][4 * n4 + 2], o1); o1 = fmaf(d1.w, wf[p][4 * n4 + 3], o1);
-                }
-                o0 += __shfl_xor(o0, 1); o1 += __shfl_xor(o1, 1);
-                if (!(it & 1) && k < KS) { outp[k] = o0; outp[KS + k] = o1; }
-            }
-            __syncthreads();
-        CHAIN_STAMP()
-            if (wave0) {     // X4 publish: dh part to the unit owner, dctx part to the D-slice owner
-                for (int idx = lane; idx < R * KS; idx += 64) {
-                    const int r = idx / KS, k = idx % KS;
-                    if (!rok(r)) continue;
-                    int md, q;
-                    if (k < H) { md = k / HS; q = k % HS; } else { md = (k - H) / DS; q = HS + (k - H) % DS; }
-                    pubg(g4 + ((size_t)md * G + mem) * S4 + r * (HS + DS) + q, ep, outp[idx], fast);
-                }
             }
         }
         CHAIN_STAMP()
@@ -505,8 +573,9 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
 
 extern "C" size_t asr_decoder_chain_bwd_ws_bytes(int B, int D, int A, int H) {
     const size_t groups = (B + 1) / 2, G = 16, R = 2, HS = H / 16, AS = A / 16, DS = D / 16;
-    const size_t s4 = R * (HS + DS), s1 = R * (16 + 2), s2 = R * ((AS + 1) & ~(size_t)1), s3 = R * ((HS + 1) & ~(size_t)1);
-    return groups * 2 * G * G * (s4 + s1 + s2 + s3) * sizeof(u64) + groups * 16 * sizeof(u64);
+    const size_t s1 = R * (16 + 2), s2 = R * ((AS + 1) & ~(size_t)1), s3 = R * ((HS + 1) & ~(size_t)1);
+    (void)DS;
+    return groups * 2 * (G * G * (s1 + s2 + s3) + R * 4 * (size_t)H) * sizeof(u64) + groups * 16 * sizeof(u64);
 }
 
 template <int H, int D, int A>
@@ -514,7 +583,7 @@ static int chain_bwd_launch(hipStream_t s, asr::ChainBwdArgs& a) {
     constexpr int R = 2, G = 16, HS = H / G, AS = A / G, DS = D / G, HS2 = (HS + 1) & ~1, AS2 = (AS + 1) & ~1;
     const int groups = a.ng;
     const size_t lds = sizeof(float) * (4 + R * DS + R * HS2 + R * G * 16 + 4 + R * 16 + R * A + 32 * A + R * A + R * AS2 +
-                                        R * H + R * HS2 + R * 4 * HS + R * (H + D) + 2 * R * 16 * A + H * AS + A + (size_t)R * a.Te * DS +
+                                        R * H + R * HS2 + R * 64 * (H / 16 + 4) + (HS + DS) * R * 4 + 4 + 2 * R * 16 * A + H * AS + A + (size_t)R * a.Te * DS +
                                         (size_t)R * (a.Te + 1) + 2 * R * DS + 7 * R * HS + 16);
     if (lds > 150 * 1024) return ASR_EUNSUPPORTED;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asr::decoder_chain_bwd_kernel<H, D, A>),

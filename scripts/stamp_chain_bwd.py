@@ -16,11 +16,11 @@ for _ in range(3):
     model.step(batch)
 torch.cuda.synchronize()
 d = dbg.cpu().numpy()
-names = ["X4 gather + prefetch hand-over", "dctx_tot, S partial (wave 0)", "(b) dalpha partials", "X1 publish + gather", "(d) tanh backward",
-         "dy row reduce", "X2 publish + gather", "(e) dq partials", "X3 publish + gather", "cell pointwise", "(f) [dh|dctx] partials",
-         "X4 publish"]
-tot = float(d[:12].sum())
+names = ["gather dG (all-gather) + prefetch hand-over", "[dh|dctx] = dG.[K_h;WK_c]^T for my outputs", "dh, dctx_tot, S partial", "(b) dalpha partials",
+         "X1 publish + gather", "(d) tanh backward", "dy row reduce", "X2 publish + gather", "(e) dq partials", "X3 publish + gather",
+         "cell pointwise + dG publish"]
+tot = float(d[:11].sum())
 steps = 120
 print("cycles per step: %.0f  (%.2f us at 100 MHz s_memtime clock)" % (tot / steps, tot / steps / 100.0))
-for n, v in zip(names, d[:12]):
-    print("  %-34s %6.1f %%  %7.0f ticks/step" % (n, 100.0 * v / tot, v / steps))
+for n, v in zip(names, d[:11]):
+    print("  %-50s %6.1f %%  %7.0f ticks/step" % (n, 100.0 * v / tot, v / steps))
