@@ -259,23 +259,6 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
         u64* g1 = gpar; u64* g2 = g1 + G * G * S1; u64* g3 = g2 + G * G * S2; u64* g4 = g3 + G * G * S3;
         const u64* g4prev = gbase + (size_t)((s - 1) & 1) * NPAR + G * G * (S1 + S2 + S3);     // dG of the previous (later-time) step
         // ---- operands of this step that do not depend on any exchange (waves >= 2 fetch them)
-        if (pfw) {
-#pragma unroll
-            for (int j = 0; j < NPF; ++j) {
-                const int idx = tid - PF0 + PFN * j;
-                if (idx < nitems) pfl[idx] = pfr[j];
-            }
-            if (s + 1 < a.T) {
-#pragma unroll
-                for (int j = 0; j < NPF; ++j) {
-                    int idx = tid - PF0 + PFN * j;
-                    // opaque per iteration: keeps the item decode (cheap ALU) inside the loop instead of
-                    // loop-invariant address registers held across the register-critical phases
-                    asm volatile("" : "+v"(idx));
-                    if (idx < nitems) pfr[j] = pf_fetch(i - 1, idx);
-                }
-            }
-        }
         // ---- gather dG of the later step (all 4H positions of both rows; published by their owners), waves 1-2:
         // all of a thread's granule loads in flight, re-polled together until every tag matches
         if (s > 0 && tid >= 64 && tid < 64 + NGT) {
@@ -320,6 +303,26 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
         }
         __syncthreads();
         CHAIN_STAMP()
+        // ---- hand the prefetched operands of THIS step over to LDS (and fetch the next step's).  Not at the top of the
+        // step: the cell phase of the previous step (wave 0, the last phase of a step) still reads these buffers until it
+        // has passed the barrier above.
+        if (pfw) {
+#pragma unroll
+            for (int j = 0; j < NPF; ++j) {
+                const int idx = tid - PF0 + PFN * j;
+                if (idx < nitems) pfl[idx] = pfr[j];
+            }
+            if (s + 1 < a.T) {
+#pragma unroll
+                for (int j = 0; j < NPF; ++j) {
+                    int idx = tid - PF0 + PFN * j;
+                    // opaque per iteration: keeps the item decode (cheap ALU) inside the loop instead of
+                    // loop-invariant address registers held across the register-critical phases
+                    asm volatile("" : "+v"(idx));
+                    if (idx < nitems) pfr[j] = pf_fetch(i - 1, idx);
+                }
+            }
+        }
         // ---- [dh_i | dctx_carry_i] for my outputs = dG_{i+1} . [K_h ; WK_c]^T: 64 position chunks per wave, DPP-row
         // butterflies, the 4 rows of the wave meet in LDS (summed in fixed order by the consumers below)
         if (s > 0) {

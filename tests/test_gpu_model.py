@@ -449,6 +449,19 @@ def test_decoder_chain_equals_launch_path_under_scheduled_sampling(monkeypatch, 
         g0 = outs[1][3][n]
         err = np.abs(g1 - g0).max() / max(1e-3, np.abs(g0).max())
         assert err < 1e-4, (n, err)
+    if nb > 32:
+        # 256 workgroups per launch is where an intra-workgroup LDS race in the backward chain showed (a phase of the
+        # next step overwriting operands the cell phase was still reading; seen in ~40 % of runs): repeat the step
+        monkeypatch.setenv("ASR_DEC_CHAIN", "1")
+        for rep in range(4):
+            m = _chain_model(samp=0.4, seed=7)
+            m.decoder["char"].coin_rng = np.random.default_rng(5)
+            m.forward(b)
+            m.backward()
+            for n, g0 in outs[1][3].items():
+                g1 = m.variables.grad_of(n).cpu().numpy()
+                err = np.abs(g1 - g0).max() / max(1e-3, np.abs(g0).max())
+                assert err < 1e-4, (rep, n, err)
     np.testing.assert_array_equal(outs[0][1], outs[1][1])
     assert (outs[0][1][1:] != np.asarray(b["char"]).T[1:outs[0][1].shape[0]]).any()   # some tokens really were sampled
     np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=0, atol=2e-5)
