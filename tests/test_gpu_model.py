@@ -503,3 +503,41 @@ def test_persistent_lm_chain_equals_per_step_lm_cells(monkeypatch, variant):
         g0 = res[1][3][n]
         err = np.abs(g1 - g0).max() / max(1e-3, np.abs(g0).max())
         assert err < 1e-4, (n, err)
+
+
+def test_config2_full_batch_persistent_paths_equal_launch_paths(monkeypatch):
+    """BASELINE config-2 widths (H = 256, D = 512, A = 128, V = 1000, lm 256) at the bench's batch of 32 -- 16 groups =
+    256 workgroups, one per CU, the occupancy the bench runs at -- with scheduled sampling and dropout: the persistent
+    decoder chains + persistent LM chain must give the per-step launch paths' tokens, logits, loss and every gradient,
+    and do so on repeated runs (race detector; T is short so that it runs in seconds)."""
+    rng = np.random.default_rng(51)
+    kw = dict(feat=80, vocab={"char": 1000}, num_layers={"char": 3}, seed=13, params_update=dict(max_output={"char": 14}),
+              enc_update=dict(hidden_size=256, out_prob=0.9),
+              dec_update=dict(hidden_size_dec=256, lm_hidden_size=256, emb_size=256, attention_vec_size=128, samp_prob=0.3,
+                              out_prob_dec=0.9))
+    b = _batch(rng, 32, 48, 80, 15, 1000)
+
+    def run(chain):
+        monkeypatch.setenv("ASR_DEC_CHAIN", chain)
+        monkeypatch.setenv("ASR_LM_CHAIN", chain)
+        m = _model(**kw)
+        m.decoder["char"].coin_rng = np.random.default_rng(8)
+        m.global_step = 1
+        m.forward(b)
+        ws = m.decoder["char"].saved["ws"]
+        assert (ws.get("chain_ws") is not None) == (chain == "1") and (ws.get("lm_act") is not None) == (chain == "1")
+        out, tok, loss = m.outputs["char"].cpu().numpy().copy(), ws["tok"].cpu().numpy().copy(), m.total_loss.item()
+        m.backward()
+        from e2e_asr_amd import ops
+        ops.check_device_flag(torch.device(DEV))
+        return out, tok, loss, {n: m.variables.grad_of(n).cpu().numpy().copy() for n in m.variables.names()}
+
+    ref = run("0")
+    for rep in range(3):
+        got = run("1")
+        np.testing.assert_array_equal(got[1], ref[1])
+        np.testing.assert_allclose(got[0], ref[0], rtol=0, atol=5e-5)
+        np.testing.assert_allclose(got[2], ref[2], rtol=1e-6)
+        for n, g0 in ref[3].items():
+            err = np.abs(got[3][n] - g0).max() / max(1e-3, np.abs(g0).max())
+            assert err < 2e-4, (rep, n, err)
