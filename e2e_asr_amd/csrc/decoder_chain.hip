@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <cstdlib>
 
+namespace asr { extern unsigned long long* g_lstm_dbg; }
 extern "C" int asr_decoder_chain_supported(int B, int Te, int D, int A, int H);
 extern "C" size_t asr_decoder_chain_ws_bytes(int B, int D, int A, int H);
 
@@ -40,6 +41,7 @@ struct ChainArgs {
     u64* xcc_slots;          // [groups][16]
     int* err;
     int B, Te, t0, t1;
+    unsigned long long* dbg; // STAMP build only
     int g0, ng;              // this launch covers groups [g0, g0 + ng) of the batch (<= 16 groups = 256 workgroups)
 };
 
@@ -66,8 +68,15 @@ __device__ __forceinline__ void chain_publish(u64* dst, uint32_t epoch, float v,
 }
 
 // H: decoder hidden; D: encoder state width; A: attention width.  R = 2 rows, G = 16 workgroups.
-template <int H, int D, int A>
+// STAMP: diagnostic instantiation (ASR_CHAIN_STAMP=1 + asr_debug_set_buffer): s_memtime totals of wave 0 of workgroup 0
+// per phase (code between two consecutive barriers of a step; slot 15 = prologue), accumulated over the launches of a call;
+// never used for timing claims.
+template <int H, int D, int A, bool STAMP = false>
 __global__ __launch_bounds__(512) void decoder_chain_fwd_kernel(ChainArgs a) {
+    unsigned int stamp[16] = {0};
+    unsigned long long tlast = STAMP ? __builtin_amdgcn_s_memtime() : 0;
+    int sph = 0;
+#define CHAINF_STAMP() if (STAMP) { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); stamp[sph & 15] += (unsigned int)(t__ - tlast); tlast = t__; ++sph; }
     constexpr int R = 2, G = 16, NT = 512;
     constexpr int HS = H / G;            // hidden units per workgroup
     constexpr int AS = A / G;            // attention columns per workgroup
@@ -210,7 +219,9 @@ __global__ __launch_bounds__(512) void decoder_chain_fwd_kernel(ChainArgs a) {
     __syncthreads();
 
     const int nsteps = a.t1 - a.t0;
+    if (STAMP) { sph = 15; CHAINF_STAMP() }
     for (int s = 0; s < nsteps; ++s) {
+        sph = 0;
         const int i = a.t0 + s;
         const uint32_t ep = (uint32_t)(a.t0 + s + 1);      // tags unique over the segments of one call (workspace zeroed once)
         u64* gpar = gbase + (size_t)(s & 1) * NPAR;
@@ -233,7 +244,9 @@ __global__ __launch_bounds__(512) void decoder_chain_fwd_kernel(ChainArgs a) {
                 }
             }
             __syncthreads();
+        CHAINF_STAMP()
         }
+        CHAINF_STAMP()
         // ---- (2) outer cell: gates = preG + [h|ctx].[K_h ; W2K]  (K split over 32 chunks)
         {
             float acc[R][4];
@@ -263,6 +276,7 @@ __global__ __launch_bounds__(512) void decoder_chain_fwd_kernel(ChainArgs a) {
             }
         }
         __syncthreads();
+        CHAINF_STAMP()
         if (wave0 && cell) {
             const float4 s0 = *reinterpret_cast<const float4*>(sums + ((0 * HS + cuu) * R + cr) * 4);
             const float4 s1 = *reinterpret_cast<const float4*>(sums + ((1 * HS + cuu) * R + cr) * 4);
@@ -293,6 +307,7 @@ __global__ __launch_bounds__(512) void decoder_chain_fwd_kernel(ChainArgs a) {
             }
         }
         __syncthreads();
+        CHAINF_STAMP()
         {
             float acc = 0.f;
             const float4* qp = reinterpret_cast<const float4*>(ql + yr * QP + (ypart * 16 + kq) * QC);
@@ -306,6 +321,7 @@ __global__ __launch_bounds__(512) void decoder_chain_fwd_kernel(ChainArgs a) {
             if (kq == 0 && yact) ysum[(ypart * AS + ya) * R + yr] = acc;
         }
         __syncthreads();
+        CHAINF_STAMP()
         if (wave0 && tid < R * AS) {
             const int r = tid / AS, aa = tid % AS, acol = mem * AS + aa;
             const float yv = batt + ysum[(0 * AS + aa) * R + r] + ysum[(1 * AS + aa) * R + r];
@@ -324,6 +340,7 @@ __global__ __launch_bounds__(512) void decoder_chain_fwd_kernel(ChainArgs a) {
             }
         }
         __syncthreads();
+        CHAINF_STAMP()
         {
             // DPP row -> (tl = row % 16, r = row / 16); lane kq -> A/16 consecutive a (float4 steps)
             const int tl = row % 16, r = row / 16;
@@ -351,6 +368,7 @@ __global__ __launch_bounds__(512) void decoder_chain_fwd_kernel(ChainArgs a) {
             if (kq == 0) eout[row] = sc;
         }
         __syncthreads();
+        CHAINF_STAMP()
         if (wave0 && tid < 32) {
             const int tl = tid % 16, r = tid / 16;
             if (tl < TS && r0 + r < a.B)
@@ -382,36 +400,46 @@ __global__ __launch_bounds__(512) void decoder_chain_fwd_kernel(ChainArgs a) {
             }
         }
         __syncthreads();
-        if (wave < R) {      // wave r: softmax of row r over tau < len (tau = m*TS + tl  <->  slot m*MAXTS + tl)
+        CHAINF_STAMP()
+        if (wave < R) {      // wave r: softmax of row r over tau < len; slots (m, tl) <-> tau = m*TS + tl, no division
             const int r = wave, L = blenf(r);
+            float* er = el + r * G * MAXTS;
+            float ev[G * MAXTS / 64];
             float m = -INFINITY;
-            for (int tau = lane; tau < L; tau += 64) m = fmaxf(m, el[r * G * MAXTS + (tau / TS) * MAXTS + (tau % TS)]);
+#pragma unroll
+            for (int j = 0; j < G * MAXTS / 64; ++j) {
+                const int sl = lane + 64 * j, tl = sl % MAXTS, tau = (sl / MAXTS) * TS + tl;
+                const bool ok = tl < TS && tau < L;
+                ev[j] = ok ? er[sl] : -INFINITY;
+                m = fmaxf(m, ev[j]);
+            }
             m = wave_allreduce_max(m);
             float sum = 0.f;
-            for (int tau = lane; tau < L; tau += 64) {
-                float* ep2 = el + r * G * MAXTS + (tau / TS) * MAXTS + (tau % TS);
-                const float pv = __expf(*ep2 - m); *ep2 = pv; sum += pv;
-            }
+#pragma unroll
+            for (int j = 0; j < G * MAXTS / 64; ++j) { ev[j] = ev[j] > -INFINITY ? __expf(ev[j] - m) : 0.f; sum += ev[j]; }
             sum = wave_allreduce_sum(sum);
             const float inv = L > 0 ? 1.0f / sum : 0.f;
-            for (int tau = lane; tau < Te; tau += 64) {
-                float* ep2 = el + r * G * MAXTS + (tau / TS) * MAXTS + (tau % TS);
-                const float pv = tau < L ? *ep2 * inv : 0.f;
-                *ep2 = pv;
-            }
+#pragma unroll
+            for (int j = 0; j < G * MAXTS / 64; ++j) er[lane + 64 * j] = ev[j] * inv;      // zero past the length and in unused slots
         }
         __syncthreads();
+        CHAINF_STAMP()
         {
             const int dd = tid % DS, r = (tid / DS) % R, tp = tid / (DS * R);
             float cs = 0.f;
             if (tp < NTP) {
                 const int L = blenf(r);
-                for (int tau = tp; tau < L; tau += NTP)
-                    cs = fmaf(el[r * G * MAXTS + (tau / TS) * MAXTS + (tau % TS)], encl[(r * Te + tau) * DS + dd], cs);
+                for (int m = tp; m < G; m += NTP) {
+                    const float* ap = el + r * G * MAXTS + m * MAXTS;
+                    const float* xp = encl + ((size_t)r * Te + m * TS) * DS + dd;
+                    const int nt = min(TS, L - m * TS);
+                    for (int tl = 0; tl < nt; ++tl) cs = fmaf(ap[tl], xp[tl * DS], cs);
+                }
                 cpart[(tp * R + r) * DS + dd] = cs;
             }
         }
         __syncthreads();
+        CHAINF_STAMP()
         if (wave0 && tid < R * DS) {
             const int r = tid / DS, dd = tid % DS;
             float cs = 0.f;
@@ -422,15 +450,16 @@ __global__ __launch_bounds__(512) void decoder_chain_fwd_kernel(ChainArgs a) {
                 a.ctx[((size_t)i * a.B + r0 + r) * D + mem * DS + dd] = cs;
             }
         }
-        if (wave0 && mem == 0) {       // alpha of this step -> global (bookkeeping, off the critical path)
-            for (int idx = lane; idx < R * Te; idx += 64) {
-                const int r = idx / Te, tau = idx % Te;
-                if (r0 + r < a.B)
-                    a.alpha[((size_t)i * a.B + r0 + r) * Te + tau] = el[r * G * MAXTS + (tau / TS) * MAXTS + (tau % TS)];
-            }
+        if (wave0 && tid < R * MAXTS) {       // alpha of this step -> global: every workgroup stores its own position slice
+            const int r = tid / MAXTS, tl = tid % MAXTS, tau = tau0 + tl;
+            if (tl < TS && tau < Te && r0 + r < a.B)
+                a.alpha[((size_t)i * a.B + r0 + r) * Te + tau] = el[r * G * MAXTS + mem * MAXTS + tl];
         }
+        CHAINF_STAMP()
         // (LDS buffers are rewritten only after later barriers of the next step)
     }
+    if (STAMP && a.dbg && blockIdx.x == 0 && threadIdx.x == 0) { for (int i = 0; i < 16; ++i) atomicAdd(a.dbg + 16 + i, (unsigned long long)stamp[i]); }
+#undef CHAINF_STAMP
 }
 
 }  // namespace asr
@@ -457,6 +486,12 @@ static int chain_launch(hipStream_t s, asr::ChainArgs& a, int Te) {
     if (lds > 150 * 1024) return ASR_EUNSUPPORTED;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asr::decoder_chain_fwd_kernel<H, D, A>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (H == 256 && a.dbg) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asr::decoder_chain_fwd_kernel<256, 512, 128, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((asr::decoder_chain_fwd_kernel<256, 512, 128, true>), dim3(groups * G), dim3(512), lds, s, a);
+        return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
+    }
     hipLaunchKernelGGL((asr::decoder_chain_fwd_kernel<H, D, A>), dim3(groups * G), dim3(512), lds, s, a);
     return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
 }
@@ -482,6 +517,7 @@ int asr_decoder_chain_fwd(void* stream, float* gates, const float* wh, const flo
     const size_t npar = 2 * (size_t)(H + D) + 2 * (size_t)H + 2 * (size_t)A + 2 * 16 * 16;
     a.xcc_slots = a.gx + groups * 2 * npar;
     a.err = err; a.B = B; a.Te = Te; a.t0 = t0; a.t1 = t1;
+    a.dbg = getenv("ASR_CHAIN_STAMP") ? asr::g_lstm_dbg : nullptr;
     for (int g0 = 0; g0 < (int)groups; g0 += 16) {
         a.g0 = g0; a.ng = std::min<int>(16, (int)groups - g0);
         const int rc = (H == 256) ? chain_launch<256, 512, 128>(s, a, Te) : chain_launch<64, 128, 16>(s, a, Te);

@@ -8,12 +8,15 @@ import bench
 from e2e_asr_amd import _lib, ops
 from e2e_asr_amd.weights import synthetic_batch
 dev = torch.device("cuda:0")
-dbg = torch.zeros(16, dtype=torch.int64, device=dev)
+dbg = torch.zeros(32, dtype=torch.int64, device=dev)
 _lib.lib().asr_debug_set_buffer(dbg.data_ptr())
 model = bench.build_model(dev, training=True)
 batch = synthetic_batch(B=32, T=800, F=80, t_dec=121, vocab=1000, variable_len=False, seed=1)
-for _ in range(3):
+for _ in range(2):
     model.step(batch)
+torch.cuda.synchronize()
+dbg.zero_()
+model.step(batch)
 torch.cuda.synchronize()
 d = dbg.cpu().numpy()
 names = ["gather dG (all-gather) + prefetch hand-over", "[dh|dctx] = dG.[K_h;WK_c]^T for my outputs", "dh, dctx_tot, S partial", "(b) dalpha partials",
@@ -24,3 +27,11 @@ steps = 120
 print("cycles per step: %.0f  (%.2f us at 100 MHz s_memtime clock)" % (tot / steps, tot / steps / 100.0))
 for n, v in zip(names, d[:11]):
     print("  %-50s %6.1f %%  %7.0f ticks/step" % (n, 100.0 * v / tot, v / steps))
+
+f = d[16:]
+fn = ["(1) gather state [h|ctx]", "(2) cell matvec + DPP", "cell, publish q and h; (3) gather q", "y matvec", "y publish; (4) gather y", "scores (tanh)",
+      "e publish; (5) gather scores", "softmax (replicated)", "context partials", "context publish, alpha store"]
+totf = float(f[:10].sum())
+print("forward chain: %.0f cycles per step over 120 steps; prologues of the call's launches: %.0f cycles in total" % (totf / steps, float(f[15])))
+for n, v in zip(fn, f[:10]):
+    print("  %-50s %6.1f %%  %7.0f ticks/step" % (n, 100.0 * v / totf, v / steps))
