@@ -26,6 +26,14 @@ typedef unsigned long long u64;
 #define ASR_PROF_DECODER_BWD 4
 #define ASR_PROF_OPTIM 5
 
+// Optional back-off between two polls of a granule that has not arrived (s_sleep units of 64 cycles; 0 = none, the
+// default: measured, a back-off of 1 makes the forward recurrence 6 % slower and changes nothing else): a spinning wave's
+// back-to-back sc1 loads occupy the CU's memory pipeline that the publishing wave of the same workgroup needs.
+#ifndef ASR_POLL_SLEEP
+#define ASR_POLL_SLEEP 0
+#endif
+#define ASR_POLL_BACKOFF() do { if (ASR_POLL_SLEEP) __builtin_amdgcn_s_sleep(ASR_POLL_SLEEP); } while (0)
+
 namespace asr {
 
 void prof_begin(int tag, hipStream_t s);   // prof.hip
@@ -65,8 +73,12 @@ __device__ __forceinline__ float wave_allreduce_sum(float v) {
     return v;
 }
 __device__ __forceinline__ float wave_allreduce_max(float v) {
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) v = fmaxf(v, __shfl_xor(v, m));
+    v = fmaxf(v, dpp_mov<0xB1>(v));    // the four DPP row steps of row16_allreduce_sum, with max
+    v = fmaxf(v, dpp_mov<0x4E>(v));
+    v = fmaxf(v, dpp_mov<0x141>(v));
+    v = fmaxf(v, dpp_mov<0x140>(v));
+    v = fmaxf(v, __shfl_xor(v, 16));
+    v = fmaxf(v, __shfl_xor(v, 32));
     return v;
 }
 

@@ -53,6 +53,7 @@ __device__ __forceinline__ bool chain_poll2(const u64* g, uint32_t epoch, float&
         u32x4c x;
         asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(x) : "v"(p) : "memory");
         if (x.y == epoch && x.w == epoch) { v0 = __uint_as_float(x.x); v1 = __uint_as_float(x.z); return true; }
+        ASR_POLL_BACKOFF();
         if ((spins & 1023) == 1023) {
             const long long now = wall_clock64();
             if (t0 == 0) t0 = now;
@@ -388,7 +389,8 @@ __global__ __launch_bounds__(512) void decoder_chain_fwd_kernel(ChainArgs a) {
                         for (uint32_t spins = 0;; ++spins) {
                             const u64 x = __hip_atomic_load(gE + off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             if ((uint32_t)(x >> 32) == ep) { v0 = __uint_as_float((uint32_t)x); break; }
-                            if ((spins & 1023) == 1023) {
+                            ASR_POLL_BACKOFF();
+        if ((spins & 1023) == 1023) {
                                 const long long now = wall_clock64();
                                 if (t0w == 0) t0w = now; else if (now - t0w > 200000000LL) { *a.err = 1; break; }
                             }

@@ -73,6 +73,7 @@ __device__ __forceinline__ bool gather16_one(const u64* base, uint32_t epoch, fl
             s0 = a0;
             return true;
         }
+        ASR_POLL_BACKOFF();
         if ((spins & 1023) == 1023) {
             const long long now = wall_clock64();
             if (t0 == 0) t0 = now;
@@ -293,7 +294,8 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
                     } else pending = true;
                 }
                 if (!pending) break;
-                if ((spins & 1023) == 1023) {
+                ASR_POLL_BACKOFF();
+        if ((spins & 1023) == 1023) {
                     const long long now = wall_clock64();
                     if (t0w == 0) t0w = now;
                     else if (now - t0w > 200000000LL) { *a.err = 1; break; }

@@ -57,6 +57,7 @@ __device__ __forceinline__ bool poll_granule(const u64* g, uint32_t epoch, float
     for (uint32_t spins = 0;; ++spins) {
         u64 x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((uint32_t)(x >> 32) == epoch) { val = __uint_as_float((uint32_t)x); return true; }
+        ASR_POLL_BACKOFF();
         if ((spins & 1023) == 1023) {              // bounded spin: ~2 s of wall clock
             long long now = wall_clock64();
             if (t0 == 0) t0 = now;
@@ -78,6 +79,7 @@ __device__ __forceinline__ bool poll_granule2(const u64* g, uint32_t epoch, floa
         u32x4 x;
         asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(x) : "v"(p) : "memory");
         if (x.y == epoch && x.w == epoch) { v0 = __uint_as_float(x.x); v1 = __uint_as_float(x.z); return true; }
+        ASR_POLL_BACKOFF();
         if ((spins & 1023) == 1023) {
             long long now = wall_clock64();
             if (t0 == 0) t0 = now;

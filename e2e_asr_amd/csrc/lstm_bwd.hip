@@ -50,6 +50,7 @@ __device__ __forceinline__ bool poll_pair(const u64* g, uint32_t epoch, float& v
         u32x4 x;
         asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(x) : "v"(p) : "memory");
         if (x.y == epoch && x.w == epoch) { v0 = __uint_as_float(x.x); v1 = __uint_as_float(x.z); return true; }
+        ASR_POLL_BACKOFF();
         if ((spins & 1023) == 1023) {
             const long long now = wall_clock64();
             if (t0 == 0) t0 = now;
@@ -346,7 +347,8 @@ __global__ __launch_bounds__(512) void lstm_rec_bwd_ag_kernel(LstmBwdArgs a) {
                         } else pending = true;
                     }
                     if (!pending) break;
-                    if ((spins & 1023) == 1023) {
+                    ASR_POLL_BACKOFF();
+        if ((spins & 1023) == 1023) {
                         const long long now = wall_clock64();
                         if (t0w == 0) t0w = now;
                         else if (now - t0w > 200000000LL) { *a.err = 1; break; }
