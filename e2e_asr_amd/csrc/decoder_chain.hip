@@ -32,6 +32,7 @@ struct ChainArgs {
     float* gates;            // [T][B][4H] in: preG rows of the segment; out: activated i,j,f,o
     const float* wh;         // [H][4H]  K_h  (rows E.. of the outer cell's TF kernel)
     const float* wc;         // [D][4H]  W2.K_x
+    const float4* wrl;       // [16 members][KC][512 threads] float4: [K_h ; W2.K_x] re-laid in the kernel's register order
     const float* w_att; const float* b_att; const float* v;     // [H][A], [A], [A]
     const float* hf;         // [B][Te][A]
     const float* enc;        // [B][Te][D]
@@ -69,6 +70,23 @@ __device__ __forceinline__ void chain_publish(u64* dst, uint32_t epoch, float v,
 }
 
 // H: decoder hidden; D: encoder state width; A: attention width.  R = 2 rows, G = 16 workgroups.
+// [K_h ; W2.K_x] -> the forward kernel's register order: out[((mem*KC + i)*512 + tid)] = the 4 gate weights of state row
+// k = ((row/16)*16 + kq)*KC + i for unit mem*HS + row%16 (tid = 16*row + kq); zero for padding rows / idle unit slots.
+template <int H, int D>
+__global__ __launch_bounds__(512) void chain_relayout_kernel(const float* wh, const float* wc, float4* out) {
+    constexpr int G = 16, HS = H / G, KS = H + D, KSP = (KS + 127) / 128 * 128, KC = KSP / 32, H4 = 4 * H;
+    const int mem = blockIdx.x / KC, i = blockIdx.x % KC, tid = threadIdx.x;
+    const int kq = tid & 15, row = tid >> 4, cu = row % 16, cpart_id = row / 16;
+    const int k = (cpart_id * 16 + kq) * KC + i;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (cu < HS && k < KS) {
+        const float* wr = (k < H) ? wh + (size_t)k * H4 : wc + (size_t)(k - H) * H4;
+        const int j = mem * HS + cu;
+        v = make_float4(wr[j], wr[H + j], wr[2 * H + j], wr[3 * H + j]);
+    }
+    out[(size_t)blockIdx.x * 512 + tid] = v;
+}
+
 // STAMP: diagnostic instantiation (ASR_CHAIN_STAMP=1 + asr_debug_set_buffer): s_memtime totals of wave 0 of workgroup 0
 // per phase (code between two consecutive barriers of a step; slot 15 = prologue), accumulated over the launches of a call;
 // never used for timing claims.
@@ -143,17 +161,13 @@ __global__ __launch_bounds__(512) void decoder_chain_fwd_kernel(ChainArgs a) {
     const int cu = row % 16, cpart_id = row / 16;            // unit slot (0..15), K part
     const bool cact = cu < HS;
     const int cchunk = cpart_id * 16 + kq;                   // chunk 0..31 of the state vector
+    // weights in register order, re-laid once per call by chain_relayout_kernel: one coalesced 16-byte load per (i, thread)
+    // (read straight from the TF layout this took 96 strided 4-byte loads per thread: most of a 29 us prologue per launch)
     float wb[KC][4];
     {
-        const int j = mem * HS + (cact ? cu : 0);
+        const float4* wp = a.wrl + (size_t)mem * KC * NT + tid;
 #pragma unroll
-        for (int i = 0; i < KC; ++i) {
-            const int k = cchunk * KC + i;                   // 0..KSP-1: [h | ctx | zero pad]
-            const bool kok = cact && k < KS;
-            const float* wr = (k < H) ? a.wh + (size_t)k * H4 : a.wc + (size_t)(kok ? k - H : 0) * H4;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) wb[i][g] = kok ? wr[g * H + j] : 0.f;
-        }
+        for (int i = 0; i < KC; ++i) { const float4 v4 = wp[(size_t)i * NT]; wb[i][0] = v4.x; wb[i][1] = v4.y; wb[i][2] = v4.z; wb[i][3] = v4.w; }
     }
     // y matvec: DPP row -> (col ya = row % 8 ..., r, part)
     const int ya = row % 8, yr = (row / 8) % 2, ypart = row / 16;
@@ -472,10 +486,17 @@ extern "C" int asr_decoder_chain_supported(int B, int Te, int D, int A, int H) {
     return (H == 256 && D == 512 && A == 128) || (H == 64 && D == 128 && A == 16);
 }
 
-extern "C" size_t asr_decoder_chain_ws_bytes(int B, int D, int A, int H) {
+static size_t chain_gran_bytes(int B, int D, int A, int H) {
     const size_t groups = (B + 1) / 2;
     const size_t npar = 2 * (size_t)(H + D) + 2 * (size_t)H + 2 * (size_t)A + 2 * 16 * 16;
-    return groups * 2 * npar * sizeof(u64) + groups * 16 * sizeof(u64);
+    return (groups * 2 * npar * sizeof(u64) + groups * 16 * sizeof(u64) + 255) / 256 * 256;
+}
+static size_t chain_relayout_bytes(int D, int H) {
+    const size_t KC = ((size_t)(H + D) + 127) / 128 * 128 / 32;
+    return 16 * KC * 512 * sizeof(float4);
+}
+extern "C" size_t asr_decoder_chain_ws_bytes(int B, int D, int A, int H) {
+    return chain_gran_bytes(B, D, A, H) + chain_relayout_bytes(D, H);      // granules + XCC slots | re-laid weights
 }
 
 template <int H, int D, int A>
@@ -509,12 +530,19 @@ int asr_decoder_chain_fwd(void* stream, float* gates, const float* wh, const flo
     if (!asr_decoder_chain_supported(B, Te, D, A, H) || t1 <= t0) return ASR_EUNSUPPORTED;
     hipStream_t s = static_cast<hipStream_t>(stream);
     // NOTE: all batch rows of a launch share the [T][B][.] row stride B, so chunking is by group range only
-    const size_t bytes = asr_decoder_chain_ws_bytes(B, D, A, H);
-    if (t0 == 0 && hipMemsetAsync(ws, 0, bytes, s) != hipSuccess) return ASR_ELAUNCH;     // once per sequence
+    const size_t bytes = chain_gran_bytes(B, D, A, H);
+    float4* wrl = reinterpret_cast<float4*>(static_cast<char*>(ws) + bytes);
+    if (t0 == 0) {                                                                          // once per sequence
+        if (hipMemsetAsync(ws, 0, bytes, s) != hipSuccess) return ASR_ELAUNCH;
+        const int KC = ((H + D + 127) / 128 * 128) / 32;
+        if (H == 256) hipLaunchKernelGGL((asr::chain_relayout_kernel<256, 512>), dim3(16 * KC), dim3(512), 0, s, wh, wc, wrl);
+        else hipLaunchKernelGGL((asr::chain_relayout_kernel<64, 128>), dim3(16 * KC), dim3(512), 0, s, wh, wc, wrl);
+    }
     ChainArgs a;
     a.gates = gates; a.wh = wh; a.wc = wc; a.w_att = w_att; a.b_att = b_att; a.v = v; a.hf = hf; a.enc = enc;
     a.enc_len = enc_len; a.dec_c = dec_c; a.dec_h = dec_h; a.alpha = alpha; a.ctx = ctx; a.y = y;
     a.gx = static_cast<u64*>(ws);
+    a.wrl = wrl;
     const size_t groups = (B + 1) / 2;
     const size_t npar = 2 * (size_t)(H + D) + 2 * (size_t)H + 2 * (size_t)A + 2 * 16 * 16;
     a.xcc_slots = a.gx + groups * 2 * npar;
