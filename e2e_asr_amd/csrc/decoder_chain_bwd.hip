@@ -113,10 +113,9 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
     // slots per (dst, src): even counts so that pairs never straddle
     constexpr int S1 = R * (MAXTS + 2);               // X1: [r][dalpha positions | S | pad]
     constexpr int S2 = R * ((AS + 1) & ~1);           // X2: [r][dy a-slice]
-    constexpr int S3 = R * ((HS + 1) & ~1);           // X3: [r][dq units]
     constexpr int AS2 = (AS + 1) & ~1, HS2 = (HS + 1) & ~1;
     static_assert(HS * G == H && AS * G == A && DS * G == D && PC % 4 == 0, "sizes");
-    constexpr int NPAR = G * G * (S1 + S2 + S3) + R * N4;  // granules per parity per group (X1, X2, X3 reduce-scatters + dG all-gather)
+    constexpr int NPAR = G * G * (S1 + S2) + R * A + R * N4;  // granules per parity per group (X1, X2 reduce-scatters + dy and dG all-gathers)
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int* lds_flag = reinterpret_cast<int*>(smem);
@@ -128,30 +127,26 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
     float* dyrow = del + R * MAXTS;                        // per DPP row partial dy [32 rows][A]
     float* dyp = dyrow + 32 * A;                      // partial dy [R][A]                            -> X2 publish
     float* dys = dyp + R * A;                         // dy for my a-slice [R][AS2]
-    float* dqp = dys + R * AS2;                       // partial dq [R][H]                            -> X3 publish
-    float* dql = dqp + R * H;                         // gathered dq_att for my units [R][HS2]
+    float* dyall = dys + R * AS2;                     // dy of both rows over ALL attention columns [R][A] (all-gather)
+    float* dql = dyall + R * A + (R * H - R * A);     // dq_att for my units [R][HS2]   (layout slot of the former [R][H] buffer kept)
     float* dga = dql + R * HS2;                       // gathered dG of the later step [R][64 chunks][CSB]
     float* fpart = dga + R * 64 * CSB;                // [dh|dctx] partial sums [NOUT][R][4 DPP rows]
     float* hfl = fpart + ((NOUT * R * 4 + 3) & ~3);   // hf slice [R][MAXTS][A]
     float* dhfl = hfl + R * MAXTS * A;                // dhf accumulator [R][MAXTS][A]
     const int Te = a.Te;
     const int TS = (Te + G - 1) / G;
-    float* wal = dhfl + R * MAXTS * A;                // W_att[:, my a-slice] [H][AS]
+    float* wal = dhfl + R * MAXTS * A;                // W_att rows of my units [HS][A]
     float* vl = wal + H * AS;                         // v [A]
     float* encl = vl + A;                             // enc slice [R][Te][DS]
     // operands of the CURRENT step that depend on no exchange: fetched one step ahead by the prefetch waves
     // (threads >= 256, which neither poll nor store) -- item order below = LDS order
     const int TeP = (Te + 1) & ~1;
-    float* pfl = encl + R * Te * DS;
-    float* yl = pfl;                                  // y_i [R][A]
-    float* alf = yl + R * A;                          // alpha_i [R][TeP]
-    float* dqcx = alf + R * TeP;                      // dctx_ap slice [R][DS]
-    float* ctxl = dqcx + R * DS;                      // ctx_i slice [R][DS]
-    float* gl = ctxl + R * DS;                        // activated gates of my units [R][HS][4]
-    float* cl = gl + R * HS * 4;                      // c_i [R][HS]
-    float* cpl = cl + R * HS;                         // c_{i-1} [R][HS]
-    float* dqa = cpl + R * HS;                        // dq_ap of my units [R][HS]
+    // double-buffered by step parity: the LAST phase of a step (cell) still reads its copy while the prefetch waves hand the
+    // next step's operands over at the top of the next step (a single buffer there was a race; behind the step's first
+    // barrier it put the prefetch issue on the critical path)
+    float* pfl_base = encl + R * Te * DS;
     const int nitems = R * A + R * TeP + 2 * R * DS + R * HS * 4 + 3 * R * HS;
+    const int nitemsP = (nitems + 3) & ~3;
 
     __builtin_amdgcn_s_setprio(3);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -188,10 +183,7 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
             wo[i][q] = ook ? wr[(pos & 3) * H + (pos >> 2)] : 0.f;
         }
     }
-    // phase (e): thread -> (r = tid / H, k = tid % H) (R*H <= 512): W_att[k][my a-slice]
-    const int ek = tid % H, er = tid / H;
-    const bool eact = tid < R * H;
-    for (int idx = tid; idx < H * AS; idx += NT) wal[idx] = a.w_att[(size_t)(idx / AS) * A + mem * AS + idx % AS];
+    for (int idx = tid; idx < HS * A; idx += NT) wal[idx] = a.w_att[(size_t)(mem * HS + idx / A) * A + idx % A];
     for (int idx = tid; idx < A; idx += NT) vl[idx] = a.v[idx];
     // hf / enc slices -> LDS, dhf accumulator = 0
     const int tau0 = mem * TS;
@@ -254,12 +246,39 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
     if (STAMP) tlast = __builtin_amdgcn_s_memtime();
     for (int s = 0; s < a.T; ++s) {
         sph = 0;
+        float* const pfl = pfl_base + (s & 1) * nitemsP;
+        float* const yl = pfl;                            // y_i [R][A]
+        float* const alf = yl + R * A;                    // alpha_i [R][TeP]
+        float* const dqcx = alf + R * TeP;                // dctx_ap slice [R][DS]
+        float* const ctxl = dqcx + R * DS;                // ctx_i slice [R][DS]
+        float* const gl = ctxl + R * DS;                  // activated gates of my units [R][HS][4]
+        float* const cl = gl + R * HS * 4;                // c_i [R][HS]
+        float* const cpl = cl + R * HS;                   // c_{i-1} [R][HS]
+        float* const dqa = cpl + R * HS;                  // dq_ap of my units [R][HS]
         const int i = a.T - 1 - s;
         const uint32_t ep = (uint32_t)(s + 1);
         u64* gpar = gbase + (size_t)(s & 1) * NPAR;
-        u64* g1 = gpar; u64* g2 = g1 + G * G * S1; u64* g3 = g2 + G * G * S2; u64* g4 = g3 + G * G * S3;
-        const u64* g4prev = gbase + (size_t)((s - 1) & 1) * NPAR + G * G * (S1 + S2 + S3);     // dG of the previous (later-time) step
+        u64* g1 = gpar; u64* g2 = g1 + G * G * S1; u64* g3 = g2 + G * G * S2; u64* g4 = g3 + R * A;
+        const u64* g4prev = gbase + (size_t)((s - 1) & 1) * NPAR + G * G * (S1 + S2) + R * A;     // dG of the previous (later-time) step
         // ---- operands of this step that do not depend on any exchange (waves >= 2 fetch them)
+        // ---- hand the prefetched operands of THIS step over to this parity's LDS copy, and fetch the next step's
+        if (pfw) {
+#pragma unroll
+            for (int j = 0; j < NPF; ++j) {
+                const int idx = tid - PF0 + PFN * j;
+                if (idx < nitems) pfl[idx] = pfr[j];
+            }
+            if (s + 1 < a.T) {
+#pragma unroll
+                for (int j = 0; j < NPF; ++j) {
+                    int idx = tid - PF0 + PFN * j;
+                    // opaque per iteration: keeps the item decode (cheap ALU) inside the loop instead of
+                    // loop-invariant address registers held across the register-critical phases
+                    asm volatile("" : "+v"(idx));
+                    if (idx < nitems) pfr[j] = pf_fetch(i - 1, idx);
+                }
+            }
+        }
         // ---- gather dG of the later step (all 4H positions of both rows; published by their owners), waves 1-2:
         // all of a thread's granule loads in flight, re-polled together until every tag matches
         if (s > 0 && tid >= 64 && tid < 64 + NGT) {
@@ -305,26 +324,6 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
         }
         __syncthreads();
         CHAIN_STAMP()
-        // ---- hand the prefetched operands of THIS step over to LDS (and fetch the next step's).  Not at the top of the
-        // step: the cell phase of the previous step (wave 0, the last phase of a step) still reads these buffers until it
-        // has passed the barrier above.
-        if (pfw) {
-#pragma unroll
-            for (int j = 0; j < NPF; ++j) {
-                const int idx = tid - PF0 + PFN * j;
-                if (idx < nitems) pfl[idx] = pfr[j];
-            }
-            if (s + 1 < a.T) {
-#pragma unroll
-                for (int j = 0; j < NPF; ++j) {
-                    int idx = tid - PF0 + PFN * j;
-                    // opaque per iteration: keeps the item decode (cheap ALU) inside the loop instead of
-                    // loop-invariant address registers held across the register-critical phases
-                    asm volatile("" : "+v"(idx));
-                    if (idx < nitems) pfr[j] = pf_fetch(i - 1, idx);
-                }
-            }
-        }
         // ---- [dh_i | dctx_carry_i] for my outputs = dG_{i+1} . [K_h ; WK_c]^T: 64 position chunks per wave, DPP-row
         // butterflies, the 4 rows of the wave meet in LDS (summed in fixed order by the consumers below)
         if (s > 0) {
@@ -488,31 +487,68 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
         }
         __syncthreads();
         CHAIN_STAMP()
-        if (wave0 && tid < R * AS) {      // save dy (dW_att = q^T . dy after the loop)
+        if (wave0 && tid < R * AS) {      // save dy (dW_att = q^T . dy after the loop) and publish it (all-gather of dy)
             const int r = tid / AS, al = tid % AS;
-            if (rok(r)) a.dY[((size_t)i * a.B + r0 + r) * A + mem * AS + al] = dys[r * AS2 + al];
+            if (rok(r)) {
+                const float x = dys[r * AS2 + al];
+                a.dY[((size_t)i * a.B + r0 + r) * A + mem * AS + al] = x;
+                pubg(g3 + (size_t)r * A + mem * AS + al, ep, x, fast);
+            }
         }
-        // ---- (e) partial dq[r][k] = dy[r][my a-slice] . W_att[k][my a-slice]
-        if (eact) {
-            float x = 0.f;
-#pragma unroll
-            for (int q = 0; q < AS; ++q) x = fmaf(dys[er * AS2 + q], wal[ek * AS + q], x);
-            dqp[tid] = x;
+        // ---- gather dy over all attention columns (R*A granules, pairs; wave 1)
+        if (wave1) {
+            constexpr int NPY = (R * A / 2 + 63) / 64;
+            for (int j = 0; j < NPY; ++j) {
+                const int pidx = tid - 64 + 64 * j;
+                if (pidx < R * A / 2) {
+                    const int idx = 2 * pidx, r = idx / A;
+                    float v0 = 0.f, v1 = 0.f;
+                    if (rok(r)) {
+                        long long t0w = 0;
+                        for (uint32_t spins = 0;; ++spins) {
+                            const u64 x0 = __hip_atomic_load(g3 + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            const u64 x1 = __hip_atomic_load(g3 + idx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if ((uint32_t)(x0 >> 32) == ep && (uint32_t)(x1 >> 32) == ep) {
+                                v0 = __uint_as_float((uint32_t)x0); v1 = __uint_as_float((uint32_t)x1); break;
+                            }
+                            ASR_POLL_BACKOFF();
+                            if ((spins & 1023) == 1023) {
+                                const long long now = wall_clock64();
+                                if (t0w == 0) t0w = now;
+                                else if (now - t0w > 200000000LL) { *a.err = 1; break; }
+                                if (__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                            }
+                        }
+                    }
+                    *reinterpret_cast<float2*>(dyall + idx) = make_float2(v0, v1);
+                }
+            }
         }
         __syncthreads();
         CHAIN_STAMP()
-        if (wave0) {     // X3 publish: to the owner of each unit slice
-            for (int idx = lane; idx < R * H; idx += 64) {
-                const int r = idx / H, k = idx % H, md = k / HS, u = k % HS;
-                if (rok(r)) pubg(g3 + ((size_t)md * G + mem) * S3 + r * HS2 + u, ep, dqp[idx], fast);
+        // ---- dq_att for my units: dq[r][u] = dy[r][:] . W_att[unit u][:]  (DPP row = one (r, u), 16 lanes over the columns)
+        {
+            const int o = row;                       // 0 .. 31
+            float x = 0.f;
+            if (o < R * HS) {
+                const int r = o / HS, u = o % HS;
+                const float* dyr = dyall + r * A;
+                const float* wr = wal + u * A;
+                if (AL % 4 == 0) {
+#pragma unroll
+                    for (int c = 0; c < AL / 4; ++c) {
+                        const int a0c = c * 64 + kq * 4;
+                        const float4 d4 = *reinterpret_cast<const float4*>(dyr + a0c);
+                        const float4 w4 = *reinterpret_cast<const float4*>(wr + a0c);
+                        x = fmaf(d4.x, w4.x, x); x = fmaf(d4.y, w4.y, x); x = fmaf(d4.z, w4.z, x); x = fmaf(d4.w, w4.w, x);
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < AL; ++q) x = fmaf(dyr[kq * AL + q], wr[kq * AL + q], x);
+                }
             }
-        }
-        // ---- X3 gather: dq_att for my units
-        if (wave1 && tid - 64 < S3) {
-            const int slot = tid - 64, r = slot / HS2, q = slot % HS2;
-            float v0 = 0.f;
-            if (rok(r) && q < HS) gather16_one<S3>(g3 + ((size_t)mem * G) * S3 + slot, ep, v0, a.err);
-            dql[r * HS2 + q] = v0;
+            x = row16_allreduce_sum(x);
+            if (kq == 0 && o < R * HS) dql[(o / HS) * HS2 + (o % HS)] = x;
         }
         __syncthreads();
         CHAIN_STAMP()
@@ -578,9 +614,9 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
 
 extern "C" size_t asr_decoder_chain_bwd_ws_bytes(int B, int D, int A, int H) {
     const size_t groups = (B + 1) / 2, G = 16, R = 2, HS = H / 16, AS = A / 16, DS = D / 16;
-    const size_t s1 = R * (16 + 2), s2 = R * ((AS + 1) & ~(size_t)1), s3 = R * ((HS + 1) & ~(size_t)1);
-    (void)DS;
-    return groups * 2 * (G * G * (s1 + s2 + s3) + R * 4 * (size_t)H) * sizeof(u64) + groups * 16 * sizeof(u64);
+    const size_t s1 = R * (16 + 2), s2 = R * ((AS + 1) & ~(size_t)1);
+    (void)DS; (void)HS;
+    return groups * 2 * (G * G * (s1 + s2) + R * (size_t)A + R * 4 * (size_t)H) * sizeof(u64) + groups * 16 * sizeof(u64);
 }
 
 template <int H, int D, int A>
@@ -589,7 +625,7 @@ static int chain_bwd_launch(hipStream_t s, asr::ChainBwdArgs& a) {
     const int groups = a.ng;
     const size_t lds = sizeof(float) * (4 + R * DS + R * HS2 + R * G * 16 + 4 + R * 16 + R * A + 32 * A + R * A + R * AS2 +
                                         R * H + R * HS2 + R * 64 * (H / 16 + 4) + (HS + DS) * R * 4 + 4 + 2 * R * 16 * A + H * AS + A + (size_t)R * a.Te * DS +
-                                        (size_t)R * (a.Te + 1) + 2 * R * DS + 7 * R * HS + 16);
+                                        2 * ((size_t)R * A + (size_t)R * (a.Te + 1) + 2 * R * DS + 7 * R * HS + 4) + 16);
     if (lds > 150 * 1024) return ASR_EUNSUPPORTED;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asr::decoder_chain_bwd_kernel<H, D, A>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -20,7 +20,7 @@ model.step(batch)
 torch.cuda.synchronize()
 d = dbg.cpu().numpy()
 names = ["gather dG (all-gather) + prefetch hand-over", "[dh|dctx] = dG.[K_h;WK_c]^T for my outputs", "dh, dctx_tot, S partial", "(b) dalpha partials",
-         "X1 publish + gather", "(d) tanh backward", "dy row reduce", "X2 publish + gather", "(e) dq partials", "X3 publish + gather",
+         "X1 publish + gather", "(d) tanh backward", "dy row reduce", "X2 publish + gather", "dY save, dy publish + gather (all-gather)", "dq for my units",
          "cell pointwise + dG publish"]
 tot = float(d[:11].sum())
 steps = 120
