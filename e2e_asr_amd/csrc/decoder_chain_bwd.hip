@@ -211,36 +211,52 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
     float dc = 0.f;
     constexpr int NPF = 5, PF0 = 256, PFN = NT - PF0;      // waves 4-7 prefetch
     const bool pfw = __builtin_amdgcn_readfirstlane(tid) >= PF0;
-    auto pf_fetch = [&](int i, int idx) -> float {
-        if (idx < R * A) { const int r = idx / A; return rok(r) ? a.y[((size_t)i * a.B + browf(r)) * A + idx % A] : 0.f; }
-        idx -= R * A;
-        if (idx < R * TeP) {
-            const int r = idx / TeP, tau = idx % TeP;
-            return (rok(r) && tau < Te) ? a.alpha[((size_t)i * a.B + browf(r)) * Te + tau] : 0.f;
+    // Per (thread, slot) descriptors of the prefetched items, built once: address of the item at time index 0 and its
+    // stride per time step (low bit: "the item of step t lives at t-1 and is zero at t = 0", the c_{t-1} rows).  The
+    // per-step fetch is then one LDS read + one multiply-add per item (decoding the item list every step put ~2000
+    // cycles of integer work of the prefetch waves in front of the step's first barrier).
+    unsigned long long* pfa = reinterpret_cast<unsigned long long*>(pfl_base + 2 * nitemsP);
+    int* pfs = reinterpret_cast<int*>(pfa + NPF * PFN);
+    if (pfw) {
+        for (int j = 0; j < NPF; ++j) {
+            int idx = tid - PF0 + PFN * j;
+            const float* ptr = nullptr; long long stride = 0; int flag = 0;
+            if (idx < nitems) {
+                if (idx < R * A) { const int r = idx / A; if (rok(r)) { ptr = a.y + (size_t)browf(r) * A + idx % A; stride = (long long)a.B * A; } }
+                else if ((idx -= R * A) < R * TeP) {
+                    const int r = idx / TeP, tau = idx % TeP;
+                    if (rok(r) && tau < Te) { ptr = a.alpha + (size_t)browf(r) * Te + tau; stride = (long long)a.B * Te; }
+                } else if ((idx -= R * TeP) < R * DS) {
+                    const int r = idx / DS; if (rok(r)) { ptr = a.dqc + (size_t)browf(r) * (H + D) + H + mem * DS + idx % DS; stride = (long long)a.B * (H + D); }
+                } else if ((idx -= R * DS) < R * DS) {
+                    const int r = idx / DS; if (rok(r)) { ptr = a.ctx + (size_t)browf(r) * D + mem * DS + idx % DS; stride = (long long)a.B * D; }
+                } else if ((idx -= R * DS) < R * HS * 4) {
+                    const int r = idx / (HS * 4), uu = (idx >> 2) % HS, g = idx & 3;
+                    if (rok(r)) { ptr = a.gates + (size_t)browf(r) * H4 + g * H + mem * HS + uu; stride = (long long)a.B * H4; }
+                } else {
+                    idx -= R * HS * 4;
+                    const int which = idx / (R * HS), rem = idx % (R * HS), r = rem / HS, uu = rem % HS;
+                    if (rok(r)) {
+                        if (which == 2) { ptr = a.dqc + (size_t)browf(r) * (H + D) + mem * HS + uu; stride = (long long)a.B * (H + D); }
+                        else { ptr = a.dec_c + (size_t)browf(r) * H + mem * HS + uu; stride = (long long)a.B * H; flag = which; }
+                    }
+                }
+            }
+            unsigned long long ad = reinterpret_cast<unsigned long long>(ptr);
+            if (ptr && flag) ad -= (unsigned long long)stride * 4ull;                  // item of step t lives at t - 1
+            pfa[j * PFN + tid - PF0] = ad;
+            pfs[j * PFN + tid - PF0] = (int)(stride * 2) | flag;
         }
-        idx -= R * TeP;
-        if (idx < R * DS) { const int r = idx / DS; return rok(r) ? a.dqc[((size_t)i * a.B + browf(r)) * (H + D) + H + mem * DS + idx % DS] : 0.f; }
-        idx -= R * DS;
-        if (idx < R * DS) { const int r = idx / DS; return rok(r) ? a.ctx[((size_t)i * a.B + browf(r)) * D + mem * DS + idx % DS] : 0.f; }
-        idx -= R * DS;
-        if (idx < R * HS * 4) {
-            const int r = idx / (HS * 4), uu = (idx >> 2) % HS, g = idx & 3;
-            return rok(r) ? a.gates[((size_t)i * a.B + browf(r)) * H4 + g * H + mem * HS + uu] : 0.f;
-        }
-        idx -= R * HS * 4;
-        const int which = idx / (R * HS), rem = idx % (R * HS), r = rem / HS, uu = rem % HS;
-        if (!rok(r)) return 0.f;
-        const size_t rowi = (size_t)i * a.B + browf(r);
-        if (which == 0) return a.dec_c[rowi * H + mem * HS + uu];
-        if (which == 1) return i > 0 ? a.dec_c[(rowi - a.B) * H + mem * HS + uu] : 0.f;
-        return a.dqc[rowi * (H + D) + mem * HS + uu];
+    }
+    auto pf_fetch = [&](int t, int j) -> float {
+        const unsigned long long ad = pfa[j * PFN + tid - PF0];
+        const int st = pfs[j * PFN + tid - PF0];
+        if (ad == 0 || ((st & 1) && t == 0)) return 0.f;
+        return *reinterpret_cast<const float*>(ad + (unsigned long long)t * (unsigned long long)(st >> 1) * 4ull);
     };
     float pfr[NPF];
 #pragma unroll
-    for (int j = 0; j < NPF; ++j) {
-        const int idx = tid - PF0 + PFN * j;
-        pfr[j] = (pfw && idx < nitems) ? pf_fetch(a.T - 1, idx) : 0.f;
-    }
+    for (int j = 0; j < NPF; ++j) pfr[j] = pfw ? pf_fetch(a.T - 1, j) : 0.f;
     __syncthreads();
 
     if (STAMP) tlast = __builtin_amdgcn_s_memtime();
@@ -270,13 +286,7 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
             }
             if (s + 1 < a.T) {
 #pragma unroll
-                for (int j = 0; j < NPF; ++j) {
-                    int idx = tid - PF0 + PFN * j;
-                    // opaque per iteration: keeps the item decode (cheap ALU) inside the loop instead of
-                    // loop-invariant address registers held across the register-critical phases
-                    asm volatile("" : "+v"(idx));
-                    if (idx < nitems) pfr[j] = pf_fetch(i - 1, idx);
-                }
+                for (int j = 0; j < NPF; ++j) pfr[j] = pf_fetch(i - 1, j);
             }
         }
         // ---- gather dG of the later step (all 4H positions of both rows; published by their owners), waves 1-2:
@@ -625,7 +635,7 @@ static int chain_bwd_launch(hipStream_t s, asr::ChainBwdArgs& a) {
     const int groups = a.ng;
     const size_t lds = sizeof(float) * (4 + R * DS + R * HS2 + R * G * 16 + 4 + R * 16 + R * A + 32 * A + R * A + R * AS2 +
                                         R * H + R * HS2 + R * 64 * (H / 16 + 4) + (HS + DS) * R * 4 + 4 + 2 * R * 16 * A + H * AS + A + (size_t)R * a.Te * DS +
-                                        2 * ((size_t)R * A + (size_t)R * (a.Te + 1) + 2 * R * DS + 7 * R * HS + 4) + 16);
+                                        2 * ((size_t)R * A + (size_t)R * (a.Te + 1) + 2 * R * DS + 7 * R * HS + 4) + 3 * 5 * 256 + 16);
     if (lds > 150 * 1024) return ASR_EUNSUPPORTED;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asr::decoder_chain_bwd_kernel<H, D, A>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
