@@ -6,20 +6,21 @@
 // forward: H/16 units, A/16 attention columns, ceil(Te/16) positions, D/16 context columns each):
 //   AG  gather dG of step i+1 (all 4H positions of both rows; all-gather, published by the owners of the units)
 //       [dh_i | dctx_carry] for my units / my D-slice = dG_{i+1} . [K_h ; W_inp[P:].K_x]^T over ALL gate columns, with the
-//       rows of my own H/16 + D/16 outputs resident in registers (the forward's structure; the first version scattered
-//       partial sums of all H + D outputs: 1536 publishing stores per workgroup and step, 27 % of the step)
-//       dctx_tot = dctx_ap[i] + dctx_carry   (saved: the caller turns sum_i alpha_i^T.dctx_i into denc)
-//   (b) partial dalpha[tau] over my D-slice for ALL positions, and the partial of the softmax scalar
-//       S = sum_tau alpha.dalpha = dctx_tot . ctx_i  (identity: ctx = sum alpha.enc)     -> X1 publish
-//   X1  gather dalpha for my positions (+ S); de = alpha (dalpha - S)
+//       rows of my own H/16 + D/16 outputs resident in registers
+//       dctx_tot = dctx_ap[i] + dctx_carry   (saved: the caller turns sum_i alpha_i^T.dctx_i into denc); my partial of the
+//       softmax scalar S = sum_tau alpha.dalpha = dctx_tot . ctx_i  (identity: ctx = sum alpha.enc)
+//   AG  gather dctx_tot over all D columns (+ the 16 partials of S)
+//       dalpha for MY positions over all D (enc rows of my positions in LDS); de = alpha (dalpha - S)
 //   (d) tanh backward on my positions: ds = de v (1 - th^2); dhf slice += ds (LDS, written once at the
 //       end); dv += de th (registers); partial dy[a] over my positions               -> X2 publish
-//   X2  gather dy for my A-slice (saved: dW_att = q^T.dy after the loop); partial dq[k] = dy.W_att[k, slice]
-//                                                                                    -> X3 publish
-//   X3  gather dq_att for my units; cell pointwise backward -> dG (in place over the saved gates), dc carry;
-//       the 4 dG values of each unit are published first (AG of the next step)
-// X1-X3 are reduce-scatters of tagged granules: destination-major [dst][src][slot]; ONE wave gathers, each lane
-// issuing its 16 source loads together and summing in fixed order (reproducible).  Wave 0 owns every global store.
+//   X2  gather dy for my A-slice (reduce-scatter over the position slices; saved: dW_att = q^T.dy after the loop)
+//   AG  gather dy over all A columns; dq_att for MY units = dy . W_att[unit, :]
+//       cell pointwise backward -> dG (in place over the saved gates), dc carry; the 4 dG values of each unit are
+//       published first (AG of the next step)
+// Three of the four exchanges are all-gathers of the SMALL vector a workgroup owns (64 / 64+1 / 16 publishing stores) with
+// the contraction done by the consumer; the first version reduce-scattered partial sums of everything (2848 publishing
+// stores per workgroup and step by one wave, 12.6 us per step; now 6.3).  Granules are tagged 8-byte {step, value} words;
+// gathering threads keep all their loads in flight and sum in fixed order (reproducible).  Wave 0 owns every global store.
 // dx = dG.K_x^T and dlm_out = dx.W_inp[:P]^T are GEMMs after the loop.
 #include "common.h"
 #include <cstdlib>
@@ -99,30 +100,33 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
     constexpr int R = 2, G = 16, NT = 512;
     constexpr int HS = H / G, AS = A / G, DS = D / G;
     constexpr int KS = H + D;
+    constexpr int NGT = 192;                          // gathering threads of the all-gathers: waves 1-3
     constexpr int N4 = 4 * H;                         // dG positions per row: p = 4*unit + gate
     constexpr int PC = N4 / 64;                       // positions per lane in the [dh|dctx] contraction (64 chunks = one wave)
     constexpr int CSB = PC + 4;                       // padded LDS chunk stride
     constexpr int NOUT = HS + DS;                     // outputs owned by this workgroup: dh of my units | dctx of my columns
     constexpr int OPW = (NOUT + 7) / 8;               // outputs per wave
     constexpr int NPAIR4 = R * N4 / 2;                // granule pairs gathered per step
-    constexpr int NGT = 192;                          // gathering threads of the dG all-gather: waves 1-3
     constexpr int NPP4 = (NPAIR4 + NGT - 1) / NGT;    // ... pairs per gathering thread
     constexpr int MAXTS = 16;
     constexpr int AL = A / 16;                        // a values per lane in the tanh phase
     constexpr int H4 = 4 * H;
     // slots per (dst, src): even counts so that pairs never straddle
-    constexpr int S1 = R * (MAXTS + 2);               // X1: [r][dalpha positions | S | pad]
+    constexpr int D1 = D + G;                         // all-gather row of dctx_tot: [D values | G partials of S]
+    constexpr int NPAIR1 = R * D1 / 2;
+    constexpr int NPP1 = (NPAIR1 + NGT - 1) / NGT;    // pairs per gathering thread (waves 1-3)
+    constexpr int DL = D / 16;                        // context columns per lane in the dalpha contraction
     constexpr int S2 = R * ((AS + 1) & ~1);           // X2: [r][dy a-slice]
     constexpr int AS2 = (AS + 1) & ~1, HS2 = (HS + 1) & ~1;
     static_assert(HS * G == H && AS * G == A && DS * G == D && PC % 4 == 0, "sizes");
-    constexpr int NPAR = G * G * (S1 + S2) + R * A + R * N4;  // granules per parity per group (X1, X2 reduce-scatters + dy and dG all-gathers)
+    constexpr int NPAR = R * D1 + G * G * S2 + R * A + R * N4;  // granules per parity per group (dctx_tot, dy, dG all-gathers + the dy reduce-scatter X2)
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int* lds_flag = reinterpret_cast<int*>(smem);
     float* dctl = smem + 4;                           // dctx_tot slice [R][DS]
     float* dhl = dctl + R * DS;                       // dh for my units [R][HS]
-    float* dal = dhl + R * HS2;                       // partial dalpha [R][G*MAXTS] (all positions)  -> X1 publish
-    float* sp = dal + R * G * MAXTS;                  // partial S [R] (+pad 2)
+    float* dctall = dhl + R * HS2;                    // dctx_tot of both rows over ALL context columns + the G partials of S [R][D1]
+    float* sp = dctall + ((R * D1 + 3) & ~3);         // S [2 + r] (+pad)
     float* del = sp + 4;                              // de for my positions [R][MAXTS]
     float* dyrow = del + R * MAXTS;                        // per DPP row partial dy [32 rows][A]
     float* dyp = dyrow + 32 * A;                      // partial dy [R][A]                            -> X2 publish
@@ -137,14 +141,14 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
     const int TS = (Te + G - 1) / G;
     float* wal = dhfl + R * MAXTS * A;                // W_att rows of my units [HS][A]
     float* vl = wal + H * AS;                         // v [A]
-    float* encl = vl + A;                             // enc slice [R][Te][DS]
+    float* encl = vl + A;                             // enc rows of my positions, all context columns [R][TS][D]
     // operands of the CURRENT step that depend on no exchange: fetched one step ahead by the prefetch waves
     // (threads >= 256, which neither poll nor store) -- item order below = LDS order
     const int TeP = (Te + 1) & ~1;
     // double-buffered by step parity: the LAST phase of a step (cell) still reads its copy while the prefetch waves hand the
     // next step's operands over at the top of the next step (a single buffer there was a race; behind the step's first
     // barrier it put the prefetch issue on the critical path)
-    float* pfl_base = encl + R * Te * DS;
+    float* pfl_base = encl + R * TS * D;
     const int nitems = R * A + R * TeP + 2 * R * DS + R * HS * 4 + 3 * R * HS;
     const int nitemsP = (nitems + 3) & ~3;
 
@@ -193,9 +197,9 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
         hfl[idx] = (tl < TS && tau < Te) ? a.hf[((size_t)browf(r) * Te + tau) * A + aa] : 0.f;
         dhfl[idx] = 0.f;
     }
-    for (int idx = tid; idx < R * Te * DS; idx += NT) {
-        const int r = idx / (Te * DS), rem = idx % (Te * DS), tau = rem / DS, dd = rem % DS;
-        encl[idx] = a.enc[((size_t)browf(r) * Te + tau) * D + mem * DS + dd];
+    for (int idx = tid; idx < R * TS * D; idx += NT) {
+        const int r = idx / (TS * D), tl = (idx / D) % TS, dcol = idx % D, tau = mem * TS + tl;
+        encl[idx] = tau < Te ? a.enc[((size_t)browf(r) * Te + tau) * D + dcol] : 0.f;
     }
     // tanh-phase mapping: DPP row -> (tl = row % 16, r = row / 16), lane kq -> AL consecutive a
     const int trow_tl = row % 16, trow_r = row / 16;
@@ -274,8 +278,8 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
         const int i = a.T - 1 - s;
         const uint32_t ep = (uint32_t)(s + 1);
         u64* gpar = gbase + (size_t)(s & 1) * NPAR;
-        u64* g1 = gpar; u64* g2 = g1 + G * G * S1; u64* g3 = g2 + G * G * S2; u64* g4 = g3 + R * A;
-        const u64* g4prev = gbase + (size_t)((s - 1) & 1) * NPAR + G * G * (S1 + S2) + R * A;     // dG of the previous (later-time) step
+        u64* g1 = gpar; u64* g2 = g1 + R * D1; u64* g3 = g2 + G * G * S2; u64* g4 = g3 + R * A;
+        const u64* g4prev = gbase + (size_t)((s - 1) & 1) * NPAR + (NPAR - R * N4);     // dG of the previous (later-time) step
         // ---- operands of this step that do not depend on any exchange (waves >= 2 fetch them)
         // ---- hand the prefetched operands of THIS step over to this parity's LDS copy, and fetch the next step's
         if (pfw) {
@@ -386,50 +390,86 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
                 if (rok(r)) {
                     const size_t rowi = (size_t)i * a.B + r0 + r;
                     x += dqcx[r * DS + dd];
+                    pubg(g1 + (size_t)r * D1 + mem * DS + dd, ep, x, fast);           // all-gather of dctx_tot: published first
                     a.dctx[rowi * D + mem * DS + dd] = x;
                     sprt = fmaf(x, ctxl[r * DS + dd], sprt);
                 }
-                dctl[r * DS + dd] = x;
             }
-            // reduce the 32 lanes of each half-wave
+            // reduce the 32 lanes of each half-wave: this workgroup's partial of S = dctx_tot . ctx_i, gathered with dctx_tot
             sprt += __shfl_xor(sprt, 16); sprt = row16_allreduce_sum(sprt);
-            if (dd0 == 0) sp[r] = sprt;
+            if (dd0 == 0 && rok(r)) pubg(g1 + (size_t)r * D1 + D + mem, ep, sprt, fast);
         }
-        __syncthreads();
-        CHAIN_STAMP()
-        // ---- (b) partial dalpha over my D-slice, all positions: thread -> (r, tau)
-        for (int idx = tid; idx < R * G * MAXTS; idx += NT) {
-            const int r = idx / (G * MAXTS), slot = idx % (G * MAXTS), tau = (slot / MAXTS) * TS + (slot % MAXTS);
-            float x = 0.f;
-            if ((slot % MAXTS) < TS && tau < blenf(r)) {
-                const float* ep2 = encl + (r * Te + tau) * DS;
-                const float* dp = dctl + r * DS;
+        // ---- gather dctx_tot of both rows over all D columns (+ the G partials of S): waves 1-3, all loads in flight
+        if (tid >= 64 && tid < 64 + NGT) {
+            bool need[NPP1];
 #pragma unroll
-                for (int dd = 0; dd < DS; ++dd) x = fmaf(ep2[dd], dp[dd], x);
+            for (int j = 0; j < NPP1; ++j) {
+                const int pidx = tid - 64 + NGT * j;
+                need[j] = pidx < NPAIR1 && rok((2 * pidx) / D1);
+                if (pidx < NPAIR1 && !need[j]) *reinterpret_cast<float2*>(dctall + 2 * pidx) = make_float2(0.f, 0.f);
             }
-            dal[idx] = x;
+            long long t0w = 0;
+            for (uint32_t spins = 0;; ++spins) {
+                u64 x[NPP1][2];
+#pragma unroll
+                for (int j = 0; j < NPP1; ++j) {
+                    const int pidx = min(tid - 64 + NGT * j, NPAIR1 - 1);
+                    x[j][0] = __hip_atomic_load(g1 + 2 * pidx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    x[j][1] = __hip_atomic_load(g1 + 2 * pidx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                bool pending = false;
+#pragma unroll
+                for (int j = 0; j < NPP1; ++j) {
+                    if (!need[j]) continue;
+                    if ((uint32_t)(x[j][0] >> 32) == ep && (uint32_t)(x[j][1] >> 32) == ep) {
+                        *reinterpret_cast<float2*>(dctall + 2 * (tid - 64 + NGT * j)) =
+                            make_float2(__uint_as_float((uint32_t)x[j][0]), __uint_as_float((uint32_t)x[j][1]));
+                        need[j] = false;
+                    } else pending = true;
+                }
+                if (!pending) break;
+                ASR_POLL_BACKOFF();
+                if ((spins & 1023) == 1023) {
+                    const long long now = wall_clock64();
+                    if (t0w == 0) t0w = now;
+                    else if (now - t0w > 200000000LL) { *a.err = 1; break; }
+                    if (__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                }
+            }
         }
         __syncthreads();
         CHAIN_STAMP()
-        if (wave0) {     // X1 publish: to the owner of each position slice, plus my S partial to everyone
-            for (int idx = lane; idx < R * G * MAXTS; idx += 64) {
-                const int r = idx / (G * MAXTS), slot = idx % (G * MAXTS), md = slot / MAXTS, tl = slot % MAXTS;
-                if (rok(r) && tl < TS)
-                    pubg(g1 + ((size_t)md * G + mem) * S1 + r * (MAXTS + 2) + tl, ep, dal[idx], fast);
+        // ---- dalpha for my positions over ALL context columns (DPP row = one (row r, position tl), 16 lanes over D) and the
+        // softmax scalar S = sum of the G partials (fixed order): del = dalpha, sp[2 + r] = S
+        {
+            const int r = trow_r, tl = trow_tl, tau = tau0 + tl;
+            float x = 0.f;
+            if (tl < TS && tau < blenf(r)) {
+                const float* dr = dctall + r * D1;
+                const float* er = encl + ((size_t)r * TS + tl) * D;
+                if (DL % 4 == 0) {
+#pragma unroll
+                    for (int c = 0; c < DL / 4; ++c) {
+                        const int d0 = c * 64 + kq * 4;
+                        const float4 d4 = *reinterpret_cast<const float4*>(dr + d0);
+                        const float4 e4 = *reinterpret_cast<const float4*>(er + d0);
+                        x = fmaf(d4.x, e4.x, x); x = fmaf(d4.y, e4.y, x); x = fmaf(d4.z, e4.z, x); x = fmaf(d4.w, e4.w, x);
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < DL; ++q) x = fmaf(dr[kq * DL + q], er[kq * DL + q], x);
+                }
             }
-            for (int idx = lane; idx < R * G; idx += 64) {
-                const int r = idx / G, md = idx % G;
-                if (rok(r)) pubg(g1 + ((size_t)md * G + mem) * S1 + r * (MAXTS + 2) + MAXTS, ep, sp[r], fast);
+            x = row16_allreduce_sum(x);
+            if (kq == 0) {
+                del[r * MAXTS + tl] = x;
+                if (tl == 0) {
+                    float st = 0.f;
+#pragma unroll
+                    for (int m = 0; m < G; ++m) st += dctall[r * D1 + D + m];
+                    sp[2 + r] = st;
+                }
             }
-        }
-        // ---- X1 gather: dalpha for my positions and S; de = alpha (dalpha - S)
-        if (wave1 && tid - 64 < S1) {
-            const int slot = tid - 64, r = slot / (MAXTS + 2), q = slot % (MAXTS + 2);
-            float v0 = 0.f;
-            // slots beyond TS (except the S slot) are never published: skip them
-            if (rok(r) && (q < TS || q == MAXTS)) gather16_one<S1>(g1 + ((size_t)mem * G) * S1 + slot, ep, v0, a.err);
-            if (q == MAXTS) sp[2 + r] = v0;                           // total S of row r
-            else if (q < MAXTS) del[r * MAXTS + q] = v0;
         }
         __syncthreads();
         CHAIN_STAMP()
@@ -624,17 +664,17 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
 
 extern "C" size_t asr_decoder_chain_bwd_ws_bytes(int B, int D, int A, int H) {
     const size_t groups = (B + 1) / 2, G = 16, R = 2, HS = H / 16, AS = A / 16, DS = D / 16;
-    const size_t s1 = R * (16 + 2), s2 = R * ((AS + 1) & ~(size_t)1);
+    const size_t s2 = R * ((AS + 1) & ~(size_t)1);
     (void)DS; (void)HS;
-    return groups * 2 * (G * G * (s1 + s2) + R * (size_t)A + R * 4 * (size_t)H) * sizeof(u64) + groups * 16 * sizeof(u64);
+    return groups * 2 * (R * ((size_t)D + G) + G * G * s2 + R * (size_t)A + R * 4 * (size_t)H) * sizeof(u64) + groups * 16 * sizeof(u64);
 }
 
 template <int H, int D, int A>
 static int chain_bwd_launch(hipStream_t s, asr::ChainBwdArgs& a) {
     constexpr int R = 2, G = 16, HS = H / G, AS = A / G, DS = D / G, HS2 = (HS + 1) & ~1, AS2 = (AS + 1) & ~1;
     const int groups = a.ng;
-    const size_t lds = sizeof(float) * (4 + R * DS + R * HS2 + R * G * 16 + 4 + R * 16 + R * A + 32 * A + R * A + R * AS2 +
-                                        R * H + R * HS2 + R * 64 * (H / 16 + 4) + (HS + DS) * R * 4 + 4 + 2 * R * 16 * A + H * AS + A + (size_t)R * a.Te * DS +
+    const size_t lds = sizeof(float) * (4 + R * DS + R * HS2 + R * (D + G) + 4 + 4 + R * 16 + R * A + 32 * A + R * A + R * AS2 +
+                                        R * H + R * HS2 + R * 64 * (H / 16 + 4) + (HS + DS) * R * 4 + 4 + 2 * R * 16 * A + H * AS + A + (size_t)R * ((a.Te + G - 1) / G) * D +
                                         2 * ((size_t)R * A + (size_t)R * (a.Te + 1) + 2 * R * DS + 7 * R * HS + 4) + 3 * 5 * 256 + 16);
     if (lds > 150 * 1024) return ASR_EUNSUPPORTED;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asr::decoder_chain_bwd_kernel<H, D, A>),

@@ -19,13 +19,13 @@ dbg.zero_()
 model.step(batch)
 torch.cuda.synchronize()
 d = dbg.cpu().numpy()
-names = ["gather dG (all-gather) + prefetch hand-over", "[dh|dctx] = dG.[K_h;WK_c]^T for my outputs", "dh, dctx_tot, S partial", "(b) dalpha partials",
-         "X1 publish + gather", "(d) tanh backward", "dy row reduce", "X2 publish + gather", "dY save, dy publish + gather (all-gather)", "dq for my units",
-         "cell pointwise + dG publish"]
-tot = float(d[:11].sum())
+names = ["gather dG (all-gather) + prefetch hand-over", "[dh|dctx] = dG.[K_h;WK_c]^T for my outputs", "dh, dctx_tot: publish + gather (all-gather)",
+         "dalpha for my positions, S", "(d) tanh backward", "dy row reduce", "X2 publish + gather (reduce-scatter)",
+         "dY save, dy publish + gather (all-gather)", "dq for my units", "cell pointwise + dG publish"]
+tot = float(d[:10].sum())
 steps = 120
 print("cycles per step: %.0f  (%.2f us at 100 MHz s_memtime clock)" % (tot / steps, tot / steps / 100.0))
-for n, v in zip(names, d[:11]):
+for n, v in zip(names, d[:10]):
     print("  %-50s %6.1f %%  %7.0f ticks/step" % (n, 100.0 * v / tot, v / steps))
 
 f = d[16:]
