@@ -175,13 +175,6 @@ class BeamSearch(BaseParams):
         get_top_k.keep = keep
         return get_top_k
 
-    def _zero_state(self, k, D):
-        p, lp = self.dec_params, self.lm_params
-        z = lambda n: torch.zeros((k, n), device=self.device, dtype=torch.float32)
-        return dict(dc=z(p.dec_lstm_w.shape[1] // 4), dh=z(p.dec_lstm_w.shape[1] // 4),
-                    dlc=z(p.lm_lstm_w.shape[1] // 4), dlh=z(p.lm_lstm_w.shape[1] // 4),
-                    lc=z(lp.lstm_w.shape[1] // 4), lh=z(lp.lstm_w.shape[1] // 4), ctx=z(D))
-
     def __call__(self, encoder_hidden_states):
         """Beam search for batch size 1 (beam_search.py:224-338)."""
         sp = self.search_params

@@ -99,7 +99,6 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
 #define CHAIN_STAMP() if (STAMP) { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); stamp[sph & 15] += (unsigned int)(t__ - tlast); tlast = t__; ++sph; }
     constexpr int R = 2, G = 16, NT = 512;
     constexpr int HS = H / G, AS = A / G, DS = D / G;
-    constexpr int KS = H + D;
     constexpr int NGT = 192;                          // gathering threads of the all-gathers: waves 1-3
     constexpr int N4 = 4 * H;                         // dG positions per row: p = 4*unit + gate
     constexpr int PC = N4 / 64;                       // positions per lane in the [dh|dctx] contraction (64 chunks = one wave)
@@ -123,7 +122,7 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int* lds_flag = reinterpret_cast<int*>(smem);
-    float* dctl = smem + 4;                           // dctx_tot slice [R][DS]
+    float* dctl = smem + 4;                           // (spare) [R][DS]
     float* dhl = dctl + R * DS;                       // dh for my units [R][HS]
     float* dctall = dhl + R * HS2;                    // dctx_tot of both rows over ALL context columns + the G partials of S [R][D1]
     float* sp = dctall + ((R * D1 + 3) & ~3);         // S [2 + r] (+pad)
