@@ -22,6 +22,7 @@
 // columns is again 4 DPP butterflies.
 #include "common.h"
 #include <cstdlib>
+namespace asr { extern unsigned long long* g_lstm_dbg; }
 
 namespace asr {
 
@@ -39,6 +40,7 @@ struct LstmBwdArgs {
     // addressing as in LstmRecArgs (csrc/lstm.hip): row of (b,t) in gates/act = b*sb + t*st; in dout =
     // b*osb + t*ost with leading dimension ldo; dropout counter = (boff+b)*dsb + t*dst
     int sb, st, osb, ost, ldo, dsb, dst;
+    unsigned long long* dbg;   // STAMP build only
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -245,8 +247,13 @@ __global__ __launch_bounds__(512) void lstm_rec_bwd_kernel(LstmBwdArgs a) {
 // Same structure as the forward kernel (one exchange, two barriers per step); the reduce-scatter above needs
 // a third barrier and 4x the publishing stores.  Exchange volume per step: R*4H granules per group (4x the
 // forward's), polled by every workgroup of the group with all of a thread's loads in flight.
-template <int H, int R>
+// STAMP: diagnostic instantiation (ASR_LSTM_STAMP=1 + asr_debug_set_buffer): s_memtime totals of thread 0 (a cell wave) and
+// thread 511 (a polling wave) of workgroup 0: [poll | barrier 1 | matvec | barrier 2 | cell]; never used for timing claims.
+template <int H, int R, bool STAMP = false>
 __global__ __launch_bounds__(512) void lstm_rec_bwd_ag_kernel(LstmBwdArgs a) {
+    unsigned int stamp[5] = {0, 0, 0, 0, 0};
+    unsigned long long tlast = STAMP ? __builtin_amdgcn_s_memtime() : 0;
+#define BPTT_STAMP(i) if (STAMP) { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); stamp[i] += (unsigned int)(t__ - tlast); tlast = t__; }
     constexpr int HS = 32, NT = 512;
     constexpr int G = H / HS;
     constexpr int N = 4 * H;           // dG columns per row; position p = 4*unit + gate
@@ -254,12 +261,16 @@ __global__ __launch_bounds__(512) void lstm_rec_bwd_ag_kernel(LstmBwdArgs a) {
     constexpr int CSB = PC + 4;        // padded LDS chunk stride
     constexpr int NCELL = R * HS;
     constexpr int NCW = (NCELL + 63) / 64 * 64;
-    constexpr int NPOLL = NT - NCW;
+    constexpr int NPOLL = NT - NCW - 64;           // the last wave is the LOADER: it never polls
     constexpr int NPAIR = R * N / 2;
     constexpr int NPP = (NPAIR + NPOLL - 1) / NPOLL;   // pairs per polling thread
-    static_assert(NCW < NT && PC % 4 == 0, "mapping");
+    static_assert(NCW + 64 < NT && PC % 4 == 0 && NCELL <= 64, "mapping");
     __shared__ __attribute__((aligned(16))) float dgl[R * 64 * CSB];
     __shared__ __attribute__((aligned(16))) float sums[R * HS * 4];
+    // operands of the cell, by step parity: {dout*mask, A, Ki, Kj | Kf, Ko, f, -} per cell thread, filled one step ahead by the
+    // loader wave -- the cell waves issue NO loads, so they never wait on vmcnt (which would also drain their own
+    // publishing / bookkeeping stores: 0.3 us of a 1.8 us step alone, 0.6 us with the weight-gradient GEMMs co-running)
+    __shared__ __attribute__((aligned(16))) float opnd[2][NCELL][8];
 
     __builtin_amdgcn_s_setprio(3);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -298,22 +309,45 @@ __global__ __launch_bounds__(512) void lstm_rec_bwd_ag_kernel(LstmBwdArgs a) {
     u64* hxg = a.hx + (size_t)grp * 2 * R * N;
     const bool fast = group_shares_xcd(a.xcc_slots + (size_t)grp * 16, G, mem, tid, a.err);
 
+    // loader wave (last wave): lane l serves cell thread l
+    const bool loader_wave = __builtin_amdgcn_readfirstlane(tid) >= NT - 64;
+    const int ll = tid - (NT - 64);
+    const bool lact = loader_wave && ll < NCELL;
+    const int lcr = min(max(ll, 0) / HS, R - 1), lcu = max(ll, 0) % HS;
+    const int lcb = min(r0 + lcr, a.B - 1);
+    const int lclen = (lact && r0 + lcr < a.B) ? min(a.len[r0 + lcr], a.T) : 0;
     float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
     float dout_v = 0.f;
     auto prefetch = [&](int s) {
-        const int t = dir ? s : (clen - 1 - s);
+        const int t = dir ? s : (lclen - 1 - s);
         const int ts = min(max(t, 0), a.T - 1);
-        const float4* rp = reinterpret_cast<const float4*>(a.act + ((((size_t)cb_safe * a.sb + (size_t)ts * a.st) * a.ND + dir) * H + cj) * 8);
+        const float4* rp = reinterpret_cast<const float4*>(a.act + ((((size_t)lcb * a.sb + (size_t)ts * a.st) * a.ND + dir) * H + j0 + lcu) * 8);
         ra = rp[0]; rb = rp[1];
-        dout_v = a.dout[((size_t)cb_safe * a.osb + (size_t)ts * a.ost) * a.ldo + dir * H + cj];
+        dout_v = a.dout[((size_t)lcb * a.osb + (size_t)ts * a.ost) * a.ldo + dir * H + j0 + lcu];
     };
-    if (cell_wave) prefetch(0);
+    // Everything of the pointwise backward that does not depend on dh / dc is formed HERE, off the chain (the cell is a
+    // dependent sequence of ~100 VALU ops on one wave otherwise: tanh, the dropout hash, the gate derivatives):
+    //   dct = dc + dh*A;  dG = {dct*Ki, dct*Kj, dct*Kf, dh*Ko};  dc' = dct*f   with dh = dout*mask + recurrent part
+    auto hand_over = [&](int s) {
+        const int t = dir ? s : (lclen - 1 - s);
+        const float gi = ra.x, gj = ra.y, gf = ra.z, go = ra.w, cc = rb.x, cp = rb.y;
+        const float tc = fast_tanh(cc);
+        float dm = dout_v;
+        if (a.keep < 1.0f)
+            dm *= keep_scale(a.seed, (uint32_t)((a.boff + r0 + lcr) * a.dsb + t * a.dst), (uint32_t)(dir * H + j0 + lcu), a.keep);
+        float4* o = reinterpret_cast<float4*>(&opnd[s & 1][ll][0]);
+        o[0] = make_float4(dm, go * (1.f - tc * tc), gj * gi * (1.f - gi), gi * (1.f - gj * gj));
+        o[1] = make_float4(cp * gf * (1.f - gf), tc * go * (1.f - go), gf, 0.f);
+    };
+    if (lact) { prefetch(0); hand_over(0); if (S > 1) prefetch(1); }
+    __syncthreads();
 
     for (int s = 0; s < S; ++s) {
         const bool live = cell && s < clen;
         const int t = dir ? s : (clen - 1 - s);
         if (s > 0) {
-            if (!cell_wave) {
+            if (lact) { hand_over(s); if (s + 1 < S) prefetch(s + 1); }
+            if (!cell_wave && !loader_wave) {
                 // all of this thread's granule loads in flight, re-polled together until every tag matches
                 const u64* src = hxg + (size_t)((s - 1) & 1) * R * N;
                 bool need[NPP];
@@ -356,7 +390,9 @@ __global__ __launch_bounds__(512) void lstm_rec_bwd_ag_kernel(LstmBwdArgs a) {
                     }
                 }
             }
+            BPTT_STAMP(0)
             __syncthreads();
+            BPTT_STAMP(1)
             // dh_rec for the own units: 4 units x R rows per lane, contraction over this lane's PC positions
             float acc[R][4];
 #pragma unroll
@@ -386,26 +422,23 @@ __global__ __launch_bounds__(512) void lstm_rec_bwd_ag_kernel(LstmBwdArgs a) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) sums[(r * HS + 4 * wave + i) * 4 + (lane >> 4)] = acc[r][i];
             }
+            BPTT_STAMP(2)
             __syncthreads();
+            BPTT_STAMP(3)
         }
         if (cell_wave && cell) {
-            float dh = dout_v;
-            if (a.keep < 1.0f)
-                dh *= keep_scale(a.seed, (uint32_t)((a.boff + cb) * a.dsb + t * a.dst), (uint32_t)(dir * H + cj), a.keep);
+            const float4 oa = *reinterpret_cast<const float4*>(&opnd[s & 1][tid][0]);   // {dout*mask, A, Ki, Kj}
+            const float4 ob = *reinterpret_cast<const float4*>(&opnd[s & 1][tid][4]);   // {Kf, Ko, f, -}
+            float dh = oa.x;
             if (s > 0) {
                 const float4 v = *reinterpret_cast<const float4*>(sums + (cr * HS + cu) * 4);
                 dh += (v.x + v.y) + (v.z + v.w);
             }
             float4 dg = make_float4(0.f, 0.f, 0.f, 0.f);
             if (live) {
-                const float gi = ra.x, gj = ra.y, gf = ra.z, go = ra.w, cc = rb.x, cp = rb.y;
-                const float tc = fast_tanh(cc);
-                const float dct = dc + dh * go * (1.f - tc * tc);
-                dg.x = dct * gj * gi * (1.f - gi);
-                dg.y = dct * gi * (1.f - gj * gj);
-                dg.z = dct * cp * gf * (1.f - gf);
-                dg.w = dh * tc * go * (1.f - go);
-                dc = dct * gf;
+                const float dct = fmaf(dh, oa.y, dc);
+                dg = make_float4(dct * oa.z, dct * oa.w, dct * ob.x, dh * ob.y);
+                dc = dct * ob.z;
             }
             // publish dG_s of this unit FIRST (zeros for rows past their length): 4 adjacent granules
             if (cb < a.B && s + 1 < S) {
@@ -428,9 +461,14 @@ __global__ __launch_bounds__(512) void lstm_rec_bwd_ag_kernel(LstmBwdArgs a) {
                 float* gp = a.gates + (((size_t)cb * a.sb + (size_t)t * a.st) * a.ND + dir) * H4 + cj;
                 gp[0] = dg.x; gp[H] = dg.y; gp[2 * H] = dg.z; gp[3 * H] = dg.w;
             }
-            if (s + 1 < S) prefetch(s + 1);
         }
+        BPTT_STAMP(4)
     }
+    if (STAMP && a.dbg && blockIdx.x == 0 && (tid == 0 || tid == NT - 1)) {
+        for (int i = 0; i < 5; ++i) atomicAdd(a.dbg + 32 + (tid == 0 ? 0 : 8) + i, (unsigned long long)stamp[i]);
+        if (tid == 0) atomicAdd(a.dbg + 32 + 7, (unsigned long long)S);
+    }
+#undef BPTT_STAMP
     // dG = 0 past each row's length (the weight/input GEMMs read every row)
     for (int r = 0; r < R; ++r) {
         if (r0 + r >= a.B) break;
@@ -449,6 +487,7 @@ static int launch_bwd_h(hipStream_t s, const LstmBwdArgs& a, int R) {
     static const bool allgather = [] { const char* e = getenv("ASR_BPTT_AG"); return !(e && e[0] == '0'); }();
     if (allgather && R <= 2) {     // more rows per group: too many granule loads per polling thread -> reduce-scatter kernel
         if (R == 1) hipLaunchKernelGGL((lstm_rec_bwd_ag_kernel<H, 1>), dim3(grid), dim3(512), 0, s, a);
+        else if (H == 256 && a.dbg) hipLaunchKernelGGL((lstm_rec_bwd_ag_kernel<256, 2, true>), dim3(grid), dim3(512), 0, s, a);
         else hipLaunchKernelGGL((lstm_rec_bwd_ag_kernel<H, 2>), dim3(grid), dim3(512), 0, s, a);
         return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
     }
@@ -505,6 +544,7 @@ extern "C" int asr_lstm_layer_bwd(void* stream, const float* x, int B, int T, in
     a.xcc_slots = reinterpret_cast<u64*>(static_cast<char*>(hx_ws) + lstm_bwd_hx_bytes(B, H, ndir));
     a.B = B; a.T = T; a.Tout = Tout; a.ND = ndir; a.boff = 0; a.keep = keep_prob; a.seed = seed;
     a.sb = T; a.st = 1; a.osb = Tout; a.ost = 1; a.ldo = ndir * H; a.dsb = Tout; a.dst = 1;
+    a.dbg = getenv("ASR_LSTM_STAMP") ? asr::g_lstm_dbg : nullptr;
     const int R = asr_lstm_pick_rows(B, ndir, G);
     const int max_groups = asr_lstm_max_wgs() / G / ndir;
     const int rows_per_launch = max_groups > 0 ? max_groups * R : R;
@@ -575,6 +615,7 @@ int asr_lstm_rec_bwd_tm(hipStream_t s, float* gates, const float* act, const flo
     a.xcc_slots = reinterpret_cast<u64*>(static_cast<char*>(hx_ws) + lstm_bwd_hx_bytes(B, H, 1));
     a.B = B; a.T = T; a.Tout = T; a.ND = 1; a.boff = 0; a.keep = keep; a.seed = seed;
     a.sb = 1; a.st = B; a.osb = 1; a.ost = B; a.ldo = ldo; a.dsb = 1; a.dst = B;
+    a.dbg = nullptr;
     const int R = asr_lstm_pick_rows(B, 1, H / 32);
     switch (H) {
         case 64: return launch_bwd_h<64>(s, a, R);

@@ -1,0 +1,50 @@
+"""Per-phase s_memtime shares of the all-gather BPTT kernel (diagnostic build, ASR_LSTM_STAMP=1): thread 0 (cell wave) and
+thread 511 (polling wave) of workgroup 0; (a) one layer alone, (b) inside the full train step, where the side-stream
+weight-gradient GEMMs co-run."""
+import os, sys
+os.environ["ASR_LSTM_STAMP"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from e2e_asr_amd import _lib, ops
+from e2e_asr_amd.weights import synthetic_batch
+dev = torch.device("cuda:0")
+dbg = torch.zeros(64, dtype=torch.int64, device=dev)
+_lib.lib().asr_debug_set_buffer(dbg.data_ptr())
+names = ["poll (gather dG)", "barrier 1", "matvec + DPP", "barrier 2", "cell + publish"]
+
+
+def report(tag):
+    d = dbg.cpu().numpy()
+    steps = float(d[32 + 7])
+    for who, off in (("cell wave (thread 0)", 32), ("polling wave (thread 511)", 40)):
+        v = d[off:off + 5].astype(float)
+        print("%s, %s: %.0f cycles per step" % (tag, who, v.sum() / steps))
+        print("   " + "  ".join("%s %.0f" % (n, x / steps) for n, x in zip(names, v)))
+
+
+# (a) alone: one BiLSTM layer, B=32, T=400
+B, T, IN, H = 32, 400, 1024, 256
+x = torch.randn(B, T, IN, device=dev) * 0.3
+ln = torch.full((B,), T, dtype=torch.int32, device=dev)
+k = [torch.randn(IN + H, 4 * H, device=dev) * 0.05 for _ in range(2)]
+bz = [torch.zeros(4 * H, device=dev) for _ in range(2)]
+dk = [torch.zeros_like(k[0]) for _ in range(2)]; db = [torch.zeros_like(bz[0]) for _ in range(2)]
+for it in range(3):
+    out, gates, act, hp = ops.lstm_layer_fwd(x, ln, k[0], bz[0], k[1], bz[1], save=True)
+    torch.cuda.synchronize()
+    if it == 2:
+        dbg.zero_()
+    ops.lstm_layer_bwd(x, ln, k[0], k[1], torch.ones_like(out), gates, act, hp, dk[0], db[0], dk[1], db[1], need_dx=True, join=True)
+    torch.cuda.synchronize()
+report("alone")
+# (b) in the train step
+model = bench.build_model(dev, training=True)
+batch = synthetic_batch(B=32, T=800, F=80, t_dec=121, vocab=1000, variable_len=False, seed=1)
+for _ in range(2):
+    model.step(batch)
+torch.cuda.synchronize()
+dbg.zero_()
+model.step(batch)
+torch.cuda.synchronize()
+report("in the train step")
