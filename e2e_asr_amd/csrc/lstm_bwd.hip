@@ -41,6 +41,7 @@ struct LstmBwdArgs {
     // b*osb + t*ost with leading dimension ldo; dropout counter = (boff+b)*dsb + t*dst
     int sb, st, osb, ost, ldo, dsb, dst;
     unsigned long long* dbg;   // STAMP build only
+    float* db_part;            // [B][ND][4H] per-utterance sums of dG over time (bias gradient partials) or nullptr
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -306,6 +307,7 @@ __global__ __launch_bounds__(512) void lstm_rec_bwd_ag_kernel(LstmBwdArgs a) {
     const int clen = (cell && cb < a.B) ? min(a.len[cb], a.T) : 0;
     const int cj = j0 + cu;
     float dc = 0.f;
+    float4 dbs = make_float4(0.f, 0.f, 0.f, 0.f);
     u64* hxg = a.hx + (size_t)grp * 2 * R * N;
     const bool fast = group_shares_xcd(a.xcc_slots + (size_t)grp * 16, G, mem, tid, a.err);
 
@@ -439,6 +441,7 @@ __global__ __launch_bounds__(512) void lstm_rec_bwd_ag_kernel(LstmBwdArgs a) {
                 const float dct = fmaf(dh, oa.y, dc);
                 dg = make_float4(dct * oa.z, dct * oa.w, dct * ob.x, dh * ob.y);
                 dc = dct * ob.z;
+                dbs.x += dg.x; dbs.y += dg.y; dbs.z += dg.z; dbs.w += dg.w;      // bias gradient: sum of dG over time
             }
             // publish dG_s of this unit FIRST (zeros for rows past their length): 4 adjacent granules
             if (cb < a.B && s + 1 < S) {
@@ -463,6 +466,10 @@ __global__ __launch_bounds__(512) void lstm_rec_bwd_ag_kernel(LstmBwdArgs a) {
             }
         }
         BPTT_STAMP(4)
+    }
+    if (a.db_part && cell && cb < a.B) {        // one row per utterance and direction: summed over the batch by a tiny colsum
+        float* dp = a.db_part + ((size_t)(a.boff + cb) * a.ND + dir) * H4 + cj;
+        dp[0] = dbs.x; dp[H] = dbs.y; dp[2 * H] = dbs.z; dp[3 * H] = dbs.w;
     }
     if (STAMP && a.dbg && blockIdx.x == 0 && (tid == 0 || tid == NT - 1)) {
         for (int i = 0; i < 5; ++i) atomicAdd(a.dbg + 32 + (tid == 0 ? 0 : 8) + i, (unsigned long long)stamp[i]);
@@ -513,8 +520,11 @@ static size_t lstm_bwd_hx_bytes(int B, int H, int ndir) {
     const size_t G = H / 32 < 4 ? 4 : H / 32;    // reduce-scatter: 2*G*H granules per row; all-gather: 2*4H
     return (size_t)ndir * (size_t)((B + 7) / 8 * 8) * 2 * G * H * sizeof(u64);
 }
+static size_t lstm_bwd_sync_bytes(int B, int H, int ndir) {
+    return lstm_bwd_hx_bytes(B, H, ndir) + (size_t)ndir * (size_t)((B + 7) / 8 * 8) * 16 * sizeof(u64);   // granules + XCC slots
+}
 extern "C" size_t asr_lstm_bwd_ws_bytes(int B, int H, int ndir) {
-    return lstm_bwd_hx_bytes(B, H, ndir) + (size_t)ndir * (size_t)((B + 7) / 8 * 8) * 16 * sizeof(u64);   // + XCC slots
+    return lstm_bwd_sync_bytes(B, H, ndir) + (size_t)B * ndir * 4 * H * sizeof(float);      // + bias-gradient partials [B][ND][4H]
 }
 
 // Backward of asr_lstm_layer_fwd.  act/hprev are the forward's saved tensors; gates (the
@@ -546,10 +556,15 @@ extern "C" int asr_lstm_layer_bwd(void* stream, const float* x, int B, int T, in
     a.sb = T; a.st = 1; a.osb = Tout; a.ost = 1; a.ldo = ndir * H; a.dsb = Tout; a.dst = 1;
     a.dbg = getenv("ASR_LSTM_STAMP") ? asr::g_lstm_dbg : nullptr;
     const int R = asr_lstm_pick_rows(B, ndir, G);
+    // the all-gather kernel (R <= 2) sums dG over time per utterance itself: the bias gradient is then a colsum over B rows
+    // instead of over B*T rows of dG (0.4 GB of side-stream reads per step at config 2)
+    static const bool ag_env = [] { const char* e = getenv("ASR_BPTT_AG"); return !(e && e[0] == '0'); }();
+    float* db_part = (ag_env && R <= 2) ? reinterpret_cast<float*>(static_cast<char*>(hx_ws) + lstm_bwd_sync_bytes(B, H, ndir)) : nullptr;
+    a.db_part = db_part;
     const int max_groups = asr_lstm_max_wgs() / G / ndir;
     const int rows_per_launch = max_groups > 0 ? max_groups * R : R;
     for (int b0 = 0; b0 < B; b0 += rows_per_launch) {
-        if (hipMemsetAsync(hx_ws, 0, asr_lstm_bwd_ws_bytes(B, H, ndir), s) != hipSuccess) return ASR_ELAUNCH;
+        if (hipMemsetAsync(hx_ws, 0, lstm_bwd_sync_bytes(B, H, ndir), s) != hipSuccess) return ASR_ELAUNCH;
         LstmBwdArgs c = a;
         c.B = (B - b0 < rows_per_launch) ? (B - b0) : rows_per_launch;
         c.boff = b0;
@@ -567,6 +582,12 @@ extern "C" int asr_lstm_layer_bwd(void* stream, const float* x, int B, int T, in
         }
         prof_end(ASR_PROF_LSTM_REC_BWD, s);
         if (rc) return rc;
+    }
+    // bias gradient from the per-utterance partials: B rows, on the caller's stream (the workspace is reused by the next
+    // layer's BPTT, so it must not wait in the side stream's queue)
+    for (int d = 0; d < ndir && db_part; ++d) {
+        int rc;
+        if ((rc = asr_colsum_f32(stream, db_part + (size_t)d * H4, ndir * H4, B, H4, d ? dbias_bw : dbias_fw, 1))) return rc;
     }
     // Input gradient dX = dG.K_x^T stays on the caller's stream (the next layer's BPTT needs it).
     // The weight/bias gradients (dK_x = X^T.dG, dK_h = Hprev^T.dG, db = colsum dG) are needed only
@@ -592,7 +613,7 @@ extern "C" int asr_lstm_layer_bwd(void* stream, const float* x, int B, int T, in
         if ((rc = asr_gemm_f32(side, 1, 0, in_dim, H4, M, x, ldx, dG, ldg, dK, H4, nullptr, 1))) return rc;
         if ((rc = asr_gemm_f32(side, 1, 0, H, H4, M, hprev + (size_t)d * H, ndir * H, dG, ldg,
                                dK + (size_t)in_dim * H4, H4, nullptr, 1))) return rc;
-        if ((rc = asr_colsum_f32(side, dG, ldg, M, H4, dB, 1))) return rc;
+        if (!db_part && (rc = asr_colsum_f32(side, dG, ldg, M, H4, dB, 1))) return rc;
     }
     hipEvent_t e_done = next_event();
     if (hipEventRecord(e_done, ss) != hipSuccess) return ASR_ELAUNCH;
@@ -615,7 +636,7 @@ int asr_lstm_rec_bwd_tm(hipStream_t s, float* gates, const float* act, const flo
     a.xcc_slots = reinterpret_cast<u64*>(static_cast<char*>(hx_ws) + lstm_bwd_hx_bytes(B, H, 1));
     a.B = B; a.T = T; a.Tout = T; a.ND = 1; a.boff = 0; a.keep = keep; a.seed = seed;
     a.sb = 1; a.st = B; a.osb = 1; a.ost = B; a.ldo = ldo; a.dsb = 1; a.dst = B;
-    a.dbg = nullptr;
+    a.dbg = nullptr; a.db_part = nullptr;
     const int R = asr_lstm_pick_rows(B, 1, H / 32);
     switch (H) {
         case 64: return launch_bwd_h<64>(s, a, R);
