@@ -117,3 +117,32 @@ def test_gradients_finite_when_recycled_memory_holds_nan():
         m.backward()
         for n in m.variables.names():
             assert torch.isfinite(m.variables.grad_of(n)).all(), n
+
+
+@pytest.mark.parametrize("tdec", [2, 3])
+def test_persistent_decoder_paths_with_one_and_two_output_steps(monkeypatch, tdec):
+    """T_out = 1 and 2: the persistent chains run a single step (no exchange of a previous step, nothing published for a
+    next one) -- must equal the per-step launch path, forward and backward."""
+    from tests.test_gpu_model import _model, _batch
+    rng = np.random.default_rng(91)
+    kw = dict(enc_update=dict(hidden_size=64), num_layers={"char": 2}, seed=4,
+              dec_update=dict(hidden_size_dec=64, lm_hidden_size=64, emb_size=24, attention_vec_size=16))
+    b = _batch(rng, 5, 19, 20, tdec, 50)
+    res = []
+    for chain in ("1", "0"):
+        monkeypatch.setenv("ASR_DEC_CHAIN", chain)
+        monkeypatch.setenv("ASR_LM_CHAIN", chain)
+        m = _model(**kw)
+        m.forward(b)
+        assert (m.decoder["char"].saved["ws"].get("chain_ws") is not None) == (chain == "1")
+        out, loss = m.outputs["char"].cpu().numpy().copy(), m.total_loss.item()
+        m.backward()
+        from e2e_asr_amd import ops
+        ops.check_device_flag(torch.device(DEV))
+        res.append((out, loss, {n: m.variables.grad_of(n).cpu().numpy().copy() for n in m.variables.names()}))
+    assert res[0][0].shape[0] == (tdec - 1) * 5
+    np.testing.assert_allclose(res[0][0], res[1][0], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(res[0][1], res[1][1], rtol=1e-6)
+    for n, g0 in res[1][2].items():
+        err = np.abs(res[0][2][n] - g0).max() / max(1e-3, np.abs(g0).max())
+        assert err < 1e-4, (n, err)
