@@ -90,3 +90,25 @@ def test_model_bf16_logits_and_gradients_close_to_fp64_oracle():
         g16 = res["bf16"][2][n]
         cos = float((g32 * g16).sum() / (np.linalg.norm(g32) * np.linalg.norm(g16) + 1e-30))
         assert cos > 0.995, (n, cos)
+
+
+def test_config3_full_size_logits_vs_oracle():
+    """BASELINE config 3's per-GPU workload at FULL size (B = 32, T = 800, bf16 MFMA operands in the GEMMs): logits within
+    5e-2 absolute and loss within 1 % of the float64 oracle (the exact fp32 path: 3e-7 on the same batch)."""
+    from tests.test_gpu_model import _model, _f64
+    from e2e_asr_amd import ops
+    from e2e_asr_amd.weights import synthetic_batch
+    from oracle import asr_oracle as O
+    ops.set_gemm_precision("bf16")
+    m = _model(feat=80, vocab={"char": 1000}, params_update=dict(max_output={"char": 120}), seed=17)
+    b = synthetic_batch(B=32, T=800, F=80, t_dec=121, vocab=1000, variable_len=True, seed=4321)
+    m.forward(b)
+    ops.check_device_flag(torch.device(DEV))
+    out = m.outputs["char"].cpu().numpy()
+    w = _f64(m.variables.to_arrays())
+    b64 = dict(b); b64["logmel"] = b["logmel"].astype(np.float64)
+    r = O.seq2seq_forward(b64, w, is_training=True)
+    err = np.abs(out - r["outputs"]["char"]).max()
+    assert 1e-5 < err < 5e-2, err
+    assert abs(m.total_loss.item() - r["total_loss"]) < 1e-2 * abs(r["total_loss"])
+    print("config-3 (bf16 operands) full size: max |logit diff| = %.3g" % err)

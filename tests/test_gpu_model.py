@@ -541,3 +541,24 @@ def test_config2_full_batch_persistent_paths_equal_launch_paths(monkeypatch):
         for n, g0 in ref[3].items():
             err = np.abs(got[3][n] - g0).max() / max(1e-3, np.abs(g0).max())
             assert err < 2e-4, (rep, n, err)
+
+
+def test_config2_full_size_logits_and_loss_vs_oracle():
+    """The bench workload itself -- BASELINE config 2 at FULL size (B = 32, T = 800, F = 80, 4-layer pyramidal BiLSTM(256),
+    attention decoder(256), V = 1000, 120 output steps, ragged lengths) -- against the float64 oracle: logits within the
+    north-star tolerance 1e-3 (measured ~1e-6), loss to 1e-5 relative.  The oracle needs ~20 s of CPU for this one."""
+    from e2e_asr_amd.weights import synthetic_batch
+    m = _model(feat=80, vocab={"char": 1000}, params_update=dict(max_output={"char": 120}), seed=17)
+    b = synthetic_batch(B=32, T=800, F=80, t_dec=121, vocab=1000, variable_len=True, seed=4321)
+    m.forward(b)
+    from e2e_asr_amd import ops
+    ops.check_device_flag(torch.device(DEV))
+    out = m.outputs["char"].cpu().numpy()
+    w = _f64(m.variables.to_arrays())
+    b64 = dict(b); b64["logmel"] = b["logmel"].astype(np.float64)
+    r = O.seq2seq_forward(b64, w, is_training=True)
+    assert out.shape == r["outputs"]["char"].shape
+    err = np.abs(out - r["outputs"]["char"]).max()
+    assert err < 1e-3, err
+    assert abs(m.total_loss.item() - r["total_loss"]) < 1e-5 * abs(r["total_loss"])
+    print("config-2 full size: max |logit diff| = %.3g" % err)
