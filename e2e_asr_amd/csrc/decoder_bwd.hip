@@ -316,6 +316,7 @@ extern "C" int asr_decoder_chain_supported(int B, int Te, int D, int A, int H);
 extern "C" int asr_decoder_lm_chain_supported(int B, int lmH);
 int asr_lstm_rec_bwd_tm(hipStream_t s, float* gates, const float* act, const float* dout, int ldo, const float* kh,
                         const int* full_len, void* hx_ws, int* err, int B, int T, int H, float keep, unsigned seed);
+bool asr_decoder_chain_bwd_fits(int Te, int D, int A, int H);
 int asr_decoder_chain_bwd(void* stream, float* gates, const float* dec_c, const float* alpha, const float* y,
                           const float* ctx, const float* dqc, const float* wh, const float* wc, const float* w_att,
                           const float* v, const float* hf, const float* enc, const int* enc_len, float* dY, float* dctx,
@@ -373,7 +374,7 @@ extern "C" int asr_attn_decoder_bwd(void* stream, const asr_dec_weights* w, cons
     const int ldXH = E + H, ldLC = P + D, ldEH = E + lmH;
     // ---- persistent chain (csrc/decoder_chain_bwd.hip): the whole reverse-time recursion in one launch
     const bool use_chain = bw->chain_ws && bw->wc && ws->y && ws->err &&
-                           asr_decoder_chain_supported(B, Te, D, A, H);
+                           asr_decoder_chain_supported(B, Te, D, A, H) && asr_decoder_chain_bwd_fits(Te, D, A, H);
     int dv_rows = B;
     if (use_chain) {
         // wc = W_inp[P:] . K_x : the context rows of the composed input weight (decoder.hip, forward chain)

@@ -122,19 +122,24 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int* lds_flag = reinterpret_cast<int*>(smem);
-    float* dctl = smem + 4;                           // (spare) [R][DS]
-    float* dhl = dctl + R * DS;                       // dh for my units [R][HS]
-    float* dctall = dhl + R * HS2;                    // dctx_tot of both rows over ALL context columns + the G partials of S [R][D1]
-    float* sp = dctall + ((R * D1 + 3) & ~3);         // S [2 + r] (+pad)
+    float* dhl = smem + 4;                            // dh for my units [R][HS]
+    float* sp = dhl + R * HS2;                        // S [2 + r] (+pad)
     float* del = sp + 4;                              // de for my positions [R][MAXTS]
-    float* dyrow = del + R * MAXTS;                        // per DPP row partial dy [32 rows][A]
-    float* dyp = dyrow + 32 * A;                      // partial dy [R][A]                            -> X2 publish
+    // One region, two lives: [dctall | dga | fpart] serve the first phases of a step (dG gather, [dh|dctx] contraction,
+    // dctx_tot gather, dalpha), dyrow the tanh / dy-reduce phases after them (and the dv reduction of the epilogue); every
+    // hand-over between the two is separated by barriers.  (Without the overlay Te = 256 needs 168 KB of LDS.)
+    float* uni = del + R * MAXTS;
+    float* dctall = uni;                              // dctx_tot of both rows over ALL context columns + the G partials of S [R][D1]
+    float* dga = dctall + ((R * D1 + 3) & ~3);        // gathered dG of the later step [R][64 chunks][CSB]
+    float* fpart = dga + R * 64 * CSB;                // [dh|dctx] partial sums [NOUT][R][4 DPP rows]
+    float* dyrow = uni;                               // per DPP row partial dy [32 rows][A]
+    constexpr int UNI_A = ((R * D1 + 3) & ~3) + R * 64 * CSB + ((NOUT * R * 4 + 3) & ~3);
+    constexpr int UNI = UNI_A > 32 * A ? UNI_A : 32 * A;
+    float* dyp = uni + UNI;                           // partial dy [R][A]                            -> X2 publish
     float* dys = dyp + R * A;                         // dy for my a-slice [R][AS2]
     float* dyall = dys + R * AS2;                     // dy of both rows over ALL attention columns [R][A] (all-gather)
-    float* dql = dyall + R * A + (R * H - R * A);     // dq_att for my units [R][HS2]   (layout slot of the former [R][H] buffer kept)
-    float* dga = dql + R * HS2;                       // gathered dG of the later step [R][64 chunks][CSB]
-    float* fpart = dga + R * 64 * CSB;                // [dh|dctx] partial sums [NOUT][R][4 DPP rows]
-    float* hfl = fpart + ((NOUT * R * 4 + 3) & ~3);   // hf slice [R][MAXTS][A]
+    float* dql = dyall + R * A;                       // dq_att for my units [R][HS2]
+    float* hfl = dql + R * HS2;                       // hf slice [R][MAXTS][A]
     float* dhfl = hfl + R * MAXTS * A;                // dhf accumulator [R][MAXTS][A]
     const int Te = a.Te;
     const int TS = (Te + G - 1) / G;
@@ -668,14 +673,25 @@ extern "C" size_t asr_decoder_chain_bwd_ws_bytes(int B, int D, int A, int H) {
     return groups * 2 * (R * ((size_t)D + G) + G * G * s2 + R * (size_t)A + R * 4 * (size_t)H) * sizeof(u64) + groups * 16 * sizeof(u64);
 }
 
+// Dynamic LDS of the backward chain kernel (floats, in carve order); the hardware limit is 160 KB per workgroup.
+size_t asr_decoder_chain_bwd_lds_bytes(int Te, int D, int A, int H) {
+    const size_t R = 2, G = 16, HS = H / G, AS = A / G, DS = D / G, HS2 = (HS + 1) & ~(size_t)1, AS2 = (AS + 1) & ~(size_t)1;
+    const size_t D1 = D + G, CSB = (size_t)4 * H / 64 + 4, NOUT = HS + DS, TS = ((size_t)Te + G - 1) / G, TeP = ((size_t)Te + 1) & ~(size_t)1;
+    const size_t uni_a = ((R * D1 + 3) & ~(size_t)3) + R * 64 * CSB + ((NOUT * R * 4 + 3) & ~(size_t)3);
+    const size_t uni = uni_a > 32 * (size_t)A ? uni_a : 32 * (size_t)A;
+    const size_t nitems = R * A + R * TeP + 2 * R * DS + R * HS * 4 + 3 * R * HS, nitemsP = (nitems + 3) & ~(size_t)3;
+    const size_t floats = 4 + R * HS2 + 4 + R * 16 + uni + R * A + R * AS2 + R * A + R * HS2 + 2 * R * 16 * A + HS * A + A +
+                          R * TS * D + 2 * nitemsP + 3 * 5 * 256;
+    return floats * sizeof(float) + 64;
+}
+bool asr_decoder_chain_bwd_fits(int Te, int D, int A, int H) { return asr_decoder_chain_bwd_lds_bytes(Te, D, A, H) <= 160 * 1024 - 64; }
+
 template <int H, int D, int A>
 static int chain_bwd_launch(hipStream_t s, asr::ChainBwdArgs& a) {
     constexpr int R = 2, G = 16, HS = H / G, AS = A / G, DS = D / G, HS2 = (HS + 1) & ~1, AS2 = (AS + 1) & ~1;
     const int groups = a.ng;
-    const size_t lds = sizeof(float) * (4 + R * DS + R * HS2 + R * (D + G) + 4 + 4 + R * 16 + R * A + 32 * A + R * A + R * AS2 +
-                                        R * H + R * HS2 + R * 64 * (H / 16 + 4) + (HS + DS) * R * 4 + 4 + 2 * R * 16 * A + H * AS + A + (size_t)R * ((a.Te + G - 1) / G) * D +
-                                        2 * ((size_t)R * A + (size_t)R * (a.Te + 1) + 2 * R * DS + 7 * R * HS + 4) + 3 * 5 * 256 + 16);
-    if (lds > 150 * 1024) return ASR_EUNSUPPORTED;
+    const size_t lds = asr_decoder_chain_bwd_lds_bytes(a.Te, D, A, H);
+    if (lds > 160 * 1024 - 64) return ASR_EUNSUPPORTED;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asr::decoder_chain_bwd_kernel<H, D, A>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (H == 256 && a.dbg) {
