@@ -211,7 +211,7 @@ def _np_keep_scale(seed, a, b, keep):
     return np.where(u < np.float32(keep), np.float32(1.0) / np.float32(keep), np.float32(0.0)).astype(np.float64)
 
 
-@pytest.mark.parametrize("case", ["plain", "multitask_simple", "uni", "dropout"])
+@pytest.mark.parametrize("case", ["plain", "multitask_simple", "multitask_chain", "uni", "dropout"])
 def test_full_model_gradients_vs_autograd(case):
     """tf.gradients parity: every trainable variable's gradient from the HIP backward against
     torch autograd (float64) through the oracle twin, on the same batch/tokens/masks."""
@@ -223,6 +223,10 @@ def test_full_model_gradients_vs_autograd(case):
     if case == "multitask_simple":
         tasks = ("char", "phone")
         kw["dec_update"]["lm_hidden_size"] = 20
+        kw["num_layers"] = {"char": 3, "phone": 2}
+    if case == "multitask_chain":      # config-4 shape: two decoders on different encoder depths, both on the persistent chains
+        tasks = ("char", "phone")
+        kw["dec_update"].update(hidden_size_dec=64, lm_hidden_size=64)
         kw["num_layers"] = {"char": 3, "phone": 2}
     if case == "uni":
         kw["enc_update"]["bi_dir"] = False; bi = False
