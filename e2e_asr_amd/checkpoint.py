@@ -4,7 +4,8 @@ The reference saves TF checkpoints (train.py:202-203,353-371) and reads them bac
 variable name (beam_search.py:56-98; tf_utils.restore_common_variables, tf_utils.py:53-63).  TF is
 not a dependency here; the container is an .npz whose keys are exactly those names (plus
 `<name>/Adam`, `<name>/Adam_1` optimizer slots and `global_step`, `learning_rate`), so a script
-with TensorFlow can convert in either direction with ckpt_reader.get_tensor / tf.train.Saver."""
+with TensorFlow can convert in either direction with ckpt_reader.get_tensor / tf.train.Saver.
+A path ending in `.safetensors` selects that container instead (same keys; `/` is legal in its tensor names)."""
 import os
 
 import numpy as np
@@ -22,6 +23,12 @@ def save(path, variables, global_step=0, learning_rate=None, extra=None):
         arrays["learning_rate"] = np.asarray(learning_rate, np.float64)
     for k, v in (extra or {}).items():
         arrays[k] = np.asarray(v)
+    if path.endswith(".safetensors"):
+        from safetensors.numpy import save_file
+        tmp = path + ".tmp"
+        save_file({k: np.ascontiguousarray(v) for k, v in arrays.items()}, tmp)
+        os.replace(tmp, path)
+        return path
     tmp = path + ".tmp.npz"
     np.savez(tmp, **arrays)
     os.replace(tmp, path if path.endswith(".npz") else path + ".npz")
@@ -29,6 +36,9 @@ def save(path, variables, global_step=0, learning_rate=None, extra=None):
 
 
 def load(path):
+    if path.endswith(".safetensors"):
+        from safetensors.numpy import load_file
+        return dict(load_file(path))
     return dict(np.load(path if path.endswith(".npz") else path + ".npz"))
 
 

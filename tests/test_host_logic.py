@@ -2,6 +2,7 @@
 import argparse
 
 import numpy as np
+import pytest
 
 from e2e_asr_amd.base_params import BaseParams, Bunch
 
@@ -71,3 +72,40 @@ def test_encoder_layer_input_widths():
     assert encoder_layer_inputs(80, 256, True, 5) == [80, 1024, 1024, 1024, 512]   # max_scaling_down 8 stops the pyramid
     w = init_weights()
     assert sum(v.size for v in w.values()) == 10616552
+
+
+@pytest.mark.parametrize("ext", [".npz", ".safetensors"])
+def test_checkpoint_containers_roundtrip_under_tf_names(tmp_path, ext):
+    """Checkpoint interchange: weights, Adam slots, global_step and learning rate under the reference's TF
+    variable names, in an .npz or a .safetensors container; warm start by name intersection skips optimizer slots
+    (tf_utils.py:53-63, 86-89)."""
+    import torch
+    from e2e_asr_amd import checkpoint
+    from e2e_asr_amd.variables import VariableStore
+    rng = np.random.default_rng(0)
+    names = ["model/encoder/RNNLayer1/bidirectional_rnn/fw/basic_lstm_cell/kernel", "model/rnn_decoder_char/AttnV",
+             "model/rnn_decoder_char/rnn/OutputProjection/bias"]
+    arrays = {n: rng.standard_normal(s).astype(np.float32) for n, s in zip(names, [(7, 12), (5,), (9,)])}
+    st = VariableStore.from_arrays(arrays, "cpu")
+    m, v = st.ensure_adam("Adam")
+    m.copy_(torch.arange(m.numel(), dtype=torch.float32)); v.fill_(0.25)
+    path = checkpoint.save(str(tmp_path / ("asr.ckpt-7" + ext)), st, global_step=7, learning_rate=5e-4)
+    assert path.endswith(ext)
+    got = checkpoint.load(path)
+    for n in names:
+        np.testing.assert_array_equal(got[n], arrays[n])
+        assert got[n + "/Adam"].shape == arrays[n].shape and got[n + "/Adam_1"].shape == arrays[n].shape
+    assert int(got["global_step"]) == 7 and float(got["learning_rate"]) == 5e-4
+    st2 = VariableStore.from_arrays({n: np.zeros_like(a) for n, a in arrays.items()}, "cpu")
+    gs, lr = checkpoint.restore(st2, path)
+    assert (gs, lr) == (7, 5e-4) and torch.equal(st2.flat, st.flat)
+    m2, v2 = st2.ensure_adam("Adam")
+    for (_, _, off, n) in st._specs:                      # the flat store pads between variables; slots exist per variable
+        assert torch.equal(m2[off:off + n], m[off:off + n]) and torch.equal(v2[off:off + n], v[off:off + n])
+    # warm start of a DIFFERENT model: only the common names, never the optimizer slots
+    other = VariableStore.from_arrays({names[1]: np.zeros(5, np.float32), "model/rnn_decoder_phone/AttnV": np.ones(5, np.float32)}, "cpu")
+    restored = checkpoint.restore_common_variables(other, path)
+    assert list(restored) == [names[1]]
+    np.testing.assert_array_equal(other[names[1]].numpy(), arrays[names[1]])
+    assert float(other["model/rnn_decoder_phone/AttnV"].sum()) == 5.0
+    assert set(checkpoint.get_matching_variables("rnn_decoder_char", path)) == {names[1], names[2]}
