@@ -89,6 +89,7 @@ SIGNATURES = {
     "asr_scatter_add_rows_ld": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int]),
     "asr_side_join": (C.c_int, [vp]),
     "asr_decoder_chain_supported": (C.c_int, [C.c_int] * 5),
+    "asr_decoder_chain_rows": (C.c_int, [C.c_int]),
     "asr_pyramid_reduce_fwd": (C.c_int, [vp, vp, vp, vp, vp] + [C.c_int] * 4),
     "asr_pyramid_reduce_bwd": (C.c_int, [vp, vp, vp] + [C.c_int] * 4),
     "asr_sigmoid_f32": (C.c_int, [vp, vp, vp, C.c_size_t]),

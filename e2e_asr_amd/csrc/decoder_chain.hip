@@ -90,13 +90,16 @@ __global__ __launch_bounds__(512) void chain_relayout_kernel(const float* wh, co
 // STAMP: diagnostic instantiation (ASR_CHAIN_STAMP=1 + asr_debug_set_buffer): s_memtime totals of wave 0 of workgroup 0
 // per phase (code between two consecutive barriers of a step; slot 15 = prologue), accumulated over the launches of a call;
 // never used for timing claims.
-template <int H, int D, int A, bool STAMP = false>
+// R: utterances per group.  R = 2 holds up to 16 encoder positions per workgroup (Te <= 256); R = 1 trades the second row for
+// 32 positions per workgroup (Te <= 512, the depth-2 tap of the phone decoder): R * MAXTS = 32 = the DPP rows of a workgroup.
+template <int H, int D, int A, int R = 2, bool STAMP = false>
 __global__ __launch_bounds__(512) void decoder_chain_fwd_kernel(ChainArgs a) {
     unsigned int stamp[16] = {0};
     unsigned long long tlast = STAMP ? __builtin_amdgcn_s_memtime() : 0;
     int sph = 0;
 #define CHAINF_STAMP() if (STAMP) { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); stamp[sph & 15] += (unsigned int)(t__ - tlast); tlast = t__; ++sph; }
-    constexpr int R = 2, G = 16, NT = 512;
+    constexpr int G = 16, NT = 512;
+    static_assert(R == 1 || R == 2, "rows per group");
     constexpr int HS = H / G;            // hidden units per workgroup
     constexpr int AS = A / G;            // attention columns per workgroup
     constexpr int DS = D / G;            // context columns per workgroup
@@ -106,7 +109,7 @@ __global__ __launch_bounds__(512) void decoder_chain_fwd_kernel(ChainArgs a) {
     constexpr int KCP = KC + 4;          // padded chunk stride in LDS
     constexpr int QP = (H + 127) / 128 * 128;     // padded query length
     constexpr int QC = QP / 32;          // q values per lane in the y matvec
-    constexpr int MAXTS = 16;            // encoder positions per workgroup (Te <= 256)
+    constexpr int MAXTS = 32 / R;        // encoder positions per workgroup (Te <= 16 * MAXTS)
     static_assert(HS * G == H && AS * G == A && DS * G == D && HS <= 16 && AS <= 8, "sizes");
     static_assert(KC % 4 == 0 && QC % 4 == 0 && KS % 2 == 0 && H % 2 == 0 && A % 2 == 0, "mapping");
     constexpr int H4 = 4 * H;
@@ -170,8 +173,9 @@ __global__ __launch_bounds__(512) void decoder_chain_fwd_kernel(ChainArgs a) {
         for (int i = 0; i < KC; ++i) { const float4 v4 = wp[(size_t)i * NT]; wb[i][0] = v4.x; wb[i][1] = v4.y; wb[i][2] = v4.z; wb[i][3] = v4.w; }
     }
     // y matvec: DPP row -> (col ya = row % 8 ..., r, part)
-    const int ya = row % 8, yr = (row / 8) % 2, ypart = row / 16;
-    const bool yact = ya < AS;
+    const int ya = row % 8, yslot = (row / 8) % 2, ypart = row / 16;
+    const bool yact = ya < AS && yslot < R;        // (R = 1: the second row slot idles)
+    const int yr = yslot < R ? yslot : 0;
     float wy[QC];
     {
         const int acol = mem * AS + (yact ? ya : 0);
@@ -357,8 +361,8 @@ __global__ __launch_bounds__(512) void decoder_chain_fwd_kernel(ChainArgs a) {
         __syncthreads();
         CHAINF_STAMP()
         {
-            // DPP row -> (tl = row % 16, r = row / 16); lane kq -> A/16 consecutive a (float4 steps)
-            const int tl = row % 16, r = row / 16;
+            // DPP row -> (tl = row % MAXTS, r = row / MAXTS); lane kq -> A/16 consecutive a (float4 steps)
+            const int tl = row % MAXTS, r = row / MAXTS;
             float sc = 0.f;
             if (tl < TS) {
                 constexpr int AL = A / 16;
@@ -385,7 +389,7 @@ __global__ __launch_bounds__(512) void decoder_chain_fwd_kernel(ChainArgs a) {
         __syncthreads();
         CHAINF_STAMP()
         if (wave0 && tid < 32) {
-            const int tl = tid % 16, r = tid / 16;
+            const int tl = tid % MAXTS, r = tid / MAXTS;
             if (tl < TS && r0 + r < a.B)
                 chain_publish(gE + (size_t)r * G * MAXTS + mem * MAXTS + tl, ep, eout[tid], fast);
         }
@@ -480,16 +484,22 @@ __global__ __launch_bounds__(512) void decoder_chain_fwd_kernel(ChainArgs a) {
 
 }  // namespace asr
 
+extern "C" int asr_decoder_chain_rows(int Te) { return Te <= 256 ? 2 : 1; }
+
 extern "C" int asr_decoder_chain_supported(int B, int Te, int D, int A, int H) {
     if (getenv("ASR_DEC_CHAIN") && atoi(getenv("ASR_DEC_CHAIN")) == 0) return 0;
-    if (Te > 256 || B <= 0) return 0;
+    if (Te > 512 || Te <= 0 || B <= 0) return 0;
     return (H == 256 && D == 512 && A == 128) || (H == 64 && D == 128 && A == 16);
 }
 
-static size_t chain_gran_bytes(int B, int D, int A, int H) {
-    const size_t groups = (B + 1) / 2;
-    const size_t npar = 2 * (size_t)(H + D) + 2 * (size_t)H + 2 * (size_t)A + 2 * 16 * 16;
-    return (groups * 2 * npar * sizeof(u64) + groups * 16 * sizeof(u64) + 255) / 256 * 256;
+// granule area of one call: [groups][2 parities][S | Q | Y | E] + [groups][16] XCC slots, for R rows per group
+static size_t chain_npar(int R, int D, int A, int H) { return (size_t)R * (H + D) + (size_t)R * H + (size_t)R * A + 16 * 32; }
+static size_t chain_gran_bytes_r(int B, int D, int A, int H, int R) {
+    const size_t groups = ((size_t)B + R - 1) / R;
+    return (groups * 2 * chain_npar(R, D, A, H) * sizeof(u64) + groups * 16 * sizeof(u64) + 255) / 256 * 256;
+}
+static size_t chain_gran_bytes(int B, int D, int A, int H) {      // the workspace serves either decomposition
+    return std::max(chain_gran_bytes_r(B, D, A, H, 1), chain_gran_bytes_r(B, D, A, H, 2));
 }
 static size_t chain_relayout_bytes(int D, int H) {
     const size_t KC = ((size_t)(H + D) + 127) / 128 * 128 / 32;
@@ -499,28 +509,28 @@ extern "C" size_t asr_decoder_chain_ws_bytes(int B, int D, int A, int H) {
     return chain_gran_bytes(B, D, A, H) + chain_relayout_bytes(D, H);      // granules + XCC slots | re-laid weights
 }
 
-template <int H, int D, int A>
+template <int H, int D, int A, int R>
 static int chain_launch(hipStream_t s, asr::ChainArgs& a, int Te) {
-    constexpr int R = 2, G = 16;
+    constexpr int G = 16;
     const int groups = a.ng;
     constexpr int KSP = (H + D + 127) / 128 * 128, KCP = KSP / 32 + 4, QP = (H + 127) / 128 * 128;
     const size_t lds = sizeof(float) * (4 + (size_t)R * 32 * KCP + 2 * (H / G) * R * 4 + R * QP + 2 * (A / G) * R + 4 + R * A +
-                                        R * G * 16 + 32 + 8 * R * (D / G) + R * (H / G) * 4 + A + R * 16 * A + (size_t)R * Te * (D / G));
-    if (lds > 150 * 1024) return ASR_EUNSUPPORTED;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asr::decoder_chain_fwd_kernel<H, D, A>),
+                                        G * 32 + 32 + 8 * R * (D / G) + R * (H / G) * 4 + A + 32 * A + (size_t)R * Te * (D / G));
+    if (lds > 160 * 1024 - 64) return ASR_EUNSUPPORTED;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asr::decoder_chain_fwd_kernel<H, D, A, R>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (H == 256 && a.dbg) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asr::decoder_chain_fwd_kernel<256, 512, 128, true>),
+    if (H == 256 && R == 2 && a.dbg) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asr::decoder_chain_fwd_kernel<256, 512, 128, 2, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((asr::decoder_chain_fwd_kernel<256, 512, 128, true>), dim3(groups * G), dim3(512), lds, s, a);
+        hipLaunchKernelGGL((asr::decoder_chain_fwd_kernel<256, 512, 128, 2, true>), dim3(groups * G), dim3(512), lds, s, a);
         return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
     }
-    hipLaunchKernelGGL((asr::decoder_chain_fwd_kernel<H, D, A>), dim3(groups * G), dim3(512), lds, s, a);
+    hipLaunchKernelGGL((asr::decoder_chain_fwd_kernel<H, D, A, R>), dim3(groups * G), dim3(512), lds, s, a);
     return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
 }
 
-// Steps [t0,t1) of the decoder chain; 16 groups (32 utterances) per launch, larger batches run as consecutive
-// launches over group ranges (each range has its own granule area, so no re-zeroing in between).
+// Steps [t0,t1) of the decoder chain; 16 groups per launch (32 utterances at R = 2, 16 at R = 1), larger batches run as
+// consecutive launches over group ranges (each range has its own granule area, so no re-zeroing in between).
 // gates holds preG for those steps on entry.  ws: asr_decoder_chain_ws_bytes().
 int asr_decoder_chain_fwd(void* stream, float* gates, const float* wh, const float* wc, const float* w_att,
                           const float* b_att, const float* v, const float* hf, const float* enc, const int* enc_len,
@@ -530,6 +540,7 @@ int asr_decoder_chain_fwd(void* stream, float* gates, const float* wh, const flo
     if (!asr_decoder_chain_supported(B, Te, D, A, H) || t1 <= t0) return ASR_EUNSUPPORTED;
     hipStream_t s = static_cast<hipStream_t>(stream);
     // NOTE: all batch rows of a launch share the [T][B][.] row stride B, so chunking is by group range only
+    const int R = asr_decoder_chain_rows(Te);
     const size_t bytes = chain_gran_bytes(B, D, A, H);
     float4* wrl = reinterpret_cast<float4*>(static_cast<char*>(ws) + bytes);
     if (t0 == 0) {                                                                          // once per sequence
@@ -543,14 +554,15 @@ int asr_decoder_chain_fwd(void* stream, float* gates, const float* wh, const flo
     a.enc_len = enc_len; a.dec_c = dec_c; a.dec_h = dec_h; a.alpha = alpha; a.ctx = ctx; a.y = y;
     a.gx = static_cast<u64*>(ws);
     a.wrl = wrl;
-    const size_t groups = (B + 1) / 2;
-    const size_t npar = 2 * (size_t)(H + D) + 2 * (size_t)H + 2 * (size_t)A + 2 * 16 * 16;
-    a.xcc_slots = a.gx + groups * 2 * npar;
+    const size_t groups = ((size_t)B + R - 1) / R;
+    a.xcc_slots = a.gx + groups * 2 * chain_npar(R, D, A, H);
     a.err = err; a.B = B; a.Te = Te; a.t0 = t0; a.t1 = t1;
     a.dbg = getenv("ASR_CHAIN_STAMP") ? asr::g_lstm_dbg : nullptr;
     for (int g0 = 0; g0 < (int)groups; g0 += 16) {
         a.g0 = g0; a.ng = std::min<int>(16, (int)groups - g0);
-        const int rc = (H == 256) ? chain_launch<256, 512, 128>(s, a, Te) : chain_launch<64, 128, 16>(s, a, Te);
+        int rc;
+        if (H == 256) rc = R == 2 ? chain_launch<256, 512, 128, 2>(s, a, Te) : chain_launch<256, 512, 128, 1>(s, a, Te);
+        else rc = R == 2 ? chain_launch<64, 128, 16, 2>(s, a, Te) : chain_launch<64, 128, 16, 1>(s, a, Te);
         if (rc) return rc;
     }
     return ASR_OK;

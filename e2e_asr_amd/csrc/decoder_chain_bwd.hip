@@ -23,6 +23,7 @@
 // gathering threads keep all their loads in flight and sum in fixed order (reproducible).  Wave 0 owns every global store.
 // dx = dG.K_x^T and dlm_out = dx.W_inp[:P]^T are GEMMs after the loop.
 #include "common.h"
+#include <algorithm>
 #include <cstdlib>
 
 extern "C" int asr_decoder_chain_supported(int B, int Te, int D, int A, int H);
@@ -91,13 +92,16 @@ __device__ __forceinline__ void pubg(u64* dst, uint32_t epoch, float v, bool fas
 
 // STAMP: diagnostic instantiation (ASR_CHAIN_STAMP=1 + asr_debug_set_buffer): per-phase s_memtime totals of wave 0 of
 // workgroup 0 (phase = code between two consecutive barriers of a step); never used for timing claims.
-template <int H, int D, int A, bool STAMP = false>
+// R: utterances per group (2: up to 16 encoder positions per workgroup, Te <= 256; 1: 32 positions, Te <= 512) -- the same
+// decomposition the forward chain used for this Te (asr_decoder_chain_rows).
+template <int H, int D, int A, int R = 2, bool STAMP = false>
 __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) {
     unsigned int stamp[16] = {0};
     unsigned long long tlast = 0;
     int sph = 0;
 #define CHAIN_STAMP() if (STAMP) { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); stamp[sph & 15] += (unsigned int)(t__ - tlast); tlast = t__; ++sph; }
-    constexpr int R = 2, G = 16, NT = 512;
+    constexpr int G = 16, NT = 512;
+    static_assert(R == 1 || R == 2, "rows per group");
     constexpr int HS = H / G, AS = A / G, DS = D / G;
     constexpr int NGT = 192;                          // gathering threads of the all-gathers: waves 1-3
     constexpr int N4 = 4 * H;                         // dG positions per row: p = 4*unit + gate
@@ -107,7 +111,7 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
     constexpr int OPW = (NOUT + 7) / 8;               // outputs per wave
     constexpr int NPAIR4 = R * N4 / 2;                // granule pairs gathered per step
     constexpr int NPP4 = (NPAIR4 + NGT - 1) / NGT;    // ... pairs per gathering thread
-    constexpr int MAXTS = 16;
+    constexpr int MAXTS = 32 / R;
     constexpr int AL = A / 16;                        // a values per lane in the tanh phase
     constexpr int H4 = 4 * H;
     // slots per (dst, src): even counts so that pairs never straddle
@@ -172,7 +176,7 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
     const int blen1 = (r0 + 1 < a.B) ? min(max(a.enc_len[brow1], 0), Te) : 0;
     auto browf = [&](int r) { return r ? brow1 : brow0; };
     auto blenf = [&](int r) { return r ? blen1 : blen0; };
-    auto rok = [&](int r) { return r0 + r < a.B; };
+    auto rok = [&](int r) { return r < R && r0 + r < a.B; };
     u64* gbase = a.gx + (size_t)grp * 2 * NPAR;
     const bool fast = group_shares_xcd(a.xcc_slots + (size_t)grp * 16, G, mem, tid, a.err, lds_flag);
 
@@ -205,8 +209,8 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
         const int r = idx / (TS * D), tl = (idx / D) % TS, dcol = idx % D, tau = mem * TS + tl;
         encl[idx] = tau < Te ? a.enc[((size_t)browf(r) * Te + tau) * D + dcol] : 0.f;
     }
-    // tanh-phase mapping: DPP row -> (tl = row % 16, r = row / 16), lane kq -> AL consecutive a
-    const int trow_tl = row % 16, trow_r = row / 16;
+    // tanh-phase mapping: DPP row -> (tl = row % MAXTS, r = row / MAXTS), lane kq -> AL consecutive a
+    const int trow_tl = row % MAXTS, trow_r = row / MAXTS;
     float dvacc[AL];
 #pragma unroll
     for (int q = 0; q < AL; ++q) dvacc[q] = 0.f;
@@ -387,10 +391,10 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
         }
         if (wave0) {
             float sprt = 0.f;
-            const int r = lane / 32, dd0 = lane % 32;      // 2 rows x 32 lanes
+            const int r = lane / 32, dd0 = lane % 32;      // 2 row slots x 32 lanes (R = 1: the second slot idles)
             for (int dd = dd0; dd < DS; dd += 32) {
                 float x = 0.f;
-                if (s > 0) { const float4 v = *reinterpret_cast<const float4*>(fpart + ((HS + dd) * R + r) * 4); x = (v.x + v.y) + (v.z + v.w); }
+                if (s > 0 && r < R) { const float4 v = *reinterpret_cast<const float4*>(fpart + ((HS + dd) * R + r) * 4); x = (v.x + v.y) + (v.z + v.w); }
                 if (rok(r)) {
                     const size_t rowi = (size_t)i * a.B + r0 + r;
                     x += dqcx[r * DS + dd];
@@ -517,11 +521,11 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
         }
         __syncthreads();
         CHAIN_STAMP()
-        for (int idx = tid; idx < R * A; idx += NT) {        // partial dy[r][a] = sum over my positions (16 DPP rows)
+        for (int idx = tid; idx < R * A; idx += NT) {        // partial dy[r][a] = sum over my positions (MAXTS DPP rows)
             const int r = idx / A, aa = idx % A;
             float x = 0.f;
 #pragma unroll
-            for (int t = 0; t < 16; ++t) x += dyrow[(r * 16 + t) * A + aa];
+            for (int t = 0; t < MAXTS; ++t) x += dyrow[(r * MAXTS + t) * A + aa];
             dyp[idx] = x;
         }
         __syncthreads();
@@ -666,41 +670,48 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
 
 }  // namespace asr
 
-extern "C" size_t asr_decoder_chain_bwd_ws_bytes(int B, int D, int A, int H) {
-    const size_t groups = (B + 1) / 2, G = 16, R = 2, HS = H / 16, AS = A / 16, DS = D / 16;
+extern "C" int asr_decoder_chain_rows(int Te);
+
+static size_t chain_bwd_ws_bytes_r(int B, int D, int A, int H, int Rr) {
+    const size_t R = Rr, groups = ((size_t)B + R - 1) / R, G = 16, AS = A / 16;
     const size_t s2 = R * ((AS + 1) & ~(size_t)1);
-    (void)DS; (void)HS;
     return groups * 2 * (R * ((size_t)D + G) + G * G * s2 + R * (size_t)A + R * 4 * (size_t)H) * sizeof(u64) + groups * 16 * sizeof(u64);
+}
+extern "C" size_t asr_decoder_chain_bwd_ws_bytes(int B, int D, int A, int H) {      // serves either decomposition
+    return std::max(chain_bwd_ws_bytes_r(B, D, A, H, 1), chain_bwd_ws_bytes_r(B, D, A, H, 2));
 }
 
 // Dynamic LDS of the backward chain kernel (floats, in carve order); the hardware limit is 160 KB per workgroup.
 size_t asr_decoder_chain_bwd_lds_bytes(int Te, int D, int A, int H) {
-    const size_t R = 2, G = 16, HS = H / G, AS = A / G, DS = D / G, HS2 = (HS + 1) & ~(size_t)1, AS2 = (AS + 1) & ~(size_t)1;
+    const size_t R = asr_decoder_chain_rows(Te);
+    const size_t G = 16, HS = H / G, AS = A / G, DS = D / G, HS2 = (HS + 1) & ~(size_t)1, AS2 = (AS + 1) & ~(size_t)1;
     const size_t D1 = D + G, CSB = (size_t)4 * H / 64 + 4, NOUT = HS + DS, TS = ((size_t)Te + G - 1) / G, TeP = ((size_t)Te + 1) & ~(size_t)1;
     const size_t uni_a = ((R * D1 + 3) & ~(size_t)3) + R * 64 * CSB + ((NOUT * R * 4 + 3) & ~(size_t)3);
     const size_t uni = uni_a > 32 * (size_t)A ? uni_a : 32 * (size_t)A;
     const size_t nitems = R * A + R * TeP + 2 * R * DS + R * HS * 4 + 3 * R * HS, nitemsP = (nitems + 3) & ~(size_t)3;
-    const size_t floats = 4 + R * HS2 + 4 + R * 16 + uni + R * A + R * AS2 + R * A + R * HS2 + 2 * R * 16 * A + HS * A + A +
+    const size_t floats = 4 + R * HS2 + 4 + 32 + uni + R * A + R * AS2 + R * A + R * HS2 + 2 * 32 * A + HS * A + A +
                           R * TS * D + 2 * nitemsP + 3 * 5 * 256;
     return floats * sizeof(float) + 64;
 }
-bool asr_decoder_chain_bwd_fits(int Te, int D, int A, int H) { return asr_decoder_chain_bwd_lds_bytes(Te, D, A, H) <= 160 * 1024 - 64; }
+bool asr_decoder_chain_bwd_fits(int Te, int D, int A, int H) {
+    return Te <= 512 && asr_decoder_chain_bwd_lds_bytes(Te, D, A, H) <= 160 * 1024 - 64;
+}
 
-template <int H, int D, int A>
+template <int H, int D, int A, int R>
 static int chain_bwd_launch(hipStream_t s, asr::ChainBwdArgs& a) {
-    constexpr int R = 2, G = 16, HS = H / G, AS = A / G, DS = D / G, HS2 = (HS + 1) & ~1, AS2 = (AS + 1) & ~1;
+    constexpr int G = 16;
     const int groups = a.ng;
     const size_t lds = asr_decoder_chain_bwd_lds_bytes(a.Te, D, A, H);
     if (lds > 160 * 1024 - 64) return ASR_EUNSUPPORTED;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asr::decoder_chain_bwd_kernel<H, D, A>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asr::decoder_chain_bwd_kernel<H, D, A, R>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (H == 256 && a.dbg) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asr::decoder_chain_bwd_kernel<256, 512, 128, true>),
+    if (H == 256 && R == 2 && a.dbg) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asr::decoder_chain_bwd_kernel<256, 512, 128, 2, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((asr::decoder_chain_bwd_kernel<256, 512, 128, true>), dim3(groups * G), dim3(512), lds, s, a);
+        hipLaunchKernelGGL((asr::decoder_chain_bwd_kernel<256, 512, 128, 2, true>), dim3(groups * G), dim3(512), lds, s, a);
         return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
     }
-    hipLaunchKernelGGL((asr::decoder_chain_bwd_kernel<H, D, A>), dim3(groups * G), dim3(512), lds, s, a);
+    hipLaunchKernelGGL((asr::decoder_chain_bwd_kernel<H, D, A, R>), dim3(groups * G), dim3(512), lds, s, a);
     return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
 }
 
@@ -718,13 +729,16 @@ int asr_decoder_chain_bwd(void* stream, float* gates, const float* dec_c, const 
     a.gates = gates; a.dec_c = dec_c; a.alpha = alpha; a.y = y; a.ctx = ctx; a.dqc = dqc; a.wh = wh; a.wc = wc;
     a.w_att = w_att; a.v = v; a.hf = hf; a.enc = enc; a.enc_len = enc_len; a.dY = dY; a.dctx = dctx; a.dhf = dhf;
     a.dv_part = dv_part; a.gx = static_cast<u64*>(ws);
-    a.xcc_slots = reinterpret_cast<u64*>(static_cast<char*>(ws) + bytes) - ((size_t)((B + 1) / 2) * 16);
+    const int R = asr_decoder_chain_rows(Te);
+    const int groups = (B + R - 1) / R;
+    a.xcc_slots = reinterpret_cast<u64*>(static_cast<char*>(ws) + chain_bwd_ws_bytes_r(B, D, A, H, R)) - ((size_t)groups * 16);
     a.err = err; a.B = B; a.Te = Te; a.T = T;
     a.dbg = getenv("ASR_CHAIN_STAMP") ? asr::g_lstm_dbg : nullptr;
-    const int groups = (B + 1) / 2;
     for (int g0 = 0; g0 < groups; g0 += 16) {          // 16 groups = 256 workgroups per launch
         a.g0 = g0; a.ng = groups - g0 < 16 ? groups - g0 : 16;
-        const int rc = (H == 256) ? chain_bwd_launch<256, 512, 128>(s, a) : chain_bwd_launch<64, 128, 16>(s, a);
+        int rc;
+        if (H == 256) rc = R == 2 ? chain_bwd_launch<256, 512, 128, 2>(s, a) : chain_bwd_launch<256, 512, 128, 1>(s, a);
+        else rc = R == 2 ? chain_bwd_launch<64, 128, 16, 2>(s, a) : chain_bwd_launch<64, 128, 16, 1>(s, a);
         if (rc) return rc;
     }
     return ASR_OK;

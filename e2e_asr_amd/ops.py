@@ -387,7 +387,7 @@ def attn_decoder_bwd(wt, gt, ws, enc, enc_len, dlogits, denc, keep_lm=1.0, seed=
     P = H if wt.get("simple_w") is not None else lmH
     bw = dict(dP=f(T, B, H), dQC=f(T, B, H + D), dY=f(T, B, A), dXH=f(T, B, E + H), dLC=f(T, B, P + D),
               dlm=f(T, B, lmH) if wt.get("simple_w") is not None else None, dEH=f(T, B, E + lmH),
-              dc_dec=f(B, H), dc_lm=f(B, lmH), dhf=f(B, Te, A), dv_part=f(max(B, 16 * ((B + 1) // 2)), A),
+              dc_dec=f(B, H), dc_lm=f(B, lmH), dhf=f(B, Te, A), dv_part=f(16 * B, A),
               dctx=f(T, B, D), emb_all=f(T, B, E))
     L = _lib.lib()
     if ws.get("err") is not None and L.asr_decoder_chain_supported(B, Te, D, A, H):   # persistent backward chain

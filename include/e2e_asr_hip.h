@@ -206,7 +206,7 @@ typedef struct {              /* backward scratch (device), sized by the caller 
     float* dc_dec;            /* [B,H]  carry */
     float* dc_lm;             /* [B,lmH] carry */
     float* dhf;               /* [B,Te,A] */
-    float* dv_part;           /* [max(B, 16*ceil(B/2)),A] */
+    float* dv_part;           /* [16*B,A] (one partial per workgroup of the backward chain) */
     float* dctx;              /* [T_out,B,D] total gradient w.r.t. each step's context */
     float* emb_all;           /* [T_out,B,E] gathered embeddings */
     void*  chain_ws;          /* asr_decoder_chain_bwd_ws_bytes() bytes, or NULL: per-step launches */
@@ -252,8 +252,10 @@ int asr_beam_step(void* stream, const asr_dec_weights* w, const asr_lm_weights* 
  * ordered against `stream` with events; legal under hipGraph capture).  asr_attn_decoder_bwd leaves
  * LM-chain gradient work in flight on it: call asr_side_join(stream) before reading the gradients. */
 int asr_side_join(void* stream);
-/* Persistent decoder chain (csrc/decoder_chain.hip): used inside asr_attn_decoder_fwd when supported. */
+/* Persistent decoder chain (csrc/decoder_chain.hip): used inside asr_attn_decoder_fwd when supported (Te <= 512).
+ * asr_decoder_chain_rows: utterances per 16-workgroup group for this Te (2 up to 256 encoder positions, else 1). */
 int asr_decoder_chain_supported(int B, int Te, int D, int A, int H);
+int asr_decoder_chain_rows(int Te);
 size_t asr_decoder_chain_ws_bytes(int B, int D, int A, int H);
 size_t asr_decoder_chain_bwd_ws_bytes(int B, int D, int A, int H);
 /* LM cell chain of the decoder through the persistent recurrent kernels of csrc/lstm.hip / lstm_bwd.hip

@@ -429,6 +429,45 @@ def test_decoder_chain_path_vs_oracle_and_autograd():
         assert err < 2e-3, (name, err)
 
 
+@pytest.mark.parametrize("nb,T", [(5, 700), (19, 523)])
+def test_decoder_chain_long_encoder_one_row_groups(monkeypatch, nb, T):
+    """More than 256 encoder positions (the depth-2 tap: T/2 frames): the chain kernels run as one utterance per group
+    with 32 positions per workgroup (asr_decoder_chain_rows(Te) == 1); 19 utterances = two launches (16 + 3 groups).
+    Logits vs the float64 oracle, and logits, sampled tokens and every gradient vs the per-step launch path."""
+    from e2e_asr_amd import _lib, ops
+    L = _lib.lib()
+    Te = (T + 1) // 2
+    assert L.asr_decoder_chain_rows(Te) == 1 and L.asr_decoder_chain_rows(256) == 2
+    assert L.asr_decoder_chain_supported(nb, Te, 128, 16, 64) == 1 and L.asr_decoder_chain_supported(nb, 513, 128, 16, 64) == 0
+    rng = np.random.default_rng(31)
+    b = _batch(rng, nb, T, 20, 13, 50)
+    outs = []
+    for chain in ("1", "0"):
+        monkeypatch.setenv("ASR_DEC_CHAIN", chain)
+        m = _chain_model(samp=0.3, seed=11)
+        m.decoder["char"].coin_rng = np.random.default_rng(5)
+        m.forward(b)
+        ws = m.decoder["char"].saved["ws"]
+        assert (ws.get("chain_ws") is not None) == (chain == "1")
+        m.backward()
+        ops.check_device_flag(torch.device(DEV))
+        grads = {n: m.variables.grad_of(n).cpu().numpy().copy() for n in m.variables.names()}
+        outs.append((m.outputs["char"].cpu().numpy(), ws["tok"].cpu().numpy(), m.total_loss.item(), grads))
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+    np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=0, atol=2e-5)
+    for n, g1 in outs[0][3].items():
+        g0 = outs[1][3][n]
+        err = np.abs(g1 - g0).max() / max(1e-3, np.abs(g0).max())
+        assert err < 1e-4, (n, err)
+    if nb <= 8:        # teacher forcing against the oracle
+        monkeypatch.setenv("ASR_DEC_CHAIN", "1")
+        m = _chain_model(samp=0.0, seed=11)
+        m.forward(b)
+        b64 = dict(b); b64["logmel"] = b["logmel"].astype(np.float64)
+        r = O.seq2seq_forward(b64, _f64(m.variables.to_arrays()), num_layers={"char": 2}, is_training=True)
+        np.testing.assert_allclose(m.outputs["char"].cpu().numpy(), r["outputs"]["char"], rtol=0, atol=1e-4)
+
+
 @pytest.mark.parametrize("nb", [6, 37])
 def test_decoder_chain_equals_launch_path_under_scheduled_sampling(monkeypatch, nb):
     """Scheduled sampling cuts the sequence into segments (one persistent launch each); the result
