@@ -104,7 +104,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--mode", default="auto", choices=["auto", "train", "fwd"])
+    ap.add_argument("--mode", default="auto", choices=["auto", "train", "fwd", "eval"],
+                    help="train: full step (default); fwd: training graph forward incl. loss; eval: inference graph "
+                         "(isTraining=False: greedy argmax feedback, max_output=120 steps, eval_model.py:56-118)")
     ap.add_argument("--variable-len", action="store_true", help="lengths U[400,800] (masking run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
@@ -126,7 +128,7 @@ def main():
     from e2e_asr_amd import ops
     from e2e_asr_amd.weights import synthetic_batch
     ops.set_gemm_precision(args.dtype)
-    model = build_model(dev, training=True)
+    model = build_model(dev, training=args.mode != "eval")
     has_train = hasattr(model, "step")
     mode = args.mode if args.mode != "auto" else ("train" if has_train else "fwd")
     if world > 1:
@@ -210,7 +212,8 @@ def main():
         "config": {"workload": ("config2" if args.dtype == "f32" else "config3 (per-GPU)") + ": 4-layer pyramidal BiLSTM(256)+attn decoder(256), V=1000, per-GPU batch "
                                "32x800x80, %s step%s" % (
                                    "full train (fwd+bwd+clip+Adam%s)" % ("+RCCL all-reduce" if world > 1 else "")
-                                   if mode == "train" else "forward-only (training graph incl. loss)",
+                                   if mode == "train" else ("forward-only (training graph incl. loss)" if mode == "fwd" else
+                                                            "inference graph (greedy decode, 120 steps)"),
                                    ", variable lengths" if args.variable_len else ", all lengths 800"),
                    "mode": mode, "global_batch": world * B, "frames_per_utt": T, "parallelism": "dp%d" % world},
         "model_tflops": value * flop_per_frame / 1e12,

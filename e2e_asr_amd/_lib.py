@@ -30,7 +30,7 @@ class DecWs(C.Structure):
     _fields_ = [(n, vp) for n in (
         "hf", "tok", "lm_gates", "lm_c", "lm_h", "lm_hd", "sp", "x", "dec_gates", "dec_c",
         "dec_h", "alpha", "ctx", "p", "zeros", "y", "w2k", "chain_ws", "err",
-        "lm_act", "lm_hprev", "lm_state", "lm_len", "lm_hx")]
+        "lm_act", "lm_hprev", "lm_state", "lm_len", "lm_hx", "greedy_ws")]
 
 
 class DecBwdWs(C.Structure):
@@ -90,6 +90,9 @@ SIGNATURES = {
     "asr_side_join": (C.c_int, [vp]),
     "asr_decoder_chain_supported": (C.c_int, [C.c_int] * 5),
     "asr_decoder_chain_rows": (C.c_int, [C.c_int]),
+    "asr_decoder_greedy_supported": (C.c_int, [C.c_int] * 8),
+    "asr_decoder_greedy_ws_bytes": (C.c_size_t, [C.c_int] * 6),
+    "asr_decoder_greedy_fwd": (C.c_int, [vp] * 22 + [C.c_int] * 9),
     "asr_pyramid_reduce_fwd": (C.c_int, [vp, vp, vp, vp, vp] + [C.c_int] * 4),
     "asr_pyramid_reduce_bwd": (C.c_int, [vp, vp, vp] + [C.c_int] * 4),
     "asr_sigmoid_f32": (C.c_int, [vp, vp, vp, C.c_size_t]),

@@ -21,6 +21,13 @@
 
 extern "C" int asr_zero_finished_rows(void* stream, float* logits, const int* len, int T, int B, int V);
 extern "C" int asr_decoder_chain_supported(int B, int Te, int D, int A, int H);
+extern "C" int asr_decoder_greedy_supported(int B, int Te, int D, int A, int H, int lmH, int E, int V);
+extern "C" int asr_decoder_greedy_fwd(void* stream, const float* embedding, const float* lm_kernel, const float* lm_bias,
+                                      const float* wk, const float* bprime, const float* dec_kh, const float* w_att,
+                                      const float* b_att, const float* v, const float* ap_w, const float* ap_b,
+                                      const float* out_w, const float* out_b, const float* hf, const float* enc,
+                                      const int* enc_len, const int* seq_len, int* tok, float* logits, void* ws, int* err,
+                                      int B, int Te, int D, int A, int H, int lmH, int E, int V, int T);
 int asr_decoder_chain_fwd(void* stream, float* gates, const float* wh, const float* wc, const float* w_att,
                           const float* b_att, const float* v, const float* hf, const float* enc, const int* enc_len,
                           float* dec_c, float* dec_h, float* alpha, float* ctx, float* y, void* ws, int* err,
@@ -70,6 +77,19 @@ extern "C" int asr_attn_decoder_fwd(void* stream, const asr_dec_weights* w, cons
         return mode == 2 && samp_prob > 0.f && !(coin_host[i] < 1.0f - samp_prob);
     };
     hipEvent_t e_tok = nullptr;
+    // ---- inference graph (greedy feedback at every step): the whole loop in one launch of csrc/decoder_greedy.hip
+    if (mode == 1 && ws->greedy_ws && ws->w2k && ws->err && !w->simple_w && keep_lm >= 1.0f &&
+        asr_decoder_greedy_supported(B, Te, D, A, H, lmH, E, V)) {
+        float* wk = ws->w2k;                       // [(lmH+D), 4H] followed by b' [4H] (InputProjection folded, as below)
+        float* bprime = wk + (size_t)(lmH + D) * 4 * H;
+        if ((rc = asr_gemm_f32(stream, 0, 0, lmH + D, 4 * H, E, w->inp_w, E, w->dec_kernel, 4 * H, wk, 4 * H, nullptr, 0))) return rc;
+        if ((rc = asr_gemm_f32(stream, 0, 0, 1, 4 * H, E, w->inp_b, E, w->dec_kernel, 4 * H, bprime, 4 * H, w->dec_bias, 0))) return rc;
+        if ((rc = asr_decoder_greedy_fwd(stream, w->embedding, w->lm_kernel, w->lm_bias, wk, bprime, w->dec_kernel + (size_t)E * 4 * H,
+                                         w->attn_w, w->attn_b, w->attn_v, w->ap_w, w->ap_b, w->out_w, w->out_b, ws->hf, enc, enc_len,
+                                         seq_len, ws->tok, logits, ws->greedy_ws, ws->err, B, Te, D, A, H, lmH, E, V, T))) return rc;
+        asr::prof_end(ASR_PROF_DECODER_FWD, ms);
+        return ASR_OK;
+    }
     // ---- persistent chain path: the per-step attention chain of a whole SEGMENT (steps up to and
     // including the next feedback step) runs in one launch of csrc/decoder_chain.hip
     const bool use_chain = mode != 1 && ws->chain_ws && ws->w2k && ws->err && ws->y && ws->dec_gates &&

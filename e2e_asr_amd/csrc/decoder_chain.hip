@@ -19,6 +19,7 @@
 // wave 0 is the cell/publisher wave (owns every global store, never polls), waves 1-7 poll.
 // The same-XCD plain-store fast path is used when the group's XCC ids agree.
 #include "common.h"
+#include "granule.h"
 #include <algorithm>
 #include <cstdlib>
 
@@ -45,29 +46,6 @@ struct ChainArgs {
     unsigned long long* dbg; // STAMP build only
     int g0, ng;              // this launch covers groups [g0, g0 + ng) of the batch (<= 16 groups = 256 workgroups)
 };
-
-typedef unsigned int u32x4c __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ bool chain_poll2(const u64* g, uint32_t epoch, float& v0, float& v1, int* err) {
-    long long t0 = 0;
-    const u32x4c* p = reinterpret_cast<const u32x4c*>(g);
-    for (uint32_t spins = 0;; ++spins) {
-        u32x4c x;
-        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(x) : "v"(p) : "memory");
-        if (x.y == epoch && x.w == epoch) { v0 = __uint_as_float(x.x); v1 = __uint_as_float(x.z); return true; }
-        ASR_POLL_BACKOFF();
-        if ((spins & 1023) == 1023) {
-            const long long now = wall_clock64();
-            if (t0 == 0) t0 = now;
-            else if (now - t0 > 200000000LL) { *err = 1; v0 = v1 = 0.f; return false; }
-            if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { v0 = v1 = 0.f; return false; }
-        }
-    }
-}
-__device__ __forceinline__ void chain_publish(u64* dst, uint32_t epoch, float v, bool fast) {
-    const u64 gv = ((u64)epoch << 32) | __float_as_uint(v);
-    if (fast) asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(dst), "v"(gv) : "memory");
-    else __hip_atomic_store(dst, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 
 // H: decoder hidden; D: encoder state width; A: attention width.  R = 2 rows, G = 16 workgroups.
 // [K_h ; W2.K_x] -> the forward kernel's register order: out[((mem*KC + i)*512 + tid)] = the 4 gate weights of state row

@@ -1,0 +1,576 @@
+// Persistent attention decoder, inference graph (isTraining=False): ALL steps of the greedy decode loop
+// (attn_decoder.py:76-162 with loop_function = argmax feedback, decoder.py:139-154; eval_model.py:56-118) in ONE launch.
+//
+// In the inference graph every step's input token is the argmax of the previous step's logits, so nothing can be
+// hoisted out of the loop except products with constants: the whole step
+//     tok_i -> LM cell -> [InputProjection folded] outer cell -> q = c_i -> y -> e -> alpha -> ctx_i
+//           -> AttnProjection -> OutputProjection -> argmax -> tok_{i+1}
+// is one dependency chain.  As separate launches that chain is seven kernels and two stream hand-overs per step
+// (74 us per step at config 2, of which 49 us inside skinny kernels that re-read their weights from L2); here a
+// step is eight granule exchanges inside a persistent kernel whose weights never leave the chip.
+//
+// Decomposition: groups of R = 4 utterances never talk to each other; a group is G = 32 workgroups -- ONE XCD, so every
+// exchange stays in that XCD's L2 -- and 8 groups (32 utterances) fill the 256 CUs.  Each workgroup owns 1/32 of every
+// weight matrix, in REGISTERS, cut by output column: 8 LM units (K_h of the LM cell, 256x32), 8 decoder units
+// ([WK_P ; K_h ; WK_c], 1024x32, with InputProjection folded as in decoder_chain.hip), 4 attention columns of W_att,
+// 8 AttnProjection columns (768x8), 32 vocabulary columns of OutputProjection (256x32); plus, in LDS, the hf rows of
+// its <= 8 encoder positions and 16 context columns of the group's enc rows.  The embedding never enters a matvec:
+// EK = embedding . K_x(LM) + b (one [V,4lmH] GEMM per call) turns "embed tok, multiply" into a row lookup, and the
+// h-part of the LM gates for step i+1 is formed while step i's logits are still being reduced.
+//
+// Exchanges are all-gathers of tagged 8-byte granules (granule.h); wave 0 is the cell/publisher wave (never polls),
+// waves 1-6 poll, wave 7 writes the logits out.  Activations are not saved: this is the inference graph.
+#include "common.h"
+#include "granule.h"
+#include <algorithm>
+#include <cstdlib>
+
+namespace asr {
+
+struct GreedyArgs {
+    const float* ek;         // [V][4*LMH]  embedding . K_x(LM) + b_lm
+    const float* lm_kh;      // [LMH][4*LMH] recurrent rows of the LM cell kernel
+    const float* wk;         // [LMH + D][4H] W_inp . K_x (rows: LM output | context)
+    const float* bprime;     // [4H] b_inp . K_x + b_dec
+    const float* dec_kh;     // [H][4H] recurrent rows of the outer cell kernel
+    const float* w_att; const float* b_att; const float* v;       // [H][A], [A], [A]
+    const float* ap_w; const float* ap_b;                         // [H+D][H], [H]
+    const float* out_w; const float* out_b;                       // [H][V], [V]
+    const float* hf;         // [B][Te][A]
+    const float* enc;        // [B][Te][D]
+    const int* enc_len;      // [B]
+    const int* seq_len;      // [B]  rows emit zeros from step seq_len[b] on
+    int* tok;                // [T][B] in: row 0 (GO); out: rows 1.. = argmax of the previous step
+    float* logits;           // [T][B][V]
+    u64* gx;                 // granules [groups][2 parities][NPAR]
+    u64* xcc_slots;          // [groups][32]
+    int* err;
+    int B, Te, T, V, g0, ng;
+};
+
+// (value, index) argmax combine with first-max tie-breaking (np.argmax / tf.argmax); NaN never wins
+__device__ __forceinline__ void amax_take(float& bv, int& bi, float ov, int oi) {
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+}
+
+template <int H, int D, int A, int LMH>
+__global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
+    constexpr int R = 4, G = 32, NT = 512, MAXTS = 8, VS = 32;
+    constexpr int HS = H / G, LS = LMH / G, AS = A / G, DS = D / G, PS = H / G;
+    constexpr int KD = LMH + H + D;              // outer cell input [lm_out | h | ctx]
+    constexpr int KA = H + D;                    // AttnProjection input [q | ctx]
+    constexpr int H4 = 4 * H, L4 = 4 * LMH;
+    constexpr int AL = A / 16;
+    static_assert(HS == 8 && LS == 8 && PS == 8 && AS == 4 && DS == 16, "thread maps below are cut for 8/8/8/4/16 slices");
+    static_assert(LMH == 256 && H == 256 && KD == 1024 && KA == 768 && AL % 4 == 0, "K ranges: parts of 64 / 256 / 192 / 256 values");
+    constexpr int NPOLL = NT - 128;              // waves 1..6
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int* lds_flag = reinterpret_cast<int*>(smem);
+    float* v_dec = smem + 4;                     // [R][KD]   [lm_out_i | h_{i-1} | ctx_{i-1}]
+    float* v_ap = v_dec + R * KD;                // [R][KA]   [q_i | ctx_i]
+    float* v_p = v_ap + R * KA;                  // [R][H]    AttnProjection output
+    float* yl = v_p + R * H;                     // [R][A]
+    float* el = yl + R * A;                      // [R][G*MAXTS] scores / alpha
+    float* sums = el + R * G * MAXTS;            // [4 parts][8 units][R][4 gates]  outer cell
+    float* lmsum = sums + 4 * 8 * R * 4;         // same, LM cell (h-part, formed one step ahead)
+    float* ysum = lmsum + 4 * 8 * R * 4;         // [4][AS][R]
+    float* psum = ysum + 4 * AS * R;             // [4][PS][R]
+    float* cpart = psum + 4 * PS * R;            // [8][R][DS]
+    float* eout = cpart + 8 * R * DS;            // [32]
+    float* lg = eout + 32;                       // [R][VS] logits of my vocabulary slice
+    float* mv = lg + R * VS;                     // [R][G] partial maxima, then [R][G] their indices (int)
+    int* mi = reinterpret_cast<int*>(mv + R * G);
+    float* vl = mv + 2 * R * G;                  // [A]
+    float* hfl = vl + A;                         // [R][MAXTS][A]
+    const int Te = a.Te, V = a.V;
+    const int TS = (Te + G - 1) / G;
+    float* encl = hfl + R * MAXTS * A;           // [R][Te][DS]
+
+    const int grp_l = blockIdx.x & 7, mem = blockIdx.x >> 3;       // round-robin dispatch: a group = the 32 workgroups of one XCD
+    if (grp_l >= a.ng) return;
+    __builtin_amdgcn_s_setprio(3);
+    const int grp = a.g0 + grp_l;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kq = lane & 15, row = tid >> 4;
+    const int u8 = row & 7, part = row >> 3;
+    const int r0 = grp * R;
+    const bool wave0 = __builtin_amdgcn_readfirstlane(tid) < 64;
+    const bool wave7 = __builtin_amdgcn_readfirstlane(tid) >= NT - 64;
+    const bool poller = !wave0 && !wave7;
+    auto rok = [&](int r) { return r0 + r < a.B; };
+    auto browf = [&](int r) { return min(r0 + r, a.B - 1); };
+    int blen[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) blen[r] = rok(r) ? min(max(a.enc_len[browf(r)], 0), Te) : 0;
+    constexpr int NLM = R * LMH, NQH = 2 * R * H, NY = R * A, NE = R * G * MAXTS, NC = R * D, NP = R * H, NM = 2 * R * G;
+    constexpr int NPAR = NLM + NQH + NY + NE + NC + NP + NM;
+    u64* gbase = a.gx + (size_t)grp * 2 * NPAR;
+    const bool fast = group_shares_xcd(a.xcc_slots + (size_t)grp * G, G, mem, tid, a.err, lds_flag);
+
+    // ---- resident weights (registers), lane kq of a DPP row <-> float4 j of a K part at k = base + (16 j + kq) * 4
+    float wlm[4][4];          // LM cell, recurrent part: K = LMH in 4 parts of 64
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int k = part * 64 + kq * 4 + e;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) wlm[e][g] = a.lm_kh[(size_t)k * L4 + g * LMH + mem * LS + u8];
+    }
+    float wdec[16][4];        // outer cell: K = KD in 4 parts of 256
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = part * 256 + (j * 16 + kq) * 4 + e;
+            const float* wr = (k < LMH) ? a.wk + (size_t)k * H4 : (k < LMH + H ? a.dec_kh + (size_t)(k - LMH) * H4 : a.wk + (size_t)(k - H) * H4);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) wdec[j * 4 + e][g] = wr[g * H + mem * HS + u8];
+        }
+    const int ycol = row & 3, ypart = (row >> 2) & 3;
+    const bool yact = row < 16;
+    float wy[4];              // y = q . W_att: K = H in 4 parts of 64 (DPP rows 0..15)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) wy[e] = yact ? a.w_att[(size_t)(ypart * 64 + kq * 4 + e) * A + mem * AS + ycol] : 0.f;
+    float wap[12];            // AttnProjection: K = KA in 4 parts of 192
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wap[j * 4 + e] = a.ap_w[(size_t)(part * 192 + (j * 16 + kq) * 4 + e) * H + mem * PS + u8];
+    const int vcol = mem * VS + row;
+    float wout[16];           // OutputProjection: one vocabulary column per DPP row, K = H
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wout[j * 4 + e] = vcol < V ? a.out_w[(size_t)((j * 16 + kq) * 4 + e) * V + vcol] : 0.f;
+    const float outb = vcol < V ? a.out_b[vcol] : 0.f;
+
+    // ---- resident activations (LDS)
+    const int tau0 = mem * TS;
+    for (int idx = tid; idx < R * MAXTS * A; idx += NT) {
+        const int r = idx / (MAXTS * A), rem = idx % (MAXTS * A), tl = rem / A, aa = rem % A, tau = tau0 + tl;
+        hfl[idx] = (tl < TS && tau < Te) ? a.hf[((size_t)browf(r) * Te + tau) * A + aa] : 0.f;
+    }
+    for (int idx = tid; idx < R * Te * DS; idx += NT) {
+        const int r = idx / (Te * DS), rem = idx % (Te * DS), tau = rem / DS, dd = rem % DS;
+        encl[idx] = a.enc[((size_t)browf(r) * Te + tau) * D + mem * DS + dd];
+    }
+    for (int idx = tid; idx < A; idx += NT) vl[idx] = a.v[idx];
+    for (int idx = tid; idx < R * KD; idx += NT) v_dec[idx] = 0.f;
+    for (int idx = tid; idx < R * KA; idx += NT) v_ap[idx] = 0.f;
+    for (int idx = tid; idx < 4 * 8 * R * 4; idx += NT) lmsum[idx] = 0.f;
+    // cell threads (wave 0): r = tid / 8, unit = tid % 8, for both cells
+    const bool cell = tid < R * 8;
+    const int cr = cell ? tid >> 3 : 0, cu = tid & 7;
+    const bool cb_ok = cell && rok(cr);
+    const int cb = browf(cr);
+    float c_lm = 0.f, c_dec = 0.f;
+    int tokr = cb_ok ? a.tok[cb] : 0;
+    tokr = min(max(tokr, 0), V - 1);
+    float bp[4], ybias = 0.f, pbias = 0.f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bp[g] = cell ? a.bprime[g * H + mem * HS + cu] : 0.f;
+    if (tid < R * AS) ybias = a.b_att[mem * AS + (tid & 3)];
+    if (cell) pbias = a.ap_b[mem * PS + cu];
+    // emit lengths of the rows a lane handles in the argmax (wave 0: r = lane / 16) and logits write-out (wave 7: r = lane / 32, + 2)
+    const int slen0 = a.seq_len[browf((lane >> 4) & 3)];
+    const int slen7a = a.seq_len[browf((lane >> 5) & 1)], slen7b = a.seq_len[browf(2 + ((lane >> 5) & 1))];
+    __syncthreads();
+
+    for (int i = 0; i < a.T; ++i) {
+        const uint32_t ep = (uint32_t)(i + 1);
+        u64* gLM = gbase + (size_t)(i & 1) * NPAR;
+        u64* gQH = gLM + NLM; u64* gY = gQH + NQH; u64* gE = gY + NY; u64* gC = gE + NE; u64* gP = gC + NC; u64* gM = gP + NP;
+        // ---- (1) LM cell of my units: gates = EK[tok_i] + h_lm_{i-1} . K_h (the matvec ran at the end of step i-1)
+        if (wave0 && cell) {
+            if (cb_ok) {
+                const float* ek = a.ek + (size_t)tokr * L4 + mem * LS + cu;
+                float4 s = make_float4(ek[0], ek[LMH], ek[2 * LMH], ek[3 * LMH]);
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const float4 x = *reinterpret_cast<const float4*>(lmsum + ((p * 8 + cu) * R + cr) * 4);
+                    s.x += x.x; s.y += x.y; s.z += x.z; s.w += x.w;
+                }
+                const float gi = fast_sigmoid(s.x), gj = fast_tanh(s.y), gf = fast_sigmoid(s.z + 1.0f), go = fast_sigmoid(s.w);
+                c_lm = c_lm * gf + gi * gj;
+                chain_publish(gLM + (size_t)cr * LMH + mem * LS + cu, ep, go * fast_tanh(c_lm), fast);
+            }
+        }
+        // ---- (2) gather lm_out_i, outer cell
+        if (poller) {
+            for (int p = tid - 64; p < NLM / 2; p += NPOLL) {
+                const int idx = 2 * p, r = idx / LMH, k = idx % LMH;
+                float v0 = 0.f, v1 = 0.f;
+                if (rok(r)) chain_poll2(gLM + idx, ep, v0, v1, a.err);
+                *reinterpret_cast<float2*>(v_dec + r * KD + k) = make_float2(v0, v1);
+            }
+        }
+        __syncthreads();
+        {
+            float acc[R][4];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                acc[r][0] = acc[r][1] = acc[r][2] = acc[r][3] = 0.f;
+                const float* sv = v_dec + r * KD + part * 256 + kq * 4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float4 x = *reinterpret_cast<const float4*>(sv + j * 64);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        acc[r][g] = fmaf(x.x, wdec[j * 4 + 0][g], acc[r][g]);
+                        acc[r][g] = fmaf(x.y, wdec[j * 4 + 1][g], acc[r][g]);
+                        acc[r][g] = fmaf(x.z, wdec[j * 4 + 2][g], acc[r][g]);
+                        acc[r][g] = fmaf(x.w, wdec[j * 4 + 3][g], acc[r][g]);
+                    }
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[r][g] = row16_allreduce_sum(acc[r][g]);
+            }
+            if (kq == 0) {
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    *reinterpret_cast<float4*>(sums + ((part * 8 + u8) * R + r) * 4) = make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
+            }
+        }
+        __syncthreads();
+        if (wave0 && cell) {
+            float4 s = make_float4(bp[0], bp[1], bp[2], bp[3]);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const float4 x = *reinterpret_cast<const float4*>(sums + ((p * 8 + cu) * R + cr) * 4);
+                s.x += x.x; s.y += x.y; s.z += x.z; s.w += x.w;
+            }
+            const float gi = fast_sigmoid(s.x), gj = fast_tanh(s.y), gf = fast_sigmoid(s.z + 1.0f), go = fast_sigmoid(s.w);
+            c_dec = c_dec * gf + gi * gj;
+            // q = cell state c (decoder.py:79-80) and h, adjacent granules
+            if (cb_ok) chain_publish2(gQH + 2 * ((size_t)cr * H + mem * HS + cu), ep, c_dec, go * fast_tanh(c_dec), fast);
+        }
+        // ---- (3) gather (q_i, h_i); y slice = q . W_att[:, slice] + b
+        if (poller) {
+            for (int p = tid - 64; p < NQH / 2; p += NPOLL) {
+                const int r = p / H, k = p % H;
+                float v0 = 0.f, v1 = 0.f;
+                if (rok(r)) chain_poll2(gQH + 2 * p, ep, v0, v1, a.err);
+                v_ap[r * KA + k] = v0;
+                v_dec[r * KD + LMH + k] = v1;
+            }
+        }
+        __syncthreads();
+        {
+            float acc[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const float4 x = *reinterpret_cast<const float4*>(v_ap + r * KA + ypart * 64 + kq * 4);
+                acc[r] = fmaf(x.x, wy[0], fmaf(x.y, wy[1], fmaf(x.z, wy[2], x.w * wy[3])));
+                acc[r] = row16_allreduce_sum(acc[r]);
+            }
+            if (kq == 0 && yact) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) ysum[(ypart * AS + ycol) * R + r] = acc[r];
+            }
+        }
+        __syncthreads();
+        if (wave0 && tid < R * AS) {
+            const int r = tid >> 2, col = tid & 3;
+            const float yv = ybias + (ysum[(0 * AS + col) * R + r] + ysum[(1 * AS + col) * R + r]) +
+                             (ysum[(2 * AS + col) * R + r] + ysum[(3 * AS + col) * R + r]);
+            if (rok(r)) chain_publish(gY + (size_t)r * A + mem * AS + col, ep, yv, fast);
+        }
+        // ---- (4) gather y, scores on my position slice
+        if (poller) {
+            for (int p = tid - 64; p < NY / 2; p += NPOLL) {
+                const int idx = 2 * p, r = idx / A;
+                float v0 = 0.f, v1 = 0.f;
+                if (rok(r)) chain_poll2(gY + idx, ep, v0, v1, a.err);
+                *reinterpret_cast<float2*>(yl + idx) = make_float2(v0, v1);
+            }
+        }
+        __syncthreads();
+        {
+            const int tl = row % MAXTS, r = row / MAXTS;     // DPP row -> (utterance, position); lane kq -> A/16 columns
+            float sc = 0.f;
+            if (tl < TS) {
+                const float* hrow = hfl + (r * MAXTS + tl) * A;
+                const float* yrow = yl + r * A;
+#pragma unroll
+                for (int c = 0; c < AL / 4; ++c) {
+                    const int a0 = c * 64 + kq * 4;
+                    const float4 h4 = *reinterpret_cast<const float4*>(hrow + a0);
+                    const float4 y4 = *reinterpret_cast<const float4*>(yrow + a0);
+                    const float4 v4 = *reinterpret_cast<const float4*>(vl + a0);
+                    sc = fmaf(v4.x, fast_tanh(h4.x + y4.x), sc); sc = fmaf(v4.y, fast_tanh(h4.y + y4.y), sc);
+                    sc = fmaf(v4.z, fast_tanh(h4.z + y4.z), sc); sc = fmaf(v4.w, fast_tanh(h4.w + y4.w), sc);
+                }
+            }
+            sc = row16_allreduce_sum(sc);
+            if (kq == 0) eout[row] = sc;
+        }
+        __syncthreads();
+        if (wave0 && tid < R * MAXTS) {
+            const int tl = tid % MAXTS, r = tid / MAXTS;
+            if (tl < TS && rok(r)) chain_publish(gE + (size_t)r * G * MAXTS + mem * MAXTS + tl, ep, eout[tid], fast);
+        }
+        // ---- (5) gather all scores, softmax over tau < len (replicated), context slice
+        if (poller) {
+            const int pairs = (TS + 1) / 2;
+            for (int p = tid - 64; p < R * G * pairs; p += NPOLL) {
+                const int r = p / (G * pairs), rem = p % (G * pairs), m = rem / pairs, tp = rem % pairs;
+                const int off = r * G * MAXTS + m * MAXTS + 2 * tp;
+                float v0 = 0.f, v1 = 0.f;
+                if (rok(r)) {
+                    if (2 * tp + 1 < TS) chain_poll2(gE + off, ep, v0, v1, a.err);
+                    else {   // odd tail: a single granule
+                        long long t0w = 0;
+                        for (uint32_t spins = 0;; ++spins) {
+                            const u64 x = __hip_atomic_load(gE + off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if ((uint32_t)(x >> 32) == ep) { v0 = __uint_as_float((uint32_t)x); break; }
+                            if ((spins & 1023) == 1023) {
+                                const long long now = wall_clock64();
+                                if (t0w == 0) t0w = now; else if (now - t0w > 200000000LL) { *a.err = 1; break; }
+                                if (__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                            }
+                        }
+                    }
+                }
+                *reinterpret_cast<float2*>(el + off) = make_float2(v0, v1);
+            }
+        }
+        __syncthreads();
+        if (wave < R) {      // wave r: softmax of utterance r; slot (m, tl) <-> tau = m*TS + tl
+            const int r = wave, L = blen[r];
+            float* er = el + r * G * MAXTS;
+            float ev[G * MAXTS / 64];
+            float m = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < G * MAXTS / 64; ++j) {
+                const int sl = lane + 64 * j, tl = sl % MAXTS, tau = (sl / MAXTS) * TS + tl;
+                const bool ok = tl < TS && tau < L;
+                ev[j] = ok ? er[sl] : -INFINITY;
+                m = fmaxf(m, ev[j]);
+            }
+            m = wave_allreduce_max(m);
+            float sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < G * MAXTS / 64; ++j) { ev[j] = ev[j] > -INFINITY ? __expf(ev[j] - m) : 0.f; sum += ev[j]; }
+            sum = wave_allreduce_sum(sum);
+            const float inv = L > 0 ? 1.0f / sum : 0.f;
+#pragma unroll
+            for (int j = 0; j < G * MAXTS / 64; ++j) er[lane + 64 * j] = ev[j] * inv;
+        }
+        __syncthreads();
+        {
+            const int dd = tid & 15, r = (tid >> 4) & 3, tp = tid >> 6;
+            const int L = blen[r];
+            float cs = 0.f;
+            for (int m = tp; m < G; m += 8) {
+                const float* ap = el + r * G * MAXTS + m * MAXTS;
+                const float* xp = encl + ((size_t)r * Te + m * TS) * DS + dd;
+                const int nt = min(TS, L - m * TS);
+                for (int tl = 0; tl < nt; ++tl) cs = fmaf(ap[tl], xp[tl * DS], cs);
+            }
+            cpart[(tp * R + r) * DS + dd] = cs;
+        }
+        __syncthreads();
+        if (wave0) {
+            const int r = lane >> 4, dd = lane & 15;
+            float cs = 0.f;
+#pragma unroll
+            for (int tp = 0; tp < 8; ++tp) cs += cpart[(tp * R + r) * DS + dd];
+            if (rok(r)) chain_publish(gC + (size_t)r * D + mem * DS + dd, ep, cs, fast);
+        }
+        // ---- (6) gather ctx_i; AttnProjection slice
+        if (poller) {
+            for (int p = tid - 64; p < NC / 2; p += NPOLL) {
+                const int idx = 2 * p, r = idx / D, k = idx % D;
+                float v0 = 0.f, v1 = 0.f;
+                if (rok(r)) chain_poll2(gC + idx, ep, v0, v1, a.err);
+                *reinterpret_cast<float2*>(v_ap + r * KA + H + k) = make_float2(v0, v1);
+                *reinterpret_cast<float2*>(v_dec + r * KD + LMH + H + k) = make_float2(v0, v1);
+            }
+        }
+        __syncthreads();
+        {
+            float acc[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                acc[r] = 0.f;
+                const float* sv = v_ap + r * KA + part * 192 + kq * 4;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const float4 x = *reinterpret_cast<const float4*>(sv + j * 64);
+                    acc[r] = fmaf(x.x, wap[j * 4 + 0], acc[r]); acc[r] = fmaf(x.y, wap[j * 4 + 1], acc[r]);
+                    acc[r] = fmaf(x.z, wap[j * 4 + 2], acc[r]); acc[r] = fmaf(x.w, wap[j * 4 + 3], acc[r]);
+                }
+                acc[r] = row16_allreduce_sum(acc[r]);
+            }
+            if (kq == 0) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) psum[(part * PS + u8) * R + r] = acc[r];
+            }
+        }
+        __syncthreads();
+        if (wave0 && cell) {
+            const float pv = pbias + (psum[(0 * PS + cu) * R + cr] + psum[(1 * PS + cu) * R + cr]) +
+                             (psum[(2 * PS + cu) * R + cr] + psum[(3 * PS + cu) * R + cr]);
+            if (cb_ok) chain_publish(gP + (size_t)cr * H + mem * PS + cu, ep, pv, fast);
+        }
+        // ---- (7) gather p; logits of my vocabulary slice (+ the h-part of the NEXT step's LM gates)
+        if (poller) {
+            for (int p = tid - 64; p < NP / 2; p += NPOLL) {
+                const int idx = 2 * p, r = idx / H;
+                float v0 = 0.f, v1 = 0.f;
+                if (rok(r)) chain_poll2(gP + idx, ep, v0, v1, a.err);
+                *reinterpret_cast<float2*>(v_p + idx) = make_float2(v0, v1);
+            }
+        }
+        __syncthreads();
+        {
+            float acc[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                acc[r] = 0.f;
+                const float* sv = v_p + r * H + kq * 4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float4 x = *reinterpret_cast<const float4*>(sv + j * 64);
+                    acc[r] = fmaf(x.x, wout[j * 4 + 0], acc[r]); acc[r] = fmaf(x.y, wout[j * 4 + 1], acc[r]);
+                    acc[r] = fmaf(x.z, wout[j * 4 + 2], acc[r]); acc[r] = fmaf(x.w, wout[j * 4 + 3], acc[r]);
+                }
+                acc[r] = row16_allreduce_sum(acc[r]);
+            }
+            if (kq == 0) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) lg[r * VS + row] = acc[r] + outb;
+            }
+            // LM cell of step i+1, recurrent part: h_lm_i . K_h for my units (v_dec[:, :LMH] holds lm_out_i)
+            float al[R][4];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const float4 x = *reinterpret_cast<const float4*>(v_dec + r * KD + part * 64 + kq * 4);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    al[r][g] = fmaf(x.x, wlm[0][g], fmaf(x.y, wlm[1][g], fmaf(x.z, wlm[2][g], x.w * wlm[3][g])));
+                    al[r][g] = row16_allreduce_sum(al[r][g]);
+                }
+            }
+            if (kq == 0) {
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    *reinterpret_cast<float4*>(lmsum + ((part * 8 + u8) * R + r) * 4) = make_float4(al[r][0], al[r][1], al[r][2], al[r][3]);
+            }
+        }
+        __syncthreads();
+        if (wave7) {         // logits -> global (raw_rnn emits zeros for finished rows, attn_decoder.py:170)
+            for (int idx = lane; idx < R * VS; idx += 64) {
+                const int r = idx / VS, c = idx % VS, vc = mem * VS + c;
+                if (rok(r) && vc < V)
+                    a.logits[((size_t)i * a.B + r0 + r) * V + vc] = (i < (idx < 64 ? slen7a : slen7b)) ? lg[idx] : 0.f;
+            }
+        }
+        int tok_next = 0;
+        if (wave0) {         // argmax over my slice: lane -> (utterance r, columns c and c + 16), then 16-lane butterflies
+            const int r = lane >> 4, c = lane & 15;
+            const bool live = rok(r) && i < slen0;
+            float bv = -INFINITY; int bi = 0x7fffffff;
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int cc = c + 16 * h2, vc = mem * VS + cc;
+                if (vc < V) amax_take(bv, bi, live ? lg[r * VS + cc] : 0.f, vc);
+            }
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+                const float ov = __shfl_xor(bv, o); const int oi = __shfl_xor(bi, o);
+                amax_take(bv, bi, ov, oi);
+            }
+            if (c == 0 && rok(r)) chain_publish2(gM + 2 * ((size_t)r * G + mem), ep, bv, __int_as_float(bi), fast);
+        }
+        // ---- (8) gather the 32 partial maxima of every utterance -> tok_{i+1} (every workgroup, redundantly)
+        if (poller) {
+            for (int p = tid - 64; p < R * G; p += NPOLL) {
+                const int r = p / G;
+                float v0 = -INFINITY, v1 = __int_as_float(0x7fffffff);
+                if (rok(r)) chain_poll2(gM + 2 * p, ep, v0, v1, a.err);
+                mv[p] = v0; mi[p] = __float_as_int(v1);
+            }
+        }
+        __syncthreads();
+        if (wave0) {
+            const int r = lane >> 4, m2 = lane & 15;
+            float bv = mv[r * G + m2]; int bi = mi[r * G + m2];
+            amax_take(bv, bi, mv[r * G + m2 + 16], mi[r * G + m2 + 16]);
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+                const float ov = __shfl_xor(bv, o); const int oi = __shfl_xor(bi, o);
+                amax_take(bv, bi, ov, oi);
+            }
+            tok_next = bi == 0x7fffffff ? 0 : bi;
+            if (mem == 0 && m2 == 0 && rok(r) && i + 1 < a.T) a.tok[(size_t)(i + 1) * a.B + r0 + r] = tok_next;
+            tokr = __shfl(tok_next, cr * 16);
+            tokr = min(max(tokr, 0), V - 1);
+        }
+        // (LDS written by this step's last phases is rewritten only after later barriers of the next step)
+    }
+}
+
+}  // namespace asr
+
+extern "C" int asr_decoder_greedy_supported(int B, int Te, int D, int A, int H, int lmH, int E, int V) {
+    if (getenv("ASR_DEC_GREEDY") && atoi(getenv("ASR_DEC_GREEDY")) == 0) return 0;
+    (void)E;
+    return B > 0 && Te > 0 && Te <= 256 && V > 0 && V <= 1024 && H == 256 && D == 512 && A == 128 && lmH == 256;
+}
+
+static size_t greedy_npar(int D, int A, int H, int lmH) {
+    return 4 * ((size_t)lmH + 2 * (size_t)H + A + 32 * 8 + D + H + 2 * 32);
+}
+static size_t greedy_gran_bytes(int B, int D, int A, int H, int lmH) {
+    const size_t groups = ((size_t)B + 3) / 4;
+    return (groups * 2 * greedy_npar(D, A, H, lmH) * sizeof(u64) + groups * 32 * sizeof(u64) + 255) / 256 * 256;
+}
+// granules + XCC slots | EK [V][4 lmH]
+extern "C" size_t asr_decoder_greedy_ws_bytes(int B, int D, int A, int H, int lmH, int V) {
+    return greedy_gran_bytes(B, D, A, H, lmH) + (size_t)V * 4 * lmH * sizeof(float);
+}
+
+extern "C" int asr_gemm_f32(void* stream, int transA, int transB, int M, int N, int K, const float* A, int lda,
+                            const float* B, int ldb, float* C, int ldc, const float* bias, int accumulate);
+
+// All T steps of the greedy decode.  wk / bprime: the folded InputProjection (decoder.hip); tok row 0 holds the first
+// input token of every utterance, rows 1.. are written.  ws: asr_decoder_greedy_ws_bytes().
+extern "C" int asr_decoder_greedy_fwd(void* stream, const float* embedding, const float* lm_kernel, const float* lm_bias,
+                                      const float* wk, const float* bprime, const float* dec_kh, const float* w_att,
+                                      const float* b_att, const float* v, const float* ap_w, const float* ap_b,
+                                      const float* out_w, const float* out_b, const float* hf, const float* enc,
+                                      const int* enc_len, const int* seq_len, int* tok, float* logits, void* ws, int* err,
+                                      int B, int Te, int D, int A, int H, int lmH, int E, int V, int T) {
+    using namespace asr;
+    if (!asr_decoder_greedy_supported(B, Te, D, A, H, lmH, E, V) || T <= 0) return ASR_EUNSUPPORTED;
+    if (!embedding || !lm_kernel || !lm_bias || !wk || !bprime || !dec_kh || !w_att || !b_att || !v || !ap_w || !ap_b ||
+        !out_w || !out_b || !hf || !enc || !enc_len || !seq_len || !tok || !logits || !ws || !err) return ASR_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t gbytes = greedy_gran_bytes(B, D, A, H, lmH);
+    float* ek = reinterpret_cast<float*>(static_cast<char*>(ws) + gbytes);
+    if (hipMemsetAsync(ws, 0, gbytes, s) != hipSuccess) return ASR_ELAUNCH;
+    int rc;
+    if ((rc = asr_gemm_f32(stream, 0, 0, V, 4 * lmH, E, embedding, E, lm_kernel, 4 * lmH, ek, 4 * lmH, lm_bias, 0))) return rc;
+    GreedyArgs a;
+    a.ek = ek; a.lm_kh = lm_kernel + (size_t)E * 4 * lmH; a.wk = wk; a.bprime = bprime; a.dec_kh = dec_kh;
+    a.w_att = w_att; a.b_att = b_att; a.v = v; a.ap_w = ap_w; a.ap_b = ap_b; a.out_w = out_w; a.out_b = out_b;
+    a.hf = hf; a.enc = enc; a.enc_len = enc_len; a.seq_len = seq_len; a.tok = tok; a.logits = logits;
+    a.gx = static_cast<u64*>(ws);
+    const int groups = (B + 3) / 4;
+    a.xcc_slots = a.gx + (size_t)groups * 2 * greedy_npar(D, A, H, lmH);
+    a.err = err; a.B = B; a.Te = Te; a.T = T; a.V = V;
+    constexpr int R = 4, KD = 1024, KA = 768, Hc = 256, Ac = 128, G = 32, MAXTS = 8;
+    const size_t lds = sizeof(float) * (4 + (size_t)R * KD + R * KA + R * Hc + R * Ac + R * G * MAXTS + 2 * (4 * 8 * R * 4) +
+                                        4 * 4 * R + 4 * 8 * R + 8 * R * 16 + 32 + R * 32 + 2 * R * G + Ac + R * MAXTS * Ac +
+                                        (size_t)R * Te * 16);
+    if (lds > 160 * 1024 - 64) return ASR_EUNSUPPORTED;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asr::decoder_greedy_kernel<256, 512, 128, 256>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    for (int g0 = 0; g0 < groups; g0 += 8) {            // 8 groups (one per XCD) = 256 workgroups per launch
+        a.g0 = g0; a.ng = std::min(8, groups - g0);
+        hipLaunchKernelGGL((asr::decoder_greedy_kernel<256, 512, 128, 256>), dim3(8 * G), dim3(512), lds, s, a);
+        if (hipGetLastError() != hipSuccess) return ASR_ELAUNCH;
+    }
+    return ASR_OK;
+}

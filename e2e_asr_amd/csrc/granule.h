@@ -1,0 +1,43 @@
+// Tagged 8-byte granules {tag, value}: the exchange primitive of the persistent decoder kernels
+// (decoder_chain.hip, decoder_greedy.hip).  A value is published with ONE store and polled, two granules at a time,
+// with 16-byte sc1 loads; polls are bounded (~2 s of wall clock) and raise the device error flag on a timeout.
+#pragma once
+#include "common.h"
+
+namespace asr {
+
+typedef unsigned int u32x4c __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bool chain_poll2(const u64* g, uint32_t epoch, float& v0, float& v1, int* err) {
+    long long t0 = 0;
+    const u32x4c* p = reinterpret_cast<const u32x4c*>(g);
+    for (uint32_t spins = 0;; ++spins) {
+        u32x4c x;
+        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(x) : "v"(p) : "memory");
+        if (x.y == epoch && x.w == epoch) { v0 = __uint_as_float(x.x); v1 = __uint_as_float(x.z); return true; }
+        ASR_POLL_BACKOFF();
+        if ((spins & 1023) == 1023) {
+            const long long now = wall_clock64();
+            if (t0 == 0) t0 = now;
+            else if (now - t0 > 200000000LL) { *err = 1; v0 = v1 = 0.f; return false; }
+            if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { v0 = v1 = 0.f; return false; }
+        }
+    }
+}
+__device__ __forceinline__ void chain_publish(u64* dst, uint32_t epoch, float v, bool fast) {
+    const u64 gv = ((u64)epoch << 32) | __float_as_uint(v);
+    if (fast) asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(dst), "v"(gv) : "memory");
+    else __hip_atomic_store(dst, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// two adjacent granules (16-byte aligned) with one store on the fast path
+__device__ __forceinline__ void chain_publish2(u64* dst, uint32_t epoch, float v0, float v1, bool fast) {
+    if (fast) {
+        const u32x4c q = {__float_as_uint(v0), epoch, __float_as_uint(v1), epoch};
+        asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(dst), "v"(q) : "memory");
+    } else {
+        __hip_atomic_store(dst, ((u64)epoch << 32) | __float_as_uint(v0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(dst + 1, ((u64)epoch << 32) | __float_as_uint(v1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+}  // namespace asr

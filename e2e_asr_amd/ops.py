@@ -361,6 +361,10 @@ def attn_decoder_fwd(wt, dec_inp, seq_len, enc, enc_len, mode=0, coin=None, samp
             ws["lm_state"] = f(2, 2, B, lmH)
             ws["lm_len"] = torch.full((B,), T, device=dev, dtype=torch.int32)
             ws["lm_hx"] = _hx(dev, L.asr_lstm_ws_bytes(B, lmH, 1))
+    if mode == 1 and wt.get("simple_w") is None and keep_lm >= 1.0 and L.asr_decoder_greedy_supported(B, Te, D, A, H, lmH, E, V):
+        ws["w2k"] = f(lmH + D + 1, 4 * H)         # inference graph: the whole greedy loop in one persistent launch
+        ws["greedy_ws"] = _hx(dev, L.asr_decoder_greedy_ws_bytes(B, D, A, H, lmH, V))
+        ws["err"] = _Flag.get(dev)
     logits = f(T * B, V)
     cw = _dec_struct(_lib.DecWeights, wt)
     cd = _lib.DecDims(B, Te, D, A, H, lmH, E, V, T)

@@ -186,6 +186,7 @@ typedef struct {              /* activations: outputs of the forward, inputs of 
     float* lm_state;          /* [2,2,B,lmH]     (h,c) hand-over between scheduled-sampling segments */
     int*   lm_len;            /* [B] ints, each >= T_out */
     void*  lm_hx;             /* asr_lstm_ws_bytes(B, lmH, 1) bytes */
+    void*  greedy_ws;         /* asr_decoder_greedy_ws_bytes() bytes: mode 1 runs as ONE persistent launch (needs w2k, err); NULL = per-step launches */
 } asr_dec_ws;
 
 /* mode 0: teacher forcing; 1: greedy (eval, decoder.py:139-154); 2: scheduled sampling
@@ -256,6 +257,17 @@ int asr_side_join(void* stream);
  * asr_decoder_chain_rows: utterances per 16-workgroup group for this Te (2 up to 256 encoder positions, else 1). */
 int asr_decoder_chain_supported(int B, int Te, int D, int A, int H);
 int asr_decoder_chain_rows(int Te);
+/* Inference graph (mode 1) as one persistent launch (csrc/decoder_greedy.hip): argmax feedback, LM cell, attention,
+ * projections of all steps on chip.  Used inside asr_attn_decoder_fwd when supported and ws->greedy_ws is set; only the
+ * logits and tok are produced (no saved activations). */
+int asr_decoder_greedy_supported(int B, int Te, int D, int A, int H, int lmH, int E, int V);
+size_t asr_decoder_greedy_ws_bytes(int B, int D, int A, int H, int lmH, int V);
+int asr_decoder_greedy_fwd(void* stream, const float* embedding, const float* lm_kernel, const float* lm_bias,
+                           const float* wk, const float* bprime, const float* dec_kh, const float* w_att,
+                           const float* b_att, const float* v, const float* ap_w, const float* ap_b,
+                           const float* out_w, const float* out_b, const float* hf, const float* enc,
+                           const int* enc_len, const int* seq_len, int* tok, float* logits, void* ws, int* err,
+                           int B, int Te, int D, int A, int H, int lmH, int E, int V, int T);
 size_t asr_decoder_chain_ws_bytes(int B, int D, int A, int H);
 size_t asr_decoder_chain_bwd_ws_bytes(int B, int D, int A, int H);
 /* LM cell chain of the decoder through the persistent recurrent kernels of csrc/lstm.hip / lstm_bwd.hip

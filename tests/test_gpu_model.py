@@ -393,6 +393,41 @@ def test_train_loop_checkpoint_resume_and_eval(tmp_path):
     assert ids.ndim == 1 and len(ids) >= 1
 
 
+# ------------------------------------------------------------------ inference graph: persistent greedy decoder
+@pytest.mark.parametrize("nb,T,nl", [(7, 64, 4), (37, 96, 4), (6, 512, 2)])
+def test_greedy_decoder_one_launch_equals_per_step_path_and_oracle(monkeypatch, nb, T, nl):
+    """csrc/decoder_greedy.hip: the inference graph (argmax feedback at every step, max_output steps) of the config-2
+    decoder in ONE persistent launch.  Same token ids and logits as the per-step launch path; logits and ids vs the float64
+    oracle (eval_model.py:56-118 semantics).  7 utterances = a half-empty group; 37 = two launches (8 + 2 groups);
+    T=512 at depth 2 = 256 encoder positions (the kernel's limit: 8 positions per workgroup)."""
+    from e2e_asr_amd import _lib, ops
+    L = _lib.lib()
+    Te = T >> (nl - 1)
+    assert L.asr_decoder_greedy_supported(nb, Te, 512, 128, 256, 256, 256, 1000) == 1
+    assert L.asr_decoder_greedy_supported(nb, 257, 512, 128, 256, 256, 256, 1000) == 0
+    rng = np.random.default_rng(41)
+    b = _batch(rng, nb, T, 80, 21, 1000)
+    outs = []
+    for greedy in ("1", "0"):
+        monkeypatch.setenv("ASR_DEC_GREEDY", greedy)
+        m = _model(feat=80, vocab={"char": 1000}, num_layers={"char": nl}, training=False, params_update=dict(max_output={"char": 14}))
+        m.forward(b)
+        ops.check_device_flag(torch.device(DEV))
+        ws = m.decoder["char"].saved["ws"] if getattr(m.decoder["char"], "saved", None) else None
+        if ws is not None:
+            assert (ws.get("greedy_ws") is not None) == (greedy == "1")
+        outs.append((m.outputs["char"].cpu().numpy(), m.greedy_ids().cpu().numpy()))
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+    np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=0, atol=2e-5)
+    assert len(np.unique(outs[0][1])) > 3                      # a real decode, not a constant
+    if nb <= 8:
+        w = _f64(m.variables.to_arrays())
+        b64 = dict(b); b64["logmel"] = b["logmel"].astype(np.float64)
+        r = O.seq2seq_forward(b64, w, num_layers={"char": nl}, is_training=False, max_output={"char": 14})
+        np.testing.assert_allclose(outs[0][0], r["outputs"]["char"], rtol=0, atol=1e-3)
+        np.testing.assert_array_equal(outs[0][1], O.greedy_decode_ids(r["outputs"]["char"], nb))
+
+
 # ------------------------------------------------------------------ persistent decoder chain
 def _chain_model(samp=0.0, seed=3):
     return _model(enc_update=dict(hidden_size=64), num_layers={"char": 2}, seed=seed,
