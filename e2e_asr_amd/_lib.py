@@ -47,6 +47,10 @@ class BeamState(C.Structure):
     _fields_ = [(n, vp) for n in ("dc", "dh", "dlc", "dlh", "lc", "lh", "ctx")]
 
 
+class BeamBook(C.Structure):
+    _fields_ = [(n, vp) for n in ("ints", "cum", "state", "bp", "fin", "fin_score")]
+
+
 class DecGrads(C.Structure):
     _fields_ = [(n, vp) for n in (
         "embedding", "attn_enc_w", "attn_v", "attn_w", "attn_b", "lm_kernel", "lm_bias",
@@ -100,6 +104,7 @@ SIGNATURES = {
     "asr_beam_scratch_floats": (C.c_size_t, [C.c_int] * 5),
     "asr_beam_step": (C.c_int, [vp] * 13),
     "asr_beam_gather": (C.c_int, [vp, vp, C.c_int, vp, vp] + [C.c_int] * 4),
+    "asr_beam_select": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, vp]),
     "asr_set_gemm_precision": (C.c_int, [C.c_int]),
     "asr_get_gemm_precision": (C.c_int, []),
     "asr_decoder_chain_ws_bytes": (C.c_size_t, [C.c_int] * 4),

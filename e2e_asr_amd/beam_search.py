@@ -4,13 +4,19 @@ beam_search.py (31-338).
 The reference runs everything in NumPy float64, one hypothesis at a time.  Here the k live
 hypotheses of a step are the rows of one small batch on the GPU: both LSTM cells, the
 projections, the attention (encoder states shared by all rows) and the external LM run through
-the same HIP step kernels as training.  What stays on the host is what the reference's
-semantics are defined by: log-softmax + `log p_dec + lm_weight * log p_lm` in float64 on the
-device logits, `np.argpartition` top-k per hypothesis and over the k*k continuations
-(:214, :300), parent = idx // k (:306), EOS shrinking the beam (:323-327) and first-max
-selection of the result (:336).  Token indices therefore equal the float64 oracle's unless two
-candidates tie within float32 logit resolution (~1e-6).
+the same HIP step kernels as training.  Scoring follows the reference's definition -- log-softmax +
+`log p_dec + lm_weight * log p_lm` in float64 on the device logits, top-k per hypothesis and over
+the k*k continuations (:214, :300), parent = idx // k (:306), EOS shrinking the beam (:323-327),
+first-max selection of the result (:336) -- and runs in one of two places:
+
+* device-resident (default; `asr_beam_select`): selection and bookkeeping stay on the GPU, the host only enqueues
+  three library calls per step and reads the back-pointers once at the end (plus a 4-byte liveness check every 8 steps);
+* host (`ASR_BEAM_HOST=1`, and whenever beam_size > 16 or V > 1024): `get_top_k` as the reference structures it, one
+  D2H copy of the logits per step and NumPy float64 scoring with `np.argpartition`.
+
+Token indices equal the float64 oracle's unless two candidates tie within float32 logit resolution (~1e-6).
 """
+import os
 import ctypes as C
 
 import numpy as np
@@ -173,12 +179,69 @@ class BeamSearch(BaseParams):
                 out.append((idx, comb[r][idx], score[r][idx]))
             return out
         get_top_k.keep = keep
+        get_top_k.structs = (cw, clm, cst, (Te, D, A, H, lmH, E, V, extH))
         return get_top_k
+
+    def _decode_on_device(self, get_top_k, max_steps=120):
+        """The loop of beam_search.py:255-337 with scoring, selection and bookkeeping on the device."""
+        sp = self.search_params
+        sets, hf, ln, scratch, logits, ints, enc = get_top_k.keep
+        cw, clm, cst, dims = get_top_k.structs
+        Te, D, A, H, lmH, E, V, extH = dims
+        kmax = int(sp.beam_size)
+        dev = self.device
+        L = _lib.lib()
+        cum = torch.zeros(kmax, dtype=torch.float64, device=dev)
+        state = torch.tensor([1, kmax, 0, 0], dtype=torch.int32, device=dev)
+        bp = torch.zeros((max_steps, kmax, 2), dtype=torch.int32, device=dev)
+        fin = torch.zeros((kmax, 2), dtype=torch.int32, device=dev)
+        fin_score = torch.zeros(kmax, dtype=torch.float64, device=dev)
+        book = ops._dec_struct(_lib.BeamBook, dict(ints=ints, cum=cum, state=state, bp=bp, fin=fin, fin_score=fin_score))
+        host = np.zeros(2 * kmax, np.int32)
+        host[0] = data_utils.GO_ID
+        ints.copy_(torch.from_numpy(host))
+        for t in sets[0].values():
+            t.zero_()
+        cd = _lib.DecDims(kmax, Te, D, A, H, lmH, E, V, 1)
+        st = ops._stream()
+        for s in range(max_steps):
+            if s:
+                ops._check(L.asr_beam_gather(st, ops._p(ints[kmax:]), kmax, C.byref(cst[1]), C.byref(cst[0]), H, lmH, extH, D),
+                           "asr_beam_gather")
+            ops._check(L.asr_beam_step(st, C.byref(cw), C.byref(clm), C.byref(cd), ops._p(hf), ops._p(enc), ops._p(ln), ops._p(ints),
+                                       C.byref(cst[0]), C.byref(cst[1]), ops._p(scratch), ops._p(logits[0]), ops._p(logits[1])),
+                       "asr_beam_step")
+            ops._check(L.asr_beam_select(st, ops._p(logits[0]), ops._p(logits[1]), V, kmax, max_steps, data_utils.EOS_ID,
+                                         float(sp.lm_weight), float(sp.word_ins_penalty), C.byref(book)), "asr_beam_select")
+            if s % 8 == 7 and int(state[1].item()) == 0:           # every hypothesis finished (:269)
+                break
+        n_live, _, n_fin, n_steps = [int(x) for x in state.cpu().numpy()]
+        bp_h, fin_h, fin_s, cum_h = bp.cpu().numpy(), fin.cpu().numpy(), fin_score.cpu().numpy(), cum.cpu().numpy()
+
+        def backtrack(step, row):                  # tokens of the hypothesis that entered step `step + 1` as row `row`
+            seq = []
+            while step >= 0:
+                row, tok = bp_h[step, row]
+                seq.append(int(tok)); step -= 1
+            return seq[::-1]
+        # final_output_list = finished (in finishing order) + live rows; first max wins (:334-337)
+        cands = [(float(fin_s[j]), ("fin", j)) for j in range(n_fin)] + [(float(cum_h[j]), ("live", j)) for j in range(n_live)]
+        best = max(range(len(cands)), key=lambda i: (cands[i][0], -i))
+        kind, j = cands[best][1]
+        if kind == "fin":
+            step, parent = int(fin_h[j, 0]), int(fin_h[j, 1])
+            seq = (backtrack(step - 1, parent) if step > 0 else []) + [data_utils.EOS_ID]
+        else:
+            seq = backtrack(n_steps - 1, j)
+        return np.asarray(seq, dtype=np.int64)
 
     def __call__(self, encoder_hidden_states):
         """Beam search for batch size 1 (beam_search.py:224-338)."""
         sp = self.search_params
         get_top_k = self.top_k_setup_with_lm(encoder_hidden_states)
+        V = self.dec_params.out_w.shape[1]
+        if os.environ.get("ASR_BEAM_HOST", "0") != "1" and 1 <= int(sp.beam_size) <= 16 and V <= 1024:
+            return self._decode_on_device(get_top_k)
         D = encoder_hidden_states.shape[-1]
         k = sp.beam_size
         output_list, final_output_list = [], []

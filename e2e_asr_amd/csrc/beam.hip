@@ -77,3 +77,148 @@ extern "C" int asr_beam_gather(void* stream, const int* sel, int k, const asr_be
     ASR_CHECK_LAUNCH();
     return ASR_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Device-resident scoring / selection / bookkeeping of one beam step (beam_search.py:196-214 and :290-327), so that a
+// whole utterance is decoded without a host round trip per step: float64 log-softmax of both logit vectors
+// (`np.log(softmax(x))`, :196-198, :205-207), score = log p_dec + lm_weight * log p_lm + carried score (:208, :290),
+// top-k per hypothesis (:214) then over the k*k continuations (:300), parent = candidate / k (:306), carried score =
+// score + word_ins_penalty * len (:320-322), EOS -> finished list and k -= 1 (:323-327).  Winners are taken in
+// descending score order (ties: lower candidate index), where NumPy's argpartition leaves an implementation-defined order;
+// the order only matters between exactly equal float64 scores.
+namespace asr {
+
+struct BeamSelArgs {
+    const float* logits; const float* logits_lm;     // [kmax][V]
+    double lm_weight, wip;
+    int V, kmax, eos, max_steps;
+    int* ints;            // [2*kmax]  tokens | parent rows of the NEXT step's rows
+    double* cum;          // [kmax]    carried scores, row order
+    int* state;           // [4]       rows fed to this step, beam width left (k), finished count, step index
+    int* bp;              // [max_steps][kmax][2]  (parent row, token) of the rows that leave step s
+    int* fin;             // [cap][2]  (step, parent row) of finished hypotheses, in finishing order
+    double* fin_score;    // [cap]
+};
+
+__device__ __forceinline__ void dmax_take(double& bv, int& bi, double ov, int oi) {
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+}
+__device__ __forceinline__ void wave_argmax(double& bv, int& bi) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const double ov = __shfl_xor(bv, o); const int oi = __shfl_xor(bi, o);
+        dmax_take(bv, bi, ov, oi);
+    }
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// one workgroup of 16 waves: wave r scores hypothesis r (V <= 1024: 16 values per lane)
+__global__ __launch_bounds__(1024) void beam_select_kernel(BeamSelArgs a) {
+    constexpr int VPL = 16, KM = 16;
+    __shared__ double cs[KM][KM];
+    __shared__ int ci[KM][KM];
+    __shared__ double wsc[KM];
+    __shared__ int wr[KM], wv[KM];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_rows = a.state[0], k = a.state[1], s = a.state[3];
+    if (n_rows <= 0 || k <= 0) return;
+    const int V = a.V;
+    if (wave < n_rows) {
+        double sc[VPL];
+        {
+            float x[VPL], xl[VPL];
+            float m = -INFINITY, ml = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) {
+                const int v = lane + 64 * j;
+                x[j] = v < V ? a.logits[(size_t)wave * V + v] : -INFINITY;
+                xl[j] = v < V ? a.logits_lm[(size_t)wave * V + v] : -INFINITY;
+                m = fmaxf(m, x[j]); ml = fmaxf(ml, xl[j]);
+            }
+            m = wave_allreduce_max(m); ml = wave_allreduce_max(ml);
+            double e[VPL], el[VPL], sum = 0.0, suml = 0.0;
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) {
+                const bool ok = lane + 64 * j < V;
+                e[j] = ok ? exp((double)x[j] - (double)m) : 0.0;
+                el[j] = ok ? exp((double)xl[j] - (double)ml) : 0.0;
+                sum += e[j]; suml += el[j];
+            }
+            sum = wave_sum_f64(sum); suml = wave_sum_f64(suml);
+            const double c0 = a.cum[wave];
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) {
+                const bool ok = lane + 64 * j < V;
+                sc[j] = ok ? (log(e[j] / sum) + a.lm_weight * log(el[j] / suml)) + c0 : -INFINITY;
+            }
+        }
+        for (int it = 0; it < k; ++it) {       // top-k of this hypothesis (:214)
+            double bv = -INFINITY; int bi = 0x7fffffff;
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) dmax_take(bv, bi, sc[j], lane + 64 * j);
+            wave_argmax(bv, bi);
+            if (lane == 0) { cs[wave][it] = bv; ci[wave][it] = bi; }
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) if (lane + 64 * j == bi) sc[j] = -INFINITY;
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {                           // top-k over the n_rows * k continuations, candidate c = row * k + it (:294-306)
+        double cv[4]; int cc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = lane + 64 * q;
+            const bool ok = c < n_rows * k;
+            cv[q] = ok ? cs[c / k][c % k] : -INFINITY;
+            cc[q] = ok ? c : 0x7fffffff;
+        }
+        for (int it = 0; it < k; ++it) {
+            double bv = -INFINITY; int bi = 0x7fffffff;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dmax_take(bv, bi, cv[q], cc[q]);
+            wave_argmax(bv, bi);
+            if (lane == 0) {
+                const bool ok = bi != 0x7fffffff;
+                wsc[it] = bv; wr[it] = ok ? bi / k : 0; wv[it] = ok ? ci[bi / k][bi % k] : -1;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (cc[q] == bi) cv[q] = -INFINITY;
+        }
+        if (lane == 0) {                       // bookkeeping (:306-327)
+            int live = 0, nfin = a.state[2];
+            for (int j = 0; j < k; ++j) {
+                if (wv[j] < 0) continue;                                   // fewer candidates than k (cannot happen for V >= k)
+                const double ns = s == 0 ? wsc[j] : wsc[j] + a.wip * (double)(s + 1);
+                if (wv[j] == a.eos) {
+                    a.fin[2 * nfin] = s; a.fin[2 * nfin + 1] = wr[j]; a.fin_score[nfin] = ns; ++nfin;
+                } else {
+                    a.ints[live] = wv[j]; a.ints[a.kmax + live] = wr[j]; a.cum[live] = ns;
+                    a.bp[((size_t)s * a.kmax + live) * 2] = wr[j]; a.bp[((size_t)s * a.kmax + live) * 2 + 1] = wv[j];
+                    ++live;
+                }
+            }
+            for (int j = live; j < a.kmax; ++j) { a.ints[j] = 0; a.ints[a.kmax + j] = 0; }
+            a.state[0] = live; a.state[1] = live; a.state[2] = nfin; a.state[3] = s + 1;
+        }
+    }
+}
+
+}  // namespace asr
+
+extern "C" int asr_beam_select(void* stream, const float* logits, const float* logits_lm, int V, int kmax, int max_steps,
+                               int eos_id, double lm_weight, double word_ins_penalty, const asr_beam_book* book) {
+    if (!logits || !logits_lm || !book || !book->ints || !book->cum || !book->state || !book->bp || !book->fin || !book->fin_score)
+        return ASR_EINVAL;
+    if (V <= 0 || V > 1024 || kmax <= 0 || kmax > 16 || max_steps <= 0) return ASR_EUNSUPPORTED;
+    asr::BeamSelArgs a;
+    a.logits = logits; a.logits_lm = logits_lm; a.lm_weight = lm_weight; a.wip = word_ins_penalty;
+    a.V = V; a.kmax = kmax; a.eos = eos_id; a.max_steps = max_steps;
+    a.ints = book->ints; a.cum = book->cum; a.state = book->state; a.bp = book->bp; a.fin = book->fin; a.fin_score = book->fin_score;
+    hipLaunchKernelGGL(asr::beam_select_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), a);
+    ASR_CHECK_LAUNCH();
+    return ASR_OK;
+}

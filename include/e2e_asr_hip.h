@@ -248,6 +248,21 @@ int asr_beam_step(void* stream, const asr_dec_weights* w, const asr_lm_weights* 
                   const float* hf, const float* enc, const int* enc_len, const int* tokens,
                   const asr_beam_state* in, const asr_beam_state* out, float* scratch,
                   float* logits, float* logits_lm);
+/* Device-resident scoring, selection and bookkeeping of one beam step (beam_search.py:196-214, 290-327): float64
+ * log-softmax of both logit vectors, score = log p_dec + lm_weight*log p_lm + carried, top-k per hypothesis then over
+ * the continuations, parent = candidate / k, EOS -> finished list and k -= 1.  With asr_beam_gather (sel = ints + kmax)
+ * and asr_beam_step (tokens = ints, B = kmax rows; rows >= state[0] are ignored) a whole utterance decodes without a
+ * host round trip per step.  Caller initialises state = {1, beam, 0, 0}, cum = 0, ints[0] = GO.  V <= 1024, kmax <= 16. */
+typedef struct {
+    int*    ints;       /* [2*kmax] tokens | parent rows of the next step's rows */
+    double* cum;        /* [kmax] carried scores */
+    int*    state;      /* [4] rows fed to the step, beam width left, finished count, step index */
+    int*    bp;         /* [max_steps,kmax,2] (parent row, token) of the rows leaving each step */
+    int*    fin;        /* [beam,2] (step, parent row) of finished hypotheses, in finishing order */
+    double* fin_score;  /* [beam] */
+} asr_beam_book;
+int asr_beam_select(void* stream, const float* logits, const float* logits_lm, int V, int kmax, int max_steps,
+                    int eos_id, double lm_weight, double word_ins_penalty, const asr_beam_book* book);
 
 /* The decoder entry points run the LM cell chain on a library-owned side stream (forked from and
  * ordered against `stream` with events; legal under hipGraph capture).  asr_attn_decoder_bwd leaves

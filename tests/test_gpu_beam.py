@@ -47,3 +47,23 @@ def test_beam_search_config5_shapes():
     ref = O.beam_search(enc, wd, wl, beam_size=16, lm_weight=0.1)
     np.testing.assert_array_equal(got, ref)
     assert got.dtype.kind == "i" and 1 <= len(got) <= 120
+
+
+@pytest.mark.parametrize("k,wip", [(4, 0.0), (16, 0.3)])
+def test_beam_device_selection_equals_host_scoring(golden_dir, monkeypatch, k, wip):
+    """asr_beam_select (float64 log-softmax, top-k, parents, EOS bookkeeping on the device; back-pointers read once at the
+    end) against the host path that scores with NumPy as the reference structures it -- same token ids, with a word
+    insertion penalty and a vocabulary small enough (37) that hypotheses do finish and shrink the beam."""
+    from e2e_asr_amd.beam_search import BeamSearch
+    g = np.load(os.path.join(golden_dir, "decoder_step_plain.npz"))
+    wd, wl = _weights(g, "w_dec/"), _weights(g, "w_lm/")
+    sp = BeamSearch.class_params()
+    sp.beam_size = k; sp.lm_weight = 0.1; sp.lm_path = wl; sp.word_ins_penalty = wip
+    bs = BeamSearch(wd, sp)
+    rng = np.random.default_rng(3)
+    for enc in (g["enc_T100"], g["enc_T100"][:37] * 1.5, (rng.standard_normal((64, g["enc_T100"].shape[1])) * 0.5).astype(np.float32)):
+        monkeypatch.setenv("ASR_BEAM_HOST", "0")
+        dev_ids = bs(enc)
+        monkeypatch.setenv("ASR_BEAM_HOST", "1")
+        host_ids = bs(enc)
+        np.testing.assert_array_equal(dev_ids, host_ids)
