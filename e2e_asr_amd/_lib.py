@@ -48,7 +48,7 @@ class BeamState(C.Structure):
 
 
 class BeamBook(C.Structure):
-    _fields_ = [(n, vp) for n in ("ints", "cum", "state", "bp", "fin", "fin_score")]
+    _fields_ = [(n, vp) for n in ("ints", "cum", "state", "bp", "fin", "fin_score", "cand", "cand_idx")]
 
 
 class DecGrads(C.Structure):

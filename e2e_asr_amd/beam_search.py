@@ -196,7 +196,10 @@ class BeamSearch(BaseParams):
         bp = torch.zeros((max_steps, kmax, 2), dtype=torch.int32, device=dev)
         fin = torch.zeros((kmax, 2), dtype=torch.int32, device=dev)
         fin_score = torch.zeros(kmax, dtype=torch.float64, device=dev)
-        book = ops._dec_struct(_lib.BeamBook, dict(ints=ints, cum=cum, state=state, bp=bp, fin=fin, fin_score=fin_score))
+        cand = torch.zeros((kmax, 16), dtype=torch.float64, device=dev)
+        cand_idx = torch.zeros((kmax, 16), dtype=torch.int32, device=dev)
+        book = ops._dec_struct(_lib.BeamBook, dict(ints=ints, cum=cum, state=state, bp=bp, fin=fin, fin_score=fin_score,
+                                                   cand=cand, cand_idx=cand_idx))
         host = np.zeros(2 * kmax, np.int32)
         host[0] = data_utils.GO_ID
         ints.copy_(torch.from_numpy(host))

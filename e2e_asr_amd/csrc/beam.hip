@@ -98,17 +98,43 @@ struct BeamSelArgs {
     int* bp;              // [max_steps][kmax][2]  (parent row, token) of the rows that leave step s
     int* fin;             // [cap][2]  (step, parent row) of finished hypotheses, in finishing order
     double* fin_score;    // [cap]
+    double* cand;         // [kmax][16] scratch: top-k scores of every hypothesis
+    int* cand_idx;        // [kmax][16] ... and their tokens
 };
 
 __device__ __forceinline__ void dmax_take(double& bv, int& bi, double ov, int oi) {
     if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
 }
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_f64(double v) {
+    const unsigned long long u = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned int)u, CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned int)(u >> 32), CTRL, 0xF, 0xF, true);
+    return __longlong_as_double(((unsigned long long)(unsigned int)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double wave_max_f64(double v) {      // the butterflies of wave_allreduce_max, on 64-bit values
+    v = fmax(v, dpp_mov_f64<0xB1>(v));
+    v = fmax(v, dpp_mov_f64<0x4E>(v));
+    v = fmax(v, dpp_mov_f64<0x141>(v));
+    v = fmax(v, dpp_mov_f64<0x140>(v));
+    v = fmax(v, __shfl_xor(v, 16));
+    v = fmax(v, __shfl_xor(v, 32));
+    return v;
+}
+// wave-wide (max value, lowest index among the lanes holding it): one 64-bit max reduction and a ballot; the index
+// reduction runs only when several lanes tie (a (value, index) butterfly on every call was ~2000 cycles, 32 times per step)
 __device__ __forceinline__ void wave_argmax(double& bv, int& bi) {
+    const double m = wave_max_f64(bv);
+    const bool mine = bv == m;
+    const unsigned long long mask = __ballot(mine);
+    int idx;
+    if (__popcll(mask) == 1) idx = __shfl(bi, __ffsll((long long)mask) - 1);
+    else {
+        idx = mine ? bi : 0x7fffffff;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const double ov = __shfl_xor(bv, o); const int oi = __shfl_xor(bi, o);
-        dmax_take(bv, bi, ov, oi);
+        for (int o = 1; o < 64; o <<= 1) idx = min(idx, __shfl_xor(idx, o));
     }
+    bv = m; bi = idx;
 }
 __device__ __forceinline__ double wave_sum_f64(double v) {
 #pragma unroll
@@ -116,94 +142,118 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
     return v;
 }
 
-// one workgroup of 16 waves: wave r scores hypothesis r (V <= 1024: 16 values per lane)
-__global__ __launch_bounds__(1024) void beam_select_kernel(BeamSelArgs a) {
-    constexpr int VPL = 16, KM = 16;
-    __shared__ double cs[KM][KM];
-    __shared__ int ci[KM][KM];
-    __shared__ double wsc[KM];
-    __shared__ int wr[KM], wv[KM];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n_rows = a.state[0], k = a.state[1], s = a.state[3];
-    if (n_rows <= 0 || k <= 0) return;
+// One workgroup per hypothesis (256 threads, 4 values per lane for V <= 1024): float64 scores of its V continuations and
+// their top-k -> cand[row][k].  (All rows in ONE workgroup put ~10^5 float64 exp / div / log on a single CU: 71 us.)
+__global__ __launch_bounds__(256) void beam_score_kernel(BeamSelArgs a) {
+    constexpr int VPL = 4, KM = 16;
+    __shared__ float smax[2][4];
+    __shared__ double ssum[2][4];
+    __shared__ double cs[4][KM];
+    __shared__ int ci[4][KM];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row = blockIdx.x;
+    const int n_rows = a.state[0], k = a.state[1];
+    if (row >= n_rows || k <= 0) return;
     const int V = a.V;
-    if (wave < n_rows) {
-        double sc[VPL];
-        {
-            float x[VPL], xl[VPL];
-            float m = -INFINITY, ml = -INFINITY;
+    float x[VPL], xl[VPL];
+    float m = -INFINITY, ml = -INFINITY;
 #pragma unroll
-            for (int j = 0; j < VPL; ++j) {
-                const int v = lane + 64 * j;
-                x[j] = v < V ? a.logits[(size_t)wave * V + v] : -INFINITY;
-                xl[j] = v < V ? a.logits_lm[(size_t)wave * V + v] : -INFINITY;
-                m = fmaxf(m, x[j]); ml = fmaxf(ml, xl[j]);
-            }
-            m = wave_allreduce_max(m); ml = wave_allreduce_max(ml);
-            double e[VPL], el[VPL], sum = 0.0, suml = 0.0;
+    for (int j = 0; j < VPL; ++j) {
+        const int v = tid + 256 * j;
+        x[j] = v < V ? a.logits[(size_t)row * V + v] : -INFINITY;
+        xl[j] = v < V ? a.logits_lm[(size_t)row * V + v] : -INFINITY;
+        m = fmaxf(m, x[j]); ml = fmaxf(ml, xl[j]);
+    }
+    m = wave_allreduce_max(m); ml = wave_allreduce_max(ml);
+    if (lane == 0) { smax[0][wave] = m; smax[1][wave] = ml; }
+    __syncthreads();
+    m = fmaxf(fmaxf(smax[0][0], smax[0][1]), fmaxf(smax[0][2], smax[0][3]));
+    ml = fmaxf(fmaxf(smax[1][0], smax[1][1]), fmaxf(smax[1][2], smax[1][3]));
+    double e[VPL], el[VPL], sum = 0.0, suml = 0.0;
 #pragma unroll
-            for (int j = 0; j < VPL; ++j) {
-                const bool ok = lane + 64 * j < V;
-                e[j] = ok ? exp((double)x[j] - (double)m) : 0.0;
-                el[j] = ok ? exp((double)xl[j] - (double)ml) : 0.0;
-                sum += e[j]; suml += el[j];
-            }
-            sum = wave_sum_f64(sum); suml = wave_sum_f64(suml);
-            const double c0 = a.cum[wave];
+    for (int j = 0; j < VPL; ++j) {
+        const bool ok = tid + 256 * j < V;
+        e[j] = ok ? exp((double)x[j] - (double)m) : 0.0;
+        el[j] = ok ? exp((double)xl[j] - (double)ml) : 0.0;
+        sum += e[j]; suml += el[j];
+    }
+    sum = wave_sum_f64(sum); suml = wave_sum_f64(suml);
+    if (lane == 0) { ssum[0][wave] = sum; ssum[1][wave] = suml; }
+    __syncthreads();
+    sum = (ssum[0][0] + ssum[0][1]) + (ssum[0][2] + ssum[0][3]);
+    suml = (ssum[1][0] + ssum[1][1]) + (ssum[1][2] + ssum[1][3]);
+    const double c0 = a.cum[row];
+    double sc[VPL];
 #pragma unroll
-            for (int j = 0; j < VPL; ++j) {
-                const bool ok = lane + 64 * j < V;
-                sc[j] = ok ? (log(e[j] / sum) + a.lm_weight * log(el[j] / suml)) + c0 : -INFINITY;
-            }
-        }
-        for (int it = 0; it < k; ++it) {       // top-k of this hypothesis (:214)
-            double bv = -INFINITY; int bi = 0x7fffffff;
+    for (int j = 0; j < VPL; ++j) {
+        const bool ok = tid + 256 * j < V;
+        sc[j] = ok ? (log(e[j] / sum) + a.lm_weight * log(el[j] / suml)) + c0 : -INFINITY;
+    }
+    for (int it = 0; it < k; ++it) {           // top-k of this wave's quarter
+        double bv = -INFINITY; int bi = 0x7fffffff;
 #pragma unroll
-            for (int j = 0; j < VPL; ++j) dmax_take(bv, bi, sc[j], lane + 64 * j);
-            wave_argmax(bv, bi);
-            if (lane == 0) { cs[wave][it] = bv; ci[wave][it] = bi; }
+        for (int j = 0; j < VPL; ++j) dmax_take(bv, bi, sc[j], tid + 256 * j);
+        wave_argmax(bv, bi);
+        if (lane == 0) { cs[wave][it] = bv; ci[wave][it] = bi; }
 #pragma unroll
-            for (int j = 0; j < VPL; ++j) if (lane + 64 * j == bi) sc[j] = -INFINITY;
-        }
+        for (int j = 0; j < VPL; ++j) if (tid + 256 * j == bi) sc[j] = -INFINITY;
     }
     __syncthreads();
-    if (wave == 0) {                           // top-k over the n_rows * k continuations, candidate c = row * k + it (:294-306)
-        double cv[4]; int cc[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int c = lane + 64 * q;
-            const bool ok = c < n_rows * k;
-            cv[q] = ok ? cs[c / k][c % k] : -INFINITY;
-            cc[q] = ok ? c : 0x7fffffff;
-        }
+    if (wave == 0) {                           // top-k of the hypothesis (:214) from the 4 * k quarter winners
+        const bool ok = lane < 4 * k;
+        double cv = ok ? cs[lane / k][lane % k] : -INFINITY;
+        const int cx = ok ? ci[lane / k][lane % k] : 0x7fffffff;
         for (int it = 0; it < k; ++it) {
-            double bv = -INFINITY; int bi = 0x7fffffff;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) dmax_take(bv, bi, cv[q], cc[q]);
+            double bv = cv; int bi = cx;
             wave_argmax(bv, bi);
-            if (lane == 0) {
-                const bool ok = bi != 0x7fffffff;
-                wsc[it] = bv; wr[it] = ok ? bi / k : 0; wv[it] = ok ? ci[bi / k][bi % k] : -1;
-            }
+            if (lane == 0) { a.cand[row * KM + it] = bv; a.cand_idx[row * KM + it] = bi; }
+            if (cx == bi) cv = -INFINITY;
+        }
+    }
+}
+
+// top-k over the n_rows * k continuations, candidate c = row * k + it (:294-306), and the bookkeeping (:306-327)
+__global__ __launch_bounds__(64) void beam_merge_kernel(BeamSelArgs a) {
+    constexpr int KM = 16;
+    __shared__ double wsc[KM];
+    __shared__ int wr[KM], wv[KM];
+    const int lane = threadIdx.x;
+    const int n_rows = a.state[0], k = a.state[1], s = a.state[3];
+    if (n_rows <= 0 || k <= 0) return;
+    double cv[4]; int cc[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) if (cc[q] == bi) cv[q] = -INFINITY;
+    for (int q = 0; q < 4; ++q) {
+        const int c = lane + 64 * q;
+        const bool ok = c < n_rows * k;
+        cv[q] = ok ? a.cand[(c / k) * KM + c % k] : -INFINITY;
+        cc[q] = ok ? c : 0x7fffffff;
+    }
+    for (int it = 0; it < k; ++it) {
+        double bv = -INFINITY; int bi = 0x7fffffff;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dmax_take(bv, bi, cv[q], cc[q]);
+        wave_argmax(bv, bi);
+        if (lane == 0) {
+            const bool ok = bi != 0x7fffffff;
+            wsc[it] = bv; wr[it] = ok ? bi / k : 0; wv[it] = ok ? a.cand_idx[(bi / k) * KM + bi % k] : -1;
         }
-        if (lane == 0) {                       // bookkeeping (:306-327)
-            int live = 0, nfin = a.state[2];
-            for (int j = 0; j < k; ++j) {
-                if (wv[j] < 0) continue;                                   // fewer candidates than k (cannot happen for V >= k)
-                const double ns = s == 0 ? wsc[j] : wsc[j] + a.wip * (double)(s + 1);
-                if (wv[j] == a.eos) {
-                    a.fin[2 * nfin] = s; a.fin[2 * nfin + 1] = wr[j]; a.fin_score[nfin] = ns; ++nfin;
-                } else {
-                    a.ints[live] = wv[j]; a.ints[a.kmax + live] = wr[j]; a.cum[live] = ns;
-                    a.bp[((size_t)s * a.kmax + live) * 2] = wr[j]; a.bp[((size_t)s * a.kmax + live) * 2 + 1] = wv[j];
-                    ++live;
-                }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) if (cc[q] == bi) cv[q] = -INFINITY;
+    }
+    if (lane == 0) {
+        int live = 0, nfin = a.state[2];
+        for (int j = 0; j < k; ++j) {
+            if (wv[j] < 0 || wv[j] == 0x7fffffff) continue;                // fewer candidates than k (cannot happen for V >= k)
+            const double ns = s == 0 ? wsc[j] : wsc[j] + a.wip * (double)(s + 1);
+            if (wv[j] == a.eos) {
+                a.fin[2 * nfin] = s; a.fin[2 * nfin + 1] = wr[j]; a.fin_score[nfin] = ns; ++nfin;
+            } else {
+                a.ints[live] = wv[j]; a.ints[a.kmax + live] = wr[j]; a.cum[live] = ns;
+                a.bp[((size_t)s * a.kmax + live) * 2] = wr[j]; a.bp[((size_t)s * a.kmax + live) * 2 + 1] = wv[j];
+                ++live;
             }
-            for (int j = live; j < a.kmax; ++j) { a.ints[j] = 0; a.ints[a.kmax + j] = 0; }
-            a.state[0] = live; a.state[1] = live; a.state[2] = nfin; a.state[3] = s + 1;
         }
+        for (int j = live; j < a.kmax; ++j) { a.ints[j] = 0; a.ints[a.kmax + j] = 0; }
+        a.state[0] = live; a.state[1] = live; a.state[2] = nfin; a.state[3] = s + 1;
     }
 }
 
@@ -211,14 +261,17 @@ __global__ __launch_bounds__(1024) void beam_select_kernel(BeamSelArgs a) {
 
 extern "C" int asr_beam_select(void* stream, const float* logits, const float* logits_lm, int V, int kmax, int max_steps,
                                int eos_id, double lm_weight, double word_ins_penalty, const asr_beam_book* book) {
-    if (!logits || !logits_lm || !book || !book->ints || !book->cum || !book->state || !book->bp || !book->fin || !book->fin_score)
+    if (!logits || !logits_lm || !book || !book->ints || !book->cum || !book->state || !book->bp || !book->fin || !book->fin_score ||
+        !book->cand || !book->cand_idx)
         return ASR_EINVAL;
     if (V <= 0 || V > 1024 || kmax <= 0 || kmax > 16 || max_steps <= 0) return ASR_EUNSUPPORTED;
     asr::BeamSelArgs a;
     a.logits = logits; a.logits_lm = logits_lm; a.lm_weight = lm_weight; a.wip = word_ins_penalty;
     a.V = V; a.kmax = kmax; a.eos = eos_id; a.max_steps = max_steps;
     a.ints = book->ints; a.cum = book->cum; a.state = book->state; a.bp = book->bp; a.fin = book->fin; a.fin_score = book->fin_score;
-    hipLaunchKernelGGL(asr::beam_select_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), a);
+    a.cand = book->cand; a.cand_idx = book->cand_idx;
+    hipLaunchKernelGGL(asr::beam_score_kernel, dim3(kmax), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    hipLaunchKernelGGL(asr::beam_merge_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), a);
     ASR_CHECK_LAUNCH();
     return ASR_OK;
 }

@@ -260,6 +260,8 @@ typedef struct {
     int*    bp;         /* [max_steps,kmax,2] (parent row, token) of the rows leaving each step */
     int*    fin;        /* [beam,2] (step, parent row) of finished hypotheses, in finishing order */
     double* fin_score;  /* [beam] */
+    double* cand;       /* [kmax,16] scratch */
+    int*    cand_idx;   /* [kmax,16] scratch */
 } asr_beam_book;
 int asr_beam_select(void* stream, const float* logits, const float* logits_lm, int V, int kmax, int max_steps,
                     int eos_id, double lm_weight, double word_ins_penalty, const asr_beam_book* book);
