@@ -154,7 +154,9 @@ extern "C" int asr_colsum_f32(void* stream, const float* x, int ldx, int M, int 
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (!accumulate && hipMemsetAsync(out, 0, sizeof(float) * N, s) != hipSuccess) return ASR_ELAUNCH;
     const int nx = (N + 63) / 64;
-    int slabs = std::max(1, std::min(M / 256, (512 + nx - 1) / nx));
+    // enough workgroups for memory-level parallelism: a thread walks its rows with 4 loads in flight, so short strips
+    // (>= 8 rows per thread) and up to ~2048 workgroups; slabs meet through one atomic per column
+    int slabs = std::max(1, std::min(M / 32, (2048 + nx - 1) / nx));
     const int rows_per_slab = (M + slabs - 1) / slabs;
     slabs = (M + rows_per_slab - 1) / rows_per_slab;
     if (M == 0) return ASR_OK;
