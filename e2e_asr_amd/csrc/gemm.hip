@@ -407,7 +407,10 @@ extern "C" int asr_gemm_f32_batched(void* stream, int transA, int transB, int M,
     }
     // whole tiles, aligned operands: the variant without bounds checks (all large encoder products)
     if (M % 128 == 0 && N % 128 == 0 && K % BK == 0 && g.vecA && g.vecB && (!transA || !transB)) {
-        if (transA)       hipLaunchKernelGGL((gemm_f32_kernel<true, false, 128, true>), dim3(nwg, splits, batch), dim3(256), 0, s, g);
+        // ASR_GEMM_TA_PAD (bytes, experiment knob): extra dynamic LDS per workgroup of the weight-gradient form, i.e. fewer of
+        // them co-resident with the persistent BPTT workgroup of the CU they share
+        static const int ta_pad = [] { const char* e = getenv("ASR_GEMM_TA_PAD"); return e ? atoi(e) : 0; }();
+        if (transA)       hipLaunchKernelGGL((gemm_f32_kernel<true, false, 128, true>), dim3(nwg, splits, batch), dim3(256), ta_pad, s, g);
         else if (transB)  hipLaunchKernelGGL((gemm_f32_kernel<false, true, 128, true>), dim3(nwg, splits, batch), dim3(256), 0, s, g);
         else              hipLaunchKernelGGL((gemm_f32_kernel<false, false, 128, true>), dim3(nwg, splits, batch), dim3(256), 0, s, g);
         ASR_CHECK_LAUNCH();

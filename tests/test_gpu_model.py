@@ -428,6 +428,39 @@ def test_greedy_decoder_one_launch_equals_per_step_path_and_oracle(monkeypatch, 
         np.testing.assert_array_equal(outs[0][1], O.greedy_decode_ids(r["outputs"]["char"], nb))
 
 
+def test_greedy_decoder_kernel_ragged_emit_lengths_and_tiny_shapes(monkeypatch):
+    """asr_attn_decoder_fwd mode 1 through the C ABI with target lengths SHORTER than T_out (rows emit zeros from their
+    length on, attn_decoder.py:170, and feed token 0 onwards), one utterance, one encoder position, ragged encoder
+    lengths: the persistent kernel against the per-step launch path."""
+    from e2e_asr_amd import ops
+    from e2e_asr_amd.weights import init_weights
+    w = {k: v for k, v in init_weights(seed=5).items() if "rnn_decoder_char" in k}
+    pre = "model/rnn_decoder_char/"
+    wt = {}
+    for field, leaf in ops.DEC_WEIGHT_LEAVES.items():
+        a = w.get(pre + leaf)
+        if a is not None and field == "attn_enc_w":
+            a = a.reshape(a.shape[-2], a.shape[-1])
+        wt[field] = None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    rng = np.random.default_rng(8)
+    for B, Te, T, lens, elens in ((1, 1, 5, [5], [1]), (6, 23, 9, [9, 1, 4, 9, 2, 7], [23, 1, 7, 23, 12, 3])):
+        enc = torch.from_numpy((rng.standard_normal((B, Te, 512)) * 0.4).astype(np.float32)).to(DEV)
+        dec_inp = torch.ones((T + 1, B), dtype=torch.int32, device=DEV)
+        ln = torch.tensor(lens, dtype=torch.int32, device=DEV)
+        eln = torch.tensor(elens, dtype=torch.int32, device=DEV)
+        res = []
+        for greedy in ("1", "0"):
+            monkeypatch.setenv("ASR_DEC_GREEDY", greedy)
+            logits, ws = ops.attn_decoder_fwd(wt, dec_inp, ln, enc, eln, mode=1, t_out=T)
+            ops.check_device_flag(torch.device(DEV))
+            assert (ws.get("greedy_ws") is not None) == (greedy == "1")
+            res.append((logits.cpu().numpy().reshape(T, B, -1), ws["tok"].cpu().numpy()))
+        np.testing.assert_array_equal(res[0][1], res[1][1])
+        np.testing.assert_allclose(res[0][0], res[1][0], rtol=0, atol=2e-5)
+        for b in range(B):
+            assert not res[0][0][lens[b]:, b].any() and res[0][0][:lens[b], b].any()
+
+
 # ------------------------------------------------------------------ persistent decoder chain
 def _chain_model(samp=0.0, seed=3):
     return _model(enc_update=dict(hidden_size=64), num_layers={"char": 2}, seed=seed,
