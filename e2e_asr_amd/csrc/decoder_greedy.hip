@@ -25,6 +25,8 @@
 #include <algorithm>
 #include <cstdlib>
 
+namespace asr { extern unsigned long long* g_lstm_dbg; }
+
 namespace asr {
 
 struct GreedyArgs {
@@ -46,6 +48,7 @@ struct GreedyArgs {
     u64* xcc_slots;          // [groups][32]
     int* err;
     int B, Te, T, V, g0, ng;
+    unsigned long long* dbg;    // STAMP build only
 };
 
 // (value, index) argmax combine with first-max tie-breaking (np.argmax / tf.argmax); NaN never wins
@@ -53,8 +56,26 @@ __device__ __forceinline__ void amax_take(float& bv, int& bi, float ov, int oi) 
     if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
 }
 
-template <int H, int D, int A, int LMH>
+// STAMP: diagnostic instantiation (ASR_CHAIN_STAMP=1 + asr_debug_set_buffer): s_memtime totals of wave 0 of workgroup 0 per
+// phase (code up to each barrier of a step, in program order) -> dbg[48..]; never used for timing claims.
+// (max, lowest index) over the 16 lanes of a DPP row: the butterflies of row16_allreduce_sum on (value, index) pairs -- every
+// lane ends with the row's result (four ds_bpermute shuffles per stage cost ~1600 cycles per reduction, twice per step)
+template <int CTRL>
+__device__ __forceinline__ void amax_dpp(float& bv, int& bi) {
+    const float ov = dpp_mov<CTRL>(bv);
+    const int oi = __builtin_amdgcn_update_dpp(0, bi, CTRL, 0xF, 0xF, true);
+    amax_take(bv, bi, ov, oi);
+}
+__device__ __forceinline__ void row16_argmax(float& bv, int& bi) {
+    amax_dpp<0xB1>(bv, bi); amax_dpp<0x4E>(bv, bi); amax_dpp<0x141>(bv, bi); amax_dpp<0x140>(bv, bi);
+}
+
+template <int H, int D, int A, int LMH, bool STAMP = false>
 __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
+    unsigned int stamp[24] = {0};
+    unsigned long long tlast = 0;
+    int sph = 0;
+#define GREEDY_STAMP() if (STAMP) { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); stamp[sph < 23 ? sph : 23] += (unsigned int)(t__ - tlast); tlast = t__; ++sph; }
     constexpr int R = 4, G = 32, NT = 512, MAXTS = 8, VS = 32;
     constexpr int HS = H / G, LS = LMH / G, AS = A / G, DS = D / G, PS = H / G;
     constexpr int KD = LMH + H + D;              // outer cell input [lm_out | h | ctx]
@@ -176,7 +197,9 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
     const int slen7a = a.seq_len[browf((lane >> 5) & 1)], slen7b = a.seq_len[browf(2 + ((lane >> 5) & 1))];
     __syncthreads();
 
+    if (STAMP) tlast = __builtin_amdgcn_s_memtime();
     for (int i = 0; i < a.T; ++i) {
+        sph = 0;
         const uint32_t ep = (uint32_t)(i + 1);
         u64* gLM = gbase + (size_t)(i & 1) * NPAR;
         u64* gQH = gLM + NLM; u64* gY = gQH + NQH; u64* gE = gY + NY; u64* gC = gE + NE; u64* gP = gC + NC; u64* gM = gP + NP;
@@ -205,6 +228,7 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
             }
         }
         __syncthreads();
+        GREEDY_STAMP()
         {
             float acc[R][4];
 #pragma unroll
@@ -232,6 +256,7 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
             }
         }
         __syncthreads();
+        GREEDY_STAMP()
         if (wave0 && cell) {
             float4 s = make_float4(bp[0], bp[1], bp[2], bp[3]);
 #pragma unroll
@@ -255,6 +280,7 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
             }
         }
         __syncthreads();
+        GREEDY_STAMP()
         {
             float acc[R];
 #pragma unroll
@@ -269,6 +295,7 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
             }
         }
         __syncthreads();
+        GREEDY_STAMP()
         if (wave0 && tid < R * AS) {
             const int r = tid >> 2, col = tid & 3;
             const float yv = ybias + (ysum[(0 * AS + col) * R + r] + ysum[(1 * AS + col) * R + r]) +
@@ -285,6 +312,7 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
             }
         }
         __syncthreads();
+        GREEDY_STAMP()
         {
             const int tl = row % MAXTS, r = row / MAXTS;     // DPP row -> (utterance, position); lane kq -> A/16 columns
             float sc = 0.f;
@@ -305,6 +333,7 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
             if (kq == 0) eout[row] = sc;
         }
         __syncthreads();
+        GREEDY_STAMP()
         if (wave0 && tid < R * MAXTS) {
             const int tl = tid % MAXTS, r = tid / MAXTS;
             if (tl < TS && rok(r)) chain_publish(gE + (size_t)r * G * MAXTS + mem * MAXTS + tl, ep, eout[tid], fast);
@@ -335,6 +364,7 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
             }
         }
         __syncthreads();
+        GREEDY_STAMP()
         if (wave < R) {      // wave r: softmax of utterance r; slot (m, tl) <-> tau = m*TS + tl
             const int r = wave, L = blen[r];
             float* er = el + r * G * MAXTS;
@@ -357,19 +387,23 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
             for (int j = 0; j < G * MAXTS / 64; ++j) er[lane + 64 * j] = ev[j] * inv;
         }
         __syncthreads();
+        GREEDY_STAMP()
         {
+            // alpha is exactly zero past the length and in unused slots (tl >= TS), so every thread runs the same loops
+            // (positions past Te are clamped onto the last row: alpha = 0 there)
             const int dd = tid & 15, r = (tid >> 4) & 3, tp = tid >> 6;
-            const int L = blen[r];
             float cs = 0.f;
-            for (int m = tp; m < G; m += 8) {
+#pragma unroll
+            for (int mm = 0; mm < G / 8; ++mm) {
+                const int m = tp + 8 * mm;
                 const float* ap = el + r * G * MAXTS + m * MAXTS;
-                const float* xp = encl + ((size_t)r * Te + m * TS) * DS + dd;
-                const int nt = min(TS, L - m * TS);
-                for (int tl = 0; tl < nt; ++tl) cs = fmaf(ap[tl], xp[tl * DS], cs);
+                const float* xr = encl + (size_t)r * Te * DS + dd;
+                for (int tl = 0; tl < TS; ++tl) cs = fmaf(ap[tl], xr[min(m * TS + tl, Te - 1) * DS], cs);   // (unrolling to 8 spills)
             }
             cpart[(tp * R + r) * DS + dd] = cs;
         }
         __syncthreads();
+        GREEDY_STAMP()
         if (wave0) {
             const int r = lane >> 4, dd = lane & 15;
             float cs = 0.f;
@@ -388,6 +422,7 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
             }
         }
         __syncthreads();
+        GREEDY_STAMP()
         {
             float acc[R];
 #pragma unroll
@@ -408,6 +443,7 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
             }
         }
         __syncthreads();
+        GREEDY_STAMP()
         if (wave0 && cell) {
             const float pv = pbias + (psum[(0 * PS + cu) * R + cr] + psum[(1 * PS + cu) * R + cr]) +
                              (psum[(2 * PS + cu) * R + cr] + psum[(3 * PS + cu) * R + cr]);
@@ -423,6 +459,7 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
             }
         }
         __syncthreads();
+        GREEDY_STAMP()
         {
             float acc[R];
 #pragma unroll
@@ -459,6 +496,7 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
             }
         }
         __syncthreads();
+        GREEDY_STAMP()
         if (wave7) {         // logits -> global (raw_rnn emits zeros for finished rows, attn_decoder.py:170)
             for (int idx = lane; idx < R * VS; idx += 64) {
                 const int r = idx / VS, c = idx % VS, vc = mem * VS + c;
@@ -476,11 +514,7 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
                 const int cc = c + 16 * h2, vc = mem * VS + cc;
                 if (vc < V) amax_take(bv, bi, live ? lg[r * VS + cc] : 0.f, vc);
             }
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) {
-                const float ov = __shfl_xor(bv, o); const int oi = __shfl_xor(bi, o);
-                amax_take(bv, bi, ov, oi);
-            }
+            row16_argmax(bv, bi);
             if (c == 0 && rok(r)) chain_publish2(gM + 2 * ((size_t)r * G + mem), ep, bv, __int_as_float(bi), fast);
         }
         // ---- (8) gather the 32 partial maxima of every utterance -> tok_{i+1} (every workgroup, redundantly)
@@ -493,22 +527,22 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
             }
         }
         __syncthreads();
+        GREEDY_STAMP()
         if (wave0) {
             const int r = lane >> 4, m2 = lane & 15;
             float bv = mv[r * G + m2]; int bi = mi[r * G + m2];
             amax_take(bv, bi, mv[r * G + m2 + 16], mi[r * G + m2 + 16]);
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) {
-                const float ov = __shfl_xor(bv, o); const int oi = __shfl_xor(bi, o);
-                amax_take(bv, bi, ov, oi);
-            }
+            row16_argmax(bv, bi);
             tok_next = bi == 0x7fffffff ? 0 : bi;
             if (mem == 0 && m2 == 0 && rok(r) && i + 1 < a.T) a.tok[(size_t)(i + 1) * a.B + r0 + r] = tok_next;
             tokr = __shfl(tok_next, cr * 16);
             tokr = min(max(tokr, 0), V - 1);
         }
+        GREEDY_STAMP()
         // (LDS written by this step's last phases is rewritten only after later barriers of the next step)
     }
+    if (STAMP && a.dbg && blockIdx.x == 0 && threadIdx.x == 0) { for (int j = 0; j < 24; ++j) a.dbg[48 + j] = stamp[j]; }
+#undef GREEDY_STAMP
 }
 
 }  // namespace asr
@@ -567,9 +601,13 @@ extern "C" int asr_decoder_greedy_fwd(void* stream, const float* embedding, cons
     if (lds > 160 * 1024 - 64) return ASR_EUNSUPPORTED;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asr::decoder_greedy_kernel<256, 512, 128, 256>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    a.dbg = getenv("ASR_CHAIN_STAMP") ? asr::g_lstm_dbg : nullptr;
+    if (a.dbg) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asr::decoder_greedy_kernel<256, 512, 128, 256, true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     for (int g0 = 0; g0 < groups; g0 += 8) {            // 8 groups (one per XCD) = 256 workgroups per launch
         a.g0 = g0; a.ng = std::min(8, groups - g0);
-        hipLaunchKernelGGL((asr::decoder_greedy_kernel<256, 512, 128, 256>), dim3(8 * G), dim3(512), lds, s, a);
+        if (a.dbg) hipLaunchKernelGGL((asr::decoder_greedy_kernel<256, 512, 128, 256, true>), dim3(8 * G), dim3(512), lds, s, a);
+        else hipLaunchKernelGGL((asr::decoder_greedy_kernel<256, 512, 128, 256>), dim3(8 * G), dim3(512), lds, s, a);
         if (hipGetLastError() != hipSuccess) return ASR_ELAUNCH;
     }
     return ASR_OK;
