@@ -121,7 +121,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("ASR_FORCE_DIST") == "1":      # (ASR_FORCE_DIST: rehearse the RCCL calls on one GPU under torchrun)
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
@@ -176,6 +176,29 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     ops.check_device_flag(dev)
+    comm = None
+    if dist is not None and mode == "train":
+        # the exchange alone: all-reduce of a buffer the size of the flat fp32 gradient, bus bandwidth by the
+        # ring formula 2(N-1)/N * bytes / time, next to the 7 x ~153 GB/s of xGMI links per GPU.  Outside the timed region.
+        try:
+            buf = torch.zeros(model.variables.flat.numel(), device=dev, dtype=torch.float32)
+            for _ in range(3):
+                dist.all_reduce(buf)
+            torch.cuda.synchronize()
+            dist.barrier()
+            tc = time.perf_counter()
+            for _ in range(10):
+                dist.all_reduce(buf)
+            torch.cuda.synchronize()
+            dtc = (time.perf_counter() - tc) / 10
+            nbytes = buf.numel() * 4
+            comm = {"op": "all_reduce(sum) fp32 flat gradient", "bytes": nbytes, "ms": dtc * 1e3,
+                    "busbw_GBps": 2.0 * (world - 1) / max(world, 1) * nbytes / dtc / 1e9,
+                    "link_peak_GBps": 153.0, "links_per_gpu": 7,
+                    "placement": "one blocking all-reduce after backward (ASR_DP_OVERLAP=1: per-layer buckets under the BPTT)"}
+            del buf
+        except Exception as e:      # never lose the bench line to the side measurement
+            comm = {"error": repr(e)}
     rec_ms, rec_n = ops.prof_read("lstm_rec_fwd")
     recb_ms, recb_n = ops.prof_read("lstm_rec_bwd")
     decf_ms, decf_n = ops.prof_read("decoder_fwd")
@@ -226,6 +249,8 @@ def main():
         "phases_ms_per_step": {"lstm_rec_fwd": rec_per_step_ms, "lstm_rec_bwd": recb_ms / args.steps,
                                "decoder_fwd": decf_ms / args.steps},
     }
+    if comm is not None:
+        out["comm"] = comm
     out["roofline_gemm"] = gemm_roofline(dev)
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()

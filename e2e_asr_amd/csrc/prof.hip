@@ -1,6 +1,7 @@
 // Optional HIP-event timing of individual kernels on the stream they are launched on
 // (bench.py's roofline leg).  Disabled by default: zero overhead on the product path.
 #include "common.h"
+#include <cstdlib>
 #include <vector>
 
 namespace asr {
@@ -58,7 +59,19 @@ static size_t g_ev_next = 0;
 static hipEvent_t g_join = nullptr;      // last event recorded on the side stream, not yet joined
 
 hipStream_t side_stream() {
-    if (!g_side) (void)hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking);
+    if (!g_side) {
+        // ASR_SIDE_PRIO: 1 = lowest (default), -1 = highest, 0 = the default priority.  Streams of one priority share a small
+        // pool of hardware queues: with RCCL's streams in the process (every multi-GPU run) a default-priority side stream
+        // landed on the MAIN stream's queue and nothing overlapped (train step 12.9 instead of 12.1 ms, measured under
+        // torchrun with ASR_FORCE_DIST=1); a stream of another priority gets a queue of its own.  Lowest, because the side
+        // stream carries throughput work (weight-gradient GEMMs) next to the latency-bound recurrences of the main stream.
+        int lo = 0, hi = 0;
+        const char* e = getenv("ASR_SIDE_PRIO");
+        const int want = e ? atoi(e) : 1;
+        if (want != 0 && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
+            (void)hipStreamCreateWithPriority(&g_side, hipStreamNonBlocking, want < 0 ? hi : lo);
+        if (!g_side) (void)hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking);
+    }
     return g_side;
 }
 hipEvent_t next_event() {
