@@ -29,6 +29,7 @@ struct GemmArgs {
     int accumulate;   // C += result
     int splits;       // K split over blockIdx.y; >1 => atomicAdd epilogue into a pre-zeroed / accumulated C
     int vecA, vecB;   // 16-B vector loads legal for this operand
+    int xcd_split;    // split-K with one 1-D grid: K slice s runs entirely on XCD s % 8 (splits is a multiple of 8)
     long long sA, sB, sC;   // batch strides (elements); batch index = blockIdx.z
 };
 
@@ -119,8 +120,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     // contiguous run of row-tiles that re-use the same B panel / neighbouring A panels.
     const int ntn = (a.N + BN - 1) / BN, ntm = (a.M + BM - 1) / BM;
     const int nwg = ntn * ntm;
-    int bid = blockIdx.x;
-    {
+    int bid = blockIdx.x, ksl = blockIdx.y;
+    if (a.xcd_split) {
+        // weight-gradient form (few tiles, long K): workgroup L runs on XCD L & 7; give each XCD whole K slices (slice =
+        // xcd + 8 * round), all tiles of a slice on ONE L2: every element of X and dG is then fetched by one XCD only
+        // (with the slices spread over the XCDs each XCD streamed all of dG: ~4x the fills)
+        const int xcd = bid & 7, idx = bid >> 3;
+        ksl = xcd + 8 * (idx / nwg);
+        bid = idx % nwg;
+    } else {
         const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
         bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
     }
@@ -139,7 +147,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     // split-K: this block owns k-tiles [kt0, kt1)
     const int nk_all = (a.K + BK - 1) / BK;
     const int per = (nk_all + a.splits - 1) / a.splits;
-    const int kt0 = blockIdx.y * per, kt1 = min(nk_all, kt0 + per);
+    const int kt0 = ksl * per, kt1 = min(nk_all, kt0 + per);
     if (kt0 >= kt1) return;
     if (FULL) { sa.load_full(a.A, a.lda, m0, kt0 * BK, tid); sb.load_full(a.B, a.ldb, n0, kt0 * BK, tid); }
     else {
@@ -188,7 +196,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         for (int ni = 0; ni < MI; ++ni) {
             const int n = n0 + wc * WT + ni * 32 + (lane & 31);
             if (!FULL && n >= a.N) continue;
-            const float bv = (a.bias && blockIdx.y == 0) ? a.bias[n] : 0.f;
+            const float bv = (a.bias && ksl == 0) ? a.bias[n] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wr * WT + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -377,6 +385,7 @@ extern "C" int asr_gemm_f32_batched(void* stream, int transA, int transB, int M,
         if (const char* e = getenv("ASR_GEMM_SPLITK")) splits = std::max(1, atoi(e));
     }
     g.splits = splits;
+    g.xcd_split = 0;
     if (splits > 1 && !accumulate) {
         if (hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, s) != hipSuccess) return ASR_ELAUNCH;
     }
@@ -410,6 +419,14 @@ extern "C" int asr_gemm_f32_batched(void* stream, int transA, int transB, int M,
         // ASR_GEMM_TA_PAD (bytes, experiment knob): extra dynamic LDS per workgroup of the weight-gradient form, i.e. fewer of
         // them co-resident with the persistent BPTT workgroup of the CU they share
         static const int ta_pad = [] { const char* e = getenv("ASR_GEMM_TA_PAD"); return e ? atoi(e) : 0; }();
+        static const int xs = [] { const char* e = getenv("ASR_GEMM_XCD_SPLIT"); return e ? atoi(e) : 1; }();
+        if (transA && xs && splits >= 6 && batch == 1 && nk >= 128) {          // K slices pinned to XCDs: a multiple of 8 slices
+            g.splits = (splits + 4) / 8 * 8;
+            g.xcd_split = 1;
+            hipLaunchKernelGGL((gemm_f32_kernel<true, false, 128, true>), dim3(nwg * g.splits, 1, 1), dim3(256), ta_pad, s, g);
+            ASR_CHECK_LAUNCH();
+            return ASR_OK;
+        }
         if (transA)       hipLaunchKernelGGL((gemm_f32_kernel<true, false, 128, true>), dim3(nwg, splits, batch), dim3(256), ta_pad, s, g);
         else if (transB)  hipLaunchKernelGGL((gemm_f32_kernel<false, true, 128, true>), dim3(nwg, splits, batch), dim3(256), 0, s, g);
         else              hipLaunchKernelGGL((gemm_f32_kernel<false, false, 128, true>), dim3(nwg, splits, batch), dim3(256), 0, s, g);
