@@ -263,8 +263,14 @@ __global__ __launch_bounds__(512) void lstm_rec_bwd_ag_kernel(LstmBwdArgs a) {
     constexpr int NCELL = R * HS;
     constexpr int NCW = (NCELL + 63) / 64 * 64;
     constexpr int NPOLL = NT - NCW - 64;           // the last wave is the LOADER: it never polls
-    constexpr int NPAIR = R * N / 2;
-    constexpr int NPP = (NPAIR + NPOLL - 1) / NPOLL;   // pairs per polling thread
+    // Exchange format: one 16-byte quad per unit = its four dG values, each carrying a 1-bit tag in the LOWEST MANTISSA BIT
+    // (the value is truncated to 23 mantissa bits; every workgroup, the owner included, consumes the truncated value).  A slot of
+    // parity buffer s & 1 is rewritten every second step, so one bit -- ((s >> 1) & 1) ^ 1, i.e. 1 for the first write after
+    // the host's memset to zero -- tells this step's write from the previous one; a torn read shows mixed bits and is retried.
+    // Half the bytes and half the loads of {tag32, value32} granules: 32 workgroups per XCD each read every quad of their group.
+    constexpr int NQUAD = R * N / 4;
+    constexpr int NPP = (NQUAD + NPOLL - 1) / NPOLL;   // quads per polling thread
+    static_assert(NPP >= 1 && NPP <= 3, "quads per polling thread");
     static_assert(NCW + 64 < NT && PC % 4 == 0 && NCELL <= 64, "mapping");
     __shared__ __attribute__((aligned(16))) float dgl[R * 64 * CSB];
     __shared__ __attribute__((aligned(16))) float sums[R * HS * 4];
@@ -308,7 +314,7 @@ __global__ __launch_bounds__(512) void lstm_rec_bwd_ag_kernel(LstmBwdArgs a) {
     const int cj = j0 + cu;
     float dc = 0.f;
     float4 dbs = make_float4(0.f, 0.f, 0.f, 0.f);
-    u64* hxg = a.hx + (size_t)grp * 2 * R * N;
+    uint32_t* hxg = reinterpret_cast<uint32_t*>(a.hx) + (size_t)grp * 2 * R * N;      // [2 parities][R][N] tagged floats
     const bool fast = group_shares_xcd(a.xcc_slots + (size_t)grp * 16, G, mem, tid, a.err);
 
     // loader wave (last wave): lane l serves cell thread l
@@ -350,41 +356,51 @@ __global__ __launch_bounds__(512) void lstm_rec_bwd_ag_kernel(LstmBwdArgs a) {
         if (s > 0) {
             if (lact) { hand_over(s); if (s + 1 < S) prefetch(s + 1); }
             if (!cell_wave && !loader_wave) {
-                // all of this thread's granule loads in flight, re-polled together until every tag matches
-                const u64* src = hxg + (size_t)((s - 1) & 1) * R * N;
+                // all of this thread's quads in flight, re-polled together until every tag bit matches
+                typedef unsigned int u32x4q __attribute__((ext_vector_type(4)));
+                const uint32_t* src = hxg + (size_t)((s - 1) & 1) * R * N;
+                const uint32_t want = ((((uint32_t)(s - 1)) >> 1) & 1u) ^ 1u;       // tag bit of the step that published
                 bool need[NPP];
+                const u32x4q* qp[NPP];
 #pragma unroll
                 for (int j = 0; j < NPP; ++j) {
-                    const int pidx = tid - NCW + NPOLL * j;
-                    need[j] = pidx < NPAIR && r0 + (2 * pidx) / N < a.B;
-                    if (pidx < NPAIR && !need[j]) {
-                        const int idx = 2 * pidx, r = idx / N, pos = idx % N;
-                        *reinterpret_cast<float2*>(dgl + (r * 64 + pos / PC) * CSB + (pos % PC)) = make_float2(0.f, 0.f);
+                    const int qidx = tid - NCW + NPOLL * j;
+                    need[j] = qidx < NQUAD && r0 + (4 * qidx) / N < a.B;
+                    qp[j] = reinterpret_cast<const u32x4q*>(src) + min(qidx, NQUAD - 1);
+                    if (qidx < NQUAD && !need[j]) {
+                        const int idx = 4 * qidx, r = idx / N, pos = idx % N;
+                        *reinterpret_cast<float4*>(dgl + (r * 64 + pos / PC) * CSB + (pos % PC)) = make_float4(0.f, 0.f, 0.f, 0.f);
                     }
                 }
                 long long t0w = 0;
                 for (uint32_t spins = 0;; ++spins) {
-                    u64 x[NPP][2];
-#pragma unroll
-                    for (int j = 0; j < NPP; ++j) {
-                        const int pidx = min(tid - NCW + NPOLL * j, NPAIR - 1);
-                        x[j][0] = __hip_atomic_load(src + 2 * pidx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        x[j][1] = __hip_atomic_load(src + 2 * pidx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    u32x4q x[NPP];
+                    if constexpr (NPP == 1) {
+                        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(x[0]) : "v"(qp[0]) : "memory");
+                    } else if constexpr (NPP == 2) {
+                        asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+                                     : "=&v"(x[0]), "=&v"(x[1]) : "v"(qp[0]), "v"(qp[1]) : "memory");
+                    } else {
+                        asm volatile("global_load_dwordx4 %0, %3, off sc1\n\tglobal_load_dwordx4 %1, %4, off sc1\n\t"
+                                     "global_load_dwordx4 %2, %5, off sc1\n\ts_waitcnt vmcnt(0)"
+                                     : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]) : "v"(qp[0]), "v"(qp[1]), "v"(qp[2]) : "memory");
                     }
                     bool pending = false;
 #pragma unroll
                     for (int j = 0; j < NPP; ++j) {
                         if (!need[j]) continue;
-                        if ((uint32_t)(x[j][0] >> 32) == (uint32_t)s && (uint32_t)(x[j][1] >> 32) == (uint32_t)s) {
-                            const int idx = 2 * (tid - NCW + NPOLL * j), r = idx / N, pos = idx % N;
-                            *reinterpret_cast<float2*>(dgl + (r * 64 + pos / PC) * CSB + (pos % PC)) =
-                                make_float2(__uint_as_float((uint32_t)x[j][0]), __uint_as_float((uint32_t)x[j][1]));
+                        const uint32_t bits = (x[j].x & 1u) + (x[j].y & 1u) + (x[j].z & 1u) + (x[j].w & 1u);
+                        if (bits == 4u * want) {
+                            const int idx = 4 * (tid - NCW + NPOLL * j), r = idx / N, pos = idx % N;
+                            *reinterpret_cast<float4*>(dgl + (r * 64 + pos / PC) * CSB + (pos % PC)) =
+                                make_float4(__uint_as_float(x[j].x & ~1u), __uint_as_float(x[j].y & ~1u),
+                                            __uint_as_float(x[j].z & ~1u), __uint_as_float(x[j].w & ~1u));
                             need[j] = false;
                         } else pending = true;
                     }
                     if (!pending) break;
                     ASR_POLL_BACKOFF();
-        if ((spins & 1023) == 1023) {
+                    if ((spins & 1023) == 1023) {
                         const long long now = wall_clock64();
                         if (t0w == 0) t0w = now;
                         else if (now - t0w > 200000000LL) { *a.err = 1; break; }
@@ -443,21 +459,19 @@ __global__ __launch_bounds__(512) void lstm_rec_bwd_ag_kernel(LstmBwdArgs a) {
                 dc = dct * ob.z;
                 dbs.x += dg.x; dbs.y += dg.y; dbs.z += dg.z; dbs.w += dg.w;      // bias gradient: sum of dG over time
             }
-            // publish dG_s of this unit FIRST (zeros for rows past their length): 4 adjacent granules
+            // publish dG_s of this unit FIRST (zeros for rows past their length): one tagged quad
             if (cb < a.B && s + 1 < S) {
-                u64* dst = hxg + ((size_t)(s & 1) * R + cr) * N + 4 * cj;
-                const uint32_t tg = (uint32_t)(s + 1);
-                if (fast) {
-                    typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
-                    const u32x4s g0 = {__float_as_uint(dg.x), tg, __float_as_uint(dg.y), tg};
-                    const u32x4s g1 = {__float_as_uint(dg.z), tg, __float_as_uint(dg.w), tg};
-                    asm volatile("global_store_dwordx4 %0, %1, off\n\tglobal_store_dwordx4 %0, %2, off offset:16"
-                                 :: "v"(dst), "v"(g0), "v"(g1) : "memory");
-                } else {
-                    __hip_atomic_store(dst + 0, ((u64)tg << 32) | __float_as_uint(dg.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(dst + 1, ((u64)tg << 32) | __float_as_uint(dg.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(dst + 2, ((u64)tg << 32) | __float_as_uint(dg.z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(dst + 3, ((u64)tg << 32) | __float_as_uint(dg.w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                uint32_t* dst = hxg + ((size_t)(s & 1) * R + cr) * N + 4 * cj;
+                const uint32_t tb = ((((uint32_t)s) >> 1) & 1u) ^ 1u;
+                typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
+                const u32x4s g0 = {(__float_as_uint(dg.x) & ~1u) | tb, (__float_as_uint(dg.y) & ~1u) | tb,
+                                   (__float_as_uint(dg.z) & ~1u) | tb, (__float_as_uint(dg.w) & ~1u) | tb};
+                if (fast) asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(dst), "v"(g0) : "memory");
+                else {
+                    __hip_atomic_store(dst + 0, g0.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(dst + 1, g0.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(dst + 2, g0.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(dst + 3, g0.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
             if (live) {       // bookkeeping, off the critical path
