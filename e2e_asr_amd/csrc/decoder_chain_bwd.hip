@@ -109,8 +109,11 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
     constexpr int CSB = PC + 4;                       // padded LDS chunk stride
     constexpr int NOUT = HS + DS;                     // outputs owned by this workgroup: dh of my units | dctx of my columns
     constexpr int OPW = (NOUT + 7) / 8;               // outputs per wave
-    constexpr int NPAIR4 = R * N4 / 2;                // granule pairs gathered per step
-    constexpr int NPP4 = (NPAIR4 + NGT - 1) / NGT;    // ... pairs per gathering thread
+    // dG travels as 16-byte quads (the four gate values of a unit), each value carrying a 1-bit tag in its lowest mantissa bit
+    // -- the format of the encoder BPTT (csrc/lstm_bwd.hip): half the bytes and loads of {tag32, value32} granules
+    constexpr int NQUAD4 = R * N4 / 4;                // quads gathered per step
+    constexpr int NPP4 = (NQUAD4 + NGT - 1) / NGT;    // ... per gathering thread
+    static_assert(NPP4 >= 1 && NPP4 <= 3, "quads per gathering thread");
     constexpr int MAXTS = 32 / R;
     constexpr int AL = A / 16;                        // a values per lane in the tanh phase
     constexpr int H4 = 4 * H;
@@ -304,39 +307,50 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
         // ---- gather dG of the later step (all 4H positions of both rows; published by their owners), waves 1-2:
         // all of a thread's granule loads in flight, re-polled together until every tag matches
         if (s > 0 && tid >= 64 && tid < 64 + NGT) {
+            typedef unsigned int u32x4q __attribute__((ext_vector_type(4)));
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(g4prev);
+            const uint32_t want = ((((uint32_t)(s - 1)) >> 1) & 1u) ^ 1u;
             bool need[NPP4];
+            const u32x4q* qp[NPP4];
 #pragma unroll
             for (int j = 0; j < NPP4; ++j) {
-                const int pidx = tid - 64 + NGT * j;
-                need[j] = pidx < NPAIR4 && rok((2 * pidx) / N4);
-                if (pidx < NPAIR4 && !need[j]) {
-                    const int idx = 2 * pidx, r = idx / N4, pos = idx % N4;
-                    *reinterpret_cast<float2*>(dga + (r * 64 + pos / PC) * CSB + (pos % PC)) = make_float2(0.f, 0.f);
+                const int qidx = tid - 64 + NGT * j;
+                need[j] = qidx < NQUAD4 && rok((4 * qidx) / N4);
+                qp[j] = reinterpret_cast<const u32x4q*>(src) + min(qidx, NQUAD4 - 1);
+                if (qidx < NQUAD4 && !need[j]) {
+                    const int idx = 4 * qidx, r = idx / N4, pos = idx % N4;
+                    *reinterpret_cast<float4*>(dga + (r * 64 + pos / PC) * CSB + (pos % PC)) = make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
             long long t0w = 0;
             for (uint32_t spins = 0;; ++spins) {
-                u64 x[NPP4][2];
-#pragma unroll
-                for (int j = 0; j < NPP4; ++j) {
-                    const int pidx = min(tid - 64 + NGT * j, NPAIR4 - 1);
-                    x[j][0] = __hip_atomic_load(g4prev + 2 * pidx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    x[j][1] = __hip_atomic_load(g4prev + 2 * pidx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                u32x4q x[NPP4];
+                if constexpr (NPP4 == 1) {
+                    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(x[0]) : "v"(qp[0]) : "memory");
+                } else if constexpr (NPP4 == 2) {
+                    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+                                 : "=&v"(x[0]), "=&v"(x[1]) : "v"(qp[0]), "v"(qp[1]) : "memory");
+                } else {
+                    asm volatile("global_load_dwordx4 %0, %3, off sc1\n\tglobal_load_dwordx4 %1, %4, off sc1\n\t"
+                                 "global_load_dwordx4 %2, %5, off sc1\n\ts_waitcnt vmcnt(0)"
+                                 : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]) : "v"(qp[0]), "v"(qp[1]), "v"(qp[2]) : "memory");
                 }
                 bool pending = false;
 #pragma unroll
                 for (int j = 0; j < NPP4; ++j) {
                     if (!need[j]) continue;
-                    if ((uint32_t)(x[j][0] >> 32) == (uint32_t)s && (uint32_t)(x[j][1] >> 32) == (uint32_t)s) {
-                        const int idx = 2 * (tid - 64 + NGT * j), r = idx / N4, pos = idx % N4;
-                        *reinterpret_cast<float2*>(dga + (r * 64 + pos / PC) * CSB + (pos % PC)) =
-                            make_float2(__uint_as_float((uint32_t)x[j][0]), __uint_as_float((uint32_t)x[j][1]));
+                    const uint32_t bits = (x[j].x & 1u) + (x[j].y & 1u) + (x[j].z & 1u) + (x[j].w & 1u);
+                    if (bits == 4u * want) {
+                        const int idx = 4 * (tid - 64 + NGT * j), r = idx / N4, pos = idx % N4;
+                        *reinterpret_cast<float4*>(dga + (r * 64 + pos / PC) * CSB + (pos % PC)) =
+                            make_float4(__uint_as_float(x[j].x & ~1u), __uint_as_float(x[j].y & ~1u),
+                                        __uint_as_float(x[j].z & ~1u), __uint_as_float(x[j].w & ~1u));
                         need[j] = false;
                     } else pending = true;
                 }
                 if (!pending) break;
                 ASR_POLL_BACKOFF();
-        if ((spins & 1023) == 1023) {
+                if ((spins & 1023) == 1023) {
                     const long long now = wall_clock64();
                     if (t0w == 0) t0w = now;
                     else if (now - t0w > 200000000LL) { *a.err = 1; break; }
@@ -629,18 +643,19 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
                 dg.z = dct * cp * gf * (1.f - gf);
                 dg.w = dh * tc * go * (1.f - go);
                 dc = dct * gf;
-                // publish dG_i of this unit FIRST: 4 adjacent granules (all-gather; the peers contract it with their rows)
+                // publish dG_i of this unit FIRST: one tagged quad (all-gather; the peers contract it with their rows)
                 if (s + 1 < a.T) {
-                    u64* dst = g4 + (size_t)cr * N4 + 4 * cj;
-                    if (fast) {
-                        typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
-                        const u32x4s q0 = {__float_as_uint(dg.x), ep, __float_as_uint(dg.y), ep};
-                        const u32x4s q1 = {__float_as_uint(dg.z), ep, __float_as_uint(dg.w), ep};
-                        asm volatile("global_store_dwordx4 %0, %1, off\n\tglobal_store_dwordx4 %0, %2, off offset:16"
-                                     :: "v"(dst), "v"(q0), "v"(q1) : "memory");
-                    } else {
-                        pubg(dst + 0, ep, dg.x, false); pubg(dst + 1, ep, dg.y, false);
-                        pubg(dst + 2, ep, dg.z, false); pubg(dst + 3, ep, dg.w, false);
+                    uint32_t* dst = reinterpret_cast<uint32_t*>(g4) + (size_t)cr * N4 + 4 * cj;
+                    const uint32_t tb = ((((uint32_t)s) >> 1) & 1u) ^ 1u;
+                    typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
+                    const u32x4s q0 = {(__float_as_uint(dg.x) & ~1u) | tb, (__float_as_uint(dg.y) & ~1u) | tb,
+                                       (__float_as_uint(dg.z) & ~1u) | tb, (__float_as_uint(dg.w) & ~1u) | tb};
+                    if (fast) asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(dst), "v"(q0) : "memory");
+                    else {
+                        __hip_atomic_store(dst + 0, q0.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(dst + 1, q0.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(dst + 2, q0.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(dst + 3, q0.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                 }
                 gp[0] = dg.x; gp[H] = dg.y; gp[2 * H] = dg.z; gp[3 * H] = dg.w;

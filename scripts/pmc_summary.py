@@ -46,16 +46,17 @@ steps = 800 + 400 + 200 + 100
 #   backward: read act 8H + dout H, write dG 4H                                   = 13H floats
 alg_fwd = steps * B * 2 * 14 * H * 4 // 4
 alg_bwd = steps * B * 2 * 13 * H * 4 // 4
-# exchange granules (8 B each) per launch: forward R*H per group-step = B*2*H per step; backward (all-gather of dG) 4x
+# exchange bytes per launch: forward {tag32,value32} granules (8 B) of R*H values per group-step = B*2*H per step; backward:
+# all-gather of dG = 4x the values, as 1-bit-tagged floats (4 B each)
 gran_fwd = steps * B * 2 * H * 8 // 4
-gran_bwd = 4 * gran_fwd
+gran_bwd = 2 * gran_fwd
 traffic = {
     "note": "HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KiB * 1024: separate --pmc passes (rocprofv3 --pmc FETCH_SIZE / "
             "--pmc WRITE_SIZE, --kernel-trace only), FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of wide "
             "coalesced reads; mixed access widths here are uncalibrated). Average over the 4 launches per step (T=800/400/200/100). "
             "The exchange granules are written with sc1 / plain stores and polled with sc1 loads: they are L2 traffic that the "
             "memory-side counters also see when lines are written through.",
-    "lstm_rec_bwd_bytes_per_launch": per_launch("lstm_rec_bwd_ag_kernel<256, 2>") or per_launch("lstm_rec_bwd_kernel<256, 2>"),
+    "lstm_rec_bwd_bytes_per_launch": per_launch("lstm_rec_bwd_ag_kernel<256, 2") or per_launch("lstm_rec_bwd_kernel<256, 2>"),
     "lstm_rec_fwd_bytes_per_launch": per_launch("lstm_rec_fwd_kernel<256, 32, 2"),
     "algorithmic_bytes_per_launch": {"lstm_rec_bwd": alg_bwd, "lstm_rec_fwd": alg_fwd},
     "exchange_granule_bytes_per_launch": {"lstm_rec_fwd": gran_fwd, "lstm_rec_bwd": gran_bwd},
