@@ -201,8 +201,14 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
     for (int i = 0; i < a.T; ++i) {
         sph = 0;
         const uint32_t ep = (uint32_t)(i + 1);
+        const uint32_t tb = tag_bit(i);
         u64* gLM = gbase + (size_t)(i & 1) * NPAR;
         u64* gQH = gLM + NLM; u64* gY = gQH + NQH; u64* gE = gY + NY; u64* gC = gE + NE; u64* gP = gC + NC; u64* gM = gP + NP;
+        // every exchange but the (max, index) pairs travels as tagged floats (granule.h): the regions keep their granule-sized
+        // slots and use the first half of each
+        uint32_t* tLM = reinterpret_cast<uint32_t*>(gLM); uint32_t* tQH = reinterpret_cast<uint32_t*>(gQH);
+        uint32_t* tY = reinterpret_cast<uint32_t*>(gY); uint32_t* tE = reinterpret_cast<uint32_t*>(gE);
+        uint32_t* tC = reinterpret_cast<uint32_t*>(gC); uint32_t* tP = reinterpret_cast<uint32_t*>(gP);
         // ---- (1) LM cell of my units: gates = EK[tok_i] + h_lm_{i-1} . K_h (the matvec ran at the end of step i-1)
         if (wave0 && cell) {
             if (cb_ok) {
@@ -215,16 +221,16 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
                 }
                 const float gi = fast_sigmoid(s.x), gj = fast_tanh(s.y), gf = fast_sigmoid(s.z + 1.0f), go = fast_sigmoid(s.w);
                 c_lm = c_lm * gf + gi * gj;
-                chain_publish(gLM + (size_t)cr * LMH + mem * LS + cu, ep, go * fast_tanh(c_lm), fast);
+                tagged_publish(tLM + (size_t)cr * LMH + mem * LS + cu, tb, go * fast_tanh(c_lm), fast);
             }
         }
         // ---- (2) gather lm_out_i, outer cell
         if (poller) {
-            for (int p = tid - 64; p < NLM / 2; p += NPOLL) {
-                const int idx = 2 * p, r = idx / LMH, k = idx % LMH;
-                float v0 = 0.f, v1 = 0.f;
-                if (rok(r)) chain_poll2(gLM + idx, ep, v0, v1, a.err);
-                *reinterpret_cast<float2*>(v_dec + r * KD + k) = make_float2(v0, v1);
+            for (int p = tid - 64; p < NLM / 4; p += NPOLL) {
+                const int idx = 4 * p, r = idx / LMH, k = idx % LMH;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (rok(r)) tagged_poll4(tLM + idx, tb, v, a.err);
+                *reinterpret_cast<float4*>(v_dec + r * KD + k) = v;
             }
         }
         __syncthreads();
@@ -267,16 +273,16 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
             const float gi = fast_sigmoid(s.x), gj = fast_tanh(s.y), gf = fast_sigmoid(s.z + 1.0f), go = fast_sigmoid(s.w);
             c_dec = c_dec * gf + gi * gj;
             // q = cell state c (decoder.py:79-80) and h, adjacent granules
-            if (cb_ok) chain_publish2(gQH + 2 * ((size_t)cr * H + mem * HS + cu), ep, c_dec, go * fast_tanh(c_dec), fast);
+            if (cb_ok) tagged_publish2(tQH + 2 * ((size_t)cr * H + mem * HS + cu), tb, c_dec, go * fast_tanh(c_dec), fast);
         }
         // ---- (3) gather (q_i, h_i); y slice = q . W_att[:, slice] + b
         if (poller) {
-            for (int p = tid - 64; p < NQH / 2; p += NPOLL) {
-                const int r = p / H, k = p % H;
-                float v0 = 0.f, v1 = 0.f;
-                if (rok(r)) chain_poll2(gQH + 2 * p, ep, v0, v1, a.err);
-                v_ap[r * KA + k] = v0;
-                v_dec[r * KD + LMH + k] = v1;
+            for (int p = tid - 64; p < NQH / 4; p += NPOLL) {       // a quad = (q, h) of two adjacent units
+                const int r = (2 * p) / H, k = (2 * p) % H;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (rok(r)) tagged_poll4(tQH + 4 * p, tb, v, a.err);
+                *reinterpret_cast<float2*>(v_ap + r * KA + k) = make_float2(v.x, v.z);
+                *reinterpret_cast<float2*>(v_dec + r * KD + LMH + k) = make_float2(v.y, v.w);
             }
         }
         __syncthreads();
@@ -300,15 +306,15 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
             const int r = tid >> 2, col = tid & 3;
             const float yv = ybias + (ysum[(0 * AS + col) * R + r] + ysum[(1 * AS + col) * R + r]) +
                              (ysum[(2 * AS + col) * R + r] + ysum[(3 * AS + col) * R + r]);
-            if (rok(r)) chain_publish(gY + (size_t)r * A + mem * AS + col, ep, yv, fast);
+            if (rok(r)) tagged_publish(tY + (size_t)r * A + mem * AS + col, tb, yv, fast);
         }
         // ---- (4) gather y, scores on my position slice
         if (poller) {
-            for (int p = tid - 64; p < NY / 2; p += NPOLL) {
-                const int idx = 2 * p, r = idx / A;
-                float v0 = 0.f, v1 = 0.f;
-                if (rok(r)) chain_poll2(gY + idx, ep, v0, v1, a.err);
-                *reinterpret_cast<float2*>(yl + idx) = make_float2(v0, v1);
+            for (int p = tid - 64; p < NY / 4; p += NPOLL) {
+                const int idx = 4 * p, r = idx / A;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (rok(r)) tagged_poll4(tY + idx, tb, v, a.err);
+                *reinterpret_cast<float4*>(yl + idx) = v;
             }
         }
         __syncthreads();
@@ -335,32 +341,18 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
         __syncthreads();
         GREEDY_STAMP()
         if (wave0 && tid < R * MAXTS) {
-            const int tl = tid % MAXTS, r = tid / MAXTS;
-            if (tl < TS && rok(r)) chain_publish(gE + (size_t)r * G * MAXTS + mem * MAXTS + tl, ep, eout[tid], fast);
+            const int tl = tid % MAXTS, r = tid / MAXTS;      // all MAXTS slots (quads are polled whole; slots >= TS are masked later)
+            if (rok(r)) tagged_publish(tE + (size_t)r * G * MAXTS + mem * MAXTS + tl, tb, eout[tid], fast);
         }
         // ---- (5) gather all scores, softmax over tau < len (replicated), context slice
         if (poller) {
-            const int pairs = (TS + 1) / 2;
-            for (int p = tid - 64; p < R * G * pairs; p += NPOLL) {
-                const int r = p / (G * pairs), rem = p % (G * pairs), m = rem / pairs, tp = rem % pairs;
-                const int off = r * G * MAXTS + m * MAXTS + 2 * tp;
-                float v0 = 0.f, v1 = 0.f;
-                if (rok(r)) {
-                    if (2 * tp + 1 < TS) chain_poll2(gE + off, ep, v0, v1, a.err);
-                    else {   // odd tail: a single granule
-                        long long t0w = 0;
-                        for (uint32_t spins = 0;; ++spins) {
-                            const u64 x = __hip_atomic_load(gE + off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            if ((uint32_t)(x >> 32) == ep) { v0 = __uint_as_float((uint32_t)x); break; }
-                            if ((spins & 1023) == 1023) {
-                                const long long now = wall_clock64();
-                                if (t0w == 0) t0w = now; else if (now - t0w > 200000000LL) { *a.err = 1; break; }
-                                if (__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-                            }
-                        }
-                    }
-                }
-                *reinterpret_cast<float2*>(el + off) = make_float2(v0, v1);
+            const int nq = (TS + 3) / 4;                        // quads per (utterance, source workgroup)
+            for (int p = tid - 64; p < R * G * nq; p += NPOLL) {
+                const int r = p / (G * nq), rem = p % (G * nq), m = rem / nq, q = rem % nq;
+                const int off = r * G * MAXTS + m * MAXTS + 4 * q;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (rok(r)) tagged_poll4(tE + off, tb, v, a.err);
+                *reinterpret_cast<float4*>(el + off) = v;
             }
         }
         __syncthreads();
@@ -409,16 +401,16 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
             float cs = 0.f;
 #pragma unroll
             for (int tp = 0; tp < 8; ++tp) cs += cpart[(tp * R + r) * DS + dd];
-            if (rok(r)) chain_publish(gC + (size_t)r * D + mem * DS + dd, ep, cs, fast);
+            if (rok(r)) tagged_publish(tC + (size_t)r * D + mem * DS + dd, tb, cs, fast);
         }
         // ---- (6) gather ctx_i; AttnProjection slice
         if (poller) {
-            for (int p = tid - 64; p < NC / 2; p += NPOLL) {
-                const int idx = 2 * p, r = idx / D, k = idx % D;
-                float v0 = 0.f, v1 = 0.f;
-                if (rok(r)) chain_poll2(gC + idx, ep, v0, v1, a.err);
-                *reinterpret_cast<float2*>(v_ap + r * KA + H + k) = make_float2(v0, v1);
-                *reinterpret_cast<float2*>(v_dec + r * KD + LMH + H + k) = make_float2(v0, v1);
+            for (int p = tid - 64; p < NC / 4; p += NPOLL) {
+                const int idx = 4 * p, r = idx / D, k = idx % D;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (rok(r)) tagged_poll4(tC + idx, tb, v, a.err);
+                *reinterpret_cast<float4*>(v_ap + r * KA + H + k) = v;
+                *reinterpret_cast<float4*>(v_dec + r * KD + LMH + H + k) = v;
             }
         }
         __syncthreads();
@@ -447,15 +439,15 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
         if (wave0 && cell) {
             const float pv = pbias + (psum[(0 * PS + cu) * R + cr] + psum[(1 * PS + cu) * R + cr]) +
                              (psum[(2 * PS + cu) * R + cr] + psum[(3 * PS + cu) * R + cr]);
-            if (cb_ok) chain_publish(gP + (size_t)cr * H + mem * PS + cu, ep, pv, fast);
+            if (cb_ok) tagged_publish(tP + (size_t)cr * H + mem * PS + cu, tb, pv, fast);
         }
         // ---- (7) gather p; logits of my vocabulary slice (+ the h-part of the NEXT step's LM gates)
         if (poller) {
-            for (int p = tid - 64; p < NP / 2; p += NPOLL) {
-                const int idx = 2 * p, r = idx / H;
-                float v0 = 0.f, v1 = 0.f;
-                if (rok(r)) chain_poll2(gP + idx, ep, v0, v1, a.err);
-                *reinterpret_cast<float2*>(v_p + idx) = make_float2(v0, v1);
+            for (int p = tid - 64; p < NP / 4; p += NPOLL) {
+                const int idx = 4 * p, r = idx / H;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (rok(r)) tagged_poll4(tP + idx, tb, v, a.err);
+                *reinterpret_cast<float4*>(v_p + idx) = v;
             }
         }
         __syncthreads();

@@ -40,4 +40,47 @@ __device__ __forceinline__ void chain_publish2(u64* dst, uint32_t epoch, float v
     }
 }
 
+// ---- tagged floats: the value itself carries a 1-bit tag in its lowest mantissa bit (it is truncated to 23 mantissa bits;
+// every consumer, the owner included, uses the truncated value).  A slot of the parity buffer `step & 1` is rewritten every
+// second step, so the bit ((step >> 1) & 1) ^ 1 -- 1 for the first write after the host's memset to zero -- tells this
+// step's write from the previous one.  Four values = one 16-byte load: half the bytes and loads of {tag32, value32}
+// granules, which matters because every workgroup of a group reads every value (csrc/lstm_bwd.hip measured -16 %).
+// Valid within ONE launch over a workspace zeroed before it.
+__device__ __forceinline__ uint32_t tag_bit(int step) { return ((((uint32_t)step) >> 1) & 1u) ^ 1u; }
+__device__ __forceinline__ void tagged_publish(uint32_t* dst, uint32_t tb, float v, bool fast) {
+    const uint32_t x = (__float_as_uint(v) & ~1u) | tb;
+    if (fast) asm volatile("global_store_dword %0, %1, off" :: "v"(dst), "v"(x) : "memory");
+    else __hip_atomic_store(dst, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void tagged_publish2(uint32_t* dst, uint32_t tb, float v0, float v1, bool fast) {   // 8-byte aligned
+    const uint32_t x0 = (__float_as_uint(v0) & ~1u) | tb, x1 = (__float_as_uint(v1) & ~1u) | tb;
+    if (fast) {
+        const u64 q = ((u64)x1 << 32) | x0;
+        asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(dst), "v"(q) : "memory");
+    } else {
+        __hip_atomic_store(dst, x0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(dst + 1, x1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+// four tagged floats (16-byte aligned), polled until all four carry this step's bit
+__device__ __forceinline__ bool tagged_poll4(const uint32_t* g, uint32_t tb, float4& v, int* err) {
+    long long t0 = 0;
+    const u32x4c* p = reinterpret_cast<const u32x4c*>(g);
+    for (uint32_t spins = 0;; ++spins) {
+        u32x4c x;
+        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(x) : "v"(p) : "memory");
+        if ((x.x & 1u) + (x.y & 1u) + (x.z & 1u) + (x.w & 1u) == 4u * tb) {
+            v = make_float4(__uint_as_float(x.x & ~1u), __uint_as_float(x.y & ~1u), __uint_as_float(x.z & ~1u), __uint_as_float(x.w & ~1u));
+            return true;
+        }
+        ASR_POLL_BACKOFF();
+        if ((spins & 1023) == 1023) {
+            const long long now = wall_clock64();
+            if (t0 == 0) t0 = now;
+            else if (now - t0 > 200000000LL) { *err = 1; v = make_float4(0.f, 0.f, 0.f, 0.f); return false; }
+            if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { v = make_float4(0.f, 0.f, 0.f, 0.f); return false; }
+        }
+    }
+}
+
 }  // namespace asr
