@@ -5,6 +5,7 @@
 // (:200-207).  Scoring (float64 log-softmax, lm_weight, argpartition) stays on the host as the reference defines it.
 // Ten stream-ordered launches of the step kernels behind ONE call (skinny.hip, attention.hip).
 #include "common.h"
+#include "skinny.h"
 #include "../../include/e2e_asr_hip.h"
 
 extern "C" int asr_beam_step(void* stream, const asr_dec_weights* w, const asr_lm_weights* lm, const asr_dec_dims* d,
@@ -20,16 +21,36 @@ extern "C" int asr_beam_step(void* stream, const asr_dec_weights* w, const asr_l
     float* p = x + (size_t)k * E;                     // [k, H]
     float* alpha = p + (size_t)k * H;                 // [k, Te]
     float* lsp = alpha + (size_t)k * Te;              // [k, lm->P] external LM SimpleProjection output
+    // Without SimpleProjections the two LM cells (decoder's inner one, :183-186, and the external one, :200-203) and then the
+    // two projections behind them (InputProjection, :188-189, and the external LM's output projection, :204-207) are pairwise
+    // independent: two launches instead of four.
+    const bool paired = !w->simple_w && !lm->simple_w;
+    if (paired) {
+        asr::SkinnyArgs c0{}, c1{};
+        c0.x1 = w->embedding; c0.ld1 = E; c0.K1 = E; c0.gather1 = tokens; c0.x2 = in->dlh; c0.ld2 = lmH; c0.K2 = lmH;
+        c0.W = w->lm_kernel; c0.ldw = 4 * lmH; c0.bias = w->lm_bias; c0.M = k; c0.N = 4 * lmH; c0.H = lmH;
+        c0.c_prev = in->dlc; c0.c_out = out->dlc; c0.h_out = out->dlh; c0.keep = 1.0f;
+        c1.x1 = lm->embedding; c1.ld1 = lm->E; c1.K1 = lm->E; c1.gather1 = tokens; c1.x2 = in->lh; c1.ld2 = lm->H; c1.K2 = lm->H;
+        c1.W = lm->lstm_kernel; c1.ldw = 4 * lm->H; c1.bias = lm->lstm_bias; c1.M = k; c1.N = 4 * lm->H; c1.H = lm->H;
+        c1.c_prev = in->lc; c1.c_out = out->lc; c1.h_out = out->lh; c1.keep = 1.0f;
+        if ((rc = asr::skinny_launch_pair(static_cast<hipStream_t>(stream), true, c0, c1))) return rc;
+        asr::SkinnyArgs p0{}, p1{};
+        p0.x1 = out->dlh; p0.ld1 = lmH; p0.K1 = lmH; p0.x2 = in->ctx; p0.ld2 = D; p0.K2 = D;
+        p0.W = w->inp_w; p0.ldw = E; p0.bias = w->inp_b; p0.M = k; p0.N = E; p0.out = x; p0.ldo = E;
+        p1.x1 = out->lh; p1.ld1 = lm->H; p1.K1 = lm->H; p1.W = lm->out_w; p1.ldw = lm->V; p1.bias = lm->out_b;
+        p1.M = k; p1.N = lm->V; p1.out = logits_lm; p1.ldo = lm->V;
+        if ((rc = asr::skinny_launch_pair(static_cast<hipStream_t>(stream), false, p0, p1))) return rc;
+    }
     // decoder's inner LM cell on emb[token]  (:183-186)
-    if ((rc = asr_lstm_cell_fwd(stream, w->embedding, E, E, tokens, in->dlh, in->dlc, w->lm_kernel, w->lm_bias, lmH, k,
-                                out->dlc, out->dlh, nullptr, nullptr, 1.0f, 0, 0))) return rc;
+    if (!paired && (rc = asr_lstm_cell_fwd(stream, w->embedding, E, E, tokens, in->dlh, in->dlc, w->lm_kernel, w->lm_bias, lmH, k,
+                                           out->dlc, out->dlh, nullptr, nullptr, 1.0f, 0, 0))) return rc;
     const float* o = out->dlh; int P = lmH;
     if (w->simple_w) {
         if ((rc = asr_linear_fwd(stream, o, lmH, lmH, nullptr, nullptr, 0, 0, w->simple_w, H, w->simple_b, sp, H, k, H, nullptr, 0))) return rc;
         o = sp; P = H;
     }
     // x = [lm_out, ctx_prev] . W_inp + b  (:188-189), outer cell (:190-191)
-    if ((rc = asr_linear_fwd(stream, o, P, P, nullptr, in->ctx, D, D, w->inp_w, E, w->inp_b, x, E, k, E, nullptr, 0))) return rc;
+    if (!paired && (rc = asr_linear_fwd(stream, o, P, P, nullptr, in->ctx, D, D, w->inp_w, E, w->inp_b, x, E, k, E, nullptr, 0))) return rc;
     if ((rc = asr_lstm_cell_fwd(stream, x, E, E, nullptr, in->dh, in->dc, w->dec_kernel, w->dec_bias, H, k,
                                 out->dc, out->dh, nullptr, nullptr, 1.0f, 0, 0))) return rc;
     // attention with query = c (:193), AttnProjection, OutputProjection (:194-198)
@@ -38,6 +59,7 @@ extern "C" int asr_beam_step(void* stream, const asr_dec_weights* w, const asr_l
     if ((rc = asr_linear_fwd(stream, out->dc, H, H, nullptr, out->ctx, D, D, w->ap_w, H, w->ap_b, p, H, k, H, nullptr, 0))) return rc;
     if ((rc = asr_linear_fwd(stream, p, H, H, nullptr, nullptr, 0, 0, w->out_w, V, w->out_b, logits, V, k, V, nullptr, 0))) return rc;
     // external LM (:200-207)
+    if (paired) return ASR_OK;
     if ((rc = asr_lstm_cell_fwd(stream, lm->embedding, lm->E, lm->E, tokens, in->lh, in->lc, lm->lstm_kernel, lm->lstm_bias,
                                 lm->H, k, out->lc, out->lh, nullptr, nullptr, 1.0f, 0, 0))) return rc;
     const float* lo = out->lh; int LP = lm->H;

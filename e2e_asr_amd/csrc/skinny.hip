@@ -15,35 +15,23 @@
 // MFMA result layout (row = 4*(lane>>4) + reg) hands each lane the i,j,f,o of ONE unit for
 // ONE batch row and the cell runs in registers.
 #include "common.h"
+#include "skinny.h"
 
 namespace asr {
 
-struct SkinnyArgs {
-    const float* x1; int ld1; int K1; const int* gather1;   // row b of X1 = x1 + (gather1? gather1[b] : b)*ld1
-    const float* x2; int ld2; int K2;
-    const float* W; int ldw; const float* bias;
-    int M, N;
-    // linear mode
-    float* out; int ldo; int accumulate;
-    const int* zero_from; int zero_t;     // rows with zero_t >= zero_from[b] are written as zeros (raw_rnn emit)
-    // LSTM mode (H > 0)
-    int H; const float* c_prev; float* c_out; float* h_out; float* hdrop_out; float* gates_out;
-    float keep; uint32_t seed; uint32_t step;
-};
 
 // WT: the weight is given transposed, W[n][k] (row stride ldw along n) -- the data-gradient
 // products dY.W^T of the backward pass; the lane then reads 4 consecutive k as one float4.
 template <bool LSTM, bool WT>
-__global__ __launch_bounds__(256) void skinny_kernel(SkinnyArgs a) {
-    __shared__ float red[3][4][64];
+__device__ __forceinline__ void skinny_body(const SkinnyArgs& a, const int bx, const int by, float (*red)[4][64]) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int nl = lane & 15, g4 = lane >> 4;
     const int K = a.K1 + a.K2;
     // column of W feeding output row nl of the MFMA tile
     int colW; bool colok;
-    if (LSTM) { const int j = blockIdx.x * 4 + (nl >> 2); colW = (nl & 3) * a.H + j; colok = j < a.H; }
-    else      { colW = blockIdx.x * 16 + nl; colok = colW < a.N; }
-    const int brow = blockIdx.y * 16 + nl;      // batch row this lane supplies as MFMA B operand
+    if (LSTM) { const int j = bx * 4 + (nl >> 2); colW = (nl & 3) * a.H + j; colok = j < a.H; }
+    else      { colW = bx * 16 + nl; colok = colW < a.N; }
+    const int brow = by * 16 + nl;      // batch row this lane supplies as MFMA B operand
     const bool rowok = brow < a.M;
     const float* xr1 = nullptr; const float* xr2 = nullptr;
     if (rowok) {
@@ -58,13 +46,13 @@ __global__ __launch_bounds__(256) void skinny_kernel(SkinnyArgs a) {
     bool ez = false;
     if (w == 0 && rowok) {
         if (LSTM) {
-            const int j = blockIdx.x * 4 + g4;
+            const int j = bx * 4 + g4;
             if (j < a.H) {
                 eb0 = a.bias[j]; eb1 = a.bias[a.H + j]; eb2 = a.bias[2 * a.H + j]; eb3 = a.bias[3 * a.H + j];
                 if (a.c_prev) ecp = a.c_prev[(size_t)brow * a.H + j];
             }
         } else {
-            const int n = blockIdx.x * 16 + 4 * g4;
+            const int n = bx * 16 + 4 * g4;
             if (a.bias) {
                 if (n < a.N) eb0 = a.bias[n];
                 if (n + 1 < a.N) eb1 = a.bias[n + 1];
@@ -117,10 +105,10 @@ __global__ __launch_bounds__(256) void skinny_kernel(SkinnyArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[r] += red[0][r][lane] + red[1][r][lane] + red[2][r][lane];
     // lane holds D[n_local = 4*g4 + r][batch = nl]
-    const int b = blockIdx.y * 16 + nl;
+    const int b = by * 16 + nl;
     if (b >= a.M) return;
     if (LSTM) {
-        const int j = blockIdx.x * 4 + g4;
+        const int j = bx * 4 + g4;
         if (j >= a.H) return;
         const int H = a.H;
         const float gi = fast_sigmoid(acc[0] + eb0);
@@ -139,7 +127,7 @@ __global__ __launch_bounds__(256) void skinny_kernel(SkinnyArgs a) {
             gp[0] = gi; gp[H] = gj; gp[2 * H] = gf; gp[3 * H] = go;
         }
     } else {
-        const int n = blockIdx.x * 16 + 4 * g4;
+        const int n = bx * 16 + 4 * g4;
         const bool z = ez;
         const float eb[4] = {eb0, eb1, eb2, eb3};
         float* op = a.out + (size_t)b * a.ldo + n;
@@ -151,6 +139,34 @@ __global__ __launch_bounds__(256) void skinny_kernel(SkinnyArgs a) {
                 op[r] = v;
             }
     }
+}
+
+template <bool LSTM, bool WT>
+__global__ __launch_bounds__(256) void skinny_kernel(SkinnyArgs a) {
+    __shared__ float red[3][4][64];
+    skinny_body<LSTM, WT>(a, blockIdx.x, blockIdx.y, red);
+}
+template <bool LSTM>
+__global__ __launch_bounds__(256) void skinny_pair_kernel(SkinnyArgs a0, SkinnyArgs a1, int nbx0) {
+    __shared__ float red[3][4][64];
+    if ((int)blockIdx.x < nbx0) skinny_body<LSTM, false>(a0, blockIdx.x, blockIdx.y, red);
+    else skinny_body<LSTM, false>(a1, blockIdx.x - nbx0, blockIdx.y, red);
+}
+
+}  // namespace asr
+static int skinny_check(const asr::SkinnyArgs& a);
+namespace asr {
+
+int skinny_launch_pair(hipStream_t s, bool lstm, const SkinnyArgs& a0, const SkinnyArgs& a1) {
+    if (int rc = skinny_check(a0)) return rc;
+    if (int rc = skinny_check(a1)) return rc;
+    if (lstm ? (a0.H <= 0 || a1.H <= 0 || (a0.H & 3) || (a1.H & 3)) : (a0.N <= 0 || a1.N <= 0 || !a0.out || !a1.out)) return ASR_EINVAL;
+    const int nb0 = lstm ? (a0.H + 3) / 4 : (a0.N + 15) / 16, nb1 = lstm ? (a1.H + 3) / 4 : (a1.N + 15) / 16;
+    const int M = a0.M > a1.M ? a0.M : a1.M;
+    dim3 grid(nb0 + nb1, (M + 15) / 16);
+    if (lstm) hipLaunchKernelGGL((skinny_pair_kernel<true>), grid, dim3(256), 0, s, a0, a1, nb0);
+    else hipLaunchKernelGGL((skinny_pair_kernel<false>), grid, dim3(256), 0, s, a0, a1, nb0);
+    return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
 }
 
 }  // namespace asr
