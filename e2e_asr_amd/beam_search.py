@@ -207,13 +207,20 @@ class BeamSearch(BaseParams):
             t.zero_()
         cd = _lib.DecDims(kmax, Te, D, A, H, lmH, E, V, 1)
         st = ops._stream()
+        in_place = self.dec_params.simple_w is None and self.lm_params.simple_w is None
         for s in range(max_steps):
-            if s:
-                ops._check(L.asr_beam_gather(st, ops._p(ints[kmax:]), kmax, C.byref(cst[1]), C.byref(cst[0]), H, lmH, extH, D),
-                           "asr_beam_gather")
-            ops._check(L.asr_beam_step(st, C.byref(cw), C.byref(clm), C.byref(cd), ops._p(hf), ops._p(enc), ops._p(ln), ops._p(ints),
-                                       C.byref(cst[0]), C.byref(cst[1]), ops._p(scratch), ops._p(logits[0]), ops._p(logits[1])),
-                       "asr_beam_step")
+            if in_place:       # the step kernels read the parents' rows of the previous step's output in place: ping-pong
+                a, b = (0, 1) if s % 2 == 0 else (1, 0)
+                ops._check(L.asr_beam_step_sel(st, C.byref(cw), C.byref(clm), C.byref(cd), ops._p(hf), ops._p(enc), ops._p(ln),
+                                               ops._p(ints), ops._p(ints[kmax:]) if s else None, C.byref(cst[a]), C.byref(cst[b]),
+                                               ops._p(scratch), ops._p(logits[0]), ops._p(logits[1])), "asr_beam_step_sel")
+            else:
+                if s:
+                    ops._check(L.asr_beam_gather(st, ops._p(ints[kmax:]), kmax, C.byref(cst[1]), C.byref(cst[0]), H, lmH, extH, D),
+                               "asr_beam_gather")
+                ops._check(L.asr_beam_step(st, C.byref(cw), C.byref(clm), C.byref(cd), ops._p(hf), ops._p(enc), ops._p(ln), ops._p(ints),
+                                           C.byref(cst[0]), C.byref(cst[1]), ops._p(scratch), ops._p(logits[0]), ops._p(logits[1])),
+                           "asr_beam_step")
             ops._check(L.asr_beam_select(st, ops._p(logits[0]), ops._p(logits[1]), V, kmax, max_steps, data_utils.EOS_ID,
                                          float(sp.lm_weight), float(sp.word_ins_penalty), C.byref(book)), "asr_beam_select")
             if s % 8 == 7 and int(state[1].item()) == 0:           # every hypothesis finished (:269)

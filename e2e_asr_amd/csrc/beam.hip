@@ -8,11 +8,25 @@
 #include "skinny.h"
 #include "../../include/e2e_asr_hip.h"
 
+extern "C" int asr_beam_step_sel(void* stream, const asr_dec_weights* w, const asr_lm_weights* lm, const asr_dec_dims* d,
+                                 const float* hf, const float* enc, const int* enc_len, const int* tokens, const int* sel,
+                                 const asr_beam_state* in, const asr_beam_state* out, float* scratch,
+                                 float* logits, float* logits_lm);
 extern "C" int asr_beam_step(void* stream, const asr_dec_weights* w, const asr_lm_weights* lm, const asr_dec_dims* d,
                              const float* hf, const float* enc, const int* enc_len, const int* tokens,
                              const asr_beam_state* in, const asr_beam_state* out, float* scratch,
                              float* logits, float* logits_lm) {
+    return asr_beam_step_sel(stream, w, lm, d, hf, enc, enc_len, tokens, nullptr, in, out, scratch, logits, logits_lm);
+}
+// sel (device, [k] ints, or NULL): row r of the step's input state is row sel[r] of `in` -- the parents of the surviving
+// hypotheses (beam_search.py:306-318) read in place by the step kernels instead of being gathered by a launch of their own.
+// With sel the SimpleProjections must be absent (ASR_EUNSUPPORTED otherwise: gather with asr_beam_gather, then sel = NULL).
+extern "C" int asr_beam_step_sel(void* stream, const asr_dec_weights* w, const asr_lm_weights* lm, const asr_dec_dims* d,
+                                 const float* hf, const float* enc, const int* enc_len, const int* tokens, const int* sel,
+                                 const asr_beam_state* in, const asr_beam_state* out, float* scratch,
+                                 float* logits, float* logits_lm) {
     if (!w || !lm || !d || !hf || !enc || !enc_len || !tokens || !in || !out || !scratch || !logits || !logits_lm) return ASR_EINVAL;
+    if (sel && (w->simple_w || lm->simple_w)) return ASR_EUNSUPPORTED;
     const int k = d->B, Te = d->Te, D = d->D, A = d->A, H = d->H, lmH = d->lmH, E = d->E, V = d->V;
     if (k <= 0) return ASR_EINVAL;
     int rc;
@@ -27,15 +41,15 @@ extern "C" int asr_beam_step(void* stream, const asr_dec_weights* w, const asr_l
     const bool paired = !w->simple_w && !lm->simple_w;
     if (paired) {
         asr::SkinnyArgs c0{}, c1{};
-        c0.x1 = w->embedding; c0.ld1 = E; c0.K1 = E; c0.gather1 = tokens; c0.x2 = in->dlh; c0.ld2 = lmH; c0.K2 = lmH;
+        c0.x1 = w->embedding; c0.ld1 = E; c0.K1 = E; c0.gather1 = tokens; c0.x2 = in->dlh; c0.ld2 = lmH; c0.K2 = lmH; c0.gather2 = sel;
         c0.W = w->lm_kernel; c0.ldw = 4 * lmH; c0.bias = w->lm_bias; c0.M = k; c0.N = 4 * lmH; c0.H = lmH;
         c0.c_prev = in->dlc; c0.c_out = out->dlc; c0.h_out = out->dlh; c0.keep = 1.0f;
-        c1.x1 = lm->embedding; c1.ld1 = lm->E; c1.K1 = lm->E; c1.gather1 = tokens; c1.x2 = in->lh; c1.ld2 = lm->H; c1.K2 = lm->H;
+        c1.x1 = lm->embedding; c1.ld1 = lm->E; c1.K1 = lm->E; c1.gather1 = tokens; c1.x2 = in->lh; c1.ld2 = lm->H; c1.K2 = lm->H; c1.gather2 = sel;
         c1.W = lm->lstm_kernel; c1.ldw = 4 * lm->H; c1.bias = lm->lstm_bias; c1.M = k; c1.N = 4 * lm->H; c1.H = lm->H;
         c1.c_prev = in->lc; c1.c_out = out->lc; c1.h_out = out->lh; c1.keep = 1.0f;
         if ((rc = asr::skinny_launch_pair(static_cast<hipStream_t>(stream), true, c0, c1))) return rc;
         asr::SkinnyArgs p0{}, p1{};
-        p0.x1 = out->dlh; p0.ld1 = lmH; p0.K1 = lmH; p0.x2 = in->ctx; p0.ld2 = D; p0.K2 = D;
+        p0.x1 = out->dlh; p0.ld1 = lmH; p0.K1 = lmH; p0.x2 = in->ctx; p0.ld2 = D; p0.K2 = D; p0.gather2 = sel;
         p0.W = w->inp_w; p0.ldw = E; p0.bias = w->inp_b; p0.M = k; p0.N = E; p0.out = x; p0.ldo = E;
         p1.x1 = out->lh; p1.ld1 = lm->H; p1.K1 = lm->H; p1.W = lm->out_w; p1.ldw = lm->V; p1.bias = lm->out_b;
         p1.M = k; p1.N = lm->V; p1.out = logits_lm; p1.ldo = lm->V;
@@ -51,8 +65,13 @@ extern "C" int asr_beam_step(void* stream, const asr_dec_weights* w, const asr_l
     }
     // x = [lm_out, ctx_prev] . W_inp + b  (:188-189), outer cell (:190-191)
     if (!paired && (rc = asr_linear_fwd(stream, o, P, P, nullptr, in->ctx, D, D, w->inp_w, E, w->inp_b, x, E, k, E, nullptr, 0))) return rc;
-    if ((rc = asr_lstm_cell_fwd(stream, x, E, E, nullptr, in->dh, in->dc, w->dec_kernel, w->dec_bias, H, k,
-                                out->dc, out->dh, nullptr, nullptr, 1.0f, 0, 0))) return rc;
+    {
+        asr::SkinnyArgs oc{};
+        oc.x1 = x; oc.ld1 = E; oc.K1 = E; oc.x2 = in->dh; oc.ld2 = H; oc.K2 = H; oc.gather2 = sel;
+        oc.W = w->dec_kernel; oc.ldw = 4 * H; oc.bias = w->dec_bias; oc.M = k; oc.N = 4 * H; oc.H = H;
+        oc.c_prev = in->dc; oc.c_out = out->dc; oc.h_out = out->dh; oc.keep = 1.0f;
+        if ((rc = asr::skinny_launch(static_cast<hipStream_t>(stream), true, oc))) return rc;
+    }
     // attention with query = c (:193), AttnProjection, OutputProjection (:194-198)
     if ((rc = asr_attention_shared_fwd(stream, out->dc, H, w->attn_w, w->attn_b, w->attn_v, hf, enc, enc_len, alpha, out->ctx,
                                        k, Te, H, A, D, 1))) return rc;

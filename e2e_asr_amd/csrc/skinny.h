@@ -7,6 +7,7 @@ namespace asr {
 struct SkinnyArgs {
     const float* x1; int ld1; int K1; const int* gather1;   // row b of X1 = x1 + (gather1? gather1[b] : b)*ld1
     const float* x2; int ld2; int K2;
+    const int* gather2;                   // row b of X2 (and of c_prev) = row gather2[b] (the beam step: parent rows); NULL = b
     const float* W; int ldw; const float* bias;
     int M, N;
     // linear mode
@@ -21,5 +22,6 @@ struct SkinnyArgs {
 // covers problem 0's column tiles, then problem 1's.  The beam step's two LM cells (decoder's and external) and the two
 // projections that follow them have no dependency on each other; as separate launches each costs 5-8 us of latency.
 int skinny_launch_pair(hipStream_t s, bool lstm, const SkinnyArgs& a0, const SkinnyArgs& a1);
+int skinny_launch(hipStream_t s, bool lstm, const SkinnyArgs& a);      // one problem, any SkinnyArgs (e.g. with gather2)
 
 }  // namespace asr

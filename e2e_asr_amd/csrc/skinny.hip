@@ -36,7 +36,7 @@ __device__ __forceinline__ void skinny_body(const SkinnyArgs& a, const int bx, c
     const float* xr1 = nullptr; const float* xr2 = nullptr;
     if (rowok) {
         xr1 = a.x1 + (size_t)(a.gather1 ? a.gather1[brow] : brow) * a.ld1;
-        if (a.K2 > 0) xr2 = a.x2 + (size_t)brow * a.ld2;
+        if (a.K2 > 0) xr2 = a.x2 + (size_t)(a.gather2 ? a.gather2[brow] : brow) * a.ld2;
     }
     const int chunk = ((K + 63) / 64) * 16;
     const int kbeg = w * chunk, kend = min(K, kbeg + chunk);
@@ -49,7 +49,7 @@ __device__ __forceinline__ void skinny_body(const SkinnyArgs& a, const int bx, c
             const int j = bx * 4 + g4;
             if (j < a.H) {
                 eb0 = a.bias[j]; eb1 = a.bias[a.H + j]; eb2 = a.bias[2 * a.H + j]; eb3 = a.bias[3 * a.H + j];
-                if (a.c_prev) ecp = a.c_prev[(size_t)brow * a.H + j];
+                if (a.c_prev) ecp = a.c_prev[(size_t)(a.gather2 ? a.gather2[brow] : brow) * a.H + j];
             }
         } else {
             const int n = bx * 16 + 4 * g4;
@@ -166,6 +166,15 @@ int skinny_launch_pair(hipStream_t s, bool lstm, const SkinnyArgs& a0, const Ski
     dim3 grid(nb0 + nb1, (M + 15) / 16);
     if (lstm) hipLaunchKernelGGL((skinny_pair_kernel<true>), grid, dim3(256), 0, s, a0, a1, nb0);
     else hipLaunchKernelGGL((skinny_pair_kernel<false>), grid, dim3(256), 0, s, a0, a1, nb0);
+    return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
+}
+
+int skinny_launch(hipStream_t s, bool lstm, const SkinnyArgs& a) {
+    if (int rc = skinny_check(a)) return rc;
+    if (lstm ? (a.H <= 0 || (a.H & 3) || !a.c_out || !a.h_out) : (a.N <= 0 || !a.out)) return ASR_EINVAL;
+    dim3 grid(lstm ? (a.H + 3) / 4 : (a.N + 15) / 16, (a.M + 15) / 16);
+    if (lstm) hipLaunchKernelGGL((skinny_kernel<true, false>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((skinny_kernel<false, false>), grid, dim3(256), 0, s, a);
     return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
 }
 

@@ -248,6 +248,12 @@ int asr_beam_step(void* stream, const asr_dec_weights* w, const asr_lm_weights* 
                   const float* hf, const float* enc, const int* enc_len, const int* tokens,
                   const asr_beam_state* in, const asr_beam_state* out, float* scratch,
                   float* logits, float* logits_lm);
+/* asr_beam_step with the parent gather folded in: input row r = row sel[r] of `in` (sel on the device; NULL = identity).
+ * Needs both SimpleProjections absent (ASR_EUNSUPPORTED otherwise); `in` and `out` are then simply swapped every step. */
+int asr_beam_step_sel(void* stream, const asr_dec_weights* w, const asr_lm_weights* lm, const asr_dec_dims* d,
+                      const float* hf, const float* enc, const int* enc_len, const int* tokens, const int* sel,
+                      const asr_beam_state* in, const asr_beam_state* out, float* scratch,
+                      float* logits, float* logits_lm);
 /* Device-resident scoring, selection and bookkeeping of one beam step (beam_search.py:196-214, 290-327): float64
  * log-softmax of both logit vectors, score = log p_dec + lm_weight*log p_lm + carried, top-k per hypothesis then over
  * the continuations, parent = candidate / k, EOS -> finished list and k -= 1.  With asr_beam_gather (sel = ints + kmax)
