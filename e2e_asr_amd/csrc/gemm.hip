@@ -380,8 +380,10 @@ extern "C" int asr_gemm_f32_batched(void* stream, int transA, int transB, int M,
     // (summation order, hence the last bits, may differ from run to run).
     int splits = 1;
     const int nk = (K + BK - 1) / BK;
-    if (transA && batch == 1 && nwg < 192 && nk >= 64) {     // weight-gradient form only: forward products stay bit-reproducible
-        splits = std::min((768 + nwg - 1) / nwg, nk / 16);
+    // (batched only when accumulating: the split needs a pre-zeroed or live C, and only batch 1 is zeroed here)
+    const int tiles_all = nwg * batch;
+    if (transA && (batch == 1 || accumulate) && tiles_all < 192 && nk >= 64) {     // weight-gradient form only: forward products stay bit-reproducible
+        splits = std::min((768 + tiles_all - 1) / tiles_all, nk / 16);
         if (const char* e = getenv("ASR_GEMM_SPLITK")) splits = std::max(1, atoi(e));
     }
     g.splits = splits;
@@ -420,10 +422,10 @@ extern "C" int asr_gemm_f32_batched(void* stream, int transA, int transB, int M,
         // them co-resident with the persistent BPTT workgroup of the CU they share
         static const int ta_pad = [] { const char* e = getenv("ASR_GEMM_TA_PAD"); return e ? atoi(e) : 0; }();
         static const int xs = [] { const char* e = getenv("ASR_GEMM_XCD_SPLIT"); return e ? atoi(e) : 1; }();
-        if (transA && xs && splits >= 6 && batch == 1 && nk >= 128) {          // K slices pinned to XCDs: a multiple of 8 slices
+        if (transA && xs && splits >= 6 && nk >= 128 && (batch == 1 || (nwg * ((splits + 4) / 8 * 8)) % 8 == 0)) {   // K slices pinned to XCDs: a multiple of 8 slices
             g.splits = (splits + 4) / 8 * 8;
             g.xcd_split = 1;
-            hipLaunchKernelGGL((gemm_f32_kernel<true, false, 128, true>), dim3(nwg * g.splits, 1, 1), dim3(256), ta_pad, s, g);
+            hipLaunchKernelGGL((gemm_f32_kernel<true, false, 128, true>), dim3(nwg * g.splits, 1, batch), dim3(256), ta_pad, s, g);
             ASR_CHECK_LAUNCH();
             return ASR_OK;
         }

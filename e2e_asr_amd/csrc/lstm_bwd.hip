@@ -524,6 +524,9 @@ static int launch_bwd_h(hipStream_t s, const LstmBwdArgs& a, int R) {
 
 }  // namespace asr
 
+extern "C" int asr_gemm_f32_batched(void* stream, int transA, int transB, int M, int N, int K,
+                                    const float* A, int lda, long long strideA, const float* B, int ldb, long long strideB,
+                                    float* C, int ldc, long long strideC, const float* bias, int accumulate, int batch);
 extern "C" int asr_gemm_f32(void*, int, int, int, int, int, const float*, int, const float*, int,
                             float*, int, const float*, int);
 extern "C" int asr_colsum_f32(void* stream, const float* x, int ldx, int M, int N, float* out, int accumulate);
@@ -618,15 +621,29 @@ extern "C" int asr_lstm_layer_bwd(void* stream, const float* x, int B, int T, in
     void* side = static_cast<void*>(ss);
     hipEvent_t e_dg = next_event();
     if (hipEventRecord(e_dg, s) != hipSuccess || hipStreamWaitEvent(ss, e_dg, 0) != hipSuccess) return ASR_ELAUNCH;
+    // both directions of a product as ONE batched launch when the two gradient buffers sit a vector-aligned stride apart
+    // (they do in the flat gradient buffer): X is then streamed once for the two dK_x instead of twice, and a launch has
+    // twice the tiles (less split-K, fewer atomics)
+    const long long dks = ndir == 2 ? (long long)(dkernel_bw - dkernel_fw) : 0;
+    const bool fuse_dirs = ndir == 2 && dks % 4 == 0;
+    if (fuse_dirs) {
+        int rc;
+        if ((rc = asr_gemm_f32_batched(side, 1, 0, in_dim, H4, M, x, ldx, 0, gates, ndir * H4, H4, dkernel_fw, H4, dks, nullptr, 1, 2)))
+            return rc;
+        if ((rc = asr_gemm_f32_batched(side, 1, 0, H, H4, M, hprev, ndir * H, H, gates, ndir * H4, H4,
+                                       dkernel_fw + (size_t)in_dim * H4, H4, dks, nullptr, 1, 2))) return rc;
+    }
     for (int d = 0; d < ndir; ++d) {
         const float* dG = gates + (size_t)d * H4;
         const int ldg = ndir * H4;
         float* dK = d ? dkernel_bw : dkernel_fw;
         float* dB = d ? dbias_bw : dbias_fw;
         int rc;
-        if ((rc = asr_gemm_f32(side, 1, 0, in_dim, H4, M, x, ldx, dG, ldg, dK, H4, nullptr, 1))) return rc;
-        if ((rc = asr_gemm_f32(side, 1, 0, H, H4, M, hprev + (size_t)d * H, ndir * H, dG, ldg,
-                               dK + (size_t)in_dim * H4, H4, nullptr, 1))) return rc;
+        if (!fuse_dirs) {
+            if ((rc = asr_gemm_f32(side, 1, 0, in_dim, H4, M, x, ldx, dG, ldg, dK, H4, nullptr, 1))) return rc;
+            if ((rc = asr_gemm_f32(side, 1, 0, H, H4, M, hprev + (size_t)d * H, ndir * H, dG, ldg,
+                                   dK + (size_t)in_dim * H4, H4, nullptr, 1))) return rc;
+        }
         if (!db_part && (rc = asr_colsum_f32(side, dG, ldg, M, H4, dB, 1))) return rc;
     }
     hipEvent_t e_done = next_event();
