@@ -69,34 +69,86 @@ def gemm_roofline(dev):
             "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak, "avg_launch_ms": ms}
 
 
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline():
-    """CPU 'port' baseline: the torch twin of the oracle (oracle/torch_ref.py: per-timestep
-    BasicLSTMCell loops with masking exactly as dynamic_rnn/raw_rnn run them, float32, autograd
-    backward, TF clip + Adam arithmetic) doing ONE full train step on a bounded sample of the same
-    workload: the full batch of 32 utterances, same architecture, but T=192 frames and 30 target
-    tokens instead of 800/120 (cost per frame is independent of T: every layer is linear in T).
-    Threads = torch's intra-op pool on this host."""
+    """CPU 'port' baseline, SURVEY 8(d) protocol: the torch twin of the oracle (oracle/torch_ref.py: per-timestep
+    BasicLSTMCell loops with masking exactly as dynamic_rnn/raw_rnn run them, float32, autograd backward, TF clip +
+    Adam arithmetic) doing full train steps on a bounded sample of the same workload -- the full batch of 32 utterances,
+    same architecture, T=96 frames / 15 target tokens instead of 800/120 -- 1 warm-up + 3 timed iterations (median),
+    weight conversion outside the timer, with torch.set_num_threads(1) (faithful to train.py:178:
+    intra_op_parallelism_threads=1), 16 threads and all host cores.  A second size (T=192 / 30 tokens) at the fastest
+    thread setting shows the per-frame cost is flat in T (every layer is linear in T), so the sample stands for the
+    800-frame batch.  `value` is the FASTEST setting (the conservative choice for the >=10x target)."""
     import torch as th
     from e2e_asr_amd.weights import init_weights, synthetic_batch
     from oracle import torch_ref as R
-    Ts, tdec = 192, 31
     w = {k: v.astype(np.float32) for k, v in init_weights(seed=10).items()}
-    batch = synthetic_batch(B=B, T=Ts, F=F, t_dec=tdec, vocab=V)
-    t0 = time.time()
-    W = R.weights_to_torch(w, dtype=th.float32)
-    total, _, _ = R.seq2seq_loss(batch, W)
-    total.backward()
-    with th.no_grad():      # clip_by_global_norm + Adam (cost only; arithmetic as seq2seq_model.py:137-155)
-        gn = th.sqrt(sum((p.grad.double() ** 2).sum() for p in W.values()))
-        sc = 5.0 / max(float(gn), 5.0)
-        for p in W.values():
-            g = p.grad * sc
-            m = 0.1 * g; v = 0.001 * g * g
-            p -= 1e-3 * m / (v.sqrt() + 1e-8)
-    dt = time.time() - t0
-    return dict(value=B * Ts / dt, unit="frames/s", cores=int(th.get_num_threads()), kind="port",
-                sample="one full train step (fwd+bwd+clip+Adam, float32 torch twin of the oracle, per-timestep loops) on "
-                       "32 utterances x %d frames x 80 mel, %d target tokens; %.1f s" % (Ts, tdec - 1, dt))
+    ncpu = os.cpu_count() or 1
+    prev_threads = th.get_num_threads()
+
+    def run(nthreads, Ts, tdec, iters):
+        th.set_num_threads(nthreads)
+        batch = synthetic_batch(B=B, T=Ts, F=F, t_dec=tdec, vocab=V)
+        W = R.weights_to_torch(w, dtype=th.float32)          # conversion outside the timer
+        times = []
+        for it in range(iters + 1):                          # iteration 0 = warm-up
+            t0 = time.perf_counter()
+            for p in W.values():
+                p.grad = None
+            total, _, _ = R.seq2seq_loss(batch, W)
+            total.backward()
+            with th.no_grad():      # clip_by_global_norm + Adam (cost only; arithmetic as seq2seq_model.py:137-155)
+                gn = th.sqrt(sum((p.grad.double() ** 2).sum() for p in W.values()))
+                sc = 5.0 / max(float(gn), 5.0)
+                for p in W.values():
+                    g = p.grad * sc
+                    m = 0.1 * g; v = 0.001 * g * g
+                    p -= 1e-3 * m / (v.sqrt() + 1e-8)
+            if it:
+                times.append(time.perf_counter() - t0)
+        med = float(np.median(times))
+        return {"threads": nthreads, "frames": B * Ts, "T": Ts, "target_tokens": tdec - 1, "iters": iters,
+                "median_s": med, "frames_per_s": B * Ts / med}
+
+    runs = []
+    for nt in sorted(set([1, min(16, ncpu), ncpu])):
+        runs.append(run(nt, 96, 16, 3))
+    best = max(runs, key=lambda r: r["frames_per_s"])
+    flat = run(best["threads"], 192, 31, 2)                   # per-frame cost at twice the length, same threads
+    th.set_num_threads(prev_threads)
+    one = [r for r in runs if r["threads"] == 1][0]
+    return dict(value=best["frames_per_s"], unit="frames/s", cores=best["threads"], kind="port",
+                sample="full train steps (fwd+bwd+clip+Adam; float32 torch twin of the oracle, per-timestep loops) on 32 "
+                       "utterances x 96 frames x 80 mel, 15 target tokens; 1 warm-up + 3 timed iterations, median; "
+                       "value = fastest thread setting",
+                cpu_model=_cpu_model(), host_cores=ncpu,
+                threads_1_frames_per_s=one["frames_per_s"], threads_all_frames_per_s=[r for r in runs if r["threads"] == ncpu][0]["frames_per_s"],
+                runs=runs, flatness_check=flat,
+                per_frame_cost_ratio_T192_vs_T96=(flat["median_s"] / flat["frames"]) / (best["median_s"] / best["frames"]))
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher: start N fresh child ranks (one process per GPU, RCCL) under
+    torch.distributed.run and relay rank 0's JSON line.  Runs BEFORE anything in this process touches the GPU (never
+    re-exec a process that has initialised HIP)."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    r = subprocess.run(cmd, env=env)
+    sys.exit(r.returncode)
 
 
 def main():
@@ -115,9 +167,24 @@ def main():
     ap.add_argument("--graph", action="store_true", help="EXPERIMENT: replay one captured step as a hipGraph (step-varying scalars frozen)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)                                  # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and not (args.gpus == 1 and world == 1):
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("ASR_BENCH_SPAWN_TEST") == "1":
+        # CPU rehearsal of the launch path only (tests/test_bench_spawn.py): rendezvous over gloo, one all-reduce, the
+        # JSON line from rank 0 -- no GPU, no model, nothing timed
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"spawn_test": True, "n_gpus": world, "sum_of_ones": float(t.item())}))
+        dist.destroy_process_group()
+        return
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
@@ -219,13 +286,18 @@ def main():
     dom_ms = recb_per_step_ms if use_bwd else rec_per_step_ms
     dom_name = "lstm_rec_bwd_ag_kernel<256,2> (persistent BPTT)" if use_bwd else "lstm_rec_fwd_kernel<256,32,2> (persistent recurrent LSTM)"
     achieved = REC_FLOP_FWD / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else None
-    traffic = None
-    tp = os.path.join(ROOT, "profiles", "traffic_r01.json")
-    if os.path.exists(tp):
-        try:
-            traffic = json.load(open(tp)).get("lstm_rec_bwd_bytes_per_launch" if use_bwd else "lstm_rec_fwd_bytes_per_launch")
-        except Exception:
-            traffic = None
+    # HBM traffic per launch cannot be read by the process that is being timed (the PMC passes are separate rocprofv3
+    # runs, MI355X_MICROARCH.md): the committed summary of those passes is quoted, and its provenance is stated.
+    traffic, traffic_source = None, None
+    for name in ("traffic_r02.json", "traffic_r01.json"):
+        tp = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(tp):
+            try:
+                traffic = json.load(open(tp)).get("lstm_rec_bwd_bytes_per_launch" if use_bwd else "lstm_rec_fwd_bytes_per_launch")
+                traffic_source = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; not measured by this run)" % name
+                break
+            except Exception:
+                traffic = None
     out = {
         "metric": "encoder+decoder frames/sec at batch32x800frx80mel", "value": value, "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
@@ -243,12 +315,19 @@ def main():
         "roofline": {"bound": "mfma", "kernel": dom_name + ", 4 launches/step",
                      "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": (achieved / PEAK_F32_MFMA_TFLOPS) if achieved else None, "traffic": traffic,
+                     "traffic_source": traffic_source,
                      "avg_launch_ms": dom_ms / 4.0, "launches": (recb_n if use_bwd else rec_n),
                      "serial_chain_steps": sum(ENC_LAYER_T), "us_per_recurrent_step": dom_ms * 1e3 / sum(ENC_LAYER_T),
                      "note": "latency-bound serial chain of 1500 dependent steps; fp32 VALU/MFMA peak is the same 157.3 TF"},
         "phases_ms_per_step": {"lstm_rec_fwd": rec_per_step_ms, "lstm_rec_bwd": recb_ms / args.steps,
                                "decoder_fwd": decf_ms / args.steps},
     }
+    sum_len = int(np.sum(batch["logmel_len"])) * world
+    out["frames_true_sum_len_per_s"] = sum_len / (dt / args.steps)      # rate on the true sum of lengths next to padded B*T
+    out["frames_padded_per_step"], out["frames_true_per_step"] = frames, sum_len
+    out["input_residency"] = ("logmel resident in HBM before the timed region; the same batch every step, so token ids and "
+                              "lengths are uploaded once (devcache). PCIe-inclusive rate not measured: the batch is 8.2 MB "
+                              "= ~0.13 ms at 63 GB/s, ~1 % of a step")
     if comm is not None:
         out["comm"] = comm
     out["roofline_gemm"] = gemm_roofline(dev)

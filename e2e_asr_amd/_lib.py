@@ -112,6 +112,7 @@ SIGNATURES = {
     "asr_decoder_chain_bwd_ws_bytes": (C.c_size_t, [C.c_int] * 4),
     "asr_decoder_lm_chain_supported": (C.c_int, [C.c_int] * 2),
     "asr_zero_finished_rows": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int]),
+    "asr_resident_wg_budget": (C.c_int, []),
     "asr_prof_enable": (C.c_int, [C.c_int]),
     "asr_debug_set_buffer": (C.c_int, [vp]),
     "asr_prof_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]),

@@ -23,12 +23,9 @@ class AttnDecoder(Decoder):
         return params
 
     def __init__(self, isTraining, params=None, scope=None, variables=None):
-        super(AttnDecoder, self).__init__(isTraining=isTraining, params=params)
-        self.scope = scope
-        self.variables = variables
+        super(AttnDecoder, self).__init__(isTraining=isTraining, params=params, scope=scope, variables=variables)
         self.cell = self.get_cell()
         self.saved = None
-        self.rng_seed = 0
         self.coin_rng = np.random.default_rng(0)
 
     def weight_tensors(self):
@@ -55,8 +52,7 @@ class AttnDecoder(Decoder):
             raise ValueError("decoder input has %d steps, need %d" % (decoder_inp.shape[0], t_out))
         if p.lm_hidden_size != p.hidden_size_dec and dec_name(self.scope, "rnn/SimpleProjection/kernel") not in self.variables:
             raise ValueError("Could not find SimpleProjection weights for lm_hidden_size != hidden_size_dec")
-        feedback = self.prepare_decoder_input(decoder_inp, None)
-        mode = {"teacher": 0, "argmax": 1, "sample": 2}[feedback]
+        mode = self.feedback_mode()          # prepare_decoder_input's choice (decoder.py:100-113); the lookup itself is fused
         coin = None
         if mode == 2:   # one uniform scalar per step for the whole batch (attn_decoder.py:132)
             coin = self.coin_rng.random(t_out)

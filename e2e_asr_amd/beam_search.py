@@ -226,6 +226,7 @@ class BeamSearch(BaseParams):
             if s % 8 == 7 and int(state[1].item()) == 0:           # every hypothesis finished (:269)
                 break
         n_live, _, n_fin, n_steps = [int(x) for x in state.cpu().numpy()]
+        ops.check_device_flag(dev)
         bp_h, fin_h, fin_s, cum_h = bp.cpu().numpy(), fin.cpu().numpy(), fin_score.cpu().numpy(), cum.cpu().numpy()
 
         def backtrack(step, row):                  # tokens of the hypothesis that entered step `step + 1` as row `row`

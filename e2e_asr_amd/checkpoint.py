@@ -55,8 +55,15 @@ def restore(variables, path, with_optimizer=True):
                 if "%s/%s" % (name, slot) in arrays:
                     m[off:off + n].copy_(torch.from_numpy(arrays["%s/%s" % (name, slot)].reshape(-1)).to(m.device))
                     v[off:off + n].copy_(torch.from_numpy(arrays["%s/%s_1" % (name, slot)].reshape(-1)).to(v.device))
-    lr = float(arrays["learning_rate"]) if "learning_rate" in arrays else None
-    return int(arrays.get("global_step", 0)), lr
+    lr = float(np.asarray(arrays["learning_rate"]).reshape(-1)[0]) if "learning_rate" in arrays else None
+    return int(np.asarray(arrays.get("global_step", 0)).reshape(-1)[0]), lr
+
+
+def load_scalars(path, keys):
+    """The non-tensor state a TF checkpoint of the reference carries besides weights and slots (epoch counters, the LM's
+    step counter and learning-rate variable): {key: python scalar} for the keys present."""
+    arrays = load(path)
+    return {k: arrays[k].reshape(-1)[0].item() for k in keys if k in arrays}
 
 
 def restore_common_variables(variables, path):

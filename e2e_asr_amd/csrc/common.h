@@ -38,6 +38,11 @@ namespace asr {
 
 void prof_begin(int tag, hipStream_t s);   // prof.hip
 void prof_end(int tag, hipStream_t s);
+// Workgroups of ONE persistent launch that are certainly co-resident: the compute units of the current device (each of
+// the persistent kernels is one 512-thread workgroup per CU), optionally lowered by ASR_LSTM_MAXWG.  Every persistent
+// launch sizes its grid by this; a group that does not fit returns ASR_EUNSUPPORTED instead of spinning into the
+// exchange timeout (prof.hip).
+int resident_wg_budget();
 hipStream_t side_stream();                 // prof.hip: library-owned side stream + pooled events
 hipEvent_t next_event();
 void set_pending_join(hipEvent_t e);

@@ -467,6 +467,7 @@ extern "C" int asr_decoder_chain_rows(int Te) { return Te <= 256 ? 2 : 1; }
 extern "C" int asr_decoder_chain_supported(int B, int Te, int D, int A, int H) {
     if (getenv("ASR_DEC_CHAIN") && atoi(getenv("ASR_DEC_CHAIN")) == 0) return 0;
     if (Te > 512 || Te <= 0 || B <= 0) return 0;
+    if (asr::resident_wg_budget() < 16) return 0;          // one 16-workgroup group must be co-resident
     return (H == 256 && D == 512 && A == 128) || (H == 64 && D == 128 && A == 16);
 }
 
@@ -536,8 +537,9 @@ int asr_decoder_chain_fwd(void* stream, float* gates, const float* wh, const flo
     a.xcc_slots = a.gx + groups * 2 * chain_npar(R, D, A, H);
     a.err = err; a.B = B; a.Te = Te; a.t0 = t0; a.t1 = t1;
     a.dbg = getenv("ASR_CHAIN_STAMP") ? asr::g_lstm_dbg : nullptr;
-    for (int g0 = 0; g0 < (int)groups; g0 += 16) {
-        a.g0 = g0; a.ng = std::min<int>(16, (int)groups - g0);
+    const int gpl = std::min(16, asr::resident_wg_budget() / 16);     // groups per launch: all of them co-resident
+    for (int g0 = 0; g0 < (int)groups; g0 += gpl) {
+        a.g0 = g0; a.ng = std::min<int>(gpl, (int)groups - g0);
         int rc;
         if (H == 256) rc = R == 2 ? chain_launch<256, 512, 128, 2>(s, a, Te) : chain_launch<256, 512, 128, 1>(s, a, Te);
         else rc = R == 2 ? chain_launch<64, 128, 16, 2>(s, a, Te) : chain_launch<64, 128, 16, 1>(s, a, Te);

@@ -749,8 +749,9 @@ int asr_decoder_chain_bwd(void* stream, float* gates, const float* dec_c, const 
     a.xcc_slots = reinterpret_cast<u64*>(static_cast<char*>(ws) + chain_bwd_ws_bytes_r(B, D, A, H, R)) - ((size_t)groups * 16);
     a.err = err; a.B = B; a.Te = Te; a.T = T;
     a.dbg = getenv("ASR_CHAIN_STAMP") ? asr::g_lstm_dbg : nullptr;
-    for (int g0 = 0; g0 < groups; g0 += 16) {          // 16 groups = 256 workgroups per launch
-        a.g0 = g0; a.ng = groups - g0 < 16 ? groups - g0 : 16;
+    const int gpl = std::min(16, asr::resident_wg_budget() / 16);     // 16 groups = 256 workgroups per launch on a whole MI355X
+    for (int g0 = 0; g0 < groups; g0 += gpl) {
+        a.g0 = g0; a.ng = groups - g0 < gpl ? groups - g0 : gpl;
         int rc;
         if (H == 256) rc = R == 2 ? chain_bwd_launch<256, 512, 128, 2>(s, a) : chain_bwd_launch<256, 512, 128, 1>(s, a);
         else rc = R == 2 ? chain_bwd_launch<64, 128, 16, 2>(s, a) : chain_bwd_launch<64, 128, 16, 1>(s, a);

@@ -542,6 +542,7 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
 extern "C" int asr_decoder_greedy_supported(int B, int Te, int D, int A, int H, int lmH, int E, int V) {
     if (getenv("ASR_DEC_GREEDY") && atoi(getenv("ASR_DEC_GREEDY")) == 0) return 0;
     (void)E;
+    if (asr::resident_wg_budget() < 256) return 0;         // 8 one-XCD groups of 32 workgroups per launch must be co-resident
     return B > 0 && Te > 0 && Te <= 256 && V > 0 && V <= 1024 && H == 256 && D == 512 && A == 128 && lmH == 256;
 }
 

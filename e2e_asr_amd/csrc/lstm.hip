@@ -319,10 +319,7 @@ extern "C" int asr_gemm_f32(void*, int, int, int, int, int, const float*, int, c
 
 // rows per group: smallest R whose grid fits one workgroup per CU (256 CUs); override for tuning
 // resident-workgroup budget of one recurrent launch (tuning knob; default one workgroup per CU)
-int asr_lstm_max_wgs() {
-    static const int v = [] { const char* e = getenv("ASR_LSTM_MAXWG"); const int x = e ? atoi(e) : 256; return x >= 64 ? x : 256; }();
-    return v;
-}
+int asr_lstm_max_wgs() { return asr::resident_wg_budget(); }
 int asr_lstm_pick_rows(int B, int ND, int G) {
     if (const char* e = getenv("ASR_LSTM_R")) { int r = atoi(e); if (r == 1 || r == 2 || r == 4 || r == 8) return r; }
     for (int R : {1, 2, 4, 8})
@@ -373,7 +370,8 @@ extern "C" int asr_lstm_layer_fwd(void* stream, const float* x, int B, int T, in
     const int R = asr_lstm_pick_rows(B, ndir, H / 32);
     // batches too large for one resident grid run as consecutive launches over row ranges
     const int max_groups = asr_lstm_max_wgs() / (H / 32) / ndir;
-    const int rows_per_launch = max_groups > 0 ? max_groups * R : R;
+    if (max_groups < 1) return ASR_EUNSUPPORTED;      // one group (both directions) cannot be co-resident on this device
+    const int rows_per_launch = max_groups * R;
     for (int b0 = 0; b0 < B; b0 += rows_per_launch) {
         LstmRecArgs c = a;
         const int nb = (B - b0 < rows_per_launch) ? (B - b0) : rows_per_launch;

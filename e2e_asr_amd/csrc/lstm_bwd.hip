@@ -579,7 +579,8 @@ extern "C" int asr_lstm_layer_bwd(void* stream, const float* x, int B, int T, in
     float* db_part = (ag_env && R <= 2) ? reinterpret_cast<float*>(static_cast<char*>(hx_ws) + lstm_bwd_sync_bytes(B, H, ndir)) : nullptr;
     a.db_part = db_part;
     const int max_groups = asr_lstm_max_wgs() / G / ndir;
-    const int rows_per_launch = max_groups > 0 ? max_groups * R : R;
+    if (max_groups < 1) return ASR_EUNSUPPORTED;      // one group (both directions) cannot be co-resident on this device
+    const int rows_per_launch = max_groups * R;
     for (int b0 = 0; b0 < B; b0 += rows_per_launch) {
         if (hipMemsetAsync(hx_ws, 0, lstm_bwd_sync_bytes(B, H, ndir), s) != hipSuccess) return ASR_ELAUNCH;
         LstmBwdArgs c = a;

@@ -49,6 +49,29 @@ extern "C" int asr_prof_read(int tag, double* total_ms, int* launches) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Co-residency budget of the persistent kernels.  They exchange data between workgroups of one launch without a grid
+// barrier, which is only safe when all those workgroups are resident at once: one 512-thread workgroup per compute unit
+// is guaranteed (each fits a CU's registers and LDS alone), so the budget is the CU count the runtime reports for the
+// current device -- 256 on an MI355X, fewer on a partitioned (CPX/DPX) or otherwise reduced device.
+// ---------------------------------------------------------------------------------------------
+namespace asr {
+int resident_wg_budget() {
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (cus[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 1;
+        cus[dev] = n;
+    }
+    int budget = cus[dev];
+    if (const char* e = getenv("ASR_LSTM_MAXWG")) { const int x = atoi(e); if (x > 0 && x < budget) budget = x; }
+    return budget;
+}
+}  // namespace asr
+extern "C" int asr_resident_wg_budget(void) { return asr::resident_wg_budget(); }
+
+// ---------------------------------------------------------------------------------------------
 // Side stream for the decoder's LM chain (decoder.hip / decoder_bwd.hip): created once, lazily.
 // Events are pooled and reused; record/wait pairs are legal inside hipGraph capture (fork/join).
 // ---------------------------------------------------------------------------------------------

@@ -16,9 +16,12 @@ class Decoder(BaseParams):
         return Bunch(out_prob_dec=0.9, hidden_size_dec=256, num_layers_dec=1, emb_size=256,
                      vocab_size=1000, samp_prob=0.1, max_output=400, use_lstm=True)
 
-    def __init__(self, isTraining=True, params=None):
+    def __init__(self, isTraining=True, params=None, scope=None, variables=None):
         self.params = self.class_params() if params is None else params
         self.isTraining = isTraining
+        self.scope = scope              # task name: variables live under model/rnn_decoder_<scope>/
+        self.variables = variables
+        self.rng_seed = 0
 
     def get_cell(self, hidden_size=None):
         """decoder.py:49-72.  The cell itself is csrc/skinny.hip's fused LSTM epilogue."""
@@ -35,27 +38,55 @@ class Decoder(BaseParams):
             state = state[-1]
         return state[0] if self.params.use_lstm else state      # state = (c, h)
 
-    def prepare_decoder_input(self, decoder_inputs, embedding):
-        """decoder.py:84-115: which feedback the loop uses.  The embedding lookup itself is
-        fused into the lm-cell kernel as a row gather."""
+    def embedding(self):
+        from .weights import dec_name
+        return self.variables[dec_name(self.scope, "decoder/embedding")]
+
+    def feedback_mode(self):
+        """Which feedback the loop uses (decoder.py:100-113): 0 teacher forcing, 1 argmax, 2 scheduled sampling."""
         if self.isTraining:
-            return "sample" if self.params.samp_prob > 0 else "teacher"
-        return "argmax"
+            return 2 if self.params.samp_prob > 0 else 0
+        return 1
+
+    def prepare_decoder_input(self, decoder_inputs):
+        """decoder.py:84-115: decoder_inputs [T,B] ids -> (embedded_inp [T,B,E], loop_function).  loop_function is None
+        under pure teacher forcing, `_sample_argmax` with scheduled sampling, `_get_argmax` in the inference graph.
+        (AttnDecoder.__call__ fuses the lookup into the LM-cell input GEMM as a row gather and the feedback into the
+        persistent kernels; it only asks `feedback_mode()`.  This method is the reference's boundary and is what a
+        caller composing its own loop uses.)"""
+        emb = self.embedding()
+        ids = decoder_inputs if torch.is_tensor(decoder_inputs) else torch.as_tensor(decoder_inputs)
+        ids = ids.to(emb.device, torch.int32).contiguous()
+        embedded_inp = ops.gather_rows(emb, ids.reshape(-1)).view(tuple(ids.shape) + (emb.shape[1],))
+        mode = self.feedback_mode()
+        if mode == 2:
+            print("Scheduled sampling!")
+            loop_function = self._sample_argmax(emb)
+        elif mode == 0:
+            loop_function = None
+        else:
+            loop_function = self._get_argmax(emb)
+        return embedded_inp, loop_function
 
     @abc.abstractmethod
     def __call__(self, decoder_inp, seq_len, encoder_hidden_states, seq_len_inp):
         pass
 
     def _get_argmax(self, embedding):
-        """decoder.py:139-154."""
+        """decoder.py:139-154: embed the arg-max symbol (first maximum, as tf.argmax / np.argmax)."""
         def loop_function(logits):
-            return embedding[ops.next_token(logits).long()]
+            return ops.gather_rows(embedding, ops.next_token(logits))
         return loop_function
 
-    def _sample_argmax(self, embedding, seed=0):
-        """decoder.py:156-180 (tf.multinomial -> Gumbel-max on device)."""
-        def loop_function(prev, step=0):
-            return embedding[ops.next_token(prev, sample=True, seed=seed, step=step).long()]
+    def _sample_argmax(self, embedding):
+        """decoder.py:156-180: embed a symbol drawn from softmax(prev) (tf.multinomial -> Gumbel-max on the device with a
+        counter-based generator keyed on (rng_seed, call index, row, symbol))."""
+        calls = [0]
+
+        def loop_function(prev):
+            tok = ops.next_token(prev, sample=True, seed=self.rng_seed, step=calls[0])
+            calls[0] += 1
+            return ops.gather_rows(embedding, tok)
         return loop_function
 
     @classmethod

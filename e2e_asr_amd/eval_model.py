@@ -7,7 +7,7 @@ import os
 
 import numpy as np
 
-from . import data_utils, swbd_utils
+from . import data_utils, ops, swbd_utils
 from .base_params import BaseParams, Bunch
 
 
@@ -81,6 +81,13 @@ class Eval(BaseParams):
         sent = "".join(pieces).replace(u"▁", " ").strip()
         return normalizer(sent) if normalizer else sent
 
+    def _check_flag(self):
+        """A persistent kernel whose exchange timed out leaves zeros and a device flag: raise instead of scoring
+        garbage hypotheses (the host has already synchronised on the ids at this point)."""
+        dev = getattr(self.model, "device", None)
+        if dev is not None and getattr(dev, "type", str(dev)[:4]) == "cuda":
+            ops.check_device_flag(dev)
+
     def _out_files(self, names):
         d = getattr(self.params, "best_model_dir", "") or ""
         if self.rev_char_vocab is None or not os.path.isdir(d):
@@ -119,6 +126,7 @@ class Eval(BaseParams):
         finally:
             for f in files or []:
                 f.close()
+        self._check_flag()
         return total_err / float(total_len) if total_len else 0.0
 
     def exec_encoder(self, batches):
@@ -129,13 +137,15 @@ class Eval(BaseParams):
         for batch in batches:
             self.model.forward(batch)
             enc = self.model.encoder_hidden_states[depth].cpu().numpy()
-            lens = self.model.seq_len_encs[depth].cpu().numpy()
+            lens = self.model.seq_len_encs[depth]                      # host int64 array (Encoder.__call__)
+            lens = np.asarray(lens.cpu() if hasattr(lens, "cpu") else lens)
             gold = np.asarray(batch["char"])
             utt_ids = batch.get("utt_id", [str(len(utt_id_list) + i) for i in range(enc.shape[0])])
             for i in range(enc.shape[0]):
                 hidden_states_list.append(enc[i, :int(lens[i])])
                 utt_id_list.append(utt_ids[i])
                 gold_id_list.append(gold[i][1:])
+        self._check_flag()
         return hidden_states_list, utt_id_list, gold_id_list
 
     def beam_search_decode(self, batches, beam_search, get_counts=False):

@@ -89,12 +89,43 @@ def check_device_flag(dev):
 _hx_cache = {}
 
 
+LSTM_KERNEL_H = (64, 128, 256, 512)     # instantiated widths of the persistent recurrent kernels (csrc/lstm.hip)
+
+
+def _padded_h(H):
+    for hp in LSTM_KERNEL_H:
+        if H <= hp:
+            return hp
+    raise ValueError("hidden size %d: the recurrent kernels go up to %d units" % (H, LSTM_KERNEL_H[-1]))
+
+
+def _pad_lstm_weights(kernel, bias, IN, H, Hp):
+    """TF kernel [IN+H,4H] / bias [4H] (gates i,j,f,o) embedded in a width-Hp cell: the extra units have all-zero
+    weights, so their state stays c = 0, h = sigmoid(0).tanh(0) = 0 for ever and they feed nothing into the real units
+    (their K_h ROWS are zero too) -- the first H units compute exactly the width-H cell."""
+    kp = kernel.new_zeros((IN + Hp, 4, Hp))
+    k3 = kernel.view(IN + H, 4, H)
+    kp[:IN, :, :H] = k3[:IN]
+    kp[IN:IN + H, :, :H] = k3[IN:]
+    bp = None
+    if bias is not None:
+        bp = bias.new_zeros((4, Hp))
+        bp[:, :H] = bias.view(4, H)
+        bp = bp.view(4 * Hp)
+    return kp.view(IN + Hp, 4 * Hp), bp
+
+
 def lstm_layer_fwd(x, seq_len, kernel_fw, bias_fw, kernel_bw=None, bias_bw=None, t_out=None,
                    save=False, keep_prob=1.0, seed=0):
     """One (Bi)LSTM layer (encoder.py:55-91).  x [B,T,in] batch-major, seq_len int32 [B].
 
     Returns out [B,t_out,ndir*H] (zeros past each length) and, when save=True, the
     gates workspace, activation records [B,T,ndir,H,8] and hprev [B,T,ndir,H] for the backward pass.
+
+    Any hidden size up to 512 (encoder.py:188-189 takes any -hsize): widths the persistent kernels are not instantiated
+    for run zero-padded to the next instantiated width (exact, see _pad_lstm_weights; the recurrence is latency-bound, so
+    the padding costs little), the saved tensors are then in the padded width.  Dropout there draws its mask over the
+    padded column index, i.e. a different but equally distributed mask.
     """
     _f32(x, "x"); _i32(seq_len, "seq_len")
     B, T, IN = x.shape
@@ -102,6 +133,14 @@ def lstm_layer_fwd(x, seq_len, kernel_fw, bias_fw, kernel_bw=None, bias_bw=None,
     ndir = 1 if kernel_bw is None else 2
     if kernel_fw.shape[0] != IN + H:
         raise ValueError("lstm kernel rows %d != in+H = %d" % (kernel_fw.shape[0], IN + H))
+    if H not in LSTM_KERNEL_H:
+        Hp = _padded_h(H)
+        kf, bf = _pad_lstm_weights(kernel_fw, bias_fw, IN, H, Hp)
+        kb, bb = _pad_lstm_weights(kernel_bw, bias_bw, IN, H, Hp) if ndir == 2 else (None, None)
+        r = lstm_layer_fwd(x, seq_len, kf, bf, kb, bb, t_out=t_out, save=save, keep_prob=keep_prob, seed=seed)
+        outp = r[0] if save else r
+        out = torch.cat([outp[:, :, d * Hp:d * Hp + H] for d in range(ndir)], 2).contiguous()
+        return (out,) + tuple(r[1:]) if save else out
     t_out = T if t_out is None else t_out
     dev = x.device
     out = torch.empty((B, t_out, ndir * H), device=dev, dtype=torch.float32)
@@ -137,6 +176,24 @@ def lstm_layer_bwd(x, seq_len, kernel_fw, kernel_bw, dout, gates, act, hprev, dk
     H = kernel_fw.shape[1] // 4
     ndir = 1 if kernel_bw is None else 2
     dev = x.device
+    if H not in LSTM_KERNEL_H:          # saved tensors are in the padded width (see lstm_layer_fwd)
+        Hp = gates.shape[-1] // 4
+        kf, _ = _pad_lstm_weights(kernel_fw, None, IN, H, Hp)
+        kb = _pad_lstm_weights(kernel_bw, None, IN, H, Hp)[0] if ndir == 2 else None
+        doutp = dout.new_zeros((B, dout.shape[1], ndir * Hp))
+        for d in range(ndir):
+            doutp[:, :, d * Hp:d * Hp + H] = dout[:, :, d * H:(d + 1) * H]
+        gk = [kf.new_zeros(kf.shape) for _ in range(ndir)]
+        gb = [kf.new_zeros(4 * Hp) for _ in range(ndir)]
+        dx = lstm_layer_bwd(x, seq_len, kf, kb, doutp, gates, act, hprev, gk[0], gb[0], gk[1] if ndir == 2 else None,
+                            gb[1] if ndir == 2 else None, need_dx=need_dx, keep_prob=keep_prob, seed=seed, join=True)
+        for d, (dk, db) in enumerate(((dk_fw, db_fw), (dk_bw, db_bw))[:ndir]):
+            g3 = gk[d].view(IN + Hp, 4, Hp)
+            dk3 = dk.view(IN + H, 4, H)
+            dk3[:IN] += g3[:IN, :, :H]
+            dk3[IN:] += g3[IN:IN + H, :, :H]
+            db.view(4, H).add_(gb[d].view(4, Hp)[:, :H])
+        return dx
     dx = torch.empty_like(x) if need_dx else None
     L = _lib.lib()
     nbytes = L.asr_lstm_bwd_ws_bytes(B, H, ndir)

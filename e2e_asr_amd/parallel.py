@@ -18,8 +18,26 @@ import torch
 import torch.distributed as dist
 
 
+class TorchDistComm(object):
+    """The exchange as DataParallel sees it: torch.distributed (backend "nccl" = RCCL on ROCm, "gloo" in the CPU tests)."""
+
+    def __init__(self, process_group=None):
+        if not dist.is_initialized():
+            raise RuntimeError("DataParallel needs torch.distributed.init_process_group() first")
+        self.group = process_group
+        self.world = dist.get_world_size(process_group)
+        self.rank = dist.get_rank(process_group)
+
+    def broadcast(self, t, src=0):
+        dist.broadcast(t, src=src, group=self.group)
+
+    def all_reduce(self, t, async_op=False):
+        """Sum over ranks, in place.  Returns a work handle (`.wait()`) when async_op."""
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+
+
 class DataParallel(object):
-    def __init__(self, model, process_group=None, overlap=None):
+    def __init__(self, model, process_group=None, overlap=None, comm=None):
         """overlap=None reads ASR_DP_OVERLAP (default off): the default path is ONE blocking all-reduce of
         the whole flat gradient after backward -- 42.5 MB, well under a millisecond of a >20 ms step,
         and the simplest thing that is correct by construction.  overlap=True launches the per-bucket
@@ -27,19 +45,33 @@ class DataParallel(object):
         import os
         if overlap is None:
             overlap = os.environ.get("ASR_DP_OVERLAP", "0") == "1"
-        if not dist.is_initialized():
-            raise RuntimeError("DataParallel needs torch.distributed.init_process_group() first")
-        self.group = process_group
-        self.world = dist.get_world_size(process_group)
-        self.rank = dist.get_rank(process_group)
+        self.comm = TorchDistComm(process_group) if comm is None else comm
+        self.world, self.rank = self.comm.world, self.comm.rank
         self.overlap = overlap
         self._pending = []
-        self._covered = 0
+        self._done = set()
         self._n = model.variables.flat.numel()
         # identical initial weights everywhere (rank 0's), like a restored checkpoint
-        dist.broadcast(model.variables.flat, src=0, group=process_group)
+        self.comm.broadcast(model.variables.flat, src=0)
         self.buckets = self.bucket_ranges(model.variables)
+        if overlap and not self.buckets_partition(self.buckets, self._n):
+            # e.g. a VariableStore built in another key order: the decoder hull would overlap encoder ranges and those
+            # regions would be reduced twice.  One blocking all-reduce of the whole buffer is always correct.
+            self.overlap = False
         model.dist = self
+        # dropout masks and the sampler's noise are per replica (a TF replica draws its own); the scheduled-sampling COIN
+        # stays common to all ranks (attn_decoder.py:132 draws one scalar for the whole batch)
+        model.rank_seed = (self.rank * 0x9E3779B1) & 0x7FFFFFFF
+
+    @staticmethod
+    def buckets_partition(buckets, n):
+        """True when the bucket ranges are pairwise disjoint and their union is exactly [0, n)."""
+        pos = 0
+        for lo, hi in sorted(r for _, r in buckets):
+            if lo != pos or hi <= lo:
+                return False
+            pos = hi
+        return pos == n
 
     @staticmethod
     def bucket_ranges(variables):
@@ -66,26 +98,29 @@ class DataParallel(object):
             ops.side_join()                  # weight gradients are produced on the side stream
         for k, (lo, hi) in self.buckets:
             if k == key:
-                self._pending.append(dist.all_reduce(flat_grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group,
-                                                     async_op=True))
-                self._covered += hi - lo
+                if k in self._done:
+                    raise RuntimeError("gradient bucket %r reduced twice in one step" % (k,))
+                self._pending.append(self.comm.all_reduce(flat_grad[lo:hi], async_op=True))
+                self._done.add(k)
 
     def all_reduce_grads(self, flat_grad):
         """Finish the exchange; returns N so the caller scales by 1/N."""
         if self.world > 1:
             if self._pending:
                 for w in self._pending:
-                    w.wait()
-                if self._covered != sum(hi - lo for _, (lo, hi) in self.buckets):
-                    raise RuntimeError("gradient buckets incomplete: %d of %d elements reduced" % (self._covered, self._n))
+                    if w is not None:
+                        w.wait()
+                missing = [k for k, _ in self.buckets if k not in self._done]
+                if missing:
+                    raise RuntimeError("gradient buckets incomplete: %r never became ready" % (missing,))
             else:
-                dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.group)
-        self._pending, self._covered = [], 0
+                self.comm.all_reduce(flat_grad)
+        self._pending, self._done = [], set()
         return self.world
 
     def all_reduce_scalar_mean(self, t):
         if self.world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            self.comm.all_reduce(t)
             t /= self.world
         return t
 
@@ -97,4 +132,10 @@ def shard_batch(batch, rank, world):
         raise ValueError("global batch %d is not divisible by world size %d" % (B, world))
     per = B // world
     sl = slice(rank * per, (rank + 1) * per)
-    return {k: (v[sl] if hasattr(v, "__len__") and len(v) == B else v) for k, v in batch.items()}
+    shard = {k: (v[sl] if hasattr(v, "__len__") and len(v) == B else v) for k, v in batch.items()}
+    # a replica's batch is padded to ITS longest utterance, as its own padded_batch would have done
+    # (speech_dataset.py:53 padded_batch): the pyramid's pad-and-reshape (encoder.py:100-115) needs T == max(len)
+    t_max = int(max(shard["logmel_len"]))
+    if shard["logmel"].shape[1] > t_max:
+        shard["logmel"] = shard["logmel"][:, :t_max]
+    return shard

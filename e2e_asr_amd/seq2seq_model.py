@@ -61,6 +61,7 @@ class Seq2SeqModel(BaseParams):
         self.outputs, self.losses, self.total_loss = {}, {}, None
         self.encoder_hidden_states, self.time_major_states, self.seq_len_encs = {}, {}, {}
         self.dist = None           # set by parallel.DataParallel
+        self.rank_seed = 0         # set by parallel.DataParallel: decorrelates dropout / sampler noise across replicas
         self._loss_ws = {}
 
     # ------------------------------------------------------------------ variables
@@ -75,7 +76,7 @@ class Seq2SeqModel(BaseParams):
             tasks=tasks, vocab={t: params.decoder_params[t].vocab_size for t in tasks},
             emb=dp.emb_size, hidden_dec=dp.hidden_size_dec, lm_hidden=dp.lm_hidden_size,
             attn_vec=dp.attention_vec_size, seed=seed, skip_step=ep.skip_step,
-            max_scaling_down=ep.max_scaling_down)
+            max_scaling_down=ep.max_scaling_down, initial_res_fac=ep.initial_res_fac)
         return VariableStore.from_arrays(arrays, device)
 
     def learning_rate_decay_op(self):
@@ -127,14 +128,14 @@ class Seq2SeqModel(BaseParams):
         for task in params.tasks:
             self.targets[task], self.target_weights[task] = create_shifted_targets(
                 self.decoder_inputs[task], self.seq_len_target[task])
-        self.encoder.dropout_seed = self.global_step
+        self.encoder.dropout_seed = (self.global_step ^ self.rank_seed) & 0x7FFFFFFF
         self.encoder_hidden_states, self.time_major_states, self.seq_len_encs = self.encoder(
             self.encoder_inputs, self.seq_len, {t: params.num_layers[t] for t in params.tasks})
         self.outputs = {}
         for task in params.tasks:
             d = params.num_layers[task]
             dec = self.decoder[task]
-            dec.rng_seed = (self.global_step * 2654435761 + sum(map(ord, task)) % 9973) & 0x7FFFFFFF
+            dec.rng_seed = ((self.global_step * 2654435761 + sum(map(ord, task)) % 9973) ^ self.rank_seed) & 0x7FFFFFFF
             if not self.isTraining and self.decoder_inputs[task].shape[0] < params.max_output[task]:
                 pad = params.max_output[task] - self.decoder_inputs[task].shape[0]
                 self.decoder_inputs[task] = torch.cat(

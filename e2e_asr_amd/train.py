@@ -35,7 +35,8 @@ class Train(BaseParams):
                      feat_length=80, data_dir="", lm_data_dir="", vocab_dir="", train_base_dir="",
                      train_dir="/tmp/asr_train", best_model_dir="/tmp/asr_train/best", lm_prob=0.0,
                      lm_params=LMModel.class_params(), lm_enc_params=LMEncoder.class_params(), run_id=1,
-                     steps_per_checkpoint=500, pretrain_lm_path="", pretrain_phone_path="", chaos=False, subset_file="")
+                     steps_per_checkpoint=500, pretrain_lm_path="", pretrain_phone_path="", chaos=False, subset_file="",
+                     steps_per_epoch=3006)      # train.py:217: "For default setup it's 3006" (epoch = global_step / 3006)
 
     def __init__(self, model_params, train_params=None, device="cuda:0"):
         self.params = self.class_params() if train_params is None else train_params
@@ -124,6 +125,7 @@ class Train(BaseParams):
         lm_model = None
         if params.lm_prob > 0:
             lm_model = LMModel(LMEncoder(params=params.lm_enc_params, variables=model.variables), params=params.lm_params)
+        self.lm_model = lm_model
         latest = os.path.join(params.train_dir, "checkpoint.txt")
         asr_err_best = 1.0
         if os.path.isfile(latest):                                                  # resume (train.py:205-215)
@@ -131,6 +133,14 @@ class Train(BaseParams):
             model.global_step, lr = checkpoint.restore(model.variables, ck)
             if lr is not None:
                 model.learning_rate = lr
+            # the TF checkpoint also carries the LM's step counter (AdamLM's beta powers follow it), its learning-rate
+            # variable and both epoch counters (tf.global_variables(), train.py:202): restore them too
+            extra = checkpoint.load_scalars(ck, ("epoch", "lm_global_step", "lm_learning_rate", "lm_epoch"))
+            model.epoch = int(extra.get("epoch", model.epoch))
+            if lm_model is not None:
+                lm_model.lm_global_step = int(extra.get("lm_global_step", 0))
+                lm_model.learning_rate = float(extra.get("lm_learning_rate", lm_model.learning_rate))
+                lm_model.epoch = int(extra.get("lm_epoch", 0))
             score_file = os.path.join(params.train_dir, "best.txt")
             if os.path.isfile(score_file):
                 try:
@@ -152,7 +162,10 @@ class Train(BaseParams):
         loss, current_step, lm_loss, lm_steps = 0.0, 0, 0.0, 0
         ckpt_start = time.time()
         lm_iter = iter(lm_set) if lm_set is not None else None
-        epoch = model.epoch
+        epoch = model.global_step // max(1, int(params.steps_per_epoch))              # train.py:217
+        save_extra = lambda: dict(epoch=model.epoch, **(dict(
+            lm_global_step=lm_model.lm_global_step, lm_learning_rate=lm_model.learning_rate, lm_epoch=lm_model.epoch)
+            if lm_model is not None else {}))
         while epoch <= params.max_epochs:
             print("\nEpochs done: %d" % epoch)
             active = [iter(s) for s in buck_train_sets]                              # train.py:261-266
@@ -167,6 +180,7 @@ class Train(BaseParams):
                         lm_iter = iter(lm_set)
                         continue
                     lm_loss += float(lm_model.step(lm_batch).item()) / params.steps_per_checkpoint
+                    ops.check_device_flag(model.device)
                     lm_steps += 1
                     if lm_steps % params.steps_per_checkpoint == 0:
                         print("LM steps: %d, Perplexity: %f" % (lm_model.lm_global_step,
@@ -181,12 +195,12 @@ class Train(BaseParams):
                 step_loss = model.step(batch)["char"]
                 current_step += 1
                 loss += float(step_loss.item()) / params.steps_per_checkpoint
+                ops.check_device_flag(model.device)      # the host is synchronised here anyway: a timed-out persistent kernel raises now
                 if current_step % params.steps_per_checkpoint:
                     continue
                 perplexity = math.exp(loss) if loss < 300 else float("inf")           # :305-312
                 print("Step %d Learning rate %.4f Checkpoint time %.2f Perplexity %.2f" % (
                     model.global_step, model.learning_rate, time.time() - ckpt_start, perplexity))
-                ops.check_device_flag(model.device)      # a persistent kernel that timed out raises here
                 asr_err_cur = self.eval_model.greedy_decode(dev_set)                  # :322
                 print("ASR error: %.4f" % asr_err_cur)
                 with open(os.path.join(params.train_dir, "asr_err.txt"), "a") as f:
@@ -204,9 +218,9 @@ class Train(BaseParams):
                     with open(os.path.join(params.train_dir, "best.txt"), "w") as f:
                         f.write(str(asr_err_best))
                     checkpoint.save(os.path.join(params.best_model_dir, "asr.ckpt-%d" % model.global_step),
-                                    model.variables, model.global_step, model.learning_rate)
+                                    model.variables, model.global_step, model.learning_rate, extra=save_extra())
                 ck = checkpoint.save(os.path.join(params.train_dir, "asr.ckpt-%d" % model.global_step),
-                                     model.variables, model.global_step, model.learning_rate)   # :370-371
+                                     model.variables, model.global_step, model.learning_rate, extra=save_extra())   # :370-371
                 with open(latest, "w") as f:
                     f.write(ck)
                 ckpt_start, loss = time.time(), 0.0

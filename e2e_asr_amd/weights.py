@@ -43,7 +43,7 @@ def encoder_layer_inputs(feat, hidden, bi_dir, depth, skip_step=2, max_scaling_d
 
 def init_weights(feat=80, hidden=256, bi_dir=True, depth=4, tasks=("char",), vocab=None,
                  emb=256, hidden_dec=256, lm_hidden=256, attn_vec=128, num_layers=None,
-                 seed=10, skip_step=2, max_scaling_down=8):
+                 seed=10, skip_step=2, max_scaling_down=8, initial_res_fac=1):
     """Random-init weights of the reference architecture.
 
     Encoder kernels U(-0.075, 0.075) (encoder.py:74), biases 0 (BasicLSTMCell default),
@@ -56,7 +56,8 @@ def init_weights(feat=80, hidden=256, bi_dir=True, depth=4, tasks=("char",), voc
     num_layers = num_layers or {"char": depth}
     w = {}
     D = hidden * (2 if bi_dir else 1)
-    for d, in_dim in enumerate(encoder_layer_inputs(feat, hidden, bi_dir, depth, skip_step, max_scaling_down), 1):
+    for d, in_dim in enumerate(encoder_layer_inputs(feat, hidden, bi_dir, depth, skip_step, max_scaling_down,
+                                                       initial_res_fac), 1):
         for direction in (("fw", "bw") if bi_dir else ("",)):
             w[enc_name(d, direction, "kernel", bi_dir)] = rng.uniform(
                 -0.075, 0.075, (in_dim + hidden, 4 * hidden)).astype(np.float32)

@@ -298,6 +298,13 @@ size_t asr_decoder_chain_bwd_ws_bytes(int B, int D, int A, int H);
 int asr_decoder_lm_chain_supported(int B, int lmH);
 int asr_zero_finished_rows(void* stream, float* logits, const int* len, int T, int B, int V);
 
+/* Workgroups of one persistent launch that are guaranteed co-resident on the current device: its compute-unit count
+ * (hipDeviceAttributeMultiprocessorCount; 256 on a whole MI355X), optionally lowered by the environment variable
+ * ASR_LSTM_MAXWG.  The persistent kernels (recurrent LSTM pair, decoder chains, greedy decoder) size every launch by it;
+ * larger batches run as consecutive launches, and a shape whose smallest group does not fit returns ASR_EUNSUPPORTED
+ * (-3) -- or selects the per-step launch path -- instead of waiting for workgroups that can never be scheduled. */
+int asr_resident_wg_budget(void);
+
 /* Optional per-kernel HIP-event timing on the launch stream (bench.py roofline leg).
  * tag: 0 lstm recurrent fwd, 1 lstm recurrent bwd, 2 gemm, 3 decoder fwd, 4 decoder bwd, 5 optimizer.
  * asr_prof_read is a HOST call that synchronises on the recorded events. */

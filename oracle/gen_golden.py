@@ -11,6 +11,8 @@ What is executed from the reference (imported, never copied):
   * basic_lstm.BasicLSTM.__call__                    (basic_lstm.py:14-23)
   * beam_search.BeamSearch.calc_attention            (beam_search.py:137-161)
   * beam_search.BeamSearch.top_k_setup_with_lm -> get_top_k (beam_search.py:163-221)
+  * data_utils.get_relevant_words / swbd_utils.reverse_swbd_normalizer (data_utils.py:20-33, swbd_utils.py:7-18)
+    -> tests/golden/text_utils.json   (`--text-only` regenerates just these)
 
 beam_search.py imports three non-numeric modules that are absent or need
 TensorFlow (bunch, tf_utils, data_utils); they are stubbed in sys.modules with
@@ -49,6 +51,43 @@ def _import_reference():
     return Bunch, num_utils, basic_lstm, beam_search
 
 
+def text_fixtures():
+    """(6) transcript utilities, run from the reference: data_utils.get_relevant_words (data_utils.py:20-33) and
+    swbd_utils.reverse_swbd_normalizer (swbd_utils.py:7-18).  Both modules `import tensorflow` at the top and use it for
+    nothing on these two code paths; an EMPTY module object stands in for the name (no arithmetic, no behaviour)."""
+    import importlib
+    import json
+    sys.path.insert(0, REF)
+    saved = {k: sys.modules.pop(k, None) for k in ("data_utils", "swbd_utils", "tensorflow")}
+    sys.modules["tensorflow"] = types.ModuleType("tensorflow")
+    try:
+        data_utils = importlib.import_module("data_utils")
+        swbd_utils = importlib.import_module("swbd_utils")
+        sents = [
+            "", "   ", "hello world", "uh i think um it is [noise] fine", "i wa- i was th- there", "-", "a-b c- -d",
+            "yeah<sp>right<sp>uh<sp>huh", "<sp><sp>", "uh-huh mm-hm", "[laughter] [vocalized-noise] ew eee ach hee oof er ha",
+            "UH Um", "it's  double  spaced", "tab\tseparated\nnewline", "ends with dash-", "hm hmm", "ah aha",
+            "! that was @ funny #", "!!", "no tags here", "a!b@c#d", "[laughter] ! [noise]", "# # #", "100% #1 fan",
+        ]
+        norm = swbd_utils.reverse_swbd_normalizer()
+        out = {"get_relevant_words": [], "reverse_swbd_normalizer": [], "normalize_then_filter": [],
+               "ignored_words": list(data_utils.IGNORED_WORDS),
+               "ids": [int(data_utils.PAD_ID), int(data_utils.GO_ID), int(data_utils.EOS_ID)]}
+        for t in sents:
+            words, rel = data_utils.get_relevant_words(t)
+            out["get_relevant_words"].append({"in": t, "words": list(words), "rel_words": list(rel)})
+            out["reverse_swbd_normalizer"].append({"in": t, "out": norm(t)})
+            words, rel = data_utils.get_relevant_words(norm(t))           # eval_model.py:91-93 composes them this way
+            out["normalize_then_filter"].append({"in": t, "words": list(words), "rel_words": list(rel)})
+        with open(os.path.join(OUT, "text_utils.json"), "w") as f:
+            json.dump(out, f, indent=1, sort_keys=True)
+    finally:
+        for k, v in saved.items():
+            sys.modules.pop(k, None)
+            if v is not None:
+                sys.modules[k] = v
+
+
 def make_decoder_weights(rng, E, H, lmH, D, A, V, simple):
     """Random float32 decoder weights keyed by TF variable name."""
     u = lambda *s: rng.uniform(-0.3, 0.3, s).astype(np.float32)
@@ -73,8 +112,12 @@ def make_decoder_weights(rng, E, H, lmH, D, A, V, simple):
 
 
 def main():
-    Bunch, num_utils, basic_lstm, beam_search = _import_reference()
     os.makedirs(OUT, exist_ok=True)
+    text_fixtures()
+    if "--text-only" in sys.argv:
+        print("text fixtures written to", os.path.abspath(OUT))
+        return
+    Bunch, num_utils, basic_lstm, beam_search = _import_reference()
     rng = np.random.default_rng(20180201)
 
     # (1) BasicLSTM single steps -------------------------------------------

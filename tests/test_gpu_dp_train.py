@@ -1,0 +1,208 @@
+"""GPU: the data-parallel hooks of the HIP train step with N = 2 on ONE card, and the training-loop branches that
+interleave the char LM (train.py:269-291) and resume it from a checkpoint.
+
+Two GPUs are not available to the tests, so rank 1 and rank 0 run one after the other in this process through a
+loop-back `comm` object: rank 1's gradient buckets are RECORDED as `DataParallel` hands them to the exchange, then rank
+0's exchange ADDS them -- exactly the sum an RCCL all-reduce would leave on rank 0.  Everything else is the product
+path: `Encoder.backward(on_layer_done)` -> `grad_ready` -> `ops.side_join()`, the bucket ranges, and the 1/N fold inside
+`asr_clip_adam_f32` (seq2seq_model.py:148-155 ordering: gradients -> exchange -> clip -> Adam)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+class LoopbackComm(object):
+    """world = 2.  mode "record": all_reduce clones the tensor it is given (keyed by call order); mode "replay": adds the
+    clone recorded at the same call index.  Calls are made in the same order on both ranks (bucket order is fixed)."""
+
+    def __init__(self, rank, store):
+        self.world, self.rank, self.store, self.calls = 2, rank, store, 0
+        self.mode = "record"
+
+    def broadcast(self, t, src=0):
+        pass                                   # both models are built from the same seed
+
+    def all_reduce(self, t, async_op=False):
+        if self.mode == "record":
+            self.store.append(t.detach().clone())
+        else:
+            peer = self.store[self.calls]
+            assert peer.shape == t.shape
+            t.add_(peer)
+        self.calls += 1
+        return None
+
+
+def _params(samp=0.0):
+    from e2e_asr_amd.attn_decoder import AttnDecoder
+    from e2e_asr_amd.seq2seq_model import Seq2SeqModel
+    p = Seq2SeqModel.class_params()
+    p.num_layers = {"char": 3}; p.max_output = {"char": 12}
+    p.encoder_params.use_lstm = True; p.encoder_params.hidden_size = 64; p.encoder_params.out_prob = 1.0
+    dp = AttnDecoder.class_params()
+    dp.hidden_size_dec = 64; dp.lm_hidden_size = 64; dp.emb_size = 24; dp.attention_vec_size = 16; dp.vocab_size = 40
+    dp.out_prob_dec = 1.0; dp.samp_prob = samp
+    p.decoder_params = {"char": dp}
+    return p
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+def test_two_rank_step_equals_one_global_batch_step(overlap):
+    """Two half-batches through DataParallel (N = 2) must leave rank 0 with the weights of ONE step on the global batch:
+    loss = mean over utterances of a length-normalised cost (losses.py:32-35), equal shards, sum of shard gradients
+    scaled by 1/N inside the fused clip+Adam kernel, clip on the global-batch gradient.  overlap=True sends the
+    gradient in per-layer buckets as the encoder's backward finishes each layer."""
+    from e2e_asr_amd import ops
+    from e2e_asr_amd.parallel import DataParallel, shard_batch
+    from e2e_asr_amd.seq2seq_model import Seq2SeqModel
+    from e2e_asr_amd.weights import synthetic_batch
+    p = _params()
+    gb = synthetic_batch(B=8, T=40, F=20, t_dec=9, vocab=40, variable_len=True, seed=5)
+    single = Seq2SeqModel(None, True, p, device=DEV, feat_length=20, seed=4)
+    for step in range(2):                                        # two steps: the Adam moments matter in the second
+        gb["logmel"] = gb["logmel"] * (1.0 + 0.1 * step)
+        loss_g = single.step(gb)["char"].item()
+        if step == 0:
+            store = []
+            ranks = [Seq2SeqModel(None, True, p, device=DEV, feat_length=20, seed=4) for _ in range(2)]
+            dps = [DataParallel(m, overlap=overlap, comm=LoopbackComm(r, store)) for r, m in enumerate(ranks)]
+            assert dps[0].buckets_partition(dps[0].buckets, ranks[0].variables.flat.numel())
+        else:
+            # rank 1 took a wrong (un-reduced) update in step 0: give it rank 0's state, as a real all-reduce would have
+            ranks[1].variables.flat.copy_(ranks[0].variables.flat)
+            for slot, (m_, v_) in ranks[0].variables.adam_slots.items():
+                m1, v1 = ranks[1].variables.ensure_adam(slot)
+                m1.copy_(m_); v1.copy_(v_)
+        del store[:]
+        dps[1].comm.mode, dps[1].comm.calls = "record", 0
+        dps[0].comm.mode, dps[0].comm.calls = "replay", 0
+        l1 = ranks[1].step(shard_batch(gb, 1, 2))["char"].item()
+        n_calls = dps[1].comm.calls
+        l0 = ranks[0].step(shard_batch(gb, 0, 2))["char"].item()
+        ops.check_device_flag(torch.device(DEV))
+        assert dps[0].comm.calls == n_calls == (len(dps[0].buckets) if overlap else 1)
+        np.testing.assert_allclose(0.5 * (l0 + l1), loss_g, rtol=1e-5)      # mean of shard means = global mean
+        a, b = ranks[0].variables.flat.cpu().numpy(), single.variables.flat.cpu().numpy()
+        np.testing.assert_allclose(a, b, rtol=0, atol=2e-5)
+        np.testing.assert_allclose(np.sqrt(ranks[0]._gnorm_sq.item()) / 2.0, np.sqrt(single._gnorm_sq.item()), rtol=1e-4)
+    assert ranks[0].global_step == single.global_step == 2
+    assert ranks[0].rank_seed != ranks[1].rank_seed              # replicas draw their own dropout masks / sampler noise
+
+
+def test_bucket_overlap_falls_back_when_ranges_do_not_partition():
+    """A variable store whose decoder variables are NOT contiguous (another key order) would make the decoder bucket's
+    hull overlap encoder ranges; DataParallel must notice and use the single blocking all-reduce."""
+    from e2e_asr_amd.parallel import DataParallel
+    from e2e_asr_amd.seq2seq_model import Seq2SeqModel
+    from e2e_asr_amd.variables import VariableStore
+    p = _params()
+    m = Seq2SeqModel(None, True, p, device=DEV, feat_length=20, seed=4)
+    arrays = m.variables.to_arrays()
+    names = list(arrays)
+    dec = [n for n in names if "rnn_decoder" in n]
+    enc = [n for n in names if "rnn_decoder" not in n]
+    shuffled = dec[:3] + enc + dec[3:]
+    m2 = Seq2SeqModel(None, True, p, variables=VariableStore.from_arrays({n: arrays[n] for n in shuffled}, DEV), device=DEV,
+                      feat_length=20)
+    dp = DataParallel(m2, overlap=True, comm=LoopbackComm(0, []))
+    assert dp.overlap is False
+    assert DataParallel(m, overlap=True, comm=LoopbackComm(0, [])).overlap is True
+
+
+class _Stop(Exception):
+    pass
+
+
+def _lm_batches(rng, n, B=6, T=9, V=12):
+    out = []
+    for _ in range(n):
+        lens = rng.integers(2, T + 1, B); lens[0] = T
+        ids = np.zeros((B, T + 1), np.int64)
+        for b in range(B):
+            ids[b, :lens[b] + 1] = rng.integers(1, V, lens[b] + 1)
+        out.append({"char": ids, "char_len": lens})
+    return out
+
+
+def test_train_loop_lm_interleave_and_resume_of_lm_state(tmp_path, monkeypatch):
+    """train.py:269-291: with lm_prob > 0 a coin per iteration chooses an LM step (own optimizer AdamLM, own step counter
+    and learning rate) or an ASR step.  (1) lm_prob = 1: only LM steps run, so only the variables the LM shares with the
+    decoder move and global_step stays 0.  (2) A run interrupted at a checkpoint and resumed must continue the LM
+    exactly: lm_global_step, the LM learning rate and both epoch counters come back, so the next LM update equals the
+    uninterrupted run's (AdamLM bias correction continues at t+1 instead of restarting at 1)."""
+    from e2e_asr_amd import checkpoint
+    from e2e_asr_amd.lm_encoder import LMEncoder
+    from e2e_asr_amd.lm_model import LMModel
+    from e2e_asr_amd.train import Train
+    from e2e_asr_amd.weights import synthetic_batch
+    p = _params()
+    p.num_layers = {"char": 2}; p.max_output = {"char": 8}; p.decoder_params["char"].vocab_size = 12
+
+    def tparams(d, lm_prob):
+        tp = Train.class_params()
+        tp.train_dir = str(tmp_path / d); tp.best_model_dir = str(tmp_path / d / "best")
+        tp.steps_per_checkpoint = 3; tp.feat_length = 20; tp.max_epochs = 100; tp.min_steps = 0; tp.lm_prob = lm_prob
+        ep = LMEncoder.class_params()
+        ep.out_prob = 1.0; ep.lm_hidden_size = 64; ep.proj_size = 64; ep.emb_size = 24; ep.vocab_size = 12
+        tp.lm_enc_params = ep
+        tp.lm_params = LMModel.class_params()
+        return tp
+    b0 = synthetic_batch(B=4, T=16, F=20, t_dec=9, vocab=12, seed=1)
+    rng = np.random.default_rng(3)
+    lm_set = _lm_batches(rng, 4)
+
+    # (1) lm_prob = 1: the ASR branch is never taken; stop the loop from the LM side after a few steps
+    tp = tparams("lm_only", 1.0)
+    tr = Train(p, tp, device=DEV)
+    taken = []
+    orig = LMModel.step
+
+    def counting_step(self, batch=None):
+        taken.append(self.lm_global_step)
+        if len(taken) > 5:
+            raise _Stop()
+        return orig(self, batch)
+    monkeypatch.setattr(LMModel, "step", counting_step)
+    with pytest.raises(_Stop):
+        tr.train([[b0] * 4], [b0], lm_set=lm_set)
+    monkeypatch.setattr(LMModel, "step", orig)
+    from e2e_asr_amd.seq2seq_model import Seq2SeqModel
+    fresh = Seq2SeqModel(None, True, p, device=DEV, feat_length=20).variables.to_arrays()
+    after = tr.model.variables.to_arrays()
+    moved = sorted(k for k in after if not np.array_equal(after[k], fresh[k]))
+    pre = "model/rnn_decoder_char/"
+    assert moved == sorted(pre + l for l in ("decoder/embedding", "rnn/basic_lstm_cell/kernel", "rnn/basic_lstm_cell/bias",
+                                             "rnn/OutputProjection/kernel", "rnn/OutputProjection/bias"))
+    assert tr.model.global_step == 0 and taken == [0, 1, 2, 3, 4, 5]        # 4 LM batches per LM epoch: the iterator restarted
+
+    # (2) interleaved run up to a checkpoint; then the SAME LM step once in the live process and once after a resume
+    tp = tparams("split", 0.5)
+    tr_a = Train(p, tp, device=DEV)
+    tr_a.train([[b0] * 50], [b0], lm_set=lm_set, max_steps=3)       # returns right after the step-3 checkpoint
+    ck = checkpoint.load(open(os.path.join(tp.train_dir, "checkpoint.txt")).read().strip())
+    lm_t = int(ck["lm_global_step"])
+    assert int(ck["global_step"]) == 3 and lm_t == tr_a.lm_model.lm_global_step and lm_t > 0
+    assert float(ck["lm_learning_rate"]) == tr_a.lm_model.learning_rate and "epoch" in ck and "lm_epoch" in ck
+    assert any(k.endswith("/AdamLM") for k in ck)
+    tr_a.lm_model.learning_rate_decay_op()                          # a decayed LM rate must survive too
+    checkpoint.save(os.path.join(tp.train_dir, "asr.ckpt-3"), tr_a.model.variables, 3, tr_a.model.learning_rate,
+                    extra=dict(epoch=tr_a.model.epoch, lm_global_step=lm_t, lm_learning_rate=tr_a.lm_model.learning_rate,
+                               lm_epoch=tr_a.lm_model.epoch))
+    tr_c = Train(p, tparams("split", 0.5), device=DEV)
+    tr_c.train([[b0] * 50], [b0], lm_set=lm_set, max_steps=0)       # restore only
+    assert tr_c.model.global_step == 3 and tr_c.lm_model.lm_global_step == lm_t
+    assert tr_c.lm_model.learning_rate == tr_a.lm_model.learning_rate == 0.5e-4
+    assert tr_c.lm_model.epoch == tr_a.lm_model.epoch
+    x = _lm_batches(np.random.default_rng(9), 1)[0]
+    la = tr_a.lm_model.step(x).item()
+    lc = tr_c.lm_model.step(x).item()
+    assert la == pytest.approx(lc, rel=1e-6)
+    wa, wc = tr_a.model.variables.flat.cpu().numpy(), tr_c.model.variables.flat.cpu().numpy()
+    np.testing.assert_allclose(wc, wa, rtol=0, atol=1e-6)           # AdamLM continued at t+1 with the restored moments
+    # without the restored step counter the update would differ by the bias-correction ratio (~1.5x at this t)
+    assert tr_c.lm_model.lm_global_step == lm_t + 1
