@@ -108,6 +108,8 @@ SIGNATURES = {
     "asr_beam_select": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, vp]),
     "asr_set_gemm_precision": (C.c_int, [C.c_int]),
     "asr_get_gemm_precision": (C.c_int, []),
+    "asr_set_gemm_split": (C.c_int, [C.c_int]),
+    "asr_get_gemm_split": (C.c_int, []),
     "asr_decoder_chain_ws_bytes": (C.c_size_t, [C.c_int] * 4),
     "asr_decoder_chain_bwd_ws_bytes": (C.c_size_t, [C.c_int] * 4),
     "asr_decoder_lm_chain_supported": (C.c_int, [C.c_int] * 2),

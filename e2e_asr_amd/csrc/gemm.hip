@@ -333,7 +333,149 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
         }
 }
 
+// ---------------------------------------------------------------------------------------------
+// fp32 product on the bf16 matrix pipe by EXACT operand splitting ("split3"): SAME interface and fp32-class accuracy.
+// Every fp32 operand value is x = h1 + h2 + h3 with three bf16 terms (h1 = bf16(x), h2 = bf16(x - h1), h3 = bf16(x - h1 -
+// h2): each residual is exactly representable, so the sum is exact, 3 x 8 = 24 significand bits), formed with three
+// v_cvt_pk_bf16_f32 per pair while the tile is staged into LDS as three bf16 planes.  The product keeps the six terms
+// a_i.b_j with i + j <= 4 (a1b1, a1b2, a2b1, a1b3, a2b2, a3b1); the three dropped ones are below 2^-24 |a||b|, the size of
+// the rounding an fp32 FMA makes itself.  Each bf16 x bf16 product is exact in fp32 and v_mfma_f32_32x32x16_bf16
+// accumulates in fp32, so the result carries the error of an fp32 GEMM with another summation order -- at 6 MFMAs of the
+// bf16 pipe (16x the fp32 matrix rate) per k-step: peak 2.5 PF / 6 = 417 TFLOP/s fp32-equivalent vs 157.3 for
+// v_mfma_f32_32x32x2_f32.  tests/test_gpu_gemm_split.py holds it to the exact-fp32 kernel's error against float64.
+// 128x128 block tile, BK = 16 (one MFMA k-step), 4 waves x 64x64, double-buffered planes (72 KB: two workgroups per CU),
+// 48-byte LDS rows (conflict-free ds_read_b128 fragments).  Whole tiles only; other shapes use the exact fp32 kernel.
+constexpr int BKS = 16, PITCHS = 24, PLANES = 128 * PITCHS;       // k-tile, LDS row pitch and plane size in bf16 elements
+
+__device__ __forceinline__ void split3_pk(float x0, float x1, uint32_t& p1, uint32_t& p2, uint32_t& p3) {
+    p1 = cvt_pk_bf16(x0, x1);
+    float r0 = x0 - __uint_as_float(p1 << 16);
+    float r1 = x1 - __uint_as_float(p1 & 0xffff0000u);
+    p2 = cvt_pk_bf16(r0, r1);
+    r0 -= __uint_as_float(p2 << 16);
+    r1 -= __uint_as_float(p2 & 0xffff0000u);
+    p3 = cvt_pk_bf16(r0, r1);
+}
+
+// One thread stages 8 consecutive k of one tile row (256 threads x 8 = 128 rows x 16 k).
+template <bool KMAJOR>
+struct StagerS3 {
+    float v[8];
+    __device__ __forceinline__ void load(const float* P, int ld, int m0, int k0, int tid) {
+        if (KMAJOR) {
+            const float* p = P + (size_t)(k0 + (tid >> 7) * 8) * ld + m0 + (tid & 127);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = p[(size_t)j * ld];
+        } else {
+            const float4* p = reinterpret_cast<const float4*>(P + (size_t)(m0 + (tid >> 1)) * ld + k0 + (tid & 1) * 8);
+            const float4 x = p[0], y = p[1];
+            v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w; v[4] = y.x; v[5] = y.y; v[6] = y.z; v[7] = y.w;
+        }
+    }
+    __device__ __forceinline__ void store(unsigned short* S, int tid) const {
+        const int row = KMAJOR ? (tid & 127) : (tid >> 1), kh = KMAJOR ? (tid >> 7) : (tid & 1);
+        uint32_t a[4], b[4], c[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) split3_pk(v[2 * j], v[2 * j + 1], a[j], b[j], c[j]);
+        unsigned short* d = S + row * PITCHS + kh * 8;
+        *reinterpret_cast<uint4*>(d) = make_uint4(a[0], a[1], a[2], a[3]);
+        *reinterpret_cast<uint4*>(d + PLANES) = make_uint4(b[0], b[1], b[2], b[3]);
+        *reinterpret_cast<uint4*>(d + 2 * PLANES) = make_uint4(c[0], c[1], c[2], c[3]);
+    }
+};
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256, 2) void gemm_split3_kernel(GemmArgs a) {
+    constexpr int BM = 128, BN = 128;
+    __shared__ __attribute__((aligned(16))) unsigned short As[2 * 3 * PLANES];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[2 * 3 * PLANES];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1;
+    a.A += (size_t)blockIdx.z * a.sA; a.B += (size_t)blockIdx.z * a.sB; a.C += (size_t)blockIdx.z * a.sC;
+    const int ntn = a.N / BN, ntm = a.M / BM;
+    const int nwg = ntn * ntm;
+    int bid = blockIdx.x, ksl = blockIdx.y;
+    if (a.xcd_split) {          // weight-gradient form: whole K slices per XCD (see gemm_f32_kernel)
+        const int xcd = bid & 7, idx = bid >> 3;
+        ksl = xcd + 8 * (idx / nwg);
+        bid = idx % nwg;
+    } else {
+        const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+    }
+    const int m0 = (bid / ntn) * BM, n0 = (bid % ntn) * BN;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    StagerS3<TA> sa;       // A natural [M,K]: k contiguous unless transposed
+    StagerS3<!TB> sb;      // B natural [K,N]: n contiguous unless transposed
+    const int nk_all = a.K / BKS;
+    const int per = (nk_all + a.splits - 1) / a.splits;
+    const int kt0 = ksl * per, nk = min(nk_all, kt0 + per);
+    if (kt0 >= nk) return;
+    sa.load(a.A, a.lda, m0, kt0 * BKS, tid);
+    sb.load(a.B, a.ldb, n0, kt0 * BKS, tid);
+    sa.store(As, tid);
+    sb.store(Bs, tid);
+    __syncthreads();
+    auto compute = [&](int cur) {
+        const unsigned short* ap = As + cur * (3 * PLANES) + (wr * 64 + (lane & 31)) * PITCHS + 8 * (lane >> 5);
+        const unsigned short* bp = Bs + cur * (3 * PLANES) + (wc * 64 + (lane & 31)) * PITCHS + 8 * (lane >> 5);
+        bf16x8 af[2][3], bf[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                af[i][pl] = *reinterpret_cast<const bf16x8*>(ap + pl * PLANES + i * 32 * PITCHS);
+                bf[i][pl] = *reinterpret_cast<const bf16x8*>(bp + pl * PLANES + i * 32 * PITCHS);
+            }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {           // smallest terms first
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+            }
+    };
+    for (int kt = kt0; kt + 1 < nk; ++kt) {
+        const int cur = (kt - kt0) & 1;
+        sa.load(a.A, a.lda, m0, (kt + 1) * BKS, tid);
+        sb.load(a.B, a.ldb, n0, (kt + 1) * BKS, tid);
+        compute(cur);
+        sa.store(As + (cur ^ 1) * (3 * PLANES), tid);
+        sb.store(Bs + (cur ^ 1) * (3 * PLANES), tid);
+        __syncthreads();
+    }
+    compute((nk - 1 - kt0) & 1);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int n = n0 + wc * 64 + ni * 32 + (lane & 31);
+            const float bv = (a.bias && ksl == 0) ? a.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                float* cp = a.C + (size_t)m * a.ldc + n;
+                float v = acc[mi][ni][r] + bv;
+                if (a.splits > 1) { atomicAdd(cp, v); }
+                else { if (a.accumulate) v += *cp; *cp = v; }
+            }
+        }
+}
+
 static int g_gemm_bf16 = 0;
+// fp32 products of whole tiles on the bf16 pipe by exact 3-way splitting (default on; ASR_GEMM_SPLIT=0 or
+// asr_set_gemm_split(0) selects v_mfma_f32_32x32x2_f32 everywhere)
+static int g_gemm_split = [] { const char* e = getenv("ASR_GEMM_SPLIT"); return e ? (atoi(e) != 0) : 1; }();
 }  // namespace asr
 
 // ---------------------------------------------------------------------------------
@@ -351,6 +493,8 @@ extern "C" int asr_set_gemm_precision(int mode) {
     return ASR_OK;
 }
 extern "C" int asr_get_gemm_precision(void) { return asr::g_gemm_bf16; }
+extern "C" int asr_set_gemm_split(int on) { asr::g_gemm_split = on != 0; return ASR_OK; }
+extern "C" int asr_get_gemm_split(void) { return asr::g_gemm_split; }
 
 extern "C" int asr_gemm_f32(void* stream, int transA, int transB, int M, int N, int K,
                             const float* A, int lda, const float* B, int ldb,
@@ -402,6 +546,21 @@ extern "C" int asr_gemm_f32_batched(void* stream, int transA, int transB, int M,
         if (transA)       hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), dim3(nwg, sp, batch), dim3(256), 0, s, g);
         else if (transB)  hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), dim3(nwg, sp, batch), dim3(256), 0, s, g);
         else              hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), dim3(nwg, sp, batch), dim3(256), 0, s, g);
+        ASR_CHECK_LAUNCH();
+        return ASR_OK;
+    }
+    if (g_gemm_split && M % 128 == 0 && N % 128 == 0 && K % BKS == 0 && g.vecA && g.vecB && !(transA && transB) &&
+        (splits > 1 || (long long)nwg * batch >= 96)) {
+        // whole tiles: fp32-accurate product on the bf16 pipe (gemm_split3_kernel); same split-K policy as the fp32 kernel
+        static const int xs = [] { const char* e = getenv("ASR_GEMM_XCD_SPLIT"); return e ? atoi(e) : 1; }();
+        g.splits = splits;
+        if (transA && xs && splits >= 6 && nk >= 128 && (batch == 1 || (nwg * ((splits + 4) / 8 * 8)) % 8 == 0)) {
+            g.splits = (splits + 4) / 8 * 8;
+            g.xcd_split = 1;
+            hipLaunchKernelGGL((gemm_split3_kernel<true, false>), dim3(nwg * g.splits, 1, batch), dim3(256), 0, s, g);
+        } else if (transA) hipLaunchKernelGGL((gemm_split3_kernel<true, false>), dim3(nwg, splits, batch), dim3(256), 0, s, g);
+        else if (transB)   hipLaunchKernelGGL((gemm_split3_kernel<false, true>), dim3(nwg, splits, batch), dim3(256), 0, s, g);
+        else               hipLaunchKernelGGL((gemm_split3_kernel<false, false>), dim3(nwg, splits, batch), dim3(256), 0, s, g);
         ASR_CHECK_LAUNCH();
         return ASR_OK;
     }

@@ -501,6 +501,16 @@ def set_gemm_precision(dtype):
     _check(_lib.lib().asr_set_gemm_precision(mode), "asr_set_gemm_precision")
 
 
+def set_gemm_split(on):
+    """fp32 products of whole tiles on the bf16 matrix pipe by exact 3-way operand splitting (default on) or on
+    v_mfma_f32_32x32x2_f32 (off).  Both are fp32-accurate; see include/e2e_asr_hip.h.  Process-wide."""
+    _check(_lib.lib().asr_set_gemm_split(int(bool(on))), "asr_set_gemm_split")
+
+
+def get_gemm_split():
+    return bool(_lib.lib().asr_get_gemm_split())
+
+
 def get_gemm_precision():
     return "bf16" if _lib.lib().asr_get_gemm_precision() else "f32"
 

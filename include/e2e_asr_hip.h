@@ -38,6 +38,14 @@ int asr_gemm_f32_batched(void* stream, int transA, int transB, int M, int N, int
  * recurrent state, attention, loss and the optimizer stay fp32.  Process-wide; set between steps. */
 int asr_set_gemm_precision(int mode);
 int asr_get_gemm_precision(void);
+/* How the fp32 products of whole 128x128x16 tiles are evaluated (mode 0 of asr_set_gemm_precision).  on (default; the
+ * environment variable ASR_GEMM_SPLIT=0 turns it off): every fp32 operand value is split EXACTLY into three bf16 terms
+ * while the tile is staged into LDS and the six leading cross products run on v_mfma_f32_32x32x16_bf16 with fp32
+ * accumulation -- the error of an fp32 GEMM in another summation order (dropped terms < 2^-24 |a||b|), at up to 2.7x
+ * the rate of v_mfma_f32_32x32x2_f32.  off: v_mfma_f32_32x32x2_f32 everywhere (bitwise an fmaf chain).  Products with
+ * partial tiles or few output tiles always use the latter.  Process-wide; set between steps. */
+int asr_set_gemm_split(int on);
+int asr_get_gemm_split(void);
 
 /* One (Bi)LSTM encoder layer over a whole padded batch -- encoder.py:55-91
  * (bidirectional_dynamic_rnn / dynamic_rnn over BasicLSTMCell with sequence_length).

@@ -87,8 +87,18 @@ def test_argument_validation_raises_valueerror():
     from e2e_asr_amd import ops
     x = torch.zeros(2, 4, 8, device=DEV); ln = torch.tensor([4, 4], dtype=torch.int32, device=DEV)
     k96 = torch.zeros(8 + 96, 4 * 96, device=DEV); b96 = torch.zeros(4 * 96, device=DEV)
-    with pytest.raises(ValueError, match="unsupported"):             # H=96 is not an instantiated recurrent size
-        ops.lstm_layer_fwd(x, ln, k96, b96)
+    assert tuple(ops.lstm_layer_fwd(x, ln, k96, b96).shape) == (2, 4, 96)   # H=96 runs zero-padded to the 128-wide kernel
+    k600 = torch.zeros(8 + 600, 4 * 600, device=DEV)
+    with pytest.raises(ValueError, match="up to 512"):              # beyond the widest instantiated recurrent kernel
+        ops.lstm_layer_fwd(x, ln, k600, torch.zeros(4 * 600, device=DEV))
+    from e2e_asr_amd import _lib
+    import ctypes as C
+    hx = torch.zeros(1 << 20, dtype=torch.uint8, device=DEV); flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    out = torch.zeros(2, 4, 96, device=DEV); gates = torch.zeros(2, 4, 1, 4 * 96, device=DEV)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    rc = _lib.lib().asr_lstm_layer_fwd(None, p(x), 2, 4, 8, 8, p(ln), 96, 1, p(k96), p(b96), None, None, p(out), 4, p(gates),
+                                       None, None, p(hx), hx.numel(), p(flag), 1.0, 0)
+    assert rc == -3                                                  # the C ABI itself: ASR_EUNSUPPORTED for H = 96
     k = torch.zeros(9 + 64, 256, device=DEV)
     with pytest.raises(ValueError, match="kernel rows"):
         ops.lstm_layer_fwd(x, ln, k, torch.zeros(256, device=DEV))
