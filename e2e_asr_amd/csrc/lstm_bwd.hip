@@ -251,7 +251,7 @@ __global__ __launch_bounds__(512) void lstm_rec_bwd_kernel(LstmBwdArgs a) {
 // STAMP: diagnostic instantiation (ASR_LSTM_STAMP=1 + asr_debug_set_buffer): s_memtime totals of thread 0 (a cell wave) and
 // thread 511 (a polling wave) of workgroup 0: [poll | barrier 1 | matvec | barrier 2 | cell]; never used for timing claims.
 template <int H, int R, bool STAMP = false>
-__global__ __launch_bounds__(512) void lstm_rec_bwd_ag_kernel(LstmBwdArgs a) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(R == 1 ? 4 : 2, 8))) void lstm_rec_bwd_ag_kernel(LstmBwdArgs a) {
     unsigned int stamp[5] = {0, 0, 0, 0, 0};
     unsigned long long tlast = STAMP ? __builtin_amdgcn_s_memtime() : 0;
 #define BPTT_STAMP(i) if (STAMP) { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); stamp[i] += (unsigned int)(t__ - tlast); tlast = t__; }

@@ -65,6 +65,8 @@ int resident_wg_budget() {
         cus[dev] = n;
     }
     int budget = cus[dev];
+    // EXPERIMENT knob: count 2 resident workgroups per CU (true only for kernels of <= 128 VGPRs and <= 80 KB LDS)
+    if (const char* e = getenv("ASR_LSTM_WG_PER_CU")) { const int x = atoi(e); if (x == 2) budget *= 2; }
     if (const char* e = getenv("ASR_LSTM_MAXWG")) { const int x = atoi(e); if (x > 0 && x < budget) budget = x; }
     return budget;
 }

@@ -1,0 +1,113 @@
+"""Summarise the rocprofv3 passes of scripts/pmc_collect.sh into profiles/ (round 2).
+
+usage: pmc_summary2.py <dir written by pmc_collect.sh> [tag]   ->  profiles/<tag>_pmc_summary.json, profiles/traffic_<tag>.json,
+                                                                 profiles/<tag>_train_kernel_stats.csv
+
+Per kernel and pass: launches, mean duration, mean counter values per dispatch, and the derived figures the north star
+asks for:
+  * MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 256 CUs x 4 SIMDs)   (MI355X_MICROARCH.md: the
+    counter counts cycles summed over SIMDs -- 32 per v_mfma_f32_32x32x16_bf16; GRBM_GUI_ACTIVE is summed over the 8 XCDs);
+  * issue-stall / parked shares of the wave cycles (SQ_WAIT_INST_ANY, SQ_WAIT_ANY, SQ_ACTIVE_INST_* over SQ_WAVE_CYCLES:
+    quad-cycle units, disjoint buckets);
+  * HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB x 1024 (gfx950 reports half of wide coalesced reads) and the
+    achieved GB/s = bytes / mean duration, next to the 8 TB/s HBM peak."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = sys.argv[1]
+tag = sys.argv[2] if len(sys.argv) > 2 else "r02"
+csv.field_size_limit(1 << 30)
+
+
+def short(name):
+    n = name.split("(")[0].replace("void ", "")
+    return n if len(n) < 120 else n[:117] + "..."
+
+
+def collect(passdir):
+    agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0, 0.0]))
+    for f in glob.glob(os.path.join(src, passdir, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            n = short(r["Kernel_Name"])
+            if "asr::" not in n:
+                continue
+            a = agg[n][r["Counter_Name"]]
+            a[0] += 1
+            a[1] += float(r["Counter_Value"])
+            a[2] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    out = {}
+    for n, cs in agg.items():
+        any_c = next(iter(cs.values()))
+        out[n] = {"launches": any_c[0], "avg_ns": any_c[2] / any_c[0],
+                  "counters_per_launch": {c: v[1] / v[0] for c, v in cs.items()}}
+    return out
+
+
+summary = {"note": __doc__.split("\n\n")[2] if False else "see scripts/pmc_summary2.py for the formulas; one counter group per rocprofv3 "
+           "pass (--kernel-trace only), passes listed by directory"}
+NSIMD = 256 * 4
+for passdir in sorted(os.listdir(src)):
+    if not os.path.isdir(os.path.join(src, passdir)):
+        continue
+    d = collect(passdir)
+    if not d:
+        continue
+    for n, v in d.items():
+        c = v["counters_per_launch"]
+        der = {}
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in c and c.get("GRBM_GUI_ACTIVE", 0) > 0:
+            cyc = c["GRBM_GUI_ACTIVE"] / 8.0
+            der["mfma_busy_fraction_of_simd_cycles"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * NSIMD)
+            der["effective_clock_GHz"] = cyc / v["avg_ns"]
+            der["counter_saturated"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] >= 2147483648.0
+        if "SQ_WAVE_CYCLES" in c and c["SQ_WAVE_CYCLES"] > 0:
+            for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS"):
+                if k in c:
+                    der[k.lower() + "_share_of_wave_cycles"] = c[k] / c["SQ_WAVE_CYCLES"]
+        if der:
+            v["derived"] = der
+    summary[passdir] = d
+
+# HBM traffic of whole train steps: FETCH and WRITE passes joined per kernel
+fetch, write = summary.get("step_fetch", {}), summary.get("step_write", {})
+traffic_rows = {}
+for n, v in fetch.items():
+    f = v["counters_per_launch"].get("FETCH_SIZE", 0.0)
+    w = write.get(n, {}).get("counters_per_launch", {}).get("WRITE_SIZE", 0.0)
+    nbytes = (2.0 * f + w) * 1024.0
+    traffic_rows[n] = {"launches": v["launches"], "avg_us": v["avg_ns"] / 1e3, "hbm_bytes_per_launch": nbytes,
+                       "achieved_GBps": nbytes / v["avg_ns"], "frac_of_8TBps": nbytes / v["avg_ns"] / 8000.0}
+summary["step_hbm_per_kernel"] = traffic_rows
+os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+json.dump(summary, open(os.path.join(ROOT, "profiles", "%s_pmc_summary.json" % tag), "w"), indent=1, sort_keys=True)
+
+
+def per_launch(prefix):
+    for n, v in traffic_rows.items():
+        if prefix in n:
+            return int(v["hbm_bytes_per_launch"])
+    return None
+
+
+B, H = 32, 256
+steps = 800 + 400 + 200 + 100
+traffic = {
+    "note": "HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KiB * 1024 from separate rocprofv3 --pmc FETCH_SIZE / --pmc "
+            "WRITE_SIZE passes (--kernel-trace only) over `bench.py --steps 3 --warmup 2 --no-cpu-baseline`; FETCH_SIZE doubled per "
+            "MI355X_MICROARCH.md (gfx950 reports 1/2 of wide coalesced reads; mixed access widths are uncalibrated).  Average "
+            "over the 4 launches per step (T = 800/400/200/100).",
+    "lstm_rec_bwd_bytes_per_launch": per_launch("lstm_rec_bwd_ag_kernel<256, 2") or per_launch("lstm_rec_bwd_ag_kernel<256, 1"),
+    "lstm_rec_fwd_bytes_per_launch": per_launch("lstm_rec_fwd_kernel<256, 32, 2") or per_launch("lstm_rec_fwd_kernel<256, 32, 1"),
+    "algorithmic_bytes_per_launch": {"lstm_rec_bwd": steps * B * 2 * 13 * H * 4 // 4, "lstm_rec_fwd": steps * B * 2 * 14 * H * 4 // 4},
+}
+json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic_%s.json" % tag), "w"), indent=1)
+for f in glob.glob(os.path.join(src, "step_stats", "**", "*kernel_stats.csv"), recursive=True):
+    shutil.copy(f, os.path.join(ROOT, "profiles", "%s_train_kernel_stats.csv" % tag))
+print(json.dumps({k: v for k, v in summary.items() if k in ("gemm_split_sq", "gemm_exact_sq", "lstm_sq")}, indent=1)[:6000])
+print(json.dumps(traffic, indent=1))
