@@ -411,20 +411,34 @@ __global__ __launch_bounds__(256, 2) void gemm_split3_kernel(GemmArgs a) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    StagerS3<TA> sa;       // A natural [M,K]: k contiguous unless transposed
-    StagerS3<!TB> sb;      // B natural [K,N]: n contiguous unless transposed
+    // Software pipeline, three k-tiles deep: while tile t is multiplied out of LDS buffer t&1, tile t+1 (global loads issued
+    // one iteration ago, long since landed) is split and written to the other buffer in four slices BETWEEN the MFMA groups --
+    // an MFMA holds the SIMD's issue port for 8 of its 32 cycles, the split's VALU work fits into the rest -- and the global
+    // loads of tile t+2 are issued at the top.  Two register sets (sa0/sb0, sa1/sb1) alternate, hence the loop unrolled by 2.
+    StagerS3<TA> sa0, sa1;       // A natural [M,K]: k contiguous unless transposed
+    StagerS3<!TB> sb0, sb1;      // B natural [K,N]: n contiguous unless transposed
     const int nk_all = a.K / BKS;
     const int per = (nk_all + a.splits - 1) / a.splits;
     const int kt0 = ksl * per, nk = min(nk_all, kt0 + per);
     if (kt0 >= nk) return;
-    sa.load(a.A, a.lda, m0, kt0 * BKS, tid);
-    sb.load(a.B, a.ldb, n0, kt0 * BKS, tid);
-    sa.store(As, tid);
-    sb.store(Bs, tid);
+    sa0.load(a.A, a.lda, m0, kt0 * BKS, tid);
+    sb0.load(a.B, a.ldb, n0, kt0 * BKS, tid);
+    if (kt0 + 1 < nk) { sa1.load(a.A, a.lda, m0, (kt0 + 1) * BKS, tid); sb1.load(a.B, a.ldb, n0, (kt0 + 1) * BKS, tid); }
+    sa0.store(As, tid);
+    sb0.store(Bs, tid);
     __syncthreads();
-    auto compute = [&](int cur) {
-        const unsigned short* ap = As + cur * (3 * PLANES) + (wr * 64 + (lane & 31)) * PITCHS + 8 * (lane >> 5);
-        const unsigned short* bp = Bs + cur * (3 * PLANES) + (wc * 64 + (lane & 31)) * PITCHS + 8 * (lane >> 5);
+    const int rowA = TA ? (tid & 127) : (tid >> 1), khA = TA ? (tid >> 7) : (tid & 1);
+    const int rowB = !TB ? (tid & 127) : (tid >> 1), khB = !TB ? (tid >> 7) : (tid & 1);
+    unsigned short* const dA = As + rowA * PITCHS + khA * 8;
+    unsigned short* const dB = Bs + rowB * PITCHS + khB * 8;
+    const unsigned short* const apb = As + (wr * 64 + (lane & 31)) * PITCHS + 8 * (lane >> 5);
+    const unsigned short* const bpb = Bs + (wc * 64 + (lane & 31)) * PITCHS + 8 * (lane >> 5);
+    // one iteration: multiply buffer `cur`; if `stage`, split registers (va, vb) into buffer cur^1 along the way
+    auto step = [&](int cur, const float* va, const float* vb, bool stage) {
+        const unsigned short* ap = apb + cur * (3 * PLANES);
+        const unsigned short* bp = bpb + cur * (3 * PLANES);
+        unsigned short* wa = dA + (cur ^ 1) * (3 * PLANES);
+        unsigned short* wb = dB + (cur ^ 1) * (3 * PLANES);
         bf16x8 af[2][3], bf[2][3];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -433,28 +447,49 @@ __global__ __launch_bounds__(256, 2) void gemm_split3_kernel(GemmArgs a) {
                 af[i][pl] = *reinterpret_cast<const bf16x8*>(ap + pl * PLANES + i * 32 * PITCHS);
                 bf[i][pl] = *reinterpret_cast<const bf16x8*>(bp + pl * PLANES + i * 32 * PITCHS);
             }
+        uint32_t pa[3][4], pb[3][4];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {           // smallest terms first
+                const int q = 2 * i + j;            // quarter q of the staging work rides on MFMA group q
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
+                if (stage) split3_pk(va[2 * q], va[2 * q + 1], pa[0][q], pa[1][q], pa[2][q]);
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
+                if (stage) split3_pk(vb[2 * q], vb[2 * q + 1], pb[0][q], pb[1][q], pb[2][q]);
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
             }
+        if (stage) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                *reinterpret_cast<uint4*>(wa + pl * PLANES) = make_uint4(pa[pl][0], pa[pl][1], pa[pl][2], pa[pl][3]);
+                *reinterpret_cast<uint4*>(wb + pl * PLANES) = make_uint4(pb[pl][0], pb[pl][1], pb[pl][2], pb[pl][3]);
+            }
+        }
     };
-    for (int kt = kt0; kt + 1 < nk; ++kt) {
-        const int cur = (kt - kt0) & 1;
-        sa.load(a.A, a.lda, m0, (kt + 1) * BKS, tid);
-        sb.load(a.B, a.ldb, n0, (kt + 1) * BKS, tid);
-        compute(cur);
-        sa.store(As + (cur ^ 1) * (3 * PLANES), tid);
-        sb.store(Bs + (cur ^ 1) * (3 * PLANES), tid);
+    int kt = kt0;
+    for (; kt + 2 < nk; kt += 2) {
+        // even tile: multiply buffer 0, stage set 1 (tile kt+1) into buffer 1, load tile kt+2 into set 0
+        sa0.load(a.A, a.lda, m0, (kt + 2) * BKS, tid);
+        sb0.load(a.B, a.ldb, n0, (kt + 2) * BKS, tid);
+        step(0, sa1.v, sb1.v, true);
+        __syncthreads();
+        // odd tile: multiply buffer 1, stage set 0 (tile kt+2) into buffer 0, load tile kt+3 into set 1
+        if (kt + 3 < nk) { sa1.load(a.A, a.lda, m0, (kt + 3) * BKS, tid); sb1.load(a.B, a.ldb, n0, (kt + 3) * BKS, tid); }
+        step(1, sa0.v, sb0.v, true);
         __syncthreads();
     }
-    compute((nk - 1 - kt0) & 1);
+    // tail: one or two tiles left; buffer 0 holds tile kt, set 1 (if any) tile kt+1
+    if (kt + 1 < nk) {
+        step(0, sa1.v, sb1.v, true);
+        __syncthreads();
+        step(1, sa0.v, sb0.v, false);
+    } else {
+        step(0, sa0.v, sb0.v, false);
+    }
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
