@@ -32,6 +32,14 @@ int asr_decoder_chain_fwd(void* stream, float* gates, const float* wh, const flo
                           const float* b_att, const float* v, const float* hf, const float* enc, const int* enc_len,
                           float* dec_c, float* dec_h, float* alpha, float* ctx, float* y, void* ws, int* err,
                           int B, int Te, int D, int A, int H, int t0, int t1);
+int asr_decoder_train_fwd(void* stream, const float* embedding, const float* lm_kernel, const float* lm_bias,
+                          const float* wk, const float* bprime, const float* dec_kh, const float* w_att,
+                          const float* b_att, const float* v, const float* ap_w, const float* ap_b,
+                          const float* out_w, const float* out_b, const float* hf, const float* enc,
+                          const int* enc_len, const int* seq_len, int* tok, const unsigned* fbmask8, float keep, unsigned seed,
+                          float* lm_out, float* lm_hprev, float* lm_act, float* dec_gates, float* dec_c, float* dec_h,
+                          float* y, float* alpha, float* ctx, void* ws, int* err,
+                          int B, int Te, int D, int A, int H, int lmH, int E, int V, int T);
 bool asr_lstm_tm_supported(int B, int H);
 int asr_lstm_rec_fwd_tm(hipStream_t s, const float* gates, const float* kh, const int* full_len, float* out, int ldo,
                         float* act, float* hprev, const float* h0, const float* c0, float* h_last, float* c_last,
@@ -90,9 +98,36 @@ extern "C" int asr_attn_decoder_fwd(void* stream, const asr_dec_weights* w, cons
         asr::prof_end(ASR_PROF_DECODER_FWD, ms);
         return ASR_OK;
     }
+    // ---- training graph in ONE persistent launch (csrc/decoder_greedy.hip, TRAIN instantiation): LM cell, outer cell and
+    // attention of every step, AttnProjection / OutputProjection / Gumbel-max draw at the scheduled-sampling feedback steps
+    // (host coins -> a 256-bit mask passed by value), LM dropout, activations saved in the layouts the backward reads.  No
+    // per-segment launches; ASR_DEC_TRAINK=0 selects the segment-wise chain path below (the path it is tested against).
+    static const bool traink_env = [] { const char* e = getenv("ASR_DEC_TRAINK"); return !(e && e[0] == '0'); }();
+    bool done_train_kernel = false;
+    if (traink_env && mode != 1 && T <= 256 && ws->greedy_ws && ws->w2k && ws->err && ws->y && ws->dec_gates && !w->simple_w &&
+        ws->lm_act && ws->lm_hprev && (keep_lm >= 1.0f || ws->lm_hd) && asr_decoder_greedy_supported(B, Te, D, A, H, lmH, E, V)) {
+        float* wk = ws->w2k;                       // [(lmH+D), 4H] followed by b' [4H] (InputProjection folded, as below)
+        float* bprime = wk + (size_t)(lmH + D) * 4 * H;
+        if ((rc = asr_gemm_f32(stream, 0, 0, lmH + D, 4 * H, E, w->inp_w, E, w->dec_kernel, 4 * H, wk, 4 * H, nullptr, 0))) return rc;
+        if ((rc = asr_gemm_f32(stream, 0, 0, 1, 4 * H, E, w->inp_b, E, w->dec_kernel, 4 * H, bprime, 4 * H, w->dec_bias, 0))) return rc;
+        unsigned fbmask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < T; ++i)
+            if (feedback(i)) fbmask[i >> 5] |= 1u << (i & 31);
+        float* lm_out_buf = keep_lm < 1.0f ? ws->lm_hd : ws->lm_h;
+        if ((rc = asr_decoder_train_fwd(stream, w->embedding, w->lm_kernel, w->lm_bias, wk, bprime, w->dec_kernel + (size_t)E * 4 * H,
+                                        w->attn_w, w->attn_b, w->attn_v, w->ap_w, w->ap_b, w->out_w, w->out_b, ws->hf, enc, enc_len,
+                                        seq_len, ws->tok, fbmask, keep_lm, seed, lm_out_buf, ws->lm_hprev, ws->lm_act, ws->dec_gates,
+                                        ws->dec_c, ws->dec_h, ws->y, ws->alpha, ws->ctx, ws->greedy_ws, ws->err,
+                                        B, Te, D, A, H, lmH, E, V, T))) return rc;
+        // x (saved for the backward) = lm_out . W_inp[:P] + b_inp + ctx_prev . W_inp[P:]  -- two GEMMs over all steps
+        if ((rc = asr_gemm_f32(stream, 0, 0, T * B, E, lmH, lm_out_buf, lmH, w->inp_w, E, ws->x, E, w->inp_b, 0))) return rc;
+        if (T > 1 && (rc = asr_gemm_f32(stream, 0, 0, (T - 1) * B, E, D, ws->ctx, D, w->inp_w + (size_t)lmH * E, E,
+                                        ws->x + (size_t)B * E, E, nullptr, 1))) return rc;
+        done_train_kernel = true;
+    }
     // ---- persistent chain path: the per-step attention chain of a whole SEGMENT (steps up to and
     // including the next feedback step) runs in one launch of csrc/decoder_chain.hip
-    const bool use_chain = mode != 1 && ws->chain_ws && ws->w2k && ws->err && ws->y && ws->dec_gates &&
+    const bool use_chain = !done_train_kernel && mode != 1 && ws->chain_ws && ws->w2k && ws->err && ws->y && ws->dec_gates &&
                            asr_decoder_chain_supported(B, Te, D, A, H);
     if (use_chain) {
         // WK = W_inp . K_x  ([P+D,E].[E,4H]) and b' = b_inp . K_x + b_dec: InputProjection folded into the
@@ -201,7 +236,7 @@ extern "C" int asr_attn_decoder_fwd(void* stream, const asr_dec_weights* w, cons
         if (T > 1 && (rc = asr_gemm_f32(stream, 0, 0, (T - 1) * B, E, D, ws->ctx, D, w->inp_w + (size_t)P * E, E,
                                         ws->x + (size_t)B * E, E, nullptr, 1))) return rc;
     }
-    for (int i = 0; i < T && !use_chain; ++i) {
+    for (int i = 0; i < T && !use_chain && !done_train_kernel; ++i) {
         const size_t o = (size_t)i * B;
         // ---- side stream: LM cell of step i
         if (feedback(i - 1) && hipStreamWaitEvent(ss, e_tok, 0) != hipSuccess) return ASR_ELAUNCH;

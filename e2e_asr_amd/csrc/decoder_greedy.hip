@@ -49,6 +49,16 @@ struct GreedyArgs {
     int* err;
     int B, Te, T, V, g0, ng;
     unsigned long long* dbg;    // STAMP build only
+    // ---- training graph (TRAIN instantiation, attn_decoder.py:126-145): tok[] holds the teacher token of EVERY step; the
+    // token of step i+1 is drawn from softmax(logits_i) (Gumbel-max, decoder.py:156-180) where bit i of fbmask is set (the
+    // host's scheduled-sampling coins); AttnProjection / OutputProjection run in the loop only at those steps (the logits of
+    // all steps come from hoisted GEMMs afterwards); DropoutWrapper on the LM output; activations saved for the backward
+    // in the layouts of decoder_chain.hip / lstm.hip (time-major rows i*B + b).
+    uint32_t fbmask[8];
+    float keep; uint32_t seed;
+    float* lm_out; float* lm_hprev; float* lm_act;       // [T][B][LMH] (dropped) output, [T][B][LMH] h_{i-1}, [T][B][LMH][8] records
+    float* dec_gates; float* dec_c; float* dec_h;        // [T][B][4H] activated i,j,f,o; [T][B][H]; [T][B][H]
+    float* y; float* alpha; float* ctx;                  // [T][B][A], [T][B][Te], [T][B][D]
 };
 
 // (value, index) argmax combine with first-max tie-breaking (np.argmax / tf.argmax); NaN never wins
@@ -70,7 +80,7 @@ __device__ __forceinline__ void row16_argmax(float& bv, int& bi) {
     amax_dpp<0xB1>(bv, bi); amax_dpp<0x4E>(bv, bi); amax_dpp<0x141>(bv, bi); amax_dpp<0x140>(bv, bi);
 }
 
-template <int H, int D, int A, int LMH, bool STAMP = false>
+template <int H, int D, int A, int LMH, bool STAMP = false, bool TRAIN = false>
 __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
     unsigned int stamp[24] = {0};
     unsigned long long tlast = 0;
@@ -106,7 +116,8 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
     float* hfl = vl + A;                         // [R][MAXTS][A]
     const int Te = a.Te, V = a.V;
     const int TS = (Te + G - 1) / G;
-    float* encl = hfl + R * MAXTS * A;           // [R][Te][DS]
+    float* v_lmh = hfl + R * MAXTS * A;          // [R][LMH]  TRAIN: undropped h_lm_i (the LM's own recurrence input)
+    float* encl = v_lmh + (TRAIN ? R * LMH : 0); // [R][Te][DS]
 
     const int grp_l = blockIdx.x & 7, mem = blockIdx.x >> 3;       // round-robin dispatch: a group = the 32 workgroups of one XCD
     if (grp_l >= a.ng) return;
@@ -124,7 +135,7 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
     int blen[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) blen[r] = rok(r) ? min(max(a.enc_len[browf(r)], 0), Te) : 0;
-    constexpr int NLM = R * LMH, NQH = 2 * R * H, NY = R * A, NE = R * G * MAXTS, NC = R * D, NP = R * H, NM = 2 * R * G;
+    constexpr int NLM = (TRAIN ? 2 : 1) * R * LMH, NQH = 2 * R * H, NY = R * A, NE = R * G * MAXTS, NC = R * D, NP = R * H, NM = 2 * R * G;
     constexpr int NPAR = NLM + NQH + NY + NE + NC + NP + NM;
     u64* gbase = a.gx + (size_t)grp * 2 * NPAR;
     const bool fast = group_shares_xcd(a.xcc_slots + (size_t)grp * G, G, mem, tid, a.err, lds_flag);
@@ -152,17 +163,27 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
     float wy[4];              // y = q . W_att: K = H in 4 parts of 64 (DPP rows 0..15)
 #pragma unroll
     for (int e = 0; e < 4; ++e) wy[e] = yact ? a.w_att[(size_t)(ypart * 64 + kq * 4 + e) * A + mem * AS + ycol] : 0.f;
-    float wap[12];            // AttnProjection: K = KA in 4 parts of 192
-#pragma unroll
-    for (int j = 0; j < 3; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) wap[j * 4 + e] = a.ap_w[(size_t)(part * 192 + (j * 16 + kq) * 4 + e) * H + mem * PS + u8];
+    // AttnProjection (K = KA in 4 parts of 192) and OutputProjection (one vocabulary column per DPP row, K = H) slices.  The
+    // inference graph needs them at every step: registers.  The training graph runs the projections at feedback steps only
+    // (~10 % of the steps): it re-reads the 28 values from L2 there and leaves the registers to the rest of the step.
     const int vcol = mem * VS + row;
-    float wout[16];           // OutputProjection: one vocabulary column per DPP row, K = H
+    // (`z` is an opaque zero: inside the step loop it keeps the compiler from hoisting the loads back out of it)
+    auto load_wap = [&](float* w, int z) {
+        const float* base = a.ap_w + z;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 3; ++j)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) wout[j * 4 + e] = vcol < V ? a.out_w[(size_t)((j * 16 + kq) * 4 + e) * V + vcol] : 0.f;
+            for (int e = 0; e < 4; ++e) w[j * 4 + e] = base[(size_t)(part * 192 + (j * 16 + kq) * 4 + e) * H + mem * PS + u8];
+    };
+    auto load_wout = [&](float* w, int z) {
+        const float* base = a.out_w + z;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[j * 4 + e] = vcol < V ? base[(size_t)((j * 16 + kq) * 4 + e) * V + vcol] : 0.f;
+    };
+    float wap_r[12], wout_r[16];
+    if (!TRAIN) { load_wap(wap_r, 0); load_wout(wout_r, 0); }
     const float outb = vcol < V ? a.out_b[vcol] : 0.f;
 
     // ---- resident activations (LDS)
@@ -184,7 +205,7 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
     const int cr = cell ? tid >> 3 : 0, cu = tid & 7;
     const bool cb_ok = cell && rok(cr);
     const int cb = browf(cr);
-    float c_lm = 0.f, c_dec = 0.f;
+    float c_lm = 0.f, c_dec = 0.f, h_lm_prev = 0.f;
     int tokr = cb_ok ? a.tok[cb] : 0;
     tokr = min(max(tokr, 0), V - 1);
     float bp[4], ybias = 0.f, pbias = 0.f;
@@ -202,6 +223,8 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
         sph = 0;
         const uint32_t ep = (uint32_t)(i + 1);
         const uint32_t tb = tag_bit(i);
+        // does step i feed its own prediction forward?  inference graph: always; training graph: at the flagged steps
+        const bool fbi = !TRAIN || (i + 1 < a.T && ((a.fbmask[(i >> 5) & 7] >> (i & 31)) & 1u));
         u64* gLM = gbase + (size_t)(i & 1) * NPAR;
         u64* gQH = gLM + NLM; u64* gY = gQH + NQH; u64* gE = gY + NY; u64* gC = gE + NE; u64* gP = gC + NC; u64* gM = gP + NP;
         // every exchange but the (max, index) pairs travels as tagged floats (granule.h): the regions keep their granule-sized
@@ -220,17 +243,44 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
                     s.x += x.x; s.y += x.y; s.z += x.z; s.w += x.w;
                 }
                 const float gi = fast_sigmoid(s.x), gj = fast_tanh(s.y), gf = fast_sigmoid(s.z + 1.0f), go = fast_sigmoid(s.w);
+                const float c_old = c_lm;
                 c_lm = c_lm * gf + gi * gj;
-                tagged_publish(tLM + (size_t)cr * LMH + mem * LS + cu, tb, go * fast_tanh(c_lm), fast);
+                const float hl = go * fast_tanh(c_lm);
+                if (TRAIN) {
+                    // DropoutWrapper(output_keep_prob) scales what the decoder sees; the LM's recurrence keeps h itself
+                    float o = hl;
+                    if (a.keep < 1.0f) o *= keep_scale(a.seed, (uint32_t)(i * a.B + cb), (uint32_t)(mem * LS + cu), a.keep);
+                    tagged_publish2(tLM + 2 * ((size_t)cr * LMH + mem * LS + cu), tb, o, hl, fast);
+                    // bookkeeping stores after the publish (this wave never polls): the record format of csrc/lstm.hip
+                    const size_t ridx = ((size_t)i * a.B + cb) * LMH + mem * LS + cu;
+                    a.lm_out[ridx] = __uint_as_float(__float_as_uint(o) & ~1u);          // as every consumer saw it
+                    a.lm_hprev[ridx] = h_lm_prev;
+                    float4* rp = reinterpret_cast<float4*>(a.lm_act + ridx * 8);
+                    rp[0] = make_float4(gi, gj, gf, go);
+                    rp[1] = make_float4(c_lm, c_old, 0.f, 0.f);
+                    h_lm_prev = __uint_as_float(__float_as_uint(hl) & ~1u);
+                } else {
+                    tagged_publish(tLM + (size_t)cr * LMH + mem * LS + cu, tb, hl, fast);
+                }
             }
         }
         // ---- (2) gather lm_out_i, outer cell
         if (poller) {
-            for (int p = tid - 64; p < NLM / 4; p += NPOLL) {
-                const int idx = 4 * p, r = idx / LMH, k = idx % LMH;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (rok(r)) tagged_poll4(tLM + idx, tb, v, a.err);
-                *reinterpret_cast<float4*>(v_dec + r * KD + k) = v;
+            if (TRAIN) {
+                for (int p = tid - 64; p < NLM / 4; p += NPOLL) {       // a quad = (dropped, plain) outputs of two adjacent units
+                    const int r = (2 * p) / LMH, k = (2 * p) % LMH;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (rok(r)) tagged_poll4(tLM + 4 * p, tb, v, a.err);
+                    *reinterpret_cast<float2*>(v_dec + r * KD + k) = make_float2(v.x, v.z);
+                    *reinterpret_cast<float2*>(v_lmh + r * LMH + k) = make_float2(v.y, v.w);
+                }
+            } else {
+                for (int p = tid - 64; p < NLM / 4; p += NPOLL) {
+                    const int idx = 4 * p, r = idx / LMH, k = idx % LMH;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (rok(r)) tagged_poll4(tLM + idx, tb, v, a.err);
+                    *reinterpret_cast<float4*>(v_dec + r * KD + k) = v;
+                }
             }
         }
         __syncthreads();
@@ -260,6 +310,26 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
                 for (int r = 0; r < R; ++r)
                     *reinterpret_cast<float4*>(sums + ((part * 8 + u8) * R + r) * 4) = make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
             }
+            if (TRAIN) {
+                // LM cell of step i+1, recurrent part: h_lm_i . K_h for my units, from the UNDROPPED h (the inference graph
+                // forms it in phase 7, which the training graph runs at feedback steps only).  lmsum was read by this step's
+                // phase 1 before the barrier above and is read again only after the barrier below.
+                float al[R][4];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const float4 x = *reinterpret_cast<const float4*>(v_lmh + r * LMH + part * 64 + kq * 4);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        al[r][g] = fmaf(x.x, wlm[0][g], fmaf(x.y, wlm[1][g], fmaf(x.z, wlm[2][g], x.w * wlm[3][g])));
+                        al[r][g] = row16_allreduce_sum(al[r][g]);
+                    }
+                }
+                if (kq == 0) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+                        *reinterpret_cast<float4*>(lmsum + ((part * 8 + u8) * R + r) * 4) = make_float4(al[r][0], al[r][1], al[r][2], al[r][3]);
+                }
+            }
         }
         __syncthreads();
         GREEDY_STAMP()
@@ -272,8 +342,16 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
             }
             const float gi = fast_sigmoid(s.x), gj = fast_tanh(s.y), gf = fast_sigmoid(s.z + 1.0f), go = fast_sigmoid(s.w);
             c_dec = c_dec * gf + gi * gj;
+            const float hd = go * fast_tanh(c_dec);
             // q = cell state c (decoder.py:79-80) and h, adjacent granules
-            if (cb_ok) tagged_publish2(tQH + 2 * ((size_t)cr * H + mem * HS + cu), tb, c_dec, go * fast_tanh(c_dec), fast);
+            if (cb_ok) tagged_publish2(tQH + 2 * ((size_t)cr * H + mem * HS + cu), tb, c_dec, hd, fast);
+            if (TRAIN && cb_ok) {
+                const size_t rowi = (size_t)i * a.B + cb;
+                float* gp = a.dec_gates + rowi * H4 + mem * HS + cu;
+                gp[0] = gi; gp[H] = gj; gp[2 * H] = gf; gp[3 * H] = go;
+                a.dec_c[rowi * H + mem * HS + cu] = c_dec;
+                a.dec_h[rowi * H + mem * HS + cu] = hd;
+            }
         }
         // ---- (3) gather (q_i, h_i); y slice = q . W_att[:, slice] + b
         if (poller) {
@@ -306,7 +384,10 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
             const int r = tid >> 2, col = tid & 3;
             const float yv = ybias + (ysum[(0 * AS + col) * R + r] + ysum[(1 * AS + col) * R + r]) +
                              (ysum[(2 * AS + col) * R + r] + ysum[(3 * AS + col) * R + r]);
-            if (rok(r)) tagged_publish(tY + (size_t)r * A + mem * AS + col, tb, yv, fast);
+            if (rok(r)) {
+                tagged_publish(tY + (size_t)r * A + mem * AS + col, tb, yv, fast);
+                if (TRAIN) a.y[((size_t)i * a.B + r0 + r) * A + mem * AS + col] = yv;
+            }
         }
         // ---- (4) gather y, scores on my position slice
         if (poller) {
@@ -401,7 +482,15 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
             float cs = 0.f;
 #pragma unroll
             for (int tp = 0; tp < 8; ++tp) cs += cpart[(tp * R + r) * DS + dd];
-            if (rok(r)) tagged_publish(tC + (size_t)r * D + mem * DS + dd, tb, cs, fast);
+            if (rok(r)) {
+                tagged_publish(tC + (size_t)r * D + mem * DS + dd, tb, cs, fast);
+                if (TRAIN) a.ctx[((size_t)i * a.B + r0 + r) * D + mem * DS + dd] = cs;
+            }
+            if (TRAIN && lane < R * MAXTS) {      // alpha of this step -> global: every workgroup stores its own position slice
+                const int ra = lane / MAXTS, tl = lane % MAXTS, tau = tau0 + tl;
+                if (tl < TS && tau < Te && rok(ra))
+                    a.alpha[((size_t)i * a.B + r0 + ra) * Te + tau] = el[ra * G * MAXTS + mem * MAXTS + tl];
+            }
         }
         // ---- (6) gather ctx_i; AttnProjection slice
         if (poller) {
@@ -415,7 +504,17 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
         }
         __syncthreads();
         GREEDY_STAMP()
+        if (!fbi) {          // training graph, teacher-forced step: no projection in the loop; the next token is the teacher's
+            if (wave0 && cell && i + 1 < a.T) {
+                tokr = cb_ok ? a.tok[(size_t)(i + 1) * a.B + cb] : 0;
+                tokr = min(max(tokr, 0), V - 1);
+            }
+            continue;        // (uniform: fbi is the same for every thread of the grid)
+        }
         {
+            float wap_l[12];
+            if (TRAIN) { int z = 0; asm volatile("" : "+s"(z)); load_wap(wap_l, z); }
+            const float* wap = TRAIN ? wap_l : wap_r;
             float acc[R];
 #pragma unroll
             for (int r = 0; r < R; ++r) {
@@ -453,6 +552,9 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
         __syncthreads();
         GREEDY_STAMP()
         {
+            float wout_l[16];
+            if (TRAIN) { int z = 0; asm volatile("" : "+s"(z)); load_wout(wout_l, z); }
+            const float* wout = TRAIN ? wout_l : wout_r;
             float acc[R];
 #pragma unroll
             for (int r = 0; r < R; ++r) {
@@ -470,26 +572,29 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
 #pragma unroll
                 for (int r = 0; r < R; ++r) lg[r * VS + row] = acc[r] + outb;
             }
-            // LM cell of step i+1, recurrent part: h_lm_i . K_h for my units (v_dec[:, :LMH] holds lm_out_i)
-            float al[R][4];
+            if (!TRAIN) {
+                // LM cell of step i+1, recurrent part: h_lm_i . K_h for my units (v_dec[:, :LMH] holds lm_out_i)
+                float al[R][4];
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const float4 x = *reinterpret_cast<const float4*>(v_dec + r * KD + part * 64 + kq * 4);
+                for (int r = 0; r < R; ++r) {
+                    const float4 x = *reinterpret_cast<const float4*>(v_dec + r * KD + part * 64 + kq * 4);
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    al[r][g] = fmaf(x.x, wlm[0][g], fmaf(x.y, wlm[1][g], fmaf(x.z, wlm[2][g], x.w * wlm[3][g])));
-                    al[r][g] = row16_allreduce_sum(al[r][g]);
+                    for (int g = 0; g < 4; ++g) {
+                        al[r][g] = fmaf(x.x, wlm[0][g], fmaf(x.y, wlm[1][g], fmaf(x.z, wlm[2][g], x.w * wlm[3][g])));
+                        al[r][g] = row16_allreduce_sum(al[r][g]);
+                    }
                 }
-            }
-            if (kq == 0) {
+                if (kq == 0) {
 #pragma unroll
-                for (int r = 0; r < R; ++r)
-                    *reinterpret_cast<float4*>(lmsum + ((part * 8 + u8) * R + r) * 4) = make_float4(al[r][0], al[r][1], al[r][2], al[r][3]);
+                    for (int r = 0; r < R; ++r)
+                        *reinterpret_cast<float4*>(lmsum + ((part * 8 + u8) * R + r) * 4) = make_float4(al[r][0], al[r][1], al[r][2], al[r][3]);
+                }
             }
         }
         __syncthreads();
         GREEDY_STAMP()
-        if (wave7) {         // logits -> global (raw_rnn emits zeros for finished rows, attn_decoder.py:170)
+        if (!TRAIN && wave7) {   // logits -> global (raw_rnn emits zeros for finished rows, attn_decoder.py:170); the training
+                                 // graph's logits come from the hoisted GEMMs over all steps
             for (int idx = lane; idx < R * VS; idx += 64) {
                 const int r = idx / VS, c = idx % VS, vc = mem * VS + c;
                 if (rok(r) && vc < V)
@@ -504,7 +609,14 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
 #pragma unroll
             for (int h2 = 0; h2 < 2; ++h2) {
                 const int cc = c + 16 * h2, vc = mem * VS + cc;
-                if (vc < V) amax_take(bv, bi, live ? lg[r * VS + cc] : 0.f, vc);
+                if (vc < V) {
+                    float val = live ? lg[r * VS + cc] : 0.f;
+                    if (TRAIN) {   // tf.multinomial as Gumbel-max, the generator of next_token_kernel (csrc/loss.hip): same draw
+                        const float u = fmaxf(uniform01(a.seed, (uint32_t)i * 65537u + (uint32_t)(r0 + r), (uint32_t)vc), 1e-12f);
+                        val -= logf(-logf(u));
+                    }
+                    amax_take(bv, bi, val, vc);
+                }
             }
             row16_argmax(bv, bi);
             if (c == 0 && rok(r)) chain_publish2(gM + 2 * ((size_t)r * G + mem), ep, bv, __int_as_float(bi), fast);
@@ -546,12 +658,12 @@ extern "C" int asr_decoder_greedy_supported(int B, int Te, int D, int A, int H, 
     return B > 0 && Te > 0 && Te <= 256 && V > 0 && V <= 1024 && H == 256 && D == 512 && A == 128 && lmH == 256;
 }
 
-static size_t greedy_npar(int D, int A, int H, int lmH) {
-    return 4 * ((size_t)lmH + 2 * (size_t)H + A + 32 * 8 + D + H + 2 * 32);
+static size_t greedy_npar(int D, int A, int H, int lmH, bool train) {      // = NPAR of the kernel instantiation
+    return 4 * ((train ? 2 : 1) * (size_t)lmH + 2 * (size_t)H + A + 32 * 8 + D + H + 2 * 32);
 }
-static size_t greedy_gran_bytes(int B, int D, int A, int H, int lmH) {
+static size_t greedy_gran_bytes(int B, int D, int A, int H, int lmH) {     // sized for the larger (training) layout
     const size_t groups = ((size_t)B + 3) / 4;
-    return (groups * 2 * greedy_npar(D, A, H, lmH) * sizeof(u64) + groups * 32 * sizeof(u64) + 255) / 256 * 256;
+    return (groups * 2 * greedy_npar(D, A, H, lmH, true) * sizeof(u64) + groups * 32 * sizeof(u64) + 255) / 256 * 256;
 }
 // granules + XCC slots | EK [V][4 lmH]
 extern "C" size_t asr_decoder_greedy_ws_bytes(int B, int D, int A, int H, int lmH, int V) {
@@ -560,6 +672,44 @@ extern "C" size_t asr_decoder_greedy_ws_bytes(int B, int D, int A, int H, int lm
 
 extern "C" int asr_gemm_f32(void* stream, int transA, int transB, int M, int N, int K, const float* A, int lda,
                             const float* B, int ldb, float* C, int ldc, const float* bias, int accumulate);
+
+// Shared launcher of the inference-graph and training-graph instantiations; `a` arrives with the mode-specific members
+// set.  ws: asr_decoder_greedy_ws_bytes().
+static int greedy_launch(void* stream, asr::GreedyArgs a, bool train, const float* embedding, const float* lm_kernel,
+                         const float* lm_bias, void* ws, int B, int Te, int D, int A, int H, int lmH, int E, int V) {
+    using namespace asr;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t gbytes = greedy_gran_bytes(B, D, A, H, lmH);
+    float* ek = reinterpret_cast<float*>(static_cast<char*>(ws) + gbytes);
+    if (hipMemsetAsync(ws, 0, gbytes, s) != hipSuccess) return ASR_ELAUNCH;
+    int rc;
+    if ((rc = asr_gemm_f32(stream, 0, 0, V, 4 * lmH, E, embedding, E, lm_kernel, 4 * lmH, ek, 4 * lmH, lm_bias, 0))) return rc;
+    a.ek = ek; a.lm_kh = lm_kernel + (size_t)E * 4 * lmH;
+    a.gx = static_cast<u64*>(ws);
+    const int groups = (B + 3) / 4;
+    a.xcc_slots = a.gx + (size_t)groups * 2 * greedy_npar(D, A, H, lmH, train);
+    a.B = B; a.Te = Te; a.V = V;
+    constexpr int R = 4, KD = 1024, KA = 768, Hc = 256, Ac = 128, G = 32, MAXTS = 8;
+    const size_t lds = sizeof(float) * (4 + (size_t)R * KD + R * KA + R * Hc + R * Ac + R * G * MAXTS + 2 * (4 * 8 * R * 4) +
+                                        4 * 4 * R + 4 * 8 * R + 8 * R * 16 + 32 + R * 32 + 2 * R * G + Ac + R * MAXTS * Ac +
+                                        (train ? (size_t)R * lmH : 0) + (size_t)R * Te * 16);
+    if (lds > 160 * 1024 - 64) return ASR_EUNSUPPORTED;
+    a.dbg = (!train && getenv("ASR_CHAIN_STAMP")) ? asr::g_lstm_dbg : nullptr;
+    if (train) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asr::decoder_greedy_kernel<256, 512, 128, 256, false, true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    else (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asr::decoder_greedy_kernel<256, 512, 128, 256>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (a.dbg) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asr::decoder_greedy_kernel<256, 512, 128, 256, true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    for (int g0 = 0; g0 < groups; g0 += 8) {            // 8 groups (one per XCD) = 256 workgroups per launch
+        a.g0 = g0; a.ng = std::min(8, groups - g0);
+        if (train) hipLaunchKernelGGL((asr::decoder_greedy_kernel<256, 512, 128, 256, false, true>), dim3(8 * G), dim3(512), lds, s, a);
+        else if (a.dbg) hipLaunchKernelGGL((asr::decoder_greedy_kernel<256, 512, 128, 256, true>), dim3(8 * G), dim3(512), lds, s, a);
+        else hipLaunchKernelGGL((asr::decoder_greedy_kernel<256, 512, 128, 256>), dim3(8 * G), dim3(512), lds, s, a);
+        if (hipGetLastError() != hipSuccess) return ASR_ELAUNCH;
+    }
+    return ASR_OK;
+}
 
 // All T steps of the greedy decode.  wk / bprime: the folded InputProjection (decoder.hip); tok row 0 holds the first
 // input token of every utterance, rows 1.. are written.  ws: asr_decoder_greedy_ws_bytes().
@@ -573,35 +723,38 @@ extern "C" int asr_decoder_greedy_fwd(void* stream, const float* embedding, cons
     if (!asr_decoder_greedy_supported(B, Te, D, A, H, lmH, E, V) || T <= 0) return ASR_EUNSUPPORTED;
     if (!embedding || !lm_kernel || !lm_bias || !wk || !bprime || !dec_kh || !w_att || !b_att || !v || !ap_w || !ap_b ||
         !out_w || !out_b || !hf || !enc || !enc_len || !seq_len || !tok || !logits || !ws || !err) return ASR_EINVAL;
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const size_t gbytes = greedy_gran_bytes(B, D, A, H, lmH);
-    float* ek = reinterpret_cast<float*>(static_cast<char*>(ws) + gbytes);
-    if (hipMemsetAsync(ws, 0, gbytes, s) != hipSuccess) return ASR_ELAUNCH;
-    int rc;
-    if ((rc = asr_gemm_f32(stream, 0, 0, V, 4 * lmH, E, embedding, E, lm_kernel, 4 * lmH, ek, 4 * lmH, lm_bias, 0))) return rc;
-    GreedyArgs a;
-    a.ek = ek; a.lm_kh = lm_kernel + (size_t)E * 4 * lmH; a.wk = wk; a.bprime = bprime; a.dec_kh = dec_kh;
+    GreedyArgs a = {};
+    a.wk = wk; a.bprime = bprime; a.dec_kh = dec_kh;
     a.w_att = w_att; a.b_att = b_att; a.v = v; a.ap_w = ap_w; a.ap_b = ap_b; a.out_w = out_w; a.out_b = out_b;
     a.hf = hf; a.enc = enc; a.enc_len = enc_len; a.seq_len = seq_len; a.tok = tok; a.logits = logits;
-    a.gx = static_cast<u64*>(ws);
-    const int groups = (B + 3) / 4;
-    a.xcc_slots = a.gx + (size_t)groups * 2 * greedy_npar(D, A, H, lmH);
-    a.err = err; a.B = B; a.Te = Te; a.T = T; a.V = V;
-    constexpr int R = 4, KD = 1024, KA = 768, Hc = 256, Ac = 128, G = 32, MAXTS = 8;
-    const size_t lds = sizeof(float) * (4 + (size_t)R * KD + R * KA + R * Hc + R * Ac + R * G * MAXTS + 2 * (4 * 8 * R * 4) +
-                                        4 * 4 * R + 4 * 8 * R + 8 * R * 16 + 32 + R * 32 + 2 * R * G + Ac + R * MAXTS * Ac +
-                                        (size_t)R * Te * 16);
-    if (lds > 160 * 1024 - 64) return ASR_EUNSUPPORTED;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asr::decoder_greedy_kernel<256, 512, 128, 256>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    a.dbg = getenv("ASR_CHAIN_STAMP") ? asr::g_lstm_dbg : nullptr;
-    if (a.dbg) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asr::decoder_greedy_kernel<256, 512, 128, 256, true>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    for (int g0 = 0; g0 < groups; g0 += 8) {            // 8 groups (one per XCD) = 256 workgroups per launch
-        a.g0 = g0; a.ng = std::min(8, groups - g0);
-        if (a.dbg) hipLaunchKernelGGL((asr::decoder_greedy_kernel<256, 512, 128, 256, true>), dim3(8 * G), dim3(512), lds, s, a);
-        else hipLaunchKernelGGL((asr::decoder_greedy_kernel<256, 512, 128, 256>), dim3(8 * G), dim3(512), lds, s, a);
-        if (hipGetLastError() != hipSuccess) return ASR_ELAUNCH;
-    }
-    return ASR_OK;
+    a.err = err; a.T = T;
+    return greedy_launch(stream, a, false, embedding, lm_kernel, lm_bias, ws, B, Te, D, A, H, lmH, E, V);
+}
+
+// Training graph (teacher forcing with scheduled-sampling feedback at the steps flagged in fbmask8, LM dropout, saved
+// activations): the same one-XCD-group kernel, TRAIN instantiation.  tok holds the teacher tokens of all T steps (rows after
+// a feedback step are overwritten with the drawn token); the logits are NOT produced here (hoisted GEMMs, decoder.hip).
+int asr_decoder_train_fwd(void* stream, const float* embedding, const float* lm_kernel, const float* lm_bias,
+                          const float* wk, const float* bprime, const float* dec_kh, const float* w_att,
+                          const float* b_att, const float* v, const float* ap_w, const float* ap_b,
+                          const float* out_w, const float* out_b, const float* hf, const float* enc,
+                          const int* enc_len, const int* seq_len, int* tok, const unsigned* fbmask8, float keep, unsigned seed,
+                          float* lm_out, float* lm_hprev, float* lm_act, float* dec_gates, float* dec_c, float* dec_h,
+                          float* y, float* alpha, float* ctx, void* ws, int* err,
+                          int B, int Te, int D, int A, int H, int lmH, int E, int V, int T) {
+    using namespace asr;
+    if (!asr_decoder_greedy_supported(B, Te, D, A, H, lmH, E, V) || T <= 0 || T > 256) return ASR_EUNSUPPORTED;
+    if (!embedding || !lm_kernel || !lm_bias || !wk || !bprime || !dec_kh || !w_att || !b_att || !v || !ap_w || !ap_b ||
+        !out_w || !out_b || !hf || !enc || !enc_len || !seq_len || !tok || !fbmask8 || !lm_out || !lm_hprev || !lm_act ||
+        !dec_gates || !dec_c || !dec_h || !y || !alpha || !ctx || !ws || !err) return ASR_EINVAL;
+    GreedyArgs a = {};
+    a.wk = wk; a.bprime = bprime; a.dec_kh = dec_kh;
+    a.w_att = w_att; a.b_att = b_att; a.v = v; a.ap_w = ap_w; a.ap_b = ap_b; a.out_w = out_w; a.out_b = out_b;
+    a.hf = hf; a.enc = enc; a.enc_len = enc_len; a.seq_len = seq_len; a.tok = tok; a.logits = nullptr;
+    a.err = err; a.T = T;
+    for (int j = 0; j < 8; ++j) a.fbmask[j] = fbmask8[j];
+    a.keep = keep; a.seed = seed;
+    a.lm_out = lm_out; a.lm_hprev = lm_hprev; a.lm_act = lm_act; a.dec_gates = dec_gates; a.dec_c = dec_c; a.dec_h = dec_h;
+    a.y = y; a.alpha = alpha; a.ctx = ctx;
+    return greedy_launch(stream, a, true, embedding, lm_kernel, lm_bias, ws, B, Te, D, A, H, lmH, E, V);
 }

@@ -6,6 +6,7 @@ Errors follow the reference's Python-exception convention: invalid arguments rai
 ValueError, launch failures RuntimeError.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -422,6 +423,10 @@ def attn_decoder_fwd(wt, dec_inp, seq_len, enc, enc_len, mode=0, coin=None, samp
         ws["w2k"] = f(lmH + D + 1, 4 * H)         # inference graph: the whole greedy loop in one persistent launch
         ws["greedy_ws"] = _hx(dev, L.asr_decoder_greedy_ws_bytes(B, D, A, H, lmH, V))
         ws["err"] = _Flag.get(dev)
+    if (mode != 1 and T <= 256 and wt.get("simple_w") is None and ws.get("lm_act") is not None and
+            os.environ.get("ASR_DEC_TRAINK", "1") != "0" and L.asr_decoder_greedy_supported(B, Te, D, A, H, lmH, E, V)):
+        # training graph in one persistent launch (TRAIN instantiation of the same kernel): needs the chain path's buffers too
+        ws["greedy_ws"] = _hx(dev, L.asr_decoder_greedy_ws_bytes(B, D, A, H, lmH, V))
     logits = f(T * B, V)
     cw = _dec_struct(_lib.DecWeights, wt)
     cd = _lib.DecDims(B, Te, D, A, H, lmH, E, V, T)

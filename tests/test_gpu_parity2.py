@@ -406,3 +406,61 @@ def test_persistent_grid_that_cannot_be_coresident_is_refused(monkeypatch):
     assert L.asr_decoder_chain_supported(4, 10, 512, 128, 256) == 0 and L.asr_decoder_greedy_supported(4, 10, 512, 128, 256, 256, 256, 1000) == 0
     monkeypatch.delenv("ASR_LSTM_MAXWG")
     assert L.asr_resident_wg_budget() == full and L.asr_decoder_chain_supported(4, 10, 512, 128, 256) == 1
+
+
+# ------------------------------------------------------------------ training graph in one persistent launch
+@pytest.mark.parametrize("nb,T", [(32, 48), (37, 96), (3, 512)])
+def test_training_decoder_one_launch_equals_segment_chain_path(monkeypatch, nb, T):
+    """csrc/decoder_greedy.hip, TRAIN instantiation: the whole training-graph decoder (teacher forcing, scheduled-sampling
+    feedback with Gumbel draws at the coin-selected steps, LM dropout, saved activations) in ONE persistent launch must give
+    the segment-wise chain path's sampled tokens, logits, loss and every gradient (the backward consumes the activations
+    the kernel saved).  32 utterances = 8 one-XCD groups = 256 workgroups; 37 = two launches; T=512 at depth 2 = 256 encoder
+    positions (8 per workgroup, the kernel's limit).  Repeated runs: race detector at full occupancy."""
+    from e2e_asr_amd import ops
+    kw = dict(feat=80, vocab={"char": 1000}, num_layers={"char": 3 if T < 512 else 2}, seed=13, max_output={"char": 14},
+              enc_update=dict(hidden_size=256, out_prob=0.9),
+              dec_update=dict(hidden_size_dec=256, lm_hidden_size=256, emb_size=256, attention_vec_size=128, samp_prob=0.3,
+                              out_prob_dec=0.9))
+    b = _batch(51 + nb, nb, T, 80, 15, 1000)
+
+    def run(traink):
+        monkeypatch.setenv("ASR_DEC_TRAINK", traink)
+        m = _model(**kw)
+        m.decoder["char"].coin_rng = np.random.default_rng(8)
+        m.global_step = 1
+        m.forward(b)
+        ws = m.decoder["char"].saved["ws"]
+        assert (ws.get("greedy_ws") is not None) == (traink == "1") and ws.get("chain_ws") is not None
+        out, tok, loss = m.outputs["char"].cpu().numpy().copy(), ws["tok"].cpu().numpy().copy(), m.total_loss.item()
+        m.backward()
+        ops.check_device_flag(torch.device(DEV))
+        return out, tok, loss, {n: m.variables.grad_of(n).cpu().numpy().copy() for n in m.variables.names()}
+
+    ref = run("0")
+    assert (ref[1][1:] != np.asarray(b["char"]).T[1:ref[1].shape[0]]).any()            # some tokens really were sampled
+    for rep in range(3 if nb >= 32 else 1):
+        got = run("1")
+        np.testing.assert_array_equal(got[1], ref[1])
+        np.testing.assert_allclose(got[0], ref[0], rtol=0, atol=5e-5)
+        np.testing.assert_allclose(got[2], ref[2], rtol=1e-6)
+        for n, g0 in ref[3].items():
+            err = np.abs(got[3][n] - g0).max() / max(1e-3, np.abs(g0).max())
+            assert err < 2e-4, (rep, n, err)
+
+
+def test_training_decoder_one_launch_teacher_forced_vs_oracle_and_autograd():
+    """The same kernel under pure teacher forcing (no feedback step at all) and ragged target / encoder lengths: logits
+    and loss vs the float64 oracle, every gradient vs float64 autograd."""
+    from e2e_asr_amd import ops
+    m = _model(feat=80, vocab={"char": 1000}, seed=31, max_output={"char": 20})
+    b = _batch(7, 7, 100, 80, 17, 1000)
+    m.forward(b)
+    assert m.decoder["char"].saved["ws"].get("greedy_ws") is not None
+    w = _f64(m.variables.to_arrays())
+    b64 = dict(b); b64["logmel"] = b["logmel"].astype(np.float64)
+    r = O.seq2seq_forward(b64, w, is_training=True)
+    np.testing.assert_allclose(m.outputs["char"].cpu().numpy(), r["outputs"]["char"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(m.total_loss.item(), r["total_loss"], rtol=1e-5)
+    m.backward()
+    ops.check_device_flag(torch.device(DEV))
+    _grad_check(m, b)
