@@ -252,10 +252,12 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
                     if (a.keep < 1.0f) o *= keep_scale(a.seed, (uint32_t)(i * a.B + cb), (uint32_t)(mem * LS + cu), a.keep);
                     tagged_publish2(tLM + 2 * ((size_t)cr * LMH + mem * LS + cu), tb, o, hl, fast);
                     // bookkeeping stores after the publish (this wave never polls): the record format of csrc/lstm.hip
-                    const size_t ridx = ((size_t)i * a.B + cb) * LMH + mem * LS + cu;
+                    // (32-bit element offsets from the uniform base pointers: SGPR base + VGPR offset addressing, no 64-bit
+                    // running pointers kept in registers across the loop)
+                    const unsigned ridx = (unsigned)((i * a.B + cb) * LMH + mem * LS + cu);
                     a.lm_out[ridx] = __uint_as_float(__float_as_uint(o) & ~1u);          // as every consumer saw it
                     a.lm_hprev[ridx] = h_lm_prev;
-                    float4* rp = reinterpret_cast<float4*>(a.lm_act + ridx * 8);
+                    float4* rp = reinterpret_cast<float4*>(a.lm_act + ridx * 8u);
                     rp[0] = make_float4(gi, gj, gf, go);
                     rp[1] = make_float4(c_lm, c_old, 0.f, 0.f);
                     h_lm_prev = __uint_as_float(__float_as_uint(hl) & ~1u);
@@ -346,9 +348,9 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
             // q = cell state c (decoder.py:79-80) and h, adjacent granules
             if (cb_ok) tagged_publish2(tQH + 2 * ((size_t)cr * H + mem * HS + cu), tb, c_dec, hd, fast);
             if (TRAIN && cb_ok) {
-                const size_t rowi = (size_t)i * a.B + cb;
-                float* gp = a.dec_gates + rowi * H4 + mem * HS + cu;
-                gp[0] = gi; gp[H] = gj; gp[2 * H] = gf; gp[3 * H] = go;
+                const unsigned rowi = (unsigned)(i * a.B + cb);
+                const unsigned go_ = rowi * H4 + mem * HS + cu;
+                a.dec_gates[go_] = gi; a.dec_gates[go_ + H] = gj; a.dec_gates[go_ + 2 * H] = gf; a.dec_gates[go_ + 3 * H] = go;
                 a.dec_c[rowi * H + mem * HS + cu] = c_dec;
                 a.dec_h[rowi * H + mem * HS + cu] = hd;
             }
@@ -386,7 +388,7 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
                              (ysum[(2 * AS + col) * R + r] + ysum[(3 * AS + col) * R + r]);
             if (rok(r)) {
                 tagged_publish(tY + (size_t)r * A + mem * AS + col, tb, yv, fast);
-                if (TRAIN) a.y[((size_t)i * a.B + r0 + r) * A + mem * AS + col] = yv;
+                if (TRAIN) a.y[(unsigned)((i * a.B + r0 + r) * A + mem * AS + col)] = yv;
             }
         }
         // ---- (4) gather y, scores on my position slice
@@ -484,12 +486,12 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
             for (int tp = 0; tp < 8; ++tp) cs += cpart[(tp * R + r) * DS + dd];
             if (rok(r)) {
                 tagged_publish(tC + (size_t)r * D + mem * DS + dd, tb, cs, fast);
-                if (TRAIN) a.ctx[((size_t)i * a.B + r0 + r) * D + mem * DS + dd] = cs;
+                if (TRAIN) a.ctx[(unsigned)((i * a.B + r0 + r) * D + mem * DS + dd)] = cs;
             }
             if (TRAIN && lane < R * MAXTS) {      // alpha of this step -> global: every workgroup stores its own position slice
                 const int ra = lane / MAXTS, tl = lane % MAXTS, tau = tau0 + tl;
                 if (tl < TS && tau < Te && rok(ra))
-                    a.alpha[((size_t)i * a.B + r0 + ra) * Te + tau] = el[ra * G * MAXTS + mem * MAXTS + tl];
+                    a.alpha[(unsigned)((i * a.B + r0 + ra) * Te + tau)] = el[ra * G * MAXTS + mem * MAXTS + tl];
             }
         }
         // ---- (6) gather ctx_i; AttnProjection slice
