@@ -67,11 +67,11 @@ SIGNATURES = {
     "asr_lstm_ws_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "asr_lstm_layer_fwd": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int,
                                      vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, C.c_size_t, vp,
-                                     C.c_float, C.c_uint]),
+                                     C.c_float, C.c_uint, vp, vp]),
     "asr_lstm_bwd_ws_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "asr_lstm_layer_bwd": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int,
                                      vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp,
-                                     vp, C.c_size_t, vp, C.c_float, C.c_uint]),
+                                     vp, C.c_size_t, vp, C.c_float, C.c_uint, vp]),
     "asr_linear_wt_fwd": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int]),
     "asr_colsum_f32": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int]),
     "asr_gather_rows": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int]),

@@ -361,15 +361,20 @@ __device__ __forceinline__ void split3_pk(float x0, float x1, uint32_t& p1, uint
 template <bool KMAJOR>
 struct StagerS3 {
     float v[8];
-    __device__ __forceinline__ void load(const float* P, int ld, int m0, int k0, int tid) {
+    // rows: valid rows of this operand from m0 on (>= 128 for a whole tile; the A operand of a product whose M is not a
+    // multiple of 128 stages zeros for the rows past M -- e.g. the layer-1 weight gradient, M = 80 features)
+    __device__ __forceinline__ void load(const float* P, int ld, int m0, int k0, int tid, int rows = 128) {
         if (KMAJOR) {
-            const float* p = P + (size_t)(k0 + (tid >> 7) * 8) * ld + m0 + (tid & 127);
+            const bool ok = (tid & 127) < rows;
+            const float* p = P + (size_t)(k0 + (tid >> 7) * 8) * ld + m0 + (ok ? (tid & 127) : 0);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = p[(size_t)j * ld];
+            for (int j = 0; j < 8; ++j) { const float x = p[(size_t)j * ld]; v[j] = ok ? x : 0.f; }
         } else {
-            const float4* p = reinterpret_cast<const float4*>(P + (size_t)(m0 + (tid >> 1)) * ld + k0 + (tid & 1) * 8);
+            const bool ok = (tid >> 1) < rows;
+            const float4* p = reinterpret_cast<const float4*>(P + (size_t)(m0 + (ok ? (tid >> 1) : 0)) * ld + k0 + (tid & 1) * 8);
             const float4 x = p[0], y = p[1];
-            v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w; v[4] = y.x; v[5] = y.y; v[6] = y.z; v[7] = y.w;
+            v[0] = ok ? x.x : 0.f; v[1] = ok ? x.y : 0.f; v[2] = ok ? x.z : 0.f; v[3] = ok ? x.w : 0.f;
+            v[4] = ok ? y.x : 0.f; v[5] = ok ? y.y : 0.f; v[6] = ok ? y.z : 0.f; v[7] = ok ? y.w : 0.f;
         }
     }
     __device__ __forceinline__ void store(unsigned short* S, int tid) const {
@@ -384,7 +389,9 @@ struct StagerS3 {
     }
 };
 
-template <bool TA, bool TB>
+// PARTM: M is not a multiple of 128 -- the A operand stages zeros for the rows past M (only that instantiation pays the
+// selects) and the epilogue skips them.
+template <bool TA, bool TB, bool PARTM = false>
 __global__ __launch_bounds__(256, 2) void gemm_split3_kernel(GemmArgs a) {
     constexpr int BM = 128, BN = 128;
     __shared__ __attribute__((aligned(16))) unsigned short As[2 * 3 * PLANES];
@@ -392,7 +399,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split3_kernel(GemmArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid >> 1, wc = wid & 1;
     a.A += (size_t)blockIdx.z * a.sA; a.B += (size_t)blockIdx.z * a.sB; a.C += (size_t)blockIdx.z * a.sC;
-    const int ntn = a.N / BN, ntm = a.M / BM;
+    const int ntn = a.N / BN, ntm = (a.M + BM - 1) / BM;
     const int nwg = ntn * ntm;
     int bid = blockIdx.x, ksl = blockIdx.y;
     if (a.xcd_split) {          // weight-gradient form: whole K slices per XCD (see gemm_f32_kernel)
@@ -421,9 +428,10 @@ __global__ __launch_bounds__(256, 2) void gemm_split3_kernel(GemmArgs a) {
     const int per = (nk_all + a.splits - 1) / a.splits;
     const int kt0 = ksl * per, nk = min(nk_all, kt0 + per);
     if (kt0 >= nk) return;
-    sa0.load(a.A, a.lda, m0, kt0 * BKS, tid);
+    const int arows = PARTM ? a.M - m0 : 128;   // >= 128 except in the last row of tiles of a partial-M product
+    sa0.load(a.A, a.lda, m0, kt0 * BKS, tid, arows);
     sb0.load(a.B, a.ldb, n0, kt0 * BKS, tid);
-    if (kt0 + 1 < nk) { sa1.load(a.A, a.lda, m0, (kt0 + 1) * BKS, tid); sb1.load(a.B, a.ldb, n0, (kt0 + 1) * BKS, tid); }
+    if (kt0 + 1 < nk) { sa1.load(a.A, a.lda, m0, (kt0 + 1) * BKS, tid, arows); sb1.load(a.B, a.ldb, n0, (kt0 + 1) * BKS, tid); }
     sa0.store(As, tid);
     sb0.store(Bs, tid);
     __syncthreads();
@@ -473,12 +481,12 @@ __global__ __launch_bounds__(256, 2) void gemm_split3_kernel(GemmArgs a) {
     int kt = kt0;
     for (; kt + 2 < nk; kt += 2) {
         // even tile: multiply buffer 0, stage set 1 (tile kt+1) into buffer 1, load tile kt+2 into set 0
-        sa0.load(a.A, a.lda, m0, (kt + 2) * BKS, tid);
+        sa0.load(a.A, a.lda, m0, (kt + 2) * BKS, tid, arows);
         sb0.load(a.B, a.ldb, n0, (kt + 2) * BKS, tid);
         step(0, sa1.v, sb1.v, true);
         __syncthreads();
         // odd tile: multiply buffer 1, stage set 0 (tile kt+2) into buffer 0, load tile kt+3 into set 1
-        if (kt + 3 < nk) { sa1.load(a.A, a.lda, m0, (kt + 3) * BKS, tid); sb1.load(a.B, a.ldb, n0, (kt + 3) * BKS, tid); }
+        if (kt + 3 < nk) { sa1.load(a.A, a.lda, m0, (kt + 3) * BKS, tid, arows); sb1.load(a.B, a.ldb, n0, (kt + 3) * BKS, tid); }
         step(1, sa0.v, sb0.v, true);
         __syncthreads();
     }
@@ -499,6 +507,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split3_kernel(GemmArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (PARTM && m >= a.M) continue;
                 float* cp = a.C + (size_t)m * a.ldc + n;
                 float v = acc[mi][ni][r] + bv;
                 if (a.splits > 1) { atomicAdd(cp, v); }
@@ -584,18 +593,23 @@ extern "C" int asr_gemm_f32_batched(void* stream, int transA, int transB, int M,
         ASR_CHECK_LAUNCH();
         return ASR_OK;
     }
-    if (g_gemm_split && M % 128 == 0 && N % 128 == 0 && K % BKS == 0 && g.vecA && g.vecB && !(transA && transB) &&
-        (splits > 1 || (long long)nwg * batch >= 96)) {
-        // whole tiles: fp32-accurate product on the bf16 pipe (gemm_split3_kernel); same split-K policy as the fp32 kernel
+    if (g_gemm_split && (M % 128 == 0 || (transA && !transB && M >= 64)) && N % 128 == 0 && K % BKS == 0 && g.vecA && g.vecB &&
+        !(transA && transB) && (splits > 1 || (long long)nwg * batch >= 96)) {
+        // whole tiles (or, for the weight-gradient form, a partial last row of tiles): fp32-accurate product on the bf16 pipe
+        // (gemm_split3_kernel); same split-K policy as the fp32 kernel
         static const int xs = [] { const char* e = getenv("ASR_GEMM_XCD_SPLIT"); return e ? atoi(e) : 1; }();
+        const bool partm = M % 128 != 0;
         g.splits = splits;
+        dim3 grid(nwg, splits, batch);
         if (transA && xs && splits >= 6 && nk >= 128 && (batch == 1 || (nwg * ((splits + 4) / 8 * 8)) % 8 == 0)) {
             g.splits = (splits + 4) / 8 * 8;
             g.xcd_split = 1;
-            hipLaunchKernelGGL((gemm_split3_kernel<true, false>), dim3(nwg * g.splits, 1, batch), dim3(256), 0, s, g);
-        } else if (transA) hipLaunchKernelGGL((gemm_split3_kernel<true, false>), dim3(nwg, splits, batch), dim3(256), 0, s, g);
-        else if (transB)   hipLaunchKernelGGL((gemm_split3_kernel<false, true>), dim3(nwg, splits, batch), dim3(256), 0, s, g);
-        else               hipLaunchKernelGGL((gemm_split3_kernel<false, false>), dim3(nwg, splits, batch), dim3(256), 0, s, g);
+            grid = dim3(nwg * g.splits, 1, batch);
+        }
+        if (transA && partm) hipLaunchKernelGGL((gemm_split3_kernel<true, false, true>), grid, dim3(256), 0, s, g);
+        else if (transA)     hipLaunchKernelGGL((gemm_split3_kernel<true, false>), grid, dim3(256), 0, s, g);
+        else if (transB)     hipLaunchKernelGGL((gemm_split3_kernel<false, true>), grid, dim3(256), 0, s, g);
+        else                 hipLaunchKernelGGL((gemm_split3_kernel<false, false>), grid, dim3(256), 0, s, g);
         ASR_CHECK_LAUNCH();
         return ASR_OK;
     }

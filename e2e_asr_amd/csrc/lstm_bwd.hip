@@ -553,7 +553,8 @@ extern "C" int asr_lstm_layer_bwd(void* stream, const float* x, int B, int T, in
                                   const float* dout, int Tout, float* gates, const float* act,
                                   const float* hprev, float* dx,
                                   float* dkernel_fw, float* dbias_fw, float* dkernel_bw, float* dbias_bw,
-                                  void* hx_ws, size_t hx_bytes, int* err_flag, float keep_prob, unsigned seed) {
+                                  void* hx_ws, size_t hx_bytes, int* err_flag, float keep_prob, unsigned seed,
+                                  const float* kx_cat) {
     using namespace asr;
     if (!x || !len || !kernel_fw || !dout || !gates || !act || !hprev || !dkernel_fw || !dbias_fw || !hx_ws || !err_flag)
         return ASR_EINVAL;
@@ -613,6 +614,12 @@ extern "C" int asr_lstm_layer_bwd(void* stream, const float* x, int B, int T, in
     // whose workgroups mostly wait on the exchange and leave the matrix pipes idle.
     // asr_side_join() orders them before the gradients are consumed.
     const int M = B * T;
+    if (dx && ndir == 2 && kx_cat) {
+        // dX = [dG_fw | dG_bw] . [K_x,fw | K_x,bw]^T as ONE product with K = 8H (dG rows are contiguous over the two
+        // directions; kx_cat is the [in, 8H] array the forward used): no second accumulating pass over dX
+        int rc;
+        if ((rc = asr_gemm_f32(stream, 0, 1, M, in_dim, 2 * H4, gates, 2 * H4, kx_cat, 2 * H4, dx, in_dim, nullptr, 0))) return rc;
+    } else
     for (int d = 0; d < ndir && dx; ++d) {
         int rc;
         if ((rc = asr_gemm_f32(stream, 0, 1, M, in_dim, H4, gates + (size_t)d * H4, ndir * H4, d ? kernel_bw : kernel_fw, H4,

@@ -89,7 +89,7 @@ class Encoder(BaseParams):
                                    keep_prob=keep, seed=seed)
             out = r[0] if save else r
             if save:
-                self.saved.append(dict(x=x, lens=lens, lens_dev=lens_dev, gates=r[1], c=r[2], hprev=r[3], out=out,
+                self.saved.append(dict(x=x, lens=lens, lens_dev=lens_dev, gates=r[1], c=r[2], hprev=r[3], kx=getattr(r[1], "kx_cat", None), out=out,
                                        T=T, t_out=t_out, keep=keep, seed=seed, depth=d))
             view = out[:, :T] if t_out != T else out
             if d in time_major_states:
@@ -136,7 +136,7 @@ class Encoder(BaseParams):
                 g = [v.grad_of(n) for n in names] + [None, None]
             dx = ops.lstm_layer_bwd(sv["x"], sv["lens_dev"], kf, kb, dout.contiguous(), sv["gates"], sv["c"], sv["hprev"],
                                     g[0], g[1], g[2], g[3], need_dx=d > 1, keep_prob=sv["keep"], seed=sv["seed"],
-                                    join=False)
+                                    join=False, kx_cat=sv["kx"])
             if on_layer_done is not None:
                 on_layer_done(d)
         self.saved = None

@@ -88,6 +88,7 @@ def check_device_flag(dev):
 
 
 _hx_cache = {}
+_KXCAT = int(os.environ.get("ASR_KXCAT", "2"))      # EXPERIMENT: 0 = one GEMM per direction, 1 = fused forward projection, 2 = + fused dX
 
 
 LSTM_KERNEL_H = (64, 128, 256, 512)     # instantiated widths of the persistent recurrent kernels (csrc/lstm.hip)
@@ -141,6 +142,8 @@ def lstm_layer_fwd(x, seq_len, kernel_fw, bias_fw, kernel_bw=None, bias_bw=None,
         r = lstm_layer_fwd(x, seq_len, kf, bf, kb, bb, t_out=t_out, save=save, keep_prob=keep_prob, seed=seed)
         outp = r[0] if save else r
         out = torch.cat([outp[:, :, d * Hp:d * Hp + H] for d in range(ndir)], 2).contiguous()
+        if save:
+            r[1].kx_cat = None       # (the padded-width array is rebuilt per direction in the backward)
         return (out,) + tuple(r[1:]) if save else out
     t_out = T if t_out is None else t_out
     dev = x.device
@@ -151,12 +154,17 @@ def lstm_layer_fwd(x, seq_len, kernel_fw, bias_fw, kernel_bw=None, bias_bw=None,
     L = _lib.lib()
     nbytes = L.asr_lstm_ws_bytes(B, H, ndir)
     hx = _hx(dev, nbytes)
+    kx_cat = bias_cat = None
+    if ndir == 2 and _KXCAT >= 1:       # input rows of the two kernels side by side: both directions' projection as ONE product (N = 8H)
+        kx_cat = torch.cat([kernel_fw[:IN], kernel_bw[:IN]], 1)
+        bias_cat = torch.cat([bias_fw, bias_bw])
     rc = L.asr_lstm_layer_fwd(_stream(), _p(x), B, T, IN, IN, _p(seq_len), H, ndir,
                               _p(_f32(kernel_fw, "kernel_fw")), _p(_f32(bias_fw, "bias_fw")),
                               _p(_f32(kernel_bw, "kernel_bw")), _p(_f32(bias_bw, "bias_bw")),
                               _p(out), t_out, _p(gates), _p(act), _p(hprev), _p(hx), nbytes,
-                              _p(_Flag.get(dev)), float(keep_prob), int(seed) & 0xFFFFFFFF)
+                              _p(_Flag.get(dev)), float(keep_prob), int(seed) & 0xFFFFFFFF, _p(kx_cat), _p(bias_cat))
     _check(rc, "asr_lstm_layer_fwd")
+    gates.kx_cat = kx_cat        # rides along for lstm_layer_bwd(kx_cat=...): dX as one product over both directions
     return (out, gates, act, hprev) if save else out
 
 
@@ -168,7 +176,7 @@ def _hx(dev, nbytes):
 
 
 def lstm_layer_bwd(x, seq_len, kernel_fw, kernel_bw, dout, gates, act, hprev, dk_fw, db_fw, dk_bw=None,
-                   db_bw=None, need_dx=True, keep_prob=1.0, seed=0, join=True):
+                   db_bw=None, need_dx=True, keep_prob=1.0, seed=0, join=True, kx_cat=None):
     """Backward of lstm_layer_fwd.  `gates` is overwritten with dG; weight/bias gradients are
     ACCUMULATED into dk_*/db_* (views of the flat gradient buffer) on the library's side stream:
     join=False leaves them in flight (overlapping the next layer's BPTT) until ops.side_join().
@@ -201,9 +209,10 @@ def lstm_layer_bwd(x, seq_len, kernel_fw, kernel_bw, dout, gates, act, hprev, dk
     rc = L.asr_lstm_layer_bwd(_stream(), _p(x), B, T, IN, IN, _p(seq_len), H, ndir, _p(kernel_fw), _p(kernel_bw),
                               _p(_f32(dout, "dout")), dout.shape[1], _p(gates), _p(act), _p(hprev), _p(dx),
                               _p(dk_fw), _p(db_fw), _p(dk_bw), _p(db_bw), _p(_hx(dev, nbytes)), nbytes,
-                              _p(_Flag.get(dev)), float(keep_prob), int(seed) & 0xFFFFFFFF)
+                              _p(_Flag.get(dev)), float(keep_prob), int(seed) & 0xFFFFFFFF,
+                              _p(kx_cat if (ndir == 2 and need_dx and _KXCAT >= 2) else None))
     _check(rc, "asr_lstm_layer_bwd")
-    keep_until_join(x, dout, gates, act, hprev, seq_len)
+    keep_until_join(x, dout, gates, act, hprev, seq_len, kx_cat)
     if join:          # weight/bias gradients are produced on the library's side stream
         side_join()
     return dx

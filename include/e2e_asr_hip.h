@@ -55,7 +55,10 @@ int asr_get_gemm_split(void);
  * act [B,T,ndir,H,8] (records {i,j,f,o | c, c_prev, -, -}) and hprev [B,T,ndir,H] (undropped
  * previous hidden states); both NULL for inference.
  * keep_prob < 1 applies DropoutWrapper(output_keep_prob) (encoder.py:49-52) to `out`.
- * err_flag: device int, set non-zero if an inter-workgroup wait timed out. H in {64,128,256,512}. */
+ * err_flag: device int, set non-zero if an inter-workgroup wait timed out. H in {64,128,256,512}.
+ * kx_cat / bias_cat (optional, ndir = 2; NULL = one product per direction): the input rows of the two kernels side by side,
+ * [in, 8H] = [kernel_fw[:in] | kernel_bw[:in]], and [bias_fw | bias_bw] -- the input projection of both directions then runs
+ * as one product with N = 8H (asr_lstm_layer_bwd takes the same array for dX as one product with K = 8H). */
 size_t asr_lstm_ws_bytes(int B, int H, int ndir);
 int asr_lstm_layer_fwd(void* stream, const float* x, int B, int T, int in_dim, int ldx,
                        const int* len, int H, int ndir,
@@ -63,7 +66,7 @@ int asr_lstm_layer_fwd(void* stream, const float* x, int B, int T, int in_dim, i
                        const float* kernel_bw, const float* bias_bw,
                        float* out, int Tout, float* gates, float* act, float* hprev,
                        void* hx_ws, size_t hx_bytes, int* err_flag,
-                       float keep_prob, unsigned seed);
+                       float keep_prob, unsigned seed, const float* kx_cat, const float* bias_cat);
 
 /* Backward of asr_lstm_layer_fwd (tf.gradients through encoder.py:55-91): persistent BPTT
  * kernel (dG overwrites `gates`), then dX = dG.K_x^T, dK_x = X^T.dG, dK_h = Hprev^T.dG and
@@ -75,7 +78,8 @@ int asr_lstm_layer_bwd(void* stream, const float* x, int B, int T, int in_dim, i
                        const float* dout, int Tout, float* gates, const float* act,
                        const float* hprev, float* dx,
                        float* dkernel_fw, float* dbias_fw, float* dkernel_bw, float* dbias_bw,
-                       void* hx_ws, size_t hx_bytes, int* err_flag, float keep_prob, unsigned seed);
+                       void* hx_ws, size_t hx_bytes, int* err_flag, float keep_prob, unsigned seed,
+                       const float* kx_cat);
 
 /* out[M,N] (+)= X.Wt^T with Wt given [N,K]: data-gradient products of the decoder backward. */
 int asr_linear_wt_fwd(void* stream, const float* x, int ldx, int K, const float* Wt, int ldw,

@@ -97,7 +97,7 @@ def test_argument_validation_raises_valueerror():
     out = torch.zeros(2, 4, 96, device=DEV); gates = torch.zeros(2, 4, 1, 4 * 96, device=DEV)
     p = lambda t: C.c_void_p(t.data_ptr())
     rc = _lib.lib().asr_lstm_layer_fwd(None, p(x), 2, 4, 8, 8, p(ln), 96, 1, p(k96), p(b96), None, None, p(out), 4, p(gates),
-                                       None, None, p(hx), hx.numel(), p(flag), 1.0, 0)
+                                       None, None, p(hx), hx.numel(), p(flag), 1.0, 0, None, None)
     assert rc == -3                                                  # the C ABI itself: ASR_EUNSUPPORTED for H = 96
     k = torch.zeros(9 + 64, 256, device=DEV)
     with pytest.raises(ValueError, match="kernel rows"):

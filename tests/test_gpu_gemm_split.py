@@ -22,7 +22,8 @@ def _run(a, b, ta, tb, split, bias=None, accumulate=False, c0=None):
 
 
 @pytest.mark.parametrize("form,M,N,K", [("NN", 1024, 1024, 1024), ("NN", 12800, 1024, 80 * 16), ("NT", 2048, 1024, 2048),
-                                        ("TN", 1024, 1024, 12800), ("TN", 256, 1024, 25600)])
+                                        ("TN", 1024, 1024, 12800), ("TN", 256, 1024, 25600),
+                                        ("TN", 80, 1024, 25600), ("TN", 200, 256, 12800)])
 @pytest.mark.parametrize("dist", ["normal", "wide"])
 def test_split_gemm_error_is_fp32_class(form, M, N, K, dist):
     rng = np.random.default_rng(hash((form, M, N, K, dist)) & 0xFFFF)
