@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libe2e_asr_hip.so")
+LIB_PATH = os.environ.get("ASR_LIB_PATH") or os.path.join(_HERE, "csrc", "libe2e_asr_hip.so")   # (override: A/B builds of experiments)
 
 c_fp = C.POINTER(C.c_float)
 c_ip = C.POINTER(C.c_int)
