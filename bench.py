@@ -247,7 +247,8 @@ def main():
     mode = args.mode if args.mode != "auto" else ("train" if has_train else "fwd")
     if world > 1:
         from e2e_asr_amd.parallel import DataParallel
-        DataParallel(model)                       # broadcast weights, hook the grad all-reduce
+        # broadcast weights, hook the grad all-reduce (config 3 = bf16: the exchange carries bfloat16, fp32 master gradient)
+        DataParallel(model, grad_dtype="bf16" if args.dtype == "bf16" else "f32")
     batch = synthetic_batch(B=B, T=T, F=F, t_dec=TDEC, vocab=V, variable_len=args.variable_len, seed=1234 + rank)
     # inputs resident in HBM before the timed region
     batch = {k: (torch.as_tensor(v).to(dev) if k == "logmel" else v) for k, v in batch.items()}
@@ -299,7 +300,8 @@ def main():
         # the exchange alone: all-reduce of a buffer the size of the flat fp32 gradient, bus bandwidth by the
         # ring formula 2(N-1)/N * bytes / time, next to the 7 x ~153 GB/s of xGMI links per GPU.  Outside the timed region.
         try:
-            buf = torch.zeros(model.variables.flat.numel(), device=dev, dtype=torch.float32)
+            cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+            buf = torch.zeros(model.variables.flat.numel(), device=dev, dtype=cdt)
             for _ in range(3):
                 dist.all_reduce(buf)
             torch.cuda.synchronize()
@@ -309,8 +311,8 @@ def main():
                 dist.all_reduce(buf)
             torch.cuda.synchronize()
             dtc = (time.perf_counter() - tc) / 10
-            nbytes = buf.numel() * 4
-            comm = {"op": "all_reduce(sum) fp32 flat gradient", "bytes": nbytes, "ms": dtc * 1e3,
+            nbytes = buf.numel() * buf.element_size()
+            comm = {"op": "all_reduce(sum) of the flat gradient as %s" % ("bfloat16 (fp32 master)" if args.dtype == "bf16" else "fp32"), "bytes": nbytes, "ms": dtc * 1e3,
                     "busbw_GBps": 2.0 * (world - 1) / max(world, 1) * nbytes / dtc / 1e9,
                     "link_peak_GBps": 153.0, "links_per_gpu": 7,
                     "placement": "one blocking all-reduce after backward (ASR_DP_OVERLAP=1: per-layer buckets under the BPTT)"}

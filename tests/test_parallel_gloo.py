@@ -34,7 +34,7 @@ def _worker(rank, world, port, q, rank_mode='overlap'):
                          attn_vec=4, seed=1 + rank)              # ranks start DIFFERENT: broadcast must fix it
         st = VariableStore.from_arrays(w, "cpu")
         model = _FakeModel(st)
-        dp = DataParallel(model, overlap=(rank_mode == 'overlap'))
+        dp = DataParallel(model, overlap=(rank_mode.startswith('overlap')), grad_dtype=('bf16' if rank_mode.endswith('bf16') else 'f32'))
         batch = synthetic_batch(B=4, T=9, F=10, t_dec=6, vocab=13, variable_len=True, seed=5)
         mine = shard_batch(batch, rank, world)
         mine["logmel"] = mine["logmel"].astype(np.float64)
@@ -53,7 +53,7 @@ def _worker(rank, world, port, q, rank_mode='overlap'):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["overlap", "blocking"])
+@pytest.mark.parametrize("mode", ["overlap", "blocking", "overlap_bf16", "blocking_bf16"])
 def test_dp_two_ranks_equals_global_batch(mode):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -78,7 +78,12 @@ def test_dp_two_ranks_equals_global_batch(mode):
     total, _, _ = R.seq2seq_loss(batch, W, num_layers={"char": 2})
     total.backward()
     for k in w0:
-        np.testing.assert_allclose(g0[k], W[k].grad.numpy(), rtol=0, atol=2e-6)
+        ref = W[k].grad.numpy()
+        if mode.endswith("bf16"):     # the exchange carried bfloat16: each shard gradient rounded once (2^-9), the sum once more
+            np.testing.assert_allclose(g0[k], ref, rtol=0, atol=8e-3 * max(1e-6, np.abs(ref).max()))
+            assert g0[k].dtype == np.float32
+        else:
+            np.testing.assert_allclose(g0[k], ref, rtol=0, atol=2e-6)
     # buckets tile the flat buffer without overlap, decoders first then layers top-down
     keys = [b[0] for b in buckets]
     assert keys == [0, 2, 1]
