@@ -61,13 +61,15 @@ def gemm_roofline(dev):
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / n
     tf = 2.0 * M * N * K / (ms * 1e-3) / 1e12
-    bf16 = ops.get_gemm_precision() == "bf16"
+    prec = ops.get_gemm_precision()
+    bf16 = prec != "f32"
     split = ops.get_gemm_split() and not bf16
     # peaks (MI355X_MICROARCH.md): dense bf16 MFMA ~2.5 PFLOP/s; fp32-input MFMA 157.3 TFLOP/s (1/16 of it).  The split3
     # kernel issues 6 bf16 MFMA products per fp32-equivalent product: its ceiling is 2500 / 6 = 416.7 TFLOP/s fp32-equivalent.
-    peak = 2500.0 if bf16 else (2500.0 / 6.0 if split else PEAK_F32_MFMA_TFLOPS)
-    name = ("gemm_bf16_kernel<NN> (fp32 operands rounded on the way into LDS: bound by reading them)" if bf16 else
-            "gemm_split3_kernel<NN> (fp32-accurate: operands split exactly into 3 bf16 planes, 6 bf16 MFMA products, fp32 "
+    peak = (2500.0 if prec == "bf16" else 2500.0 / 3.0) if bf16 else (2500.0 / 6.0 if split else PEAK_F32_MFMA_TFLOPS)
+    name = ("gemm_planes_kernel<NN, 1 plane> (fp32 operands rounded to bf16 on the way into LDS)" if prec == "bf16" else
+            "gemm_planes_kernel<NN, 2 planes> (bf16x2: three bf16 MFMA products per product; peak = bf16 dense peak / 3)" if bf16 else
+            "gemm_planes_kernel<NN, 3 planes> = split3 (fp32-accurate: operands split exactly into 3 bf16 planes, 6 bf16 MFMA products, fp32 "
             "accumulate; achieved/peak in fp32-equivalent TFLOP/s, peak = bf16 dense peak / 6)" if split else
             "gemm_f32_kernel<NN,128,full> (v_mfma_f32_32x32x2_f32)")
     return {"bound": "mfma", "kernel": "%s layer-2 input projection %dx%dx%d" % (name, M, N, K),
@@ -201,7 +203,7 @@ def main():
                          "(isTraining=False: greedy argmax feedback, max_output=120 steps, eval_model.py:56-118)")
     ap.add_argument("--variable-len", action="store_true", help="lengths U[400,800] (masking run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "bf16x2"],
                     help="bf16 = BASELINE config 3's per-GPU workload: bf16 MFMA operands in the GEMMs (fp32 accumulate, state, "
                          "recurrences); the default line is the fp32 config 2")
     ap.add_argument("--gemm", default="split3", choices=["split3", "exact"],
@@ -355,8 +357,9 @@ def main():
         "metric": "encoder+decoder frames/sec at batch32x800frx80mel", "value": value, "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": ("f32" if args.dtype == "f32" else "bf16 MFMA operands in the GEMMs; fp32 accumulate, recurrences, attention, loss, Adam"),
-        "gemm_path": ("bf16" if args.dtype != "f32" else
+        "dtype": ("f32" if args.dtype == "f32" else "bf16 MFMA operands in the GEMMs (%s); fp32 accumulate, recurrences, attention, loss, Adam" % (
+            "one plane" if args.dtype == "bf16" else "two planes, three products")),
+        "gemm_path": (args.dtype if args.dtype != "f32" else
                       "split3: fp32 in / fp32 out / fp32-accurate, evaluated on the bf16 MFMA pipe by exact 3-way operand "
                       "splitting (tests/test_gpu_gemm_split.py holds its error to the v_mfma_f32_32x32x2_f32 kernel's)"
                       if args.gemm == "split3" else "exact: v_mfma_f32_32x32x2_f32"),

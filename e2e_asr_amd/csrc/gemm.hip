@@ -211,126 +211,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
 }
 
 
-// ---------------------------------------------------------------------------------------------
-// bf16 variant (BASELINE config 3): SAME interface -- fp32 operands in memory, fp32 accumulation and
-// output -- but the operands are rounded to bf16 (v_cvt_pk_bf16_f32, round-to-nearest-even) while they are
-// staged into LDS, and the contraction runs on v_mfma_f32_32x32x16_bf16 (16x the fp32 matrix rate).  No
-// separate cast kernels and no bf16 copies in HBM: the kernel is bound by reading the fp32 operands.
-// 128x128 block tile, BK = 32 (two MFMA k-steps), 4 waves x 64x64.  LDS image [row][k] bf16 with an 80-byte
-// row pitch: a lane's operand fragment (8 consecutive k of one row, guide: A[row l&31][k = 8(l>>5)+j], B alike)
-// is one conflict-free ds_read_b128.  Whole tiles only (M,N % 128 == 0, K % 32 == 0); other shapes use the fp32 kernel.
-constexpr int BKB = 32, PITCHB = 40;       // k-tile and LDS row pitch in bf16 elements
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
     uint32_t r;
     asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
     return r;
-}
-
-// One thread stages 16 consecutive k of one tile row.  KMAJOR (memory is [k][m], m contiguous): thread ->
-// (row = tid & 127, k-half = tid >> 7), 16 coalesced scalar loads.  Otherwise ([m][k], k contiguous): thread ->
-// (row = tid >> 1, k-half = tid & 1), four 16-byte loads.
-template <bool KMAJOR>
-struct StagerB16 {
-    float v[16];
-    __device__ __forceinline__ void load(const float* P, int ld, int m0, int k0, int tid) {
-        if (KMAJOR) {
-            const float* p = P + (size_t)(k0 + (tid >> 7) * 16) * ld + m0 + (tid & 127);
-#pragma unroll
-            for (int j = 0; j < 16; ++j) v[j] = p[(size_t)j * ld];
-        } else {
-            const float4* p = reinterpret_cast<const float4*>(P + (size_t)(m0 + (tid >> 1)) * ld + k0 + (tid & 1) * 16);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { const float4 x = p[j]; v[4 * j] = x.x; v[4 * j + 1] = x.y; v[4 * j + 2] = x.z; v[4 * j + 3] = x.w; }
-        }
-    }
-    __device__ __forceinline__ void store(unsigned short* S, int tid) const {
-        const int row = KMAJOR ? (tid & 127) : (tid >> 1), kh = KMAJOR ? (tid >> 7) : (tid & 1);
-        uint4* d = reinterpret_cast<uint4*>(S + row * PITCHB + kh * 16);
-        d[0] = make_uint4(cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3]), cvt_pk_bf16(v[4], v[5]), cvt_pk_bf16(v[6], v[7]));
-        d[1] = make_uint4(cvt_pk_bf16(v[8], v[9]), cvt_pk_bf16(v[10], v[11]), cvt_pk_bf16(v[12], v[13]), cvt_pk_bf16(v[14], v[15]));
-    }
-};
-
-template <bool TA, bool TB>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
-    constexpr int BM = 128, BN = 128;
-    __shared__ __attribute__((aligned(16))) unsigned short As[2 * BM * PITCHB];
-    __shared__ __attribute__((aligned(16))) unsigned short Bs[2 * BN * PITCHB];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wr = wid >> 1, wc = wid & 1;
-    a.A += (size_t)blockIdx.z * a.sA; a.B += (size_t)blockIdx.z * a.sB; a.C += (size_t)blockIdx.z * a.sC;
-    const int ntn = a.N / BN, ntm = a.M / BM;
-    const int nwg = ntn * ntm;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
-        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
-    }
-    const int m0 = (bid / ntn) * BM, n0 = (bid % ntn) * BN;
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    StagerB16<TA> sa;      // A natural [M,K]: k contiguous unless transposed
-    StagerB16<!TB> sb;     // B natural [K,N]: n contiguous unless transposed
-    const int nk_all = a.K / BKB;
-    const int per = (nk_all + a.splits - 1) / a.splits;
-    const int kt0 = blockIdx.y * per, nk = min(nk_all, kt0 + per);
-    if (kt0 >= nk) return;
-    sa.load(a.A, a.lda, m0, kt0 * BKB, tid);
-    sb.load(a.B, a.ldb, n0, kt0 * BKB, tid);
-    sa.store(As, tid);
-    sb.store(Bs, tid);
-    __syncthreads();
-    auto compute = [&](int cur) {
-        const unsigned short* ap = As + cur * (BM * PITCHB) + (wr * 64 + (lane & 31)) * PITCHB + 8 * (lane >> 5);
-        const unsigned short* bp = Bs + cur * (BN * PITCHB) + (wc * 64 + (lane & 31)) * PITCHB + 8 * (lane >> 5);
-#pragma unroll
-        for (int ks = 0; ks < BKB / 16; ++ks) {
-            bf16x8 af[2], bf[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                af[i] = *reinterpret_cast<const bf16x8*>(ap + i * 32 * PITCHB + ks * 16);
-                bf[i] = *reinterpret_cast<const bf16x8*>(bp + i * 32 * PITCHB + ks * 16);
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
-        }
-    };
-    for (int kt = kt0; kt + 1 < nk; ++kt) {
-        const int cur = (kt - kt0) & 1;
-        sa.load(a.A, a.lda, m0, (kt + 1) * BKB, tid);
-        sb.load(a.B, a.ldb, n0, (kt + 1) * BKB, tid);
-        compute(cur);
-        sa.store(As + (cur ^ 1) * (BM * PITCHB), tid);
-        sb.store(Bs + (cur ^ 1) * (BN * PITCHB), tid);
-        __syncthreads();
-    }
-    compute((nk - 1 - kt0) & 1);
-    // C/D map identical to the fp32 32x32 tile (dtype-independent on gfx950)
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            const int n = n0 + wc * 64 + ni * 32 + (lane & 31);
-            const float bv = (a.bias && blockIdx.y == 0) ? a.bias[n] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                float* cp = a.C + (size_t)m * a.ldc + n;
-                float v = acc[mi][ni][r] + bv;
-                if (a.splits > 1) { atomicAdd(cp, v); }
-                else { if (a.accumulate) v += *cp; *cp = v; }
-            }
-        }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -345,57 +231,63 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
 // v_mfma_f32_32x32x2_f32.  tests/test_gpu_gemm_split.py holds it to the exact-fp32 kernel's error against float64.
 // 128x128 block tile, BK = 16 (one MFMA k-step), 4 waves x 64x64, double-buffered planes (72 KB: two workgroups per CU),
 // 48-byte LDS rows (conflict-free ds_read_b128 fragments).  Whole tiles only; other shapes use the exact fp32 kernel.
-constexpr int BKS = 16, PITCHS = 24, PLANES = 128 * PITCHS;       // k-tile, LDS row pitch and plane size in bf16 elements
+// The kernel is generic in the number of bf16 planes per operand value:
+//   NP = 3 (BK 16): x = h1 + h2 + h3 exactly, six products  -> fp32-accurate            ("split3", the fp32 default)
+//   NP = 2 (BK 16): x ~ h1 + h2 (16 significand bits), products a1b1 + a1b2 + a2b1       ("bf16x2": ~2^-16 relative)
+//   NP = 1 (BK 32): x ~ bf16(x), one product                                             ("bf16", BASELINE config 3)
+constexpr int BKS = 16;                     // k-tile of the NP = 2, 3 instantiations (and the granularity K must divide by)
 
-__device__ __forceinline__ void split3_pk(float x0, float x1, uint32_t& p1, uint32_t& p2, uint32_t& p3) {
-    p1 = cvt_pk_bf16(x0, x1);
-    float r0 = x0 - __uint_as_float(p1 << 16);
-    float r1 = x1 - __uint_as_float(p1 & 0xffff0000u);
-    p2 = cvt_pk_bf16(r0, r1);
-    r0 -= __uint_as_float(p2 << 16);
-    r1 -= __uint_as_float(p2 & 0xffff0000u);
-    p3 = cvt_pk_bf16(r0, r1);
+template <int NP>
+__device__ __forceinline__ void split_pk(float x0, float x1, uint32_t* p) {      // p[0..NP-1]: packed bf16 pairs, plane by plane
+    p[0] = cvt_pk_bf16(x0, x1);
+    if (NP > 1) {
+        float r0 = x0 - __uint_as_float(p[0] << 16);
+        float r1 = x1 - __uint_as_float(p[0] & 0xffff0000u);
+        p[1] = cvt_pk_bf16(r0, r1);
+        if (NP > 2) {
+            r0 -= __uint_as_float(p[1] << 16);
+            r1 -= __uint_as_float(p[1] & 0xffff0000u);
+            p[2] = cvt_pk_bf16(r0, r1);
+        }
+    }
 }
 
-// One thread stages 8 consecutive k of one tile row (256 threads x 8 = 128 rows x 16 k).
-template <bool KMAJOR>
-struct StagerS3 {
-    float v[8];
-    // rows: valid rows of this operand from m0 on (>= 128 for a whole tile; the A operand of a product whose M is not a
-    // multiple of 128 stages zeros for the rows past M -- e.g. the layer-1 weight gradient, M = 80 features)
+// One thread stages BKT/2 consecutive k of one tile row (256 threads: 128 rows x two k-halves).
+// rows: valid rows of this operand from m0 on (>= 128 for a whole tile; the A operand of a product whose M is not a
+// multiple of 128 stages zeros for the rows past M -- e.g. the layer-1 weight gradient, M = 80 features)
+template <bool KMAJOR, int BKT>
+struct StagerP {
+    static constexpr int NV = BKT / 2;
+    float v[NV];
     __device__ __forceinline__ void load(const float* P, int ld, int m0, int k0, int tid, int rows = 128) {
         if (KMAJOR) {
             const bool ok = (tid & 127) < rows;
-            const float* p = P + (size_t)(k0 + (tid >> 7) * 8) * ld + m0 + (ok ? (tid & 127) : 0);
+            const float* p = P + (size_t)(k0 + (tid >> 7) * NV) * ld + m0 + (ok ? (tid & 127) : 0);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { const float x = p[(size_t)j * ld]; v[j] = ok ? x : 0.f; }
+            for (int j = 0; j < NV; ++j) { const float x = p[(size_t)j * ld]; v[j] = ok ? x : 0.f; }
         } else {
             const bool ok = (tid >> 1) < rows;
-            const float4* p = reinterpret_cast<const float4*>(P + (size_t)(m0 + (ok ? (tid >> 1) : 0)) * ld + k0 + (tid & 1) * 8);
-            const float4 x = p[0], y = p[1];
-            v[0] = ok ? x.x : 0.f; v[1] = ok ? x.y : 0.f; v[2] = ok ? x.z : 0.f; v[3] = ok ? x.w : 0.f;
-            v[4] = ok ? y.x : 0.f; v[5] = ok ? y.y : 0.f; v[6] = ok ? y.z : 0.f; v[7] = ok ? y.w : 0.f;
-        }
-    }
-    __device__ __forceinline__ void store(unsigned short* S, int tid) const {
-        const int row = KMAJOR ? (tid & 127) : (tid >> 1), kh = KMAJOR ? (tid >> 7) : (tid & 1);
-        uint32_t a[4], b[4], c[4];
+            const float4* p = reinterpret_cast<const float4*>(P + (size_t)(m0 + (ok ? (tid >> 1) : 0)) * ld + k0 + (tid & 1) * NV);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) split3_pk(v[2 * j], v[2 * j + 1], a[j], b[j], c[j]);
-        unsigned short* d = S + row * PITCHS + kh * 8;
-        *reinterpret_cast<uint4*>(d) = make_uint4(a[0], a[1], a[2], a[3]);
-        *reinterpret_cast<uint4*>(d + PLANES) = make_uint4(b[0], b[1], b[2], b[3]);
-        *reinterpret_cast<uint4*>(d + 2 * PLANES) = make_uint4(c[0], c[1], c[2], c[3]);
+            for (int j = 0; j < NV / 4; ++j) {
+                const float4 x = p[j];
+                v[4 * j] = ok ? x.x : 0.f; v[4 * j + 1] = ok ? x.y : 0.f; v[4 * j + 2] = ok ? x.z : 0.f; v[4 * j + 3] = ok ? x.w : 0.f;
+            }
+        }
     }
 };
 
 // PARTM: M is not a multiple of 128 -- the A operand stages zeros for the rows past M (only that instantiation pays the
 // selects) and the epilogue skips them.
-template <bool TA, bool TB, bool PARTM = false>
-__global__ __launch_bounds__(256, 2) void gemm_split3_kernel(GemmArgs a) {
+template <bool TA, bool TB, bool PARTM, int NP, int BKT>
+__global__ __launch_bounds__(256, 2) void gemm_planes_kernel(GemmArgs a) {
     constexpr int BM = 128, BN = 128;
-    __shared__ __attribute__((aligned(16))) unsigned short As[2 * 3 * PLANES];
-    __shared__ __attribute__((aligned(16))) unsigned short Bs[2 * 3 * PLANES];
+    constexpr int PITCH = BKT + 8;                  // bf16 elements: 48- / 80-byte rows, conflict-free ds_read_b128 fragments
+    constexpr int PLANE = 128 * PITCH;
+    constexpr int NV = BKT / 2, NPAIR = NV / 2;     // values / packed pairs one thread stages per operand and k-tile
+    constexpr int KSTEPS = BKT / 16;
+    __shared__ __attribute__((aligned(16))) unsigned short As[2 * NP * PLANE];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[2 * NP * PLANE];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid >> 1, wc = wid & 1;
     a.A += (size_t)blockIdx.z * a.sA; a.B += (size_t)blockIdx.z * a.sB; a.C += (size_t)blockIdx.z * a.sC;
@@ -422,71 +314,100 @@ __global__ __launch_bounds__(256, 2) void gemm_split3_kernel(GemmArgs a) {
     // one iteration ago, long since landed) is split and written to the other buffer in four slices BETWEEN the MFMA groups --
     // an MFMA holds the SIMD's issue port for 8 of its 32 cycles, the split's VALU work fits into the rest -- and the global
     // loads of tile t+2 are issued at the top.  Two register sets (sa0/sb0, sa1/sb1) alternate, hence the loop unrolled by 2.
-    StagerS3<TA> sa0, sa1;       // A natural [M,K]: k contiguous unless transposed
-    StagerS3<!TB> sb0, sb1;      // B natural [K,N]: n contiguous unless transposed
-    const int nk_all = a.K / BKS;
+    StagerP<TA, BKT> sa0, sa1;       // A natural [M,K]: k contiguous unless transposed
+    StagerP<!TB, BKT> sb0, sb1;      // B natural [K,N]: n contiguous unless transposed
+    const int nk_all = a.K / BKT;
     const int per = (nk_all + a.splits - 1) / a.splits;
     const int kt0 = ksl * per, nk = min(nk_all, kt0 + per);
     if (kt0 >= nk) return;
     const int arows = PARTM ? a.M - m0 : 128;   // >= 128 except in the last row of tiles of a partial-M product
-    sa0.load(a.A, a.lda, m0, kt0 * BKS, tid, arows);
-    sb0.load(a.B, a.ldb, n0, kt0 * BKS, tid);
-    if (kt0 + 1 < nk) { sa1.load(a.A, a.lda, m0, (kt0 + 1) * BKS, tid, arows); sb1.load(a.B, a.ldb, n0, (kt0 + 1) * BKS, tid); }
-    sa0.store(As, tid);
-    sb0.store(Bs, tid);
-    __syncthreads();
     const int rowA = TA ? (tid & 127) : (tid >> 1), khA = TA ? (tid >> 7) : (tid & 1);
     const int rowB = !TB ? (tid & 127) : (tid >> 1), khB = !TB ? (tid >> 7) : (tid & 1);
-    unsigned short* const dA = As + rowA * PITCHS + khA * 8;
-    unsigned short* const dB = Bs + rowB * PITCHS + khB * 8;
-    const unsigned short* const apb = As + (wr * 64 + (lane & 31)) * PITCHS + 8 * (lane >> 5);
-    const unsigned short* const bpb = Bs + (wc * 64 + (lane & 31)) * PITCHS + 8 * (lane >> 5);
+    unsigned short* const dA = As + rowA * PITCH + khA * NV;
+    unsigned short* const dB = Bs + rowB * PITCH + khB * NV;
+    const unsigned short* const apb = As + (wr * 64 + (lane & 31)) * PITCH + 8 * (lane >> 5);
+    const unsigned short* const bpb = Bs + (wc * 64 + (lane & 31)) * PITCH + 8 * (lane >> 5);
+    // split registers v[0..NV) into the planes of buffer `buf` (prologue: all at once)
+    auto stage_all = [&](unsigned short* d, const float* v) {
+        uint32_t pk[NP][NPAIR];
+#pragma unroll
+        for (int j = 0; j < NPAIR; ++j) { uint32_t t[NP]; split_pk<NP>(v[2 * j], v[2 * j + 1], t);
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) pk[pl][j] = t[pl]; }
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+            for (int c = 0; c < NPAIR / 4; ++c)
+                *reinterpret_cast<uint4*>(d + pl * PLANE + c * 8) = make_uint4(pk[pl][4 * c], pk[pl][4 * c + 1], pk[pl][4 * c + 2], pk[pl][4 * c + 3]);
+    };
+    sa0.load(a.A, a.lda, m0, kt0 * BKT, tid, arows);
+    sb0.load(a.B, a.ldb, n0, kt0 * BKT, tid);
+    if (kt0 + 1 < nk) { sa1.load(a.A, a.lda, m0, (kt0 + 1) * BKT, tid, arows); sb1.load(a.B, a.ldb, n0, (kt0 + 1) * BKT, tid); }
+    stage_all(dA, sa0.v);
+    stage_all(dB, sb0.v);
+    __syncthreads();
     // one iteration: multiply buffer `cur`; if `stage`, split registers (va, vb) into buffer cur^1 along the way
     auto step = [&](int cur, const float* va, const float* vb, bool stage) {
-        const unsigned short* ap = apb + cur * (3 * PLANES);
-        const unsigned short* bp = bpb + cur * (3 * PLANES);
-        unsigned short* wa = dA + (cur ^ 1) * (3 * PLANES);
-        unsigned short* wb = dB + (cur ^ 1) * (3 * PLANES);
-        bf16x8 af[2][3], bf[2][3];
+        const unsigned short* ap = apb + cur * (NP * PLANE);
+        const unsigned short* bp = bpb + cur * (NP * PLANE);
+        unsigned short* wa = dA + (cur ^ 1) * (NP * PLANE);
+        unsigned short* wb = dB + (cur ^ 1) * (NP * PLANE);
+        uint32_t pa[NP][NPAIR], pb[NP][NPAIR];
+        constexpr int PPG = NPAIR / 4;              // pairs per operand riding on each of the 4 MFMA groups
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            bf16x8 af[2][NP], bf[2][NP];
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
-                af[i][pl] = *reinterpret_cast<const bf16x8*>(ap + pl * PLANES + i * 32 * PITCHS);
-                bf[i][pl] = *reinterpret_cast<const bf16x8*>(bp + pl * PLANES + i * 32 * PITCHS);
-            }
-        uint32_t pa[3][4], pb[3][4];
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+                for (int pl = 0; pl < NP; ++pl) {
+                    af[i][pl] = *reinterpret_cast<const bf16x8*>(ap + pl * PLANE + i * 32 * PITCH + ks * 16);
+                    bf[i][pl] = *reinterpret_cast<const bf16x8*>(bp + pl * PLANE + i * 32 * PITCH + ks * 16);
+                }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {           // smallest terms first
-                const int q = 2 * i + j;            // quarter q of the staging work rides on MFMA group q
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
-                if (stage) split3_pk(va[2 * q], va[2 * q + 1], pa[0][q], pa[1][q], pa[2][q]);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
-                if (stage) split3_pk(vb[2 * q], vb[2 * q + 1], pb[0][q], pb[1][q], pb[2][q]);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
-            }
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {           // smallest terms first
+                    const int q = 2 * i + j;
+                    if (NP == 3) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
+                    if (stage && ks == 0) {
+#pragma unroll
+                        for (int e = 0; e < PPG; ++e) { uint32_t t[NP]; split_pk<NP>(va[2 * (q * PPG + e)], va[2 * (q * PPG + e) + 1], t);
+#pragma unroll
+                            for (int pl = 0; pl < NP; ++pl) pa[pl][q * PPG + e] = t[pl]; }
+                    }
+                    if (NP == 3) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
+                    if (NP == 3) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
+                    if (stage && ks == KSTEPS - 1) {
+#pragma unroll
+                        for (int e = 0; e < PPG; ++e) { uint32_t t[NP]; split_pk<NP>(vb[2 * (q * PPG + e)], vb[2 * (q * PPG + e) + 1], t);
+#pragma unroll
+                            for (int pl = 0; pl < NP; ++pl) pb[pl][q * PPG + e] = t[pl]; }
+                    }
+                    if (NP >= 2) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
+                    if (NP >= 2) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+                }
+        }
         if (stage) {
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
-                *reinterpret_cast<uint4*>(wa + pl * PLANES) = make_uint4(pa[pl][0], pa[pl][1], pa[pl][2], pa[pl][3]);
-                *reinterpret_cast<uint4*>(wb + pl * PLANES) = make_uint4(pb[pl][0], pb[pl][1], pb[pl][2], pb[pl][3]);
-            }
+            for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+                for (int c = 0; c < NPAIR / 4; ++c) {
+                    *reinterpret_cast<uint4*>(wa + pl * PLANE + c * 8) = make_uint4(pa[pl][4 * c], pa[pl][4 * c + 1], pa[pl][4 * c + 2], pa[pl][4 * c + 3]);
+                    *reinterpret_cast<uint4*>(wb + pl * PLANE + c * 8) = make_uint4(pb[pl][4 * c], pb[pl][4 * c + 1], pb[pl][4 * c + 2], pb[pl][4 * c + 3]);
+                }
         }
     };
     int kt = kt0;
     for (; kt + 2 < nk; kt += 2) {
         // even tile: multiply buffer 0, stage set 1 (tile kt+1) into buffer 1, load tile kt+2 into set 0
-        sa0.load(a.A, a.lda, m0, (kt + 2) * BKS, tid, arows);
-        sb0.load(a.B, a.ldb, n0, (kt + 2) * BKS, tid);
+        sa0.load(a.A, a.lda, m0, (kt + 2) * BKT, tid, arows);
+        sb0.load(a.B, a.ldb, n0, (kt + 2) * BKT, tid);
         step(0, sa1.v, sb1.v, true);
         __syncthreads();
         // odd tile: multiply buffer 1, stage set 0 (tile kt+2) into buffer 0, load tile kt+3 into set 1
-        if (kt + 3 < nk) { sa1.load(a.A, a.lda, m0, (kt + 3) * BKS, tid, arows); sb1.load(a.B, a.ldb, n0, (kt + 3) * BKS, tid); }
+        if (kt + 3 < nk) { sa1.load(a.A, a.lda, m0, (kt + 3) * BKT, tid, arows); sb1.load(a.B, a.ldb, n0, (kt + 3) * BKT, tid); }
         step(1, sa0.v, sb0.v, true);
         __syncthreads();
     }
@@ -516,6 +437,14 @@ __global__ __launch_bounds__(256, 2) void gemm_split3_kernel(GemmArgs a) {
         }
 }
 
+template <int NP, int BKT>
+static void launch_planes(dim3 grid, hipStream_t s, const GemmArgs& g, int transA, int transB, bool partm) {
+    if (transA && partm) hipLaunchKernelGGL((gemm_planes_kernel<true, false, true, NP, BKT>), grid, dim3(256), 0, s, g);
+    else if (transA)     hipLaunchKernelGGL((gemm_planes_kernel<true, false, false, NP, BKT>), grid, dim3(256), 0, s, g);
+    else if (transB)     hipLaunchKernelGGL((gemm_planes_kernel<false, true, false, NP, BKT>), grid, dim3(256), 0, s, g);
+    else                 hipLaunchKernelGGL((gemm_planes_kernel<false, false, false, NP, BKT>), grid, dim3(256), 0, s, g);
+}
+
 static int g_gemm_bf16 = 0;
 // fp32 products of whole tiles on the bf16 pipe by exact 3-way splitting (default on; ASR_GEMM_SPLIT=0 or
 // asr_set_gemm_split(0) selects v_mfma_f32_32x32x2_f32 everywhere)
@@ -529,10 +458,11 @@ extern "C" int asr_gemm_f32_batched(void* stream, int transA, int transB, int M,
                                     const float* A, int lda, long long strideA, const float* B, int ldb, long long strideB,
                                     float* C, int ldc, long long strideC, const float* bias, int accumulate, int batch);
 
-// 0: exact fp32 MFMA everywhere (default).  1: products made of whole 128x128x32 tiles round their operands to
-// bf16 on the way into LDS and run on the bf16 matrix cores (fp32 accumulate/output); all others stay fp32.
+// 0: fp32 (default; see asr_set_gemm_split for how whole-tile products are evaluated).  1: products made of whole tiles round
+// their operands to bf16 on the way into LDS (one plane, one product; fp32 accumulate/output).  2: two bf16 planes per
+// operand, three products (~2^-16 relative).  Products with partial tiles or few output tiles stay on the exact fp32 kernel.
 extern "C" int asr_set_gemm_precision(int mode) {
-    if (mode != 0 && mode != 1) return ASR_EINVAL;
+    if (mode < 0 || mode > 2) return ASR_EINVAL;
     asr::g_gemm_bf16 = mode;
     return ASR_OK;
 }
@@ -579,24 +509,12 @@ extern "C" int asr_gemm_f32_batched(void* stream, int transA, int transB, int M,
     if (splits > 1 && !accumulate) {
         if (hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, s) != hipSuccess) return ASR_ELAUNCH;
     }
-    if (g_gemm_bf16 && M % 128 == 0 && N % 128 == 0 && K % BKB == 0 && g.vecA && g.vecB && !(transA && transB)) {
-        int sp = 1;
-        const int nkb = K / BKB;
-        if (transA && batch == 1 && nwg < 192 && nkb >= 32) sp = std::min((768 + nwg - 1) / nwg, nkb / 8);
-        g.splits = sp;
-        if (sp > 1 && !accumulate &&
-            hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, s) != hipSuccess) return ASR_ELAUNCH;
-        if (sp == 1 && splits > 1 && !accumulate) { /* C was zeroed above for the fp32 split: harmless, the kernel overwrites */ }
-        if (transA)       hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), dim3(nwg, sp, batch), dim3(256), 0, s, g);
-        else if (transB)  hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), dim3(nwg, sp, batch), dim3(256), 0, s, g);
-        else              hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), dim3(nwg, sp, batch), dim3(256), 0, s, g);
-        ASR_CHECK_LAUNCH();
-        return ASR_OK;
-    }
-    if (g_gemm_split && (M % 128 == 0 || (transA && !transB && M >= 64)) && N % 128 == 0 && K % BKS == 0 && g.vecA && g.vecB &&
-        !(transA && transB) && (splits > 1 || (long long)nwg * batch >= 96)) {
-        // whole tiles (or, for the weight-gradient form, a partial last row of tiles): fp32-accurate product on the bf16 pipe
-        // (gemm_split3_kernel); same split-K policy as the fp32 kernel
+    // bf16 matrix pipe (gemm_planes_kernel): fp32 mode with the exact 3-way split (NP = 3, fp32-accurate; default), or the
+    // reduced-precision modes of asr_set_gemm_precision: 1 = one bf16 plane (config 3), 2 = two planes / three products
+    const int np = g_gemm_bf16 == 1 ? 1 : (g_gemm_bf16 == 2 ? 2 : (g_gemm_split ? 3 : 0));
+    if (np && (M % 128 == 0 || (transA && !transB && M >= 64)) && N % 128 == 0 && K % BKS == 0 && g.vecA && g.vecB &&
+        !(transA && transB) && (np < 3 || splits > 1 || (long long)nwg * batch >= 96)) {
+        // whole tiles (or, for the weight-gradient form, a partial last row of tiles); same split-K policy as the fp32 kernel
         static const int xs = [] { const char* e = getenv("ASR_GEMM_XCD_SPLIT"); return e ? atoi(e) : 1; }();
         const bool partm = M % 128 != 0;
         g.splits = splits;
@@ -606,10 +524,10 @@ extern "C" int asr_gemm_f32_batched(void* stream, int transA, int transB, int M,
             g.xcd_split = 1;
             grid = dim3(nwg * g.splits, 1, batch);
         }
-        if (transA && partm) hipLaunchKernelGGL((gemm_split3_kernel<true, false, true>), grid, dim3(256), 0, s, g);
-        else if (transA)     hipLaunchKernelGGL((gemm_split3_kernel<true, false>), grid, dim3(256), 0, s, g);
-        else if (transB)     hipLaunchKernelGGL((gemm_split3_kernel<false, true>), grid, dim3(256), 0, s, g);
-        else                 hipLaunchKernelGGL((gemm_split3_kernel<false, false>), grid, dim3(256), 0, s, g);
+        if (np == 3)                      launch_planes<3, 16>(grid, s, g, transA, transB, partm);
+        else if (np == 2)                 launch_planes<2, 16>(grid, s, g, transA, transB, partm);
+        else if (K % 32 == 0)             launch_planes<1, 32>(grid, s, g, transA, transB, partm);
+        else                              launch_planes<1, 16>(grid, s, g, transA, transB, partm);
         ASR_CHECK_LAUNCH();
         return ASR_OK;
     }

@@ -511,7 +511,7 @@ def pyramid_reduce_bwd(dy, T, skip=2):
 def set_gemm_precision(dtype):
     """"f32" (default, exact) or "bf16": bf16 MFMA operands with fp32 accumulation for the whole-tile GEMMs
     (BASELINE config 3).  Process-wide."""
-    mode = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}[str(dtype)]
+    mode = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1, "bf16x2": 2}[str(dtype)]
     _check(_lib.lib().asr_set_gemm_precision(mode), "asr_set_gemm_precision")
 
 
@@ -526,7 +526,7 @@ def get_gemm_split():
 
 
 def get_gemm_precision():
-    return "bf16" if _lib.lib().asr_get_gemm_precision() else "f32"
+    return ("f32", "bf16", "bf16x2")[_lib.lib().asr_get_gemm_precision()]
 
 
 PROF_TAGS = {"lstm_rec_fwd": 0, "lstm_rec_bwd": 1, "gemm": 2, "decoder_fwd": 3, "decoder_bwd": 4, "optim": 5}

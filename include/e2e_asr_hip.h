@@ -32,10 +32,11 @@ int asr_gemm_f32_batched(void* stream, int transA, int transB, int M, int N, int
                          const float* A, int lda, long long strideA, const float* B, int ldb, long long strideB,
                          float* C, int ldc, long long strideC, const float* bias, int accumulate, int batch);
 
-/* Precision of the MFMA GEMMs (BASELINE config 3, "same model bf16").  0 (default): exact fp32 everywhere.
- * 1: products made of whole 128x128x32 tiles (all large encoder / decoder products) round their fp32 operands to
- * bf16 (round-to-nearest-even) while staging them into LDS and run on v_mfma_f32_32x32x16_bf16; accumulation, outputs,
- * recurrent state, attention, loss and the optimizer stay fp32.  Process-wide; set between steps. */
+/* Precision of the MFMA GEMMs.  0 (default): fp32 (asr_set_gemm_split says how).  1 (BASELINE config 3, "same model bf16"):
+ * products made of whole 128x128 tiles round their fp32 operands to bf16 (round-to-nearest-even) while staging them into LDS
+ * and run ONE v_mfma_f32_32x32x16_bf16 product.  2 ("bf16x2"): two bf16 planes per operand value (16 significand bits), three
+ * products -- ~2^-16 relative, for callers that want the bf16 pipe's speed within the fp32 north-star tolerance.  In every
+ * mode accumulation, outputs, recurrent state, attention, loss and the optimizer stay fp32.  Process-wide; set between steps. */
 int asr_set_gemm_precision(int mode);
 int asr_get_gemm_precision(void);
 /* How the fp32 products of whole 128x128x16 tiles are evaluated (mode 0 of asr_set_gemm_precision).  on (default; the

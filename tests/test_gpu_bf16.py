@@ -1,7 +1,11 @@
-"""BASELINE config 3 ("same model bf16"): GEMMs with bf16 MFMA operands (csrc/gemm.hip gemm_bf16_kernel), fp32
-accumulation and fp32 everything else.  Tolerances are stated here: the kernel itself must equal an fp64 product of
-the bf16-ROUNDED operands to fp32 accumulation error; the model's logits may move by the operand rounding
-(2^-9 relative per operand), bounded below against the float64 oracle."""
+"""BASELINE config 3 ("same model bf16"): GEMMs with bf16 MFMA operands (csrc/gemm.hip gemm_planes_kernel, one plane),
+fp32 accumulation and fp32 everything else -- and "bf16x2" (two planes, three products).  Tolerances are stated here.
+Kernel: equal to an fp64 product of the bf16-ROUNDED operands (resp. of their two-plane roundings, minus the dropped
+lo.lo term) to fp32 accumulation error.  Model, against the float64 oracle on the same fp32 weights and inputs:
+  * bf16 (one plane): the north star's 1e-3 logit tolerance is an fp32 statement and one bf16 plane (2^-9 relative per operand,
+    through four encoder layers and 120 decoder steps) does NOT meet it at full size: measured 1.3e-3; the bound asserted
+    here is 5e-3 absolute on the logits and 1 % on the loss;
+  * bf16x2: meets the 1e-3 (asserted < 1e-3 at the full config-2 size; measured ~1e-5)."""
 import numpy as np
 import pytest
 import torch
@@ -47,6 +51,31 @@ def test_gemm_bf16_equals_product_of_rounded_operands(ta, tb, M, N, K, acc):
     assert (exact - out).abs().max().item() > 1e-3
 
 
+def _two_planes(x):
+    h1 = x.to(torch.bfloat16).to(torch.float32)
+    h2 = (x - h1).to(torch.bfloat16).to(torch.float32)
+    return h1.double(), h2.double()
+
+
+@pytest.mark.parametrize("ta,tb,M,N,K", [(0, 0, 256, 128, 96), (0, 1, 128, 256, 80), (1, 0, 128, 128, 4096), (0, 0, 384, 1024, 1024)])
+def test_gemm_bf16x2_equals_three_products_of_the_two_plane_split(ta, tb, M, N, K):
+    """bf16x2: x ~ h1 + h2 (two bf16 terms, 16 significand bits); the product keeps a1b1 + a1b2 + a2b1."""
+    from e2e_asr_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(7 * M + N + K)
+    a = torch.randn((K, M) if ta else (M, K), generator=g).to(DEV)
+    b = torch.randn((N, K) if tb else (K, N), generator=g).to(DEV)
+    ops.set_gemm_precision("bf16x2")
+    assert ops.get_gemm_precision() == "bf16x2"
+    out = ops.gemm(a, b, None, bool(ta), bool(tb))
+    (a1, a2), (b1, b2) = _two_planes(a), _two_planes(b)
+    op = lambda x, t: x.t() if t else x
+    ref = op(a1, ta) @ op(b1, tb) + op(a1, ta) @ op(b2, tb) + op(a2, ta) @ op(b1, tb)
+    assert (out.double() - ref).abs().max().item() <= 2e-6 * K ** 0.5 * 4 + 1e-5
+    exact = op(a.double(), ta) @ op(b.double(), tb)
+    rel = ((out.double() - exact).abs() / (op(a.double().abs(), ta) @ op(b.double().abs(), tb))).max().item()
+    assert 2.0 ** -24 < rel < 2.0 ** -14, rel                  # ~2^-16: between fp32 and one bf16 plane
+
+
 def test_partial_tiles_fall_back_to_exact_fp32():
     from e2e_asr_amd import ops
     a = torch.randn(100, 80, device=DEV); b = torch.randn(80, 1000, device=DEV)
@@ -84,7 +113,7 @@ def test_model_bf16_logits_and_gradients_close_to_fp64_oracle():
     ref = r["outputs"]["char"]
     assert np.abs(res["f32"][0] - ref).max() < 1e-4
     d = np.abs(res["bf16"][0] - ref).max()
-    assert 1e-5 < d < 5e-2, d                                  # moved by the operand rounding, but bounded
+    assert 1e-5 < d < 5e-3, d                                  # moved by the operand rounding, but bounded
     assert abs(res["bf16"][1] - r["total_loss"]) < 1e-2 * abs(r["total_loss"])
     for n, g32 in res["f32"][2].items():
         g16 = res["bf16"][2][n]
@@ -92,14 +121,16 @@ def test_model_bf16_logits_and_gradients_close_to_fp64_oracle():
         assert cos > 0.995, (n, cos)
 
 
-def test_config3_full_size_logits_vs_oracle():
-    """BASELINE config 3's per-GPU workload at FULL size (B = 32, T = 800, bf16 MFMA operands in the GEMMs): logits within
-    5e-2 absolute and loss within 1 % of the float64 oracle (the exact fp32 path: 3e-7 on the same batch)."""
+@pytest.mark.parametrize("prec,tol", [("bf16", 5e-3), ("bf16x2", 1e-3)])
+def test_config3_full_size_logits_vs_oracle(prec, tol):
+    """BASELINE config 3's per-GPU workload at FULL size (B = 32, T = 800): logits against the float64 oracle.  One bf16 plane:
+    within 5e-3 absolute (measured 1.3e-3: above the north star's fp32 tolerance of 1e-3, stated in the module docstring) and
+    the loss within 1 %.  bf16x2 (two planes, three products): within the north star's 1e-3."""
     from tests.test_gpu_model import _model, _f64
     from e2e_asr_amd import ops
     from e2e_asr_amd.weights import synthetic_batch
     from oracle import asr_oracle as O
-    ops.set_gemm_precision("bf16")
+    ops.set_gemm_precision(prec)
     m = _model(feat=80, vocab={"char": 1000}, params_update=dict(max_output={"char": 120}), seed=17)
     b = synthetic_batch(B=32, T=800, F=80, t_dec=121, vocab=1000, variable_len=True, seed=4321)
     m.forward(b)
@@ -109,6 +140,6 @@ def test_config3_full_size_logits_vs_oracle():
     b64 = dict(b); b64["logmel"] = b["logmel"].astype(np.float64)
     r = O.seq2seq_forward(b64, w, is_training=True)
     err = np.abs(out - r["outputs"]["char"]).max()
-    assert 1e-5 < err < 5e-2, err
+    assert (1e-5 if prec == "bf16" else 0.0) < err < tol, err
     assert abs(m.total_loss.item() - r["total_loss"]) < 1e-2 * abs(r["total_loss"])
-    print("config-3 (bf16 operands) full size: max |logit diff| = %.3g" % err)
+    print("config-3 (%s operands) full size: max |logit diff| = %.3g" % (prec, err))
