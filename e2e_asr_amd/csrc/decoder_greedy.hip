@@ -219,6 +219,7 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
     __syncthreads();
 
     if (STAMP) tlast = __builtin_amdgcn_s_memtime();
+    bool lm_ready = false;      // uniform: this step's LM output is already in LDS (gathered during the previous step)
     for (int i = 0; i < a.T; ++i) {
         sph = 0;
         const uint32_t ep = (uint32_t)(i + 1);
@@ -232,47 +233,53 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
         uint32_t* tLM = reinterpret_cast<uint32_t*>(gLM); uint32_t* tQH = reinterpret_cast<uint32_t*>(gQH);
         uint32_t* tY = reinterpret_cast<uint32_t*>(gY); uint32_t* tE = reinterpret_cast<uint32_t*>(gE);
         uint32_t* tC = reinterpret_cast<uint32_t*>(gC); uint32_t* tP = reinterpret_cast<uint32_t*>(gP);
-        // ---- (1) LM cell of my units: gates = EK[tok_i] + h_lm_{i-1} . K_h (the matvec ran at the end of step i-1)
-        if (wave0 && cell) {
-            if (cb_ok) {
-                const float* ek = a.ek + (size_t)tokr * L4 + mem * LS + cu;
-                float4 s = make_float4(ek[0], ek[LMH], ek[2 * LMH], ek[3 * LMH]);
+        // ---- (1) LM cell of my units: gates = EK[tok] + h_lm_{step-1} . K_h (the matvec ran one step earlier), published into the
+        // LM region of `step`'s parity with `step`'s tag bit.  The training graph calls it for step i+1 already DURING step i when
+        // the next token is the teacher's (below): the LM recurrence depends on tokens only, not on the attention chain.
+        auto lm_cell = [&](int step, float4 s) {
+            uint32_t* tL = reinterpret_cast<uint32_t*>(gbase + (size_t)(step & 1) * NPAR);
+            const uint32_t tbs = tag_bit(step);
 #pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    const float4 x = *reinterpret_cast<const float4*>(lmsum + ((p * 8 + cu) * R + cr) * 4);
-                    s.x += x.x; s.y += x.y; s.z += x.z; s.w += x.w;
-                }
-                const float gi = fast_sigmoid(s.x), gj = fast_tanh(s.y), gf = fast_sigmoid(s.z + 1.0f), go = fast_sigmoid(s.w);
-                const float c_old = c_lm;
-                c_lm = c_lm * gf + gi * gj;
-                const float hl = go * fast_tanh(c_lm);
-                if (TRAIN) {
-                    // DropoutWrapper(output_keep_prob) scales what the decoder sees; the LM's recurrence keeps h itself
-                    float o = hl;
-                    if (a.keep < 1.0f) o *= keep_scale(a.seed, (uint32_t)(i * a.B + cb), (uint32_t)(mem * LS + cu), a.keep);
-                    tagged_publish2(tLM + 2 * ((size_t)cr * LMH + mem * LS + cu), tb, o, hl, fast);
-                    // bookkeeping stores after the publish (this wave never polls): the record format of csrc/lstm.hip
-                    // (32-bit element offsets from the uniform base pointers: SGPR base + VGPR offset addressing, no 64-bit
-                    // running pointers kept in registers across the loop)
-                    const unsigned ridx = (unsigned)((i * a.B + cb) * LMH + mem * LS + cu);
-                    a.lm_out[ridx] = __uint_as_float(__float_as_uint(o) & ~1u);          // as every consumer saw it
-                    a.lm_hprev[ridx] = h_lm_prev;
-                    float4* rp = reinterpret_cast<float4*>(a.lm_act + ridx * 8u);
-                    rp[0] = make_float4(gi, gj, gf, go);
-                    rp[1] = make_float4(c_lm, c_old, 0.f, 0.f);
-                    h_lm_prev = __uint_as_float(__float_as_uint(hl) & ~1u);
-                } else {
-                    tagged_publish(tLM + (size_t)cr * LMH + mem * LS + cu, tb, hl, fast);
-                }
+            for (int p = 0; p < 4; ++p) {
+                const float4 x = *reinterpret_cast<const float4*>(lmsum + ((p * 8 + cu) * R + cr) * 4);
+                s.x += x.x; s.y += x.y; s.z += x.z; s.w += x.w;
             }
-        }
-        // ---- (2) gather lm_out_i, outer cell
-        if (poller) {
+            const float gi = fast_sigmoid(s.x), gj = fast_tanh(s.y), gf = fast_sigmoid(s.z + 1.0f), go = fast_sigmoid(s.w);
+            const float c_old = c_lm;
+            c_lm = c_lm * gf + gi * gj;
+            const float hl = go * fast_tanh(c_lm);
+            if (TRAIN) {
+                // DropoutWrapper(output_keep_prob) scales what the decoder sees; the LM's recurrence keeps h itself
+                float o = hl;
+                if (a.keep < 1.0f) o *= keep_scale(a.seed, (uint32_t)(step * a.B + cb), (uint32_t)(mem * LS + cu), a.keep);
+                tagged_publish2(tL + 2 * ((size_t)cr * LMH + mem * LS + cu), tbs, o, hl, fast);
+                // bookkeeping stores after the publish (this wave never polls): the record format of csrc/lstm.hip
+                // (32-bit element offsets from the uniform base pointers: SGPR base + VGPR offset addressing, no 64-bit
+                // running pointers kept in registers across the loop)
+                const unsigned ridx = (unsigned)((step * a.B + cb) * LMH + mem * LS + cu);
+                a.lm_out[ridx] = __uint_as_float(__float_as_uint(o) & ~1u);          // as every consumer saw it
+                a.lm_hprev[ridx] = h_lm_prev;
+                float4* rp = reinterpret_cast<float4*>(a.lm_act + ridx * 8u);
+                rp[0] = make_float4(gi, gj, gf, go);
+                rp[1] = make_float4(c_lm, c_old, 0.f, 0.f);
+                h_lm_prev = __uint_as_float(__float_as_uint(hl) & ~1u);
+            } else {
+                tagged_publish(tL + (size_t)cr * LMH + mem * LS + cu, tbs, hl, fast);
+            }
+        };
+        auto ek_row = [&](int tok) {
+            const float* ek = a.ek + (size_t)tok * L4 + mem * LS + cu;
+            return make_float4(ek[0], ek[LMH], ek[2 * LMH], ek[3 * LMH]);
+        };
+        // ---- (2) gather lm_out of `step` into v_dec[:, :LMH] (and, training graph, the plain h into v_lmh)
+        auto lm_gather = [&](int step) {
+            const uint32_t* tL = reinterpret_cast<const uint32_t*>(gbase + (size_t)(step & 1) * NPAR);
+            const uint32_t tbs = tag_bit(step);
             if (TRAIN) {
                 for (int p = tid - 64; p < NLM / 4; p += NPOLL) {       // a quad = (dropped, plain) outputs of two adjacent units
                     const int r = (2 * p) / LMH, k = (2 * p) % LMH;
                     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (rok(r)) tagged_poll4(tLM + 4 * p, tb, v, a.err);
+                    if (rok(r)) tagged_poll4(tL + 4 * p, tbs, v, a.err);
                     *reinterpret_cast<float2*>(v_dec + r * KD + k) = make_float2(v.x, v.z);
                     *reinterpret_cast<float2*>(v_lmh + r * LMH + k) = make_float2(v.y, v.w);
                 }
@@ -280,12 +287,25 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
                 for (int p = tid - 64; p < NLM / 4; p += NPOLL) {
                     const int idx = 4 * p, r = idx / LMH, k = idx % LMH;
                     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (rok(r)) tagged_poll4(tLM + idx, tb, v, a.err);
+                    if (rok(r)) tagged_poll4(tL + idx, tbs, v, a.err);
                     *reinterpret_cast<float4*>(v_dec + r * KD + k) = v;
                 }
             }
+        };
+        // training graph: where the next token is the teacher's, the LM cell of step i+1 runs during step i (`early`) and its
+        // output is gathered together with ctx_i in phase 6, so step i+1 starts directly with the outer cell's matvec
+        const bool early = TRAIN && !fbi && i + 1 < a.T;
+        float4 ek_next = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (early && wave0 && cell && cb_ok) {      // prefetch: teacher token of step i+1 and its EK row (lands during the step)
+            int tn = a.tok[(size_t)(i + 1) * a.B + cb];
+            tn = min(max(tn, 0), V - 1);
+            ek_next = ek_row(tn);
         }
-        __syncthreads();
+        if (!lm_ready) {
+            if (wave0 && cell && cb_ok) lm_cell(i, ek_row(tokr));
+            if (poller) lm_gather(i);
+            __syncthreads();
+        }
         GREEDY_STAMP()
         {
             float acc[R][4];
@@ -354,6 +374,7 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
                 a.dec_c[rowi * H + mem * HS + cu] = c_dec;
                 a.dec_h[rowi * H + mem * HS + cu] = hd;
             }
+            if (early && cb_ok) lm_cell(i + 1, ek_next);      // lmsum = h_lm_i . K_h was formed before the barrier above
         }
         // ---- (3) gather (q_i, h_i); y slice = q . W_att[:, slice] + b
         if (poller) {
@@ -503,16 +524,13 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
                 *reinterpret_cast<float4*>(v_ap + r * KA + H + k) = v;
                 *reinterpret_cast<float4*>(v_dec + r * KD + LMH + H + k) = v;
             }
+            if (early) lm_gather(i + 1);        // published right after this step's outer cell: long since there
         }
         __syncthreads();
         GREEDY_STAMP()
-        if (!fbi) {          // training graph, teacher-forced step: no projection in the loop; the next token is the teacher's
-            if (wave0 && cell && i + 1 < a.T) {
-                tokr = cb_ok ? a.tok[(size_t)(i + 1) * a.B + cb] : 0;
-                tokr = min(max(tokr, 0), V - 1);
-            }
-            continue;        // (uniform: fbi is the same for every thread of the grid)
-        }
+        lm_ready = early;
+        if (!fbi) continue;  // training graph, teacher-forced step: no projection in the loop (uniform: fbi is the same for every
+                             // thread of the grid); the next token's LM cell has run already, or this was the last step
         {
             float wap_l[12];
             if (TRAIN) { int z = 0; asm volatile("" : "+s"(z)); load_wap(wap_l, z); }
