@@ -26,6 +26,10 @@ class AttnDecoder(Decoder):
         super(AttnDecoder, self).__init__(isTraining=isTraining, params=params, scope=scope, variables=variables)
         self.cell = self.get_cell()
         self.saved = None
+        self.multi = None
+        if self.params.num_layers_dec > 1:          # MultiRNNCell stacks: host-composed per-step path
+            from .multi_decoder import MultiLayerPath
+            self.multi = MultiLayerPath(self)
         self.coin_rng = np.random.default_rng(0)
 
     def weight_tensors(self):
@@ -60,6 +64,12 @@ class AttnDecoder(Decoder):
         tok = decoder_inp if decoder_inp.dtype == torch.int32 else decoder_inp.to(torch.int32)
         enc = encoder_hidden_states.contiguous()
         enc_len_dev = dev_i32(seq_len_inp, dev)
+        if self.multi is not None:
+            logits, sv = self.multi.forward(tok.to(dev), seq_len, enc, enc_len_dev, mode, coin, p.samp_prob, keep_lm,
+                                            self.rng_seed, t_out)
+            self.saved = dict(multi=sv, ws=dict(tok=sv["tok"]), seq_len=seq_len, t_out=t_out, keep_lm=keep_lm, seed=self.rng_seed,
+                              enc=enc, enc_len=np.asarray(seq_len_inp), enc_len_dev=enc_len_dev)
+            return logits
         logits, ws = ops.attn_decoder_fwd(
             self.weight_tensors(), tok.to(dev), dev_i32(seq_len, dev),
             enc, enc_len_dev, mode=mode, coin=coin, samp_prob=p.samp_prob, keep_lm=keep_lm,
@@ -84,6 +94,11 @@ class AttnDecoder(Decoder):
         """Gradient of __call__: accumulates weight gradients into the flat buffer and the
         encoder-state gradient into denc [B,Te,D]."""
         sv = self.saved
+        if self.multi is not None:
+            self.variables.ensure_grad()
+            self.multi.backward(sv["multi"], dlogits, denc)
+            self.saved = None
+            return
         ops.attn_decoder_bwd(self.weight_tensors(), self.grad_tensors(), sv["ws"], sv["enc"], sv["enc_len_dev"],
                              dlogits, denc, keep_lm=sv["keep_lm"], seed=sv["seed"])
         self.saved = None

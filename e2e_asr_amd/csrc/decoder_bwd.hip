@@ -511,3 +511,50 @@ extern "C" int asr_attn_decoder_bwd(void* stream, const asr_dec_weights* w, cons
     prof_end(ASR_PROF_DECODER_BWD, s);
     return ASR_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Step-level backward entry points (C ABI): the two per-step kernels of the launch-based path above, for callers that
+// compose their own decoder loop on the host -- e2e_asr_amd/multi_decoder.py (MultiRNNCell decoders, decoder.py:66-68).
+// ---------------------------------------------------------------------------------------------
+// Pointwise backward of one BasicLSTMCell step whose OUTPUT went through DropoutWrapper(output_keep_prob = keep):
+// dh = dout * mask(seed, step, row, unit) + dh_carry;  gates [B][4H] holds the activated i,j,f,o on entry and dG (gradient of
+// the pre-activations) on return; dc_carry [B][H] is read and updated (the cell-state gradient flowing to step - 1).
+extern "C" int asr_lstm_cell_bwd(void* stream, float* gates, const float* c, const float* c_prev, const float* dout, int ld_dout,
+                                 const float* dh_carry, int ld_dh, float* dc_carry, int B, int H, float keep, unsigned seed,
+                                 unsigned step) {
+    using namespace asr;
+    if (!gates || !c || !dout || !dc_carry || B <= 0 || H <= 0 || ld_dout < H || (dh_carry && ld_dh < H)) return ASR_EINVAL;
+    LmBwdArgs l;
+    l.gates = gates; l.c = c; l.c_prev = c_prev; l.dlo = dout; l.ld_dlo = ld_dout; l.dh_carry = dh_carry; l.ld_dh = ld_dh;
+    l.dc_carry = dc_carry; l.B = B; l.H = H; l.keep = keep; l.seed = seed; l.step = step;
+    hipLaunchKernelGGL(lm_cell_bwd_kernel, dim3((B * H + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), l);
+    ASR_CHECK_LAUNCH();
+    return ASR_OK;
+}
+
+// One step of the attention + query-cell backward (kernel K1 above): attention backward for the query q = c of the cell whose
+// activated gates are in `gates` (dG on return), dq folded into that cell's state gradient.  dqc [B][H+D] = this step's
+// [dq | dctx] from the AttnProjection; dctx_carry (row stride ld_carry) / dh_carry (ld_dh) = what step + 1 sent back, or NULL;
+// dhf [B][Te][A] and dv_part [B][A] are accumulated over steps (zero them first); dctx_out [B][D], dy [B][A] are this step's.
+extern "C" int asr_attn_cell_bwd(void* stream, const float* q, const float* w_att, const float* b_att, const float* v,
+                                 const float* hf, const float* enc, const int* enc_len, const float* alpha, const float* y_saved,
+                                 const float* dqc, const float* dctx_carry, int ld_carry, float* dhf, float* dctx_out, float* dy,
+                                 float* dv_part, float* gates, const float* c_prev, const float* dh_carry, int ld_dh,
+                                 float* dc_carry, int B, int Te, int H, int A, int D) {
+    using namespace asr;
+    if (!q || !w_att || !b_att || !v || !hf || !enc || !enc_len || !alpha || !dqc || !dhf || !dctx_out || !dy || !dv_part ||
+        !gates || !dc_carry || B <= 0 || Te <= 0) return ASR_EINVAL;
+    if ((A & 3) || (D & 3) || A > 256) return ASR_EUNSUPPORTED;
+    const size_t lds = dec_bwd_lds(Te, H, A, D);
+    if (lds > 150 * 1024) return ASR_EUNSUPPORTED;
+    if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_attn_cell_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    DecBwdStepArgs a;
+    a.q = q; a.w_att = w_att; a.b_att = b_att; a.v = v; a.hf = hf; a.enc = enc; a.enc_len = enc_len; a.alpha = alpha;
+    a.y_saved = y_saved; a.dqc = dqc; a.dctx_carry = dctx_carry; a.ld_carry = ld_carry; a.dhf = dhf; a.dctx_out = dctx_out;
+    a.dy = dy; a.dv_part = dv_part; a.gates = gates; a.c_prev = c_prev; a.dh_carry = dh_carry; a.ld_dh = ld_dh;
+    a.dc_carry = dc_carry; a.B = B; a.Te = Te; a.H = H; a.A = A; a.D = D;
+    hipLaunchKernelGGL(dec_attn_cell_bwd_kernel, dim3(B), dim3(DBW_NT), lds, static_cast<hipStream_t>(stream), a);
+    ASR_CHECK_LAUNCH();
+    return ASR_OK;
+}

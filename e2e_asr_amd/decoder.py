@@ -28,9 +28,10 @@ class Decoder(BaseParams):
         p = self.params
         if not p.use_lstm:
             raise NotImplementedError("GRUCell decoder: not on the hot path")
-        if p.num_layers_dec > 1:
-            raise NotImplementedError("MultiRNNCell decoder (num_layers_dec > 1) is outside the hot path")
-        return "BasicLSTMCell(%d)" % (p.hidden_size_dec if hidden_size is None else hidden_size)
+        size = p.hidden_size_dec if hidden_size is None else hidden_size
+        if p.num_layers_dec > 1:       # decoder.py:66-68 (runs through e2e_asr_amd/multi_decoder.py)
+            return "MultiRNNCell([BasicLSTMCell(%d)] * %d)" % (size, p.num_layers_dec)
+        return "BasicLSTMCell(%d)" % size
 
     def get_state(self, state):
         """decoder.py:74-82: the attention query is the LSTM CELL state c (not h)."""

@@ -232,6 +232,45 @@ def linear_wt(x, wt, out=None, accumulate=False, n=None, k=None, ldw=None):
     return out
 
 
+def gemm_batched(a, b, out, M, N, K, lda, ldb, ldc, stride_a, stride_b, stride_c, batch, trans_a=False, trans_b=False,
+                 accumulate=False):
+    """out_i[M,N] (+)= op(a_i) @ op(b_i) for `batch` problems whose operands sit strides (in elements) apart."""
+    rc = _lib.lib().asr_gemm_f32_batched(_stream(), int(trans_a), int(trans_b), M, N, K, _p(a), lda, stride_a, _p(b), ldb, stride_b,
+                                         _p(out), ldc, stride_c, None, int(accumulate), batch)
+    _check(rc, "asr_gemm_f32_batched")
+    return out
+
+
+def zero_finished_rows(logits, seq_len, T, B):
+    """raw_rnn emits zeros for finished rows (attn_decoder.py:170): rows (t, b) with t >= seq_len[b] of logits [(T*B), V]."""
+    _check(_lib.lib().asr_zero_finished_rows(_stream(), _p(logits), _p(_i32(seq_len, "seq_len")), T, B, logits.shape[1]),
+           "asr_zero_finished_rows")
+    return logits
+
+
+def lstm_cell_bwd(gates, c, c_prev, dout, dh_carry, dc_carry, keep_prob=1.0, seed=0, step=0):
+    """Pointwise backward of one lstm_cell step (see include/e2e_asr_hip.h asr_lstm_cell_bwd).  dout / dh_carry may be
+    column slices of wider row-major buffers (their row stride is passed on); gates: activated in, dG out."""
+    B, H = c.shape
+    rc = _lib.lib().asr_lstm_cell_bwd(_stream(), _p(gates), _p(c), _p(c_prev), _p(dout), dout.stride(0),
+                                      _p(dh_carry), 0 if dh_carry is None else dh_carry.stride(0), _p(dc_carry), B, H,
+                                      float(keep_prob), int(seed) & 0xFFFFFFFF, int(step))
+    _check(rc, "asr_lstm_cell_bwd")
+    return gates
+
+
+def attn_cell_bwd(q, w_att, b_att, v, hf, enc, enc_len, alpha, dqc, dctx_carry, dhf, dctx_out, dy, dv_part, gates, c_prev,
+                  dh_carry, dc_carry):
+    """One step of the attention + query-cell backward (include/e2e_asr_hip.h asr_attn_cell_bwd)."""
+    B, Te, D = enc.shape
+    H, A = w_att.shape
+    rc = _lib.lib().asr_attn_cell_bwd(_stream(), _p(q), _p(w_att), _p(b_att), _p(v), _p(hf), _p(enc), _p(enc_len), _p(alpha), None,
+                                      _p(dqc), _p(dctx_carry), 0 if dctx_carry is None else dctx_carry.stride(0), _p(dhf),
+                                      _p(dctx_out), _p(dy), _p(dv_part), _p(gates), _p(c_prev), _p(dh_carry),
+                                      0 if dh_carry is None else dh_carry.stride(0), _p(dc_carry), B, Te, H, A, D)
+    _check(rc, "asr_attn_cell_bwd")
+
+
 def colsum(x, out, accumulate=True):
     M, N = x.shape
     _check(_lib.lib().asr_colsum_f32(_stream(), _p(x), x.stride(0), M, N, _p(out), int(accumulate)), "asr_colsum_f32")

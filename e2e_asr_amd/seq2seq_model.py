@@ -76,7 +76,8 @@ class Seq2SeqModel(BaseParams):
             tasks=tasks, vocab={t: params.decoder_params[t].vocab_size for t in tasks},
             emb=dp.emb_size, hidden_dec=dp.hidden_size_dec, lm_hidden=dp.lm_hidden_size,
             attn_vec=dp.attention_vec_size, seed=seed, skip_step=ep.skip_step,
-            max_scaling_down=ep.max_scaling_down, initial_res_fac=ep.initial_res_fac)
+            max_scaling_down=ep.max_scaling_down, initial_res_fac=ep.initial_res_fac,
+            num_layers_dec=getattr(dp, "num_layers_dec", 1))
         return VariableStore.from_arrays(arrays, device)
 
     def learning_rate_decay_op(self):

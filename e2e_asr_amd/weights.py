@@ -41,9 +41,18 @@ def encoder_layer_inputs(feat, hidden, bi_dir, depth, skip_step=2, max_scaling_d
     return dims
 
 
+def multi_cell_leaf(stack, layer, leaf):
+    """Variable leaf of layer `layer` of a MultiRNNCell decoder stack (decoder.py:66-68: num_layers_dec > 1) under
+    model/rnn_decoder_<task>/.  raw_rnn's scope is `rnn`; the LM stack is built first (`multi_rnn_cell`), the outer stack
+    second (`multi_rnn_cell_1`) -- the order that gives the single-layer names `basic_lstm_cell` / `basic_lstm_cell_1`
+    (beam_search.py:56-98).  The reference ships no checkpoint or reader for such a model (its beam search maps the
+    single-layer names only), so these names are this build's reading of TF-1.x scoping, not a pinned interface."""
+    return "rnn/multi_rnn_cell%s/cell_%d/basic_lstm_cell/%s" % ("" if stack == "lm" else "_1", layer, leaf)
+
+
 def init_weights(feat=80, hidden=256, bi_dir=True, depth=4, tasks=("char",), vocab=None,
                  emb=256, hidden_dec=256, lm_hidden=256, attn_vec=128, num_layers=None,
-                 seed=10, skip_step=2, max_scaling_down=8, initial_res_fac=1):
+                 seed=10, skip_step=2, max_scaling_down=8, initial_res_fac=1, num_layers_dec=1):
     """Random-init weights of the reference architecture.
 
     Encoder kernels U(-0.075, 0.075) (encoder.py:74), biases 0 (BasicLSTMCell default),
@@ -75,10 +84,18 @@ def init_weights(feat=80, hidden=256, bi_dir=True, depth=4, tasks=("char",), voc
         w[dec_name(task, "rnn/AttnProjection/bias")] = np.zeros(H, np.float32)
         w[dec_name(task, "rnn/OutputProjection/kernel")] = _glorot(rng, (H, V))
         w[dec_name(task, "rnn/OutputProjection/bias")] = np.zeros(V, np.float32)
-        w[dec_name(task, "rnn/basic_lstm_cell/kernel")] = _glorot(rng, (E + lmH, 4 * lmH))
-        w[dec_name(task, "rnn/basic_lstm_cell/bias")] = np.zeros(4 * lmH, np.float32)
-        w[dec_name(task, "rnn/basic_lstm_cell_1/kernel")] = _glorot(rng, (E + H, 4 * H))
-        w[dec_name(task, "rnn/basic_lstm_cell_1/bias")] = np.zeros(4 * H, np.float32)
+        if num_layers_dec <= 1:
+            w[dec_name(task, "rnn/basic_lstm_cell/kernel")] = _glorot(rng, (E + lmH, 4 * lmH))
+            w[dec_name(task, "rnn/basic_lstm_cell/bias")] = np.zeros(4 * lmH, np.float32)
+            w[dec_name(task, "rnn/basic_lstm_cell_1/kernel")] = _glorot(rng, (E + H, 4 * H))
+            w[dec_name(task, "rnn/basic_lstm_cell_1/bias")] = np.zeros(4 * H, np.float32)
+        else:       # MultiRNNCell (decoder.py:66-68): the LM stack is created first, the outer stack second
+            for k in range(num_layers_dec):
+                w[dec_name(task, multi_cell_leaf("lm", k, "kernel"))] = _glorot(rng, ((E if k == 0 else lmH) + lmH, 4 * lmH))
+                w[dec_name(task, multi_cell_leaf("lm", k, "bias"))] = np.zeros(4 * lmH, np.float32)
+            for k in range(num_layers_dec):
+                w[dec_name(task, multi_cell_leaf("dec", k, "kernel"))] = _glorot(rng, ((E if k == 0 else H) + H, 4 * H))
+                w[dec_name(task, multi_cell_leaf("dec", k, "bias"))] = np.zeros(4 * H, np.float32)
         w[dec_name(task, "rnn/InputProjection/kernel")] = _glorot(rng, (P + D, E))
         w[dec_name(task, "rnn/InputProjection/bias")] = np.zeros(E, np.float32)
         if lmH != H:

@@ -237,6 +237,22 @@ int asr_attn_decoder_bwd(void* stream, const asr_dec_weights* w, const asr_dec_w
                          float* denc, float keep_lm, unsigned seed);
 int asr_scatter_add_rows_ld(void* stream, float* table_grad, const int* idx, const float* g, int rows, int width, int ldg);
 
+/* Step-level backward kernels of the launch-based decoder path, for callers that compose their own decoder loop on the host
+ * (e2e_asr_amd/multi_decoder.py: MultiRNNCell decoders, decoder.py:66-68).
+ * asr_lstm_cell_bwd: pointwise backward of one BasicLSTMCell step whose output went through DropoutWrapper(keep):
+ *   dh = dout * mask(seed, step, row, unit) + dh_carry; gates [B][4H]: activated i,j,f,o in, dG (pre-activation gradient) out;
+ *   dc_carry [B][H] read and updated.  c_prev / dh_carry may be NULL (first / last step).
+ * asr_attn_cell_bwd: attention backward for the query q = c of the cell whose activated gates are in `gates` (dG out), dq
+ *   folded into that cell's state gradient.  dqc [B][H+D] = this step's [dq | dctx] from AttnProjection; dctx_carry / dh_carry
+ *   (row strides ld_carry / ld_dh) = what step + 1 sent back, or NULL; dhf [B][Te][A], dv_part [B][A] accumulate over steps. */
+int asr_lstm_cell_bwd(void* stream, float* gates, const float* c, const float* c_prev, const float* dout, int ld_dout,
+                      const float* dh_carry, int ld_dh, float* dc_carry, int B, int H, float keep, unsigned seed, unsigned step);
+int asr_attn_cell_bwd(void* stream, const float* q, const float* w_att, const float* b_att, const float* v,
+                      const float* hf, const float* enc, const int* enc_len, const float* alpha, const float* y_saved,
+                      const float* dqc, const float* dctx_carry, int ld_carry, float* dhf, float* dctx_out, float* dy,
+                      float* dv_part, float* gates, const float* c_prev, const float* dh_carry, int ld_dh,
+                      float* dc_carry, int B, int Te, int H, int A, int D);
+
 /* One beam-search step for the k live hypotheses of one utterance: BeamSearch.get_top_k (beam_search.py:163-221) up
  * to the two logit vectors (decoder and external LM); the float64 scoring / argpartition stays on the host.
  * d->B = k rows; hf [Te,A] = enc . AttnW (asr_gemm_f32), enc [Te,D], enc_len[0] = Te.  State rows are per hypothesis

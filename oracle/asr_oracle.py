@@ -211,9 +211,20 @@ def decoder_weights(weights, task="char"):
     """beam_search.py:53-98 -- name -> role mapping (AttnW squeezed to [D,A])."""
     g = lambda leaf: weights[dec_var(task, leaf)]
     opt = lambda leaf: weights.get(dec_var(task, leaf))
+    multi = lambda stack, k, leaf: "rnn/multi_rnn_cell%s/cell_%d/basic_lstm_cell/%s" % ("" if stack == "lm" else "_1", k, leaf)
+    if opt(multi("lm", 0, "kernel")) is not None:           # MultiRNNCell decoder (decoder.py:66-68, num_layers_dec > 1)
+        L = 0
+        while opt(multi("lm", L, "kernel")) is not None:
+            L += 1
+        lm_stack = [(g(multi("lm", k, "kernel")), g(multi("lm", k, "bias"))) for k in range(L)]
+        dec_stack = [(g(multi("dec", k, "kernel")), g(multi("dec", k, "bias"))) for k in range(L)]
+    else:
+        lm_stack = [(g("rnn/basic_lstm_cell/kernel"), g("rnn/basic_lstm_cell/bias"))]
+        dec_stack = [(g("rnn/basic_lstm_cell_1/kernel"), g("rnn/basic_lstm_cell_1/bias"))]
     return dict(
-        lm_lstm_w=g("rnn/basic_lstm_cell/kernel"), lm_lstm_b=g("rnn/basic_lstm_cell/bias"),
-        dec_lstm_w=g("rnn/basic_lstm_cell_1/kernel"), dec_lstm_b=g("rnn/basic_lstm_cell_1/bias"),
+        lm_stack=lm_stack, dec_stack=dec_stack,
+        lm_lstm_w=lm_stack[0][0], lm_lstm_b=lm_stack[0][1],
+        dec_lstm_w=dec_stack[0][0], dec_lstm_b=dec_stack[0][1],
         attn_dec_w=g("rnn/Attention/kernel"), attn_dec_b=g("rnn/Attention/bias"),
         inp_w=g("rnn/InputProjection/kernel"), inp_b=g("rnn/InputProjection/bias"),
         attn_proj_w=g("rnn/AttnProjection/kernel"), attn_proj_b=g("rnn/AttnProjection/bias"),
@@ -237,9 +248,21 @@ def attention_tf(q, hf, enc, attn_mask, p):
     return ctx, alpha
 
 
+def cell_stack(x, states, stack, masks, step):
+    """MultiRNNCell.__call__ over DropoutWrapper(BasicLSTMCell) layers (decoder.py:49-72): layer k's input is layer k-1's
+    DROPPED output; the state keeps the plain (c, h).  masks: None or per layer an array indexed by step (or None).
+    Returns (top dropped output, new states)."""
+    new, inp = [], x
+    for k, (w, b) in enumerate(stack):
+        c, h = lstm_cell(inp, states[k][0], states[k][1], w, b)
+        new.append((c, h))
+        inp = h if (masks is None or masks[k] is None) else h * masks[k][step]
+    return inp, new
+
+
 def attn_decoder(dec_inp, seq_len, enc, seq_len_inp, weights, task="char",
                  is_training=False, samp_prob=0.0, lm_keep_masks=None,
-                 coin=None, sampler=None, return_aux=False):
+                 coin=None, sampler=None, return_aux=False, dec_keep_masks=None):
     """attn_decoder.py:37-172 driven by tf.nn.raw_rnn (:166).
 
     dec_inp [T_dec,B] ints; seq_len [B]; enc [B,Te,D]; seq_len_inp [B].
@@ -258,6 +281,9 @@ def attn_decoder(dec_inp, seq_len, enc, seq_len_inp, weights, task="char",
     lm_keep_masks [T_out+1, B, lmH]: DropoutWrapper on the lm cell's output
     (decoder.py:60-63).  The outer cell's dropout is a numerical no-op (its
     output is discarded, only s'.c is used).
+    num_layers_dec > 1 (MultiRNNCell, decoder.py:66-68): both cells are stacks; the query is the TOP layer's c
+    (decoder.py:77-80); lm_keep_masks / dec_keep_masks are then lists over layers (the outer stack's masks act
+    between its layers; the top layer's dropped output is discarded as before).
     """
     p = decoder_weights(weights, task)
     emb = p["embedding"]
@@ -268,32 +294,32 @@ def attn_decoder(dec_inp, seq_len, enc, seq_len_inp, weights, task="char",
     H = p["dec_lstm_w"].shape[1] // 4
     lmH = p["lm_lstm_w"].shape[1] // 4
     V = p["out_w"].shape[1]
+    L = len(p["lm_stack"])
+    lm_masks = None if lm_keep_masks is None else (list(lm_keep_masks) if L > 1 else [lm_keep_masks])
+    dec_masks = None if dec_keep_masks is None else (list(dec_keep_masks) + [None])[:L]
     T_out = int(seq_len.max())
     attn_mask = (np.arange(Te)[None, :] < seq_len_inp[:, None]).astype(dt)   # :60
     hf = np.matmul(enc, p["attn_enc_w"])                                     # :70-73
 
-    def lm_and_input(lm_in, lm_c, lm_h, ctx, step):
-        lm_c, lm_h = lstm_cell(lm_in, lm_c, lm_h, p["lm_lstm_w"], p["lm_lstm_b"])   # :148
-        lm_out = lm_h
-        if lm_keep_masks is not None:
-            lm_out = lm_out * lm_keep_masks[step]
+    def lm_and_input(lm_in, lm_st, ctx, step):
+        lm_out, lm_st = cell_stack(lm_in, lm_st, p["lm_stack"], lm_masks, step)   # :148
         if p["simple_w"] is not None:                                          # :149-151
             lm_out = np.matmul(lm_out, p["simple_w"]) + p["simple_b"]
         x = np.matmul(np.concatenate((lm_out, ctx), axis=1), p["inp_w"]) + p["inp_b"]  # :157-158
-        return x, lm_c, lm_h
+        return x, lm_st
 
     # loop_fn(time=0)                                                        :100-109
-    c = np.zeros((B, H), dt); h = np.zeros((B, H), dt)
-    lm_c = np.zeros((B, lmH), dt); lm_h = np.zeros((B, lmH), dt)
+    st = [(np.zeros((B, H), dt), np.zeros((B, H), dt)) for _ in range(L)]
+    lm_st = [(np.zeros((B, lmH), dt), np.zeros((B, lmH), dt)) for _ in range(L)]
     ctx = np.zeros((B, D), dt)
     finished = 0 >= seq_len
-    x, lm_c, lm_h = lm_and_input(emb[dec_inp[0]], lm_c, lm_h, ctx, 0)
+    x, lm_st = lm_and_input(emb[dec_inp[0]], lm_st, ctx, 0)
     outs = np.zeros((T_out, B, V), dt)
     aux = dict(alpha=[], ctx=[], q=[], tokens=[])
     t = 0
     while not finished.all():
-        nc, nh = lstm_cell(x, c, h, p["dec_lstm_w"], p["dec_lstm_b"])
-        q = nc                                                    # decoder.py:79-80
+        _, nst = cell_stack(x, st, p["dec_stack"], dec_masks, t)
+        q = nst[-1][0]                                            # decoder.py:77-80: the top layer's c
         ctx, alpha = attention_tf(q, hf, enc, attn_mask, p)                   # :114
         proj = np.matmul(np.concatenate((q, ctx), axis=1), p["attn_proj_w"]) + p["attn_proj_b"]
         logits = np.matmul(proj, p["out_w"]) + p["out_b"]                     # :124-125
@@ -311,10 +337,10 @@ def attn_decoder(dec_inp, seq_len, enc, seq_len_inp, weights, task="char",
                 lm_in = emb[tok]
             else:
                 lm_in = emb[dec_inp[t + 1]]                                   # :137
-        x, lm_c, lm_h = lm_and_input(lm_in, lm_c, lm_h, ctx, t + 1)
+        x, lm_st = lm_and_input(lm_in, lm_st, ctx, t + 1)
         fb = finished[:, None]
         outs[t] = np.where(fb, 0, logits)              # raw_rnn emit zero-fill
-        c = np.where(fb, c, nc); h = np.where(fb, h, nh)   # raw_rnn state copy-through
+        st = [(np.where(fb, c0, c1), np.where(fb, h0, h1)) for (c0, h0), (c1, h1) in zip(st, nst)]   # raw_rnn state copy-through
         finished = finished | nxt_finished
         if return_aux:
             aux["alpha"].append(alpha); aux["ctx"].append(ctx); aux["q"].append(q)

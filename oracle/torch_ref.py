@@ -86,34 +86,57 @@ def encoder(x_bm, seq_len, W, num_layers, bi_dir=True, skip_step=2, max_scaling_
     return att, lens
 
 
-def attn_decoder(dec_inp, seq_len, enc, seq_len_inp, W, task="char", lm_keep_masks=None, tokens=None):
+def attn_decoder(dec_inp, seq_len, enc, seq_len_inp, W, task="char", lm_keep_masks=None, tokens=None, dec_keep_masks=None):
     """attn_decoder.py:37-172 in training mode.  `tokens` [T_out,B]: the token actually fed
-    at each step (teacher or sampled, taken from the product path so both follow one path)."""
+    at each step (teacher or sampled, taken from the product path so both follow one path).
+    MultiRNNCell decoders (num_layers_dec > 1): stacks as in asr_oracle.cell_stack; the masks are then lists over layers."""
     g = lambda leaf: W[O.dec_var(task, leaf)]
     opt = lambda leaf: W.get(O.dec_var(task, leaf))
+    multi = lambda stack, k, leaf: "rnn/multi_rnn_cell%s/cell_%d/basic_lstm_cell/%s" % ("" if stack == "lm" else "_1", k, leaf)
+    if opt(multi("lm", 0, "kernel")) is not None:
+        L = 0
+        while opt(multi("lm", L, "kernel")) is not None:
+            L += 1
+        lm_stack = [(g(multi("lm", k, "kernel")), g(multi("lm", k, "bias"))) for k in range(L)]
+        dec_stack = [(g(multi("dec", k, "kernel")), g(multi("dec", k, "bias"))) for k in range(L)]
+    else:
+        L = 1
+        lm_stack = [(g("rnn/basic_lstm_cell/kernel"), g("rnn/basic_lstm_cell/bias"))]
+        dec_stack = [(g("rnn/basic_lstm_cell_1/kernel"), g("rnn/basic_lstm_cell_1/bias"))]
+    lm_masks = None if lm_keep_masks is None else (list(lm_keep_masks) if L > 1 else [lm_keep_masks])
+    dec_masks = None if dec_keep_masks is None else (list(dec_keep_masks) + [None])[:L]
+
+    def stack_step(x, states, stack, masks, step):
+        new, inp = [], x
+        for k, (w, b) in enumerate(stack):
+            c, h = lstm_cell(inp, states[k][0], states[k][1], w, b)
+            new.append((c, h))
+            inp = h if (masks is None or masks[k] is None) else h * masks[k][step]
+        return inp, new
     emb = g("decoder/embedding")
     seq_len = np.asarray(seq_len).astype(np.int64)
     B, Te, D = enc.shape
-    H = g("rnn/basic_lstm_cell_1/kernel").shape[1] // 4
-    lmH = g("rnn/basic_lstm_cell/kernel").shape[1] // 4
+    H = dec_stack[0][0].shape[1] // 4
+    lmH = lm_stack[0][0].shape[1] // 4
     T_out = int(seq_len.max())
     mask = (torch.arange(Te)[None] < torch.as_tensor(np.asarray(seq_len_inp))[:, None]).to(enc.dtype)
     aw = g("AttnW"); aw = aw.reshape(aw.shape[-2], aw.shape[-1])
     hf = enc @ aw
     z = lambda n: enc.new_zeros(B, n)
-    c, h, lc, lh, ctx = z(H), z(H), z(lmH), z(lmH), z(D)
+    st = [(z(H), z(H)) for _ in range(L)]
+    lst = [(z(lmH), z(lmH)) for _ in range(L)]
+    ctx = z(D)
     dec_inp = torch.as_tensor(np.asarray(dec_inp), dtype=torch.long)
     toks = dec_inp if tokens is None else torch.as_tensor(np.asarray(tokens), dtype=torch.long)
     outs = []
     fin = torch.as_tensor(0 >= seq_len)
     for t in range(T_out):
-        lc, lh = lstm_cell(emb[toks[t]], lc, lh, g("rnn/basic_lstm_cell/kernel"), g("rnn/basic_lstm_cell/bias"))
-        lo = lh if lm_keep_masks is None else lh * lm_keep_masks[t]
+        lo, lst = stack_step(emb[toks[t]], lst, lm_stack, lm_masks, t)
         if opt("rnn/SimpleProjection/kernel") is not None:
             lo = lo @ g("rnn/SimpleProjection/kernel") + g("rnn/SimpleProjection/bias")
         x = torch.cat((lo, ctx), 1) @ g("rnn/InputProjection/kernel") + g("rnn/InputProjection/bias")
-        nc, nh = lstm_cell(x, c, h, g("rnn/basic_lstm_cell_1/kernel"), g("rnn/basic_lstm_cell_1/bias"))
-        q = nc
+        _, nst = stack_step(x, st, dec_stack, dec_masks, t)
+        q = nst[-1][0]
         y = q @ g("rnn/Attention/kernel") + g("rnn/Attention/bias")
         s = (g("AttnV") * torch.tanh(hf + y[:, None, :])).sum(2)
         a = torch.softmax(s, 1) * mask
@@ -123,7 +146,7 @@ def attn_decoder(dec_inp, seq_len, enc, seq_len_inp, W, task="char", lm_keep_mas
         logits = p @ g("rnn/OutputProjection/kernel") + g("rnn/OutputProjection/bias")
         fb = fin[:, None]
         outs.append(torch.where(fb, torch.zeros_like(logits), logits))
-        c = torch.where(fb, c, nc); h = torch.where(fb, h, nh)
+        st = [(torch.where(fb, c0, c1), torch.where(fb, h0, h1)) for (c0, h0), (c1, h1) in zip(st, nst)]
         fin = fin | torch.as_tensor((t + 1) >= seq_len)
     return torch.cat(outs, 0)
 
@@ -139,7 +162,7 @@ def cross_entropy_loss(logits, targets, seq_len):
 
 
 def seq2seq_loss(batch, W, tasks=("char",), num_layers=None, bi_dir=True, avg=True, tokens=None,
-                 enc_keep_masks=None, lm_keep_masks=None):
+                 enc_keep_masks=None, lm_keep_masks=None, dec_keep_masks=None):
     """seq2seq_model.py:88-144 in training mode -> (total_loss, {task: loss}, {task: logits})."""
     num_layers = num_layers or {"char": 4}
     x = torch.as_tensor(batch["logmel"])
@@ -152,7 +175,8 @@ def seq2seq_loss(batch, W, tasks=("char",), num_layers=None, bi_dir=True, avg=Tr
         d = num_layers[task]
         outs[task] = attn_decoder(dec_inp, dlen, att[d], lens[d], W, task,
                                   lm_keep_masks=None if lm_keep_masks is None else lm_keep_masks[task],
-                                  tokens=None if tokens is None else tokens[task])
+                                  tokens=None if tokens is None else tokens[task],
+                                  dec_keep_masks=None if dec_keep_masks is None else dec_keep_masks[task])
         T_out = int(dlen.max())
         losses[task] = cross_entropy_loss(outs[task], dec_inp[1:1 + T_out], dlen)
     total = sum(losses.values())

@@ -464,3 +464,79 @@ def test_training_decoder_one_launch_teacher_forced_vs_oracle_and_autograd():
     m.backward()
     ops.check_device_flag(torch.device(DEV))
     _grad_check(m, b)
+
+
+# ------------------------------------------------------------------ MultiRNNCell decoder (num_layers_dec > 1)
+@pytest.mark.parametrize("L,keep", [(2, 1.0), (3, 0.8)])
+def test_multi_layer_decoder_vs_oracle_and_autograd(L, keep):
+    """decoder.py:66-68, 77-78: `-num_layers_dec L` builds both decoder cells as MultiRNNCell stacks of DropoutWrapper(
+    BasicLSTMCell) layers; the attention query is the TOP layer's c.  Logits and loss vs the float64 oracle and every gradient
+    vs float64 autograd, ragged lengths; with dropout the per-layer masks of the counter-based generator are reproduced on
+    the host and handed to the autograd twin."""
+    from e2e_asr_amd import ops
+    from e2e_asr_amd.multi_decoder import layer_seed
+    from oracle import torch_ref as R
+    from tests.test_gpu_model import _np_keep_scale
+    nl = {"char": 2}
+    m = _model(enc_update=dict(hidden_size=64), num_layers=nl, seed=43,
+               dec_update=dict(hidden_size_dec=32, lm_hidden_size=32, emb_size=24, attention_vec_size=16, num_layers_dec=L,
+                               out_prob_dec=keep))
+    assert m.decoder["char"].cell.startswith("MultiRNNCell")
+    b = _batch(61 + L, 5, 22, 20, 9, 50)
+    m.global_step = 2
+    m.forward(b)
+    ops.check_device_flag(torch.device(DEV))
+    B = 5
+    T_out = m.decoder["char"].saved["t_out"]
+    seed = m.decoder["char"].saved["seed"]
+    w = _f64(m.variables.to_arrays())
+    assert any("multi_rnn_cell_1/cell_%d/" % (L - 1) in k for k in w)
+    lm_masks = dec_masks = None
+    if keep < 1.0:
+        def masks(stack, nlayers):
+            out = []
+            for k in range(nlayers):
+                # (the oracle's raw_rnn restatement also runs the LM stack once past the last step: T_out + 1 rows)
+                ii, bb, jj = np.meshgrid(np.arange(T_out + 1), np.arange(B), np.arange(32), indexing="ij")
+                out.append(_np_keep_scale(layer_seed(seed, stack, k), ii * B + bb, jj, keep))
+            return out
+        lm_masks, dec_masks = masks("lm", L), masks("dec", L - 1)
+    b64 = dict(b); b64["logmel"] = b["logmel"].astype(np.float64)
+    att, _, lens = O.encoder(b64["logmel"], b64["logmel_len"], w, nl)
+    ref = O.attn_decoder(np.transpose(b["char"]), b["char_len"], att[2], lens[2], w, is_training=True,
+                         lm_keep_masks=lm_masks, dec_keep_masks=dec_masks)
+    np.testing.assert_allclose(m.outputs["char"].cpu().numpy(), ref, rtol=0, atol=1e-4)
+    m.backward()
+    ops.check_device_flag(torch.device(DEV))
+    W = R.weights_to_torch(w)
+    t = lambda ms: None if ms is None else [torch.tensor(x) for x in ms]
+    total, _, _ = R.seq2seq_loss(b64, W, num_layers=nl, lm_keep_masks=None if lm_masks is None else {"char": t(lm_masks)},
+                                 dec_keep_masks=None if dec_masks is None else {"char": t(dec_masks)})
+    np.testing.assert_allclose(m.total_loss.item(), total.item(), rtol=2e-5)
+    total.backward()
+    for name in m.variables.names():
+        ref_g = W[name].grad.numpy()
+        err = np.abs(m.variables.grad_of(name).cpu().numpy() - ref_g).max() / max(1e-3, np.abs(ref_g).max())
+        assert err < 2e-3, (name, err)
+
+
+def test_multi_layer_decoder_inference_and_sampling_modes():
+    """The same stacks in the inference graph (argmax feedback every step: ids equal to the float64 oracle's) and under
+    scheduled sampling (runs, feeds drawn tokens, stays finite)."""
+    from e2e_asr_amd import ops
+    dec = dict(hidden_size_dec=32, lm_hidden_size=32, emb_size=24, attention_vec_size=16, num_layers_dec=2)
+    m = _model(enc_update=dict(hidden_size=64), num_layers={"char": 2}, seed=47, training=False, dec_update=dec,
+               max_output={"char": 9})
+    b = _batch(71, 4, 18, 20, 8, 50)
+    out = m.forward(b)["char"].cpu().numpy()
+    w = _f64(m.variables.to_arrays())
+    b64 = dict(b); b64["logmel"] = b["logmel"].astype(np.float64)
+    r = O.seq2seq_forward(b64, w, num_layers={"char": 2}, is_training=False, max_output={"char": 9})["outputs"]["char"]
+    np.testing.assert_allclose(out, r, rtol=0, atol=1e-4)
+    np.testing.assert_array_equal(m.greedy_ids().cpu().numpy(), O.greedy_decode_ids(r, 4))
+    m2 = _model(enc_update=dict(hidden_size=64), num_layers={"char": 2}, seed=47, dec_update=dict(dec, samp_prob=0.5))
+    m2.decoder["char"].coin_rng = np.random.default_rng(3)
+    m2.step(b)
+    ops.check_device_flag(torch.device(DEV))
+    fed = m2.decoder["char"]  # saved was consumed by backward; the step ran end to end
+    assert torch.isfinite(m2.variables.flat).all() and m2.global_step == 1
