@@ -206,3 +206,53 @@ def test_train_loop_lm_interleave_and_resume_of_lm_state(tmp_path, monkeypatch):
     np.testing.assert_allclose(wc, wa, rtol=0, atol=1e-6)           # AdamLM continued at t+1 with the restored moments
     # without the restored step counter the update would differ by the bias-correction ratio (~1.5x at this t)
     assert tr_c.lm_model.lm_global_step == lm_t + 1
+
+
+def test_train_from_tfrecord_buckets_end_to_end(tmp_path):
+    """The whole caller side of the path on real files: TFRecord buckets `train_1k.<k>.*` / `dev*` / `lm*` written in the
+    reference's SequenceExample layout (speech_dataset.py:15-45, lm_dataset.py:12-31) -> Train.get_data_sets / get_lm_set ->
+    smallest-bucket-first schedule with the LM interleaved (train.py:94-131, 261-295) -> HIP train steps -> greedy dev decode,
+    asr_err.txt / best.txt / checkpoints under the TF variable names.  No dataset is injected."""
+    from e2e_asr_amd import checkpoint
+    from e2e_asr_amd.lm_dataset import write_lm_tfrecord
+    from e2e_asr_amd.lm_encoder import LMEncoder
+    from e2e_asr_amd.lm_model import LMModel
+    from e2e_asr_amd.speech_dataset import write_speech_tfrecord
+    from e2e_asr_amd.train import Train
+    rng = np.random.default_rng(11)
+    F, V = 8, 12
+
+    def corpus(n, tmin, tmax):
+        utts = []
+        for i in range(n):
+            T, L = int(rng.integers(tmin, tmax)), int(rng.integers(2, 7))
+            ch = np.concatenate([[1], rng.integers(3, V, L), [2]])
+            utts.append({"utt_id": "u%d_%d" % (tmin, i), "logmel": rng.standard_normal((T, F)).astype(np.float32), "char": ch,
+                         "char_len": len(ch) - 1, "phone": rng.integers(3, 9, L + 1), "phone_len": L})
+        return utts
+    data = tmp_path / "data"; data.mkdir()
+    write_speech_tfrecord(str(data / "train_1k.0.a"), corpus(8, 9, 16))        # bucket 0: short utterances
+    write_speech_tfrecord(str(data / "train_1k.1.a"), corpus(6, 20, 30))       # bucket 1: longer ones
+    write_speech_tfrecord(str(data / "dev.0"), corpus(5, 9, 30))
+    write_lm_tfrecord(str(data / "lm.0"), [np.concatenate([[1], rng.integers(3, V, int(rng.integers(2, 8))), [2]]).tolist()
+                                           for _ in range(10)])
+    p = _params()
+    p.num_layers = {"char": 2}; p.max_output = {"char": 8}; p.decoder_params["char"].vocab_size = V
+    tp = Train.class_params()
+    tp.data_dir = tp.lm_data_dir = str(data)
+    tp.train_dir = str(tmp_path / "run"); tp.best_model_dir = str(tmp_path / "run" / "best")
+    tp.feat_length = F; tp.batch_size = 3; tp.buck_batch_size = [4, 2]; tp.steps_per_checkpoint = 3
+    tp.max_epochs = 100; tp.min_steps = 0; tp.lm_prob = 0.3
+    ep = LMEncoder.class_params()
+    ep.out_prob = 1.0; ep.lm_hidden_size = 64; ep.proj_size = 64; ep.emb_size = 24; ep.vocab_size = V
+    tp.lm_enc_params = ep
+    tp.lm_params = LMModel.class_params(); tp.lm_params.lm_batch_size = 4
+    tr = Train(p, tp, device=DEV)
+    model = tr.train(max_steps=7)
+    assert model.global_step == 7 and tr.lm_model.lm_global_step >= 1
+    errs = [float(l) for l in open(os.path.join(tp.train_dir, "asr_err.txt"))]
+    assert len(errs) == 2 and all(e >= 0.0 for e in errs)
+    ck = checkpoint.load(open(os.path.join(tp.train_dir, "checkpoint.txt")).read().strip())
+    assert int(ck["global_step"]) == 6 and "model/encoder/RNNLayer2/bidirectional_rnn/bw/basic_lstm_cell/kernel" in ck
+    # bucket schedule: the first epoch consumes bucket 0 (8 utterances / 4 = 2 batches) before bucket 1 (3 batches of 2)
+    assert model.epoch >= 1
