@@ -89,7 +89,13 @@ __device__ __forceinline__ bool poll_granule2(const u64* g, uint32_t epoch, floa
     }
 }
 
-template <int H, int HS, int R, bool STAMP = false>
+// MF (bf16 mode of the library, BASELINE config 3): the recurrent product h_{t-1}.K_h runs on the bf16 matrix pipe instead of
+// the VALU -- K_h is rounded to bf16 once per launch into MFMA A-fragments (32 registers), h is rounded to bf16 by the pollers
+// on its way into LDS, accumulation stays fp32: out^T[16 gate columns x batch rows] = K_h^T tile . h^T, one 16-column tile per
+// wave, H/32 v_mfma_f32_16x16x32_bf16 per step (128 cycles) in place of 128 v_fma_f32 per thread plus the DPP reduction
+// (1 000-1 400 of the step's ~3 300 cycles by the in-kernel stamps).  Same operand rounding as the bf16 GEMMs.
+typedef __bf16 rbf16x8 __attribute__((ext_vector_type(8)));
+template <int H, int HS, int R, bool STAMP = false, bool MF = false>
 __global__ __launch_bounds__(16 * HS) void lstm_rec_fwd_kernel(LstmRecArgs a) {
     constexpr int KPT = H / 16;        // K values per lane
     constexpr int CS = KPT + 4;        // padded LDS chunk stride (conflict-free b128 reads)
@@ -99,8 +105,10 @@ __global__ __launch_bounds__(16 * HS) void lstm_rec_fwd_kernel(LstmRecArgs a) {
     constexpr int NCW = (NCELL + 63) / 64 * 64;   // ... rounded up to whole waves: those waves never poll
     static_assert(NCW < NT, "need at least one polling wave");
     constexpr int NPOLL = NT - NCW;    // the other waves poll; the cell waves own every store
-    __shared__ __attribute__((aligned(16))) float hl[R * 16 * CS];
+    __shared__ __attribute__((aligned(16))) float hl[MF ? 4 : R * 16 * CS];
     __shared__ __attribute__((aligned(16))) float sums[HS * R * 4];
+    __shared__ __attribute__((aligned(16))) unsigned short hb[MF ? (R + 1) * H : 8];     // MF: h as bf16, row R = zeros
+    static_assert(!MF || (HS == 32 && H % 32 == 0 && R <= 16), "MF: eight waves x 16 gate columns, batch rows in the N = 16 of the MFMA");
     unsigned long long stamp[6] = {0, 0, 0, 0, 0, 0};
     unsigned long long tlast = STAMP ? __builtin_amdgcn_s_memtime() : 0;
 
@@ -125,8 +133,19 @@ __global__ __launch_bounds__(16 * HS) void lstm_rec_fwd_kernel(LstmRecArgs a) {
     const int H4 = 4 * H;
 
     // recurrent weights -> registers (once)
-    float w[KPT][4];
-    {
+    float w[MF ? 1 : KPT][4];
+    rbf16x8 wa[MF ? H / 32 : 1];          // MF: A fragments of this wave's 16 gate columns (row m = lane & 15 -> unit wave*4 + (m >> 2),
+                                          // gate m & 3), k = 32 ks + 8 (lane >> 4) + jj
+    if (MF) {
+        const float* kh = a.kh[dir];
+        const int m = lane & 15, kg = lane >> 4;
+        const int col = (m & 3) * H + mem * HS + wave * 4 + (m >> 2);
+#pragma unroll
+        for (int ks = 0; ks < H / 32; ++ks)
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) wa[ks][jj] = (__bf16)kh[(size_t)(ks * 32 + kg * 8 + jj) * H4 + col];
+        for (int idx = tid; idx < (R + 1) * H; idx += NT) hb[idx] = 0;
+    } else {
         const float* kh = a.kh[dir];
 #pragma unroll
         for (int i = 0; i < KPT; ++i)
@@ -189,12 +208,30 @@ __global__ __launch_bounds__(16 * HS) void lstm_rec_fwd_kernel(LstmRecArgs a) {
                         if (s > 0) poll_granule2(src + idx, (uint32_t)(a.ep0 + s), v0, v1, a.err);
                         else { v0 = a.h0[(size_t)(r0 + r) * H + k]; v1 = a.h0[(size_t)(r0 + r) * H + k + 1]; }
                     }
-                    *reinterpret_cast<float2*>(hl + (r * 16 + k / KPT) * CS + (k % KPT)) = make_float2(v0, v1);
+                    if (MF) {
+                        union { __bf16 b[2]; uint32_t u; } pk;
+                        pk.b[0] = (__bf16)v0; pk.b[1] = (__bf16)v1;
+                        *reinterpret_cast<uint32_t*>(hb + r * H + k) = pk.u;
+                    } else {
+                        *reinterpret_cast<float2*>(hl + (r * 16 + k / KPT) * CS + (k % KPT)) = make_float2(v0, v1);
+                    }
                 }
             }
             ASR_STAMP(1)
             __syncthreads();
             ASR_STAMP(2)
+            if constexpr (MF) {
+                const int n = lane & 15;
+                const unsigned short* hrow = hb + (n < R ? n : R) * H + 8 * (lane >> 4);
+                f32x4 dacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < H / 32; ++ks) {
+                    const rbf16x8 bfrag = *reinterpret_cast<const rbf16x8*>(hrow + ks * 32);
+                    dacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ks], bfrag, dacc, 0, 0, 0);
+                }
+                // D: col = lane & 15 = batch row, rows (lane >> 4) * 4 + reg = the four gates of unit wave*4 + (lane >> 4)
+                if (n < R) *reinterpret_cast<float4*>(sums + (n * HS + wave * 4 + (lane >> 4)) * 4) = make_float4(dacc[0], dacc[1], dacc[2], dacc[3]);
+            } else {
             // (3) h.K_h for this lane's K chunk, (4) DPP-row reduction over the 16 chunks
 #pragma unroll
             for (int r = 0; r < R; ++r) {
@@ -220,6 +257,7 @@ __global__ __launch_bounds__(16 * HS) void lstm_rec_fwd_kernel(LstmRecArgs a) {
                 for (int r = 0; r < R; ++r)
                     *reinterpret_cast<float4*>(sums + (r * HS + u) * 4) = make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
             }
+            }   // !MF
             ASR_STAMP(3)
             __syncthreads();   // sums complete; hl free for the next step's pollers
             ASR_STAMP(4)
@@ -284,6 +322,7 @@ __global__ __launch_bounds__(16 * HS) void lstm_rec_fwd_kernel(LstmRecArgs a) {
     }
 }
 
+extern "C" int asr_get_gemm_precision(void);
 unsigned long long* g_lstm_dbg = nullptr;      // diagnostic stamp buffer (also read by decoder_chain_bwd.hip)
 extern "C" int asr_debug_set_buffer(void* p) { g_lstm_dbg = static_cast<unsigned long long*>(p); return ASR_OK; }
 
@@ -294,8 +333,12 @@ static int launch_rec(hipStream_t s, const LstmRecArgs& a0) {
     a.dbg = g_lstm_dbg;
     const int NG = (a.B + R - 1) / R;
     const int grid = a.ND * NG * (H / HS);
+    // bf16 mode of the library (asr_set_gemm_precision(1)): recurrent product on the bf16 matrix pipe (H = 256 instantiation)
+    static const bool mf_env = [] { const char* e = getenv("ASR_LSTM_MFMA"); return !(e && e[0] == '0'); }();
     if (H == 256 && R == 2 && g_lstm_dbg && getenv("ASR_LSTM_STAMP"))
         hipLaunchKernelGGL((lstm_rec_fwd_kernel<256, HS, 2, true>), dim3(grid), dim3(16 * HS), 0, s, a);
+    else if (H == 256 && mf_env && asr_get_gemm_precision() == 1)
+        hipLaunchKernelGGL((lstm_rec_fwd_kernel<256, HS, R, false, true>), dim3(grid), dim3(16 * HS), 0, s, a);
     else
     hipLaunchKernelGGL((lstm_rec_fwd_kernel<H, HS, R>), dim3(grid), dim3(16 * HS), 0, s, a);
     return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;

@@ -23,6 +23,7 @@ from .eval_model import Eval
 from .lm_encoder import LMEncoder
 from .lm_dataset import LMDataset
 from .lm_model import LMModel
+from .prefetch import DevicePrefetcher
 from .seq2seq_model import Seq2SeqModel
 from .speech_dataset import SpeechDataset
 
@@ -168,7 +169,8 @@ class Train(BaseParams):
             if lm_model is not None else {}))
         while epoch <= params.max_epochs:
             print("\nEpochs done: %d" % epoch)
-            active = [iter(s) for s in buck_train_sets]                              # train.py:261-266
+            # (each bucket's batches are staged into HBM one batch ahead of the step: the iterator's prefetch of the reference)
+            active = [iter(DevicePrefetcher(s, self.device)) for s in buck_train_sets]       # train.py:261-266
             while active:
                 if max_steps is not None and current_step >= max_steps:
                     return model

@@ -143,3 +143,53 @@ def test_config3_full_size_logits_vs_oracle(prec, tol):
     assert (1e-5 if prec == "bf16" else 0.0) < err < tol, err
     assert abs(m.total_loss.item() - r["total_loss"]) < 1e-2 * abs(r["total_loss"])
     print("config-3 (%s operands) full size: max |logit diff| = %.3g" % (prec, err))
+
+
+def _lstm_ref_bf16(x, lens, k, b, reverse, rb):
+    """float64 BasicLSTM layer (basic_lstm.py:14-23, dynamic_rnn masking) with the operand roundings of the library's bf16 mode:
+    x, K_x, K_h and the h fed back into the recurrent product go through `rb` (bf16 round-to-nearest-even, or identity)."""
+    B, T, IN = x.shape
+    H = k.shape[1] // 4
+    gx = rb(x).reshape(B * T, IN) @ rb(k[:IN]) + b
+    gx = gx.reshape(B, T, 4 * H)
+    kh = rb(k[IN:])
+    out = torch.zeros(B, T, H, dtype=torch.float64)
+    for bq in range(B):
+        c = torch.zeros(H, dtype=torch.float64); h = torch.zeros(H, dtype=torch.float64)
+        n = int(lens[bq])
+        for s in range(n):
+            t = n - 1 - s if reverse else s
+            g = gx[bq, t] + rb(h.float()) @ kh
+            i, j, f, o = g[:H], g[H:2 * H], g[2 * H:3 * H], g[3 * H:]
+            c = c * torch.sigmoid(f + 1.0) + torch.sigmoid(i) * torch.tanh(j)
+            h = torch.sigmoid(o) * torch.tanh(c)
+            out[bq, t] = h
+    return out
+
+
+def test_recurrent_product_on_the_bf16_matrix_pipe():
+    """In the library's bf16 mode the persistent forward recurrence (H = 256) forms h.K_h with v_mfma_f32_16x16x32_bf16: K_h and
+    the fed-back h rounded to bf16, fp32 accumulation, fp32 cell.  Against a float64 layer with the SAME operand roundings the
+    output agrees to fp32-level error; against the unrounded layer it differs by the bf16 operand rounding."""
+    from e2e_asr_amd import ops
+    rng = np.random.default_rng(9)
+    B, T, IN, H = 4, 32, 64, 256        # B*T = 128: the input projection is a whole-tile product, i.e. on the bf16 path too
+    x = torch.from_numpy(rng.standard_normal((B, T, IN)).astype(np.float32))
+    kf = torch.from_numpy(rng.uniform(-0.075, 0.075, (IN + H, 4 * H)).astype(np.float32))
+    kb = torch.from_numpy(rng.uniform(-0.075, 0.075, (IN + H, 4 * H)).astype(np.float32))
+    bz = torch.zeros(4 * H)
+    lens = np.array([32, 20, 1, 31])
+    ops.set_gemm_precision("bf16")
+    got = ops.lstm_layer_fwd(x.to(DEV), torch.from_numpy(lens.astype(np.int32)).to(DEV), kf.to(DEV), bz.to(DEV), kb.to(DEV),
+                             bz.to(DEV)).cpu().double()
+    ops.check_device_flag(torch.device(DEV))
+    rb = lambda v: v.to(torch.bfloat16).double()
+    ident = lambda v: v.double()
+    for d, k, rev in ((0, kf, False), (1, kb, True)):
+        ref_b = _lstm_ref_bf16(x, lens, k, bz.double(), rev, rb)
+        ref_e = _lstm_ref_bf16(x, lens, k, bz.double(), rev, ident)
+        e_b = (got[:, :, d * H:(d + 1) * H] - ref_b).abs().max().item()
+        e_e = (got[:, :, d * H:(d + 1) * H] - ref_e).abs().max().item()
+        assert e_b < 5e-4 and e_e > 4 * e_b, (d, e_b, e_e)      # (a tie flipping under fp32 vs float64 h costs ~2^-9 of one element)
+        for bq in range(B):
+            assert not got[bq, lens[bq]:].any()

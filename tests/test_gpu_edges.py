@@ -156,3 +156,20 @@ def test_persistent_decoder_paths_with_one_and_two_output_steps(monkeypatch, tde
     for n, g0 in res[1][2].items():
         err = np.abs(res[0][2][n] - g0).max() / max(1e-3, np.abs(g0).max())
         assert err < 1e-4, (n, err)
+
+
+def test_device_prefetcher_stages_batches_in_order():
+    """e2e_asr_amd/prefetch.py: batches come out in order, `logmel` already on the device (copied from pinned host memory on a
+    copy stream one batch ahead), every other key untouched; device-resident batches pass through."""
+    from e2e_asr_amd.prefetch import DevicePrefetcher
+    rng = np.random.default_rng(0)
+    src = [{"logmel": rng.standard_normal((3, 5 + i, 4)).astype(np.float32), "logmel_len": np.array([5 + i] * 3), "utt_id": i}
+           for i in range(5)]
+    src[3]["logmel"] = torch.from_numpy(src[3]["logmel"]).to(DEV)
+    got = list(DevicePrefetcher(src, DEV))
+    assert [b["utt_id"] for b in got] == list(range(5))
+    for b, s in zip(got, src):
+        assert b["logmel"].is_cuda and b["logmel_len"] is s["logmel_len"]
+        ref = s["logmel"].cpu().numpy() if torch.is_tensor(s["logmel"]) else s["logmel"]
+        np.testing.assert_array_equal((b["logmel"] * 1.0).cpu().numpy(), ref)
+    assert list(DevicePrefetcher([], DEV)) == []
