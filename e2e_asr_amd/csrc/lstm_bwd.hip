@@ -250,7 +250,12 @@ __global__ __launch_bounds__(512) void lstm_rec_bwd_kernel(LstmBwdArgs a) {
 // forward's), polled by every workgroup of the group with all of a thread's loads in flight.
 // STAMP: diagnostic instantiation (ASR_LSTM_STAMP=1 + asr_debug_set_buffer): s_memtime totals of thread 0 (a cell wave) and
 // thread 511 (a polling wave) of workgroup 0: [poll | barrier 1 | matvec | barrier 2 | cell]; never used for timing claims.
-template <int H, int R, bool STAMP = false>
+// MF (bf16 mode of the library, BASELINE config 3): the contraction dG_{s-1} . K_h^T for the own 32 units runs on the bf16
+// matrix pipe -- K_h rows rounded to bf16 once per launch into MFMA A-fragments, dG rounded to bf16 by the pollers on its way
+// into LDS, fp32 accumulation: 2 unit tiles x 4 position ranges = one (tile, range) per wave, 8 v_mfma_f32_16x16x32_bf16 per
+// step; the four range partials meet in `sums` exactly where the VALU path's four DPP-row partials do.
+typedef __bf16 qbf16x8 __attribute__((ext_vector_type(8)));
+template <int H, int R, bool STAMP = false, bool MF = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(R == 1 ? 4 : 2, 8))) void lstm_rec_bwd_ag_kernel(LstmBwdArgs a) {
     unsigned int stamp[5] = {0, 0, 0, 0, 0};
     unsigned long long tlast = STAMP ? __builtin_amdgcn_s_memtime() : 0;
@@ -272,8 +277,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(R == 1 ? 4 
     constexpr int NPP = (NQUAD + NPOLL - 1) / NPOLL;   // quads per polling thread
     static_assert(NPP >= 1 && NPP <= 3, "quads per polling thread");
     static_assert(NCW + 64 < NT && PC % 4 == 0 && NCELL <= 64, "mapping");
-    __shared__ __attribute__((aligned(16))) float dgl[R * 64 * CSB];
+    __shared__ __attribute__((aligned(16))) float dgl[MF ? 4 : R * 64 * CSB];
     __shared__ __attribute__((aligned(16))) float sums[R * HS * 4];
+    __shared__ __attribute__((aligned(16))) unsigned short dgb[MF ? (R + 1) * N : 8];     // MF: dG as bf16, row R = zeros
+    static_assert(!MF || (H == 256 && R <= 16), "MF: 2 unit tiles x 4 ranges of 256 positions over the 8 waves");
     // operands of the cell, by step parity: {dout*mask, A, Ki, Kj | Kf, Ko, f, -} per cell thread, filled one step ahead by the
     // loader wave -- the cell waves issue NO loads, so they never wait on vmcnt (which would also drain their own
     // publishing / bookkeeping stores: 0.3 us of a 1.8 us step alone, 0.6 us with the weight-gradient GEMMs co-running)
@@ -292,8 +299,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(R == 1 ? 4 
     const int j0 = mem * HS;
 
     // K_h rows of the own units (wave w: units 4w..4w+3) over this lane's PC positions -> registers
-    float w[4][PC];
-    {
+    float w[MF ? 1 : 4][MF ? 1 : PC];
+    qbf16x8 wa[MF ? 8 : 1];      // MF: wave w = (unit tile w & 1, position range w >> 1); row m = lane & 15, k = 32 ks + 8 (lane >> 4) + jj
+    if constexpr (MF) {
+        const float* kh = a.kh[dir];
+        const int unit = j0 + (wave & 1) * 16 + (lane & 15);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const int pos = (wave >> 1) * 256 + ks * 32 + 8 * (lane >> 4) + jj;
+                wa[ks][jj] = (__bf16)kh[(size_t)unit * H4 + (pos & 3) * H + (pos >> 2)];
+            }
+        for (int idx = tid; idx < (R + 1) * N; idx += NT) dgb[idx] = 0;
+    } else {
         const float* kh = a.kh[dir];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -369,7 +388,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(R == 1 ? 4 
                     qp[j] = reinterpret_cast<const u32x4q*>(src) + min(qidx, NQUAD - 1);
                     if (qidx < NQUAD && !need[j]) {
                         const int idx = 4 * qidx, r = idx / N, pos = idx % N;
-                        *reinterpret_cast<float4*>(dgl + (r * 64 + pos / PC) * CSB + (pos % PC)) = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if constexpr (MF) *reinterpret_cast<uint2*>(dgb + r * N + pos) = make_uint2(0u, 0u);
+                        else *reinterpret_cast<float4*>(dgl + (r * 64 + pos / PC) * CSB + (pos % PC)) = make_float4(0.f, 0.f, 0.f, 0.f);
                     }
                 }
                 long long t0w = 0;
@@ -392,9 +412,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(R == 1 ? 4 
                         const uint32_t bits = (x[j].x & 1u) + (x[j].y & 1u) + (x[j].z & 1u) + (x[j].w & 1u);
                         if (bits == 4u * want) {
                             const int idx = 4 * (tid - NCW + NPOLL * j), r = idx / N, pos = idx % N;
-                            *reinterpret_cast<float4*>(dgl + (r * 64 + pos / PC) * CSB + (pos % PC)) =
-                                make_float4(__uint_as_float(x[j].x & ~1u), __uint_as_float(x[j].y & ~1u),
-                                            __uint_as_float(x[j].z & ~1u), __uint_as_float(x[j].w & ~1u));
+                            if constexpr (MF) {
+                                union { __bf16 b[4]; uint2 u; } pk;
+                                pk.b[0] = (__bf16)__uint_as_float(x[j].x & ~1u); pk.b[1] = (__bf16)__uint_as_float(x[j].y & ~1u);
+                                pk.b[2] = (__bf16)__uint_as_float(x[j].z & ~1u); pk.b[3] = (__bf16)__uint_as_float(x[j].w & ~1u);
+                                *reinterpret_cast<uint2*>(dgb + r * N + pos) = pk.u;
+                            } else {
+                                *reinterpret_cast<float4*>(dgl + (r * 64 + pos / PC) * CSB + (pos % PC)) =
+                                    make_float4(__uint_as_float(x[j].x & ~1u), __uint_as_float(x[j].y & ~1u),
+                                                __uint_as_float(x[j].z & ~1u), __uint_as_float(x[j].w & ~1u));
+                            }
                             need[j] = false;
                         } else pending = true;
                     }
@@ -411,6 +438,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(R == 1 ? 4 
             BPTT_STAMP(0)
             __syncthreads();
             BPTT_STAMP(1)
+            if constexpr (MF) {
+                const int n = lane & 15;
+                const unsigned short* drow = dgb + (n < R ? n : R) * N + (wave >> 1) * 256 + 8 * (lane >> 4);
+                f32x4 dacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    const qbf16x8 bfrag = *reinterpret_cast<const qbf16x8*>(drow + ks * 32);
+                    dacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ks], bfrag, dacc, 0, 0, 0);
+                }
+                // D: col = lane & 15 = batch row, rows (lane >> 4) * 4 + reg = units of this wave's tile; partial of range wave >> 1
+                if (n < R) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        sums[(n * HS + (wave & 1) * 16 + (lane >> 4) * 4 + e) * 4 + (wave >> 1)] = dacc[e];
+                }
+            } else {
             // dh_rec for the own units: 4 units x R rows per lane, contraction over this lane's PC positions
             float acc[R][4];
 #pragma unroll
@@ -440,6 +483,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(R == 1 ? 4 
 #pragma unroll
                     for (int i = 0; i < 4; ++i) sums[(r * HS + 4 * wave + i) * 4 + (lane >> 4)] = acc[r][i];
             }
+            }   // !MF
             BPTT_STAMP(2)
             __syncthreads();
             BPTT_STAMP(3)
@@ -502,12 +546,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(R == 1 ? 4 
     }
 }
 
+}  // namespace asr
+extern "C" int asr_get_gemm_precision(void);
+namespace asr {
 template <int H>
 static int launch_bwd_h(hipStream_t s, const LstmBwdArgs& a, int R) {
     const int grid = a.ND * ((a.B + R - 1) / R) * (H / 32);
     static const bool allgather = [] { const char* e = getenv("ASR_BPTT_AG"); return !(e && e[0] == '0'); }();
     if (allgather && R <= 2) {     // more rows per group: too many granule loads per polling thread -> reduce-scatter kernel
-        if (R == 1) hipLaunchKernelGGL((lstm_rec_bwd_ag_kernel<H, 1>), dim3(grid), dim3(512), 0, s, a);
+        static const bool mf_env = [] { const char* e = getenv("ASR_LSTM_MFMA"); return !(e && e[0] == '0'); }();
+        if (H == 256 && mf_env && !a.dbg && asr_get_gemm_precision() == 1) {      // bf16 mode: contraction on the bf16 matrix pipe
+            if (R == 1) hipLaunchKernelGGL((lstm_rec_bwd_ag_kernel<256, 1, false, true>), dim3(grid), dim3(512), 0, s, a);
+            else hipLaunchKernelGGL((lstm_rec_bwd_ag_kernel<256, 2, false, true>), dim3(grid), dim3(512), 0, s, a);
+        }
+        else if (R == 1) hipLaunchKernelGGL((lstm_rec_bwd_ag_kernel<H, 1>), dim3(grid), dim3(512), 0, s, a);
         else if (H == 256 && a.dbg) hipLaunchKernelGGL((lstm_rec_bwd_ag_kernel<256, 2, true>), dim3(grid), dim3(512), 0, s, a);
         else hipLaunchKernelGGL((lstm_rec_bwd_ag_kernel<H, 2>), dim3(grid), dim3(512), 0, s, a);
         return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;

@@ -6,6 +6,7 @@ import torch
 from e2e_asr_amd import ops
 dev = torch.device("cuda:0")
 B, H = 32, 256
+ops.set_gemm_precision(os.environ.get("PREC", "f32"))      # PREC=bf16: recurrent products on the bf16 matrix pipe
 flush = torch.zeros(1 << 28, device=dev)       # 1 GiB of floats
 for T, IN in ((800, 80), (400, 1024), (100, 1024)):
     x = torch.randn(B, T, IN, device=dev) * 0.3

@@ -193,3 +193,32 @@ def test_recurrent_product_on_the_bf16_matrix_pipe():
         assert e_b < 5e-4 and e_e > 4 * e_b, (d, e_b, e_e)      # (a tie flipping under fp32 vs float64 h costs ~2^-9 of one element)
         for bq in range(B):
             assert not got[bq, lens[bq]:].any()
+
+
+def test_bptt_contraction_on_the_bf16_matrix_pipe_close_to_fp32_path():
+    """bf16 mode: the BPTT's contraction dG_{s-1}.K_h^T on v_mfma_f32_16x16x32_bf16 (K_h and the exchanged dG rounded to bf16,
+    fp32 accumulation and fp32 pointwise backward).  Every gradient of the layer stays within the operand rounding of the fp32
+    path: cosine >= 0.999, max error <= 3 % of the gradient's largest entry; both recurrence variants (R = 1, 2 rows per group)."""
+    from e2e_asr_amd import ops
+    rng = np.random.default_rng(19)
+    for B in (4, 40):                      # 40 rows bidirectional = R 2 groups; 4 rows = R 1
+        T, IN, H = 32, 64, 256
+        x = torch.from_numpy(rng.standard_normal((B, T, IN)).astype(np.float32)).to(DEV)
+        k = [torch.from_numpy(rng.uniform(-0.075, 0.075, (IN + H, 4 * H)).astype(np.float32)).to(DEV) for _ in range(2)]
+        bz = torch.zeros(4 * H, device=DEV)
+        lens = rng.integers(1, T + 1, B); lens[0] = T
+        ln = torch.from_numpy(lens.astype(np.int32)).to(DEV)
+        dout = torch.from_numpy(rng.standard_normal((B, T, 2 * H)).astype(np.float32)).to(DEV)
+        res = {}
+        for prec in ("f32", "bf16"):
+            ops.set_gemm_precision(prec)
+            out, gates, act, hp = ops.lstm_layer_fwd(x, ln, k[0], bz, k[1], bz, save=True)
+            dk = [torch.zeros_like(k[0]) for _ in range(2)]; db = [torch.zeros_like(bz) for _ in range(2)]
+            dx = ops.lstm_layer_bwd(x, ln, k[0], k[1], dout, gates, act, hp, dk[0], db[0], dk[1], db[1], need_dx=True,
+                                    kx_cat=getattr(gates, "kx_cat", None))
+            ops.check_device_flag(torch.device(DEV))
+            res[prec] = [dx.cpu().double()] + [t.cpu().double() for t in dk + db]
+        for g32, g16 in zip(res["f32"], res["bf16"]):
+            cos = float((g32 * g16).sum() / (g32.norm() * g16.norm() + 1e-30))
+            err = float((g32 - g16).abs().max() / g32.abs().max())
+            assert cos > 0.999 and err < 3e-2, (B, cos, err)
