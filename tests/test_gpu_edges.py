@@ -164,12 +164,21 @@ def test_device_prefetcher_stages_batches_in_order():
     from e2e_asr_amd.prefetch import DevicePrefetcher
     rng = np.random.default_rng(0)
     src = [{"logmel": rng.standard_normal((3, 5 + i, 4)).astype(np.float32), "logmel_len": np.array([5 + i] * 3), "utt_id": i}
-           for i in range(5)]
+           for i in range(13)]                         # more batches than the ring of pinned buffers holds
     src[3]["logmel"] = torch.from_numpy(src[3]["logmel"]).to(DEV)
     got = list(DevicePrefetcher(src, DEV))
-    assert [b["utt_id"] for b in got] == list(range(5))
+    assert [b["utt_id"] for b in got] == list(range(13))
     for b, s in zip(got, src):
         assert b["logmel"].is_cuda and b["logmel_len"] is s["logmel_len"]
         ref = s["logmel"].cpu().numpy() if torch.is_tensor(s["logmel"]) else s["logmel"]
         np.testing.assert_array_equal((b["logmel"] * 1.0).cpu().numpy(), ref)
     assert list(DevicePrefetcher([], DEV)) == []
+
+    def broken():
+        yield src[0]
+        raise RuntimeError("reader failed")
+    with pytest.raises(RuntimeError, match="reader failed"):      # a failing reader surfaces in the consumer
+        list(DevicePrefetcher(broken(), DEV))
+    it = iter(DevicePrefetcher(iter(src), DEV))                   # an abandoned iterator stops its worker
+    next(it)
+    it.close()
