@@ -100,8 +100,7 @@ class DevicePrefetcher(object):
                     if not self._put(pinned_q, stop, (dict(b), None, None)):
                         return
                     continue
-                src = x if torch.is_tensor(x) else torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
-                src = src.to(torch.float32).contiguous()
+                src = np.ascontiguousarray(x.numpy() if torch.is_tensor(x) else x, dtype=np.float32)
                 pinned = None
                 if made >= self.depth + 3:                   # ring is full: reuse a buffer whose copy has completed
                     while pinned is None and not stop.is_set():
@@ -112,14 +111,15 @@ class DevicePrefetcher(object):
                     if pinned is None:
                         return
                     ev.synchronize()
-                    if pinned.numel() < src.numel():
+                    if pinned.numel() < src.size:
                         pinned = None
                         made -= 1
                 if pinned is None:
-                    pinned = torch.empty(src.numel(), dtype=torch.float32).pin_memory()
+                    pinned = torch.empty(src.size, dtype=torch.float32).pin_memory()
                     made += 1
-                view = pinned[:src.numel()].view(src.shape)
-                view.copy_(src)
+                view = pinned[:src.size].view(src.shape)
+                np.copyto(view.numpy(), src)                 # one plain memcpy with the GIL released (torch's copy_ would fan
+                                                             # out over the intra-op pool and crowd the launching thread)
                 if not self._put(pinned_q, stop, (dict(b), view, pinned)):
                     return
             self._put(pinned_q, stop, _END)
