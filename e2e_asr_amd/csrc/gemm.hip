@@ -213,10 +213,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+// v_cvt_pk_bf16_f32 (round to nearest even), emitted by the compiler so that it tracks the instruction's hazards
 __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
-    uint32_t r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
+    const f32x2_t t = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(t, bf16x2_t));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -237,9 +239,54 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
 //   NP = 1 (BK 32): x ~ bf16(x), one product                                             ("bf16", BASELINE config 3)
 constexpr int BKS = 16;                     // k-tile of the NP = 2, 3 instantiations (and the granularity K must divide by)
 
+// Splitting fp32 into bf16 planes costs VALU issue slots next to the MFMAs (PMC: the matrix pipe is idle most of the time
+// because the waves are issuing this).  The residual x - h of a bf16 rounding is ONE instruction with v_dot2_f32_bf16
+// (h.lo * c.lo + h.hi * c.hi + x with c = (-1, 0) or (0, -1)) instead of shift / mask + subtract, and exact because the
+// residual is representable in fp32 (scratch probe on the GPU: bit-equal to the subtract, random and tiny values).  A DOT
+// result read by another VALU instruction needs 3 wait states that the hardware does NOT interlock, and the compiler cannot
+// see into inline asm (a naive asm version computed garbage; the builtin version was hazard-safe but paid a v_mov per value
+// for the two-address v_dot2c form).  So four pairs (the 8 consecutive k one thread stages per operand) are split together in
+// three asm phases whose instruction order satisfies the wait states by construction: every cvt reads residuals written at
+// least 3 instructions earlier, whatever the compiler schedules between the phases.  7 VALU per pair instead of 11.
+struct Split4 {
+    float r[8];
+    // p0 = bf16(x), r = x - p0
+    __device__ __forceinline__ void phase1(const float* x, uint32_t* p0) {
+        asm("v_cvt_pk_bf16_f32 %0, %12, %13\n\tv_cvt_pk_bf16_f32 %1, %14, %15\n\t"
+            "v_cvt_pk_bf16_f32 %2, %16, %17\n\tv_cvt_pk_bf16_f32 %3, %18, %19\n\t"
+            "v_dot2_f32_bf16 %4, %0, %20, %12\n\tv_dot2_f32_bf16 %5, %0, %21, %13\n\t"
+            "v_dot2_f32_bf16 %6, %1, %20, %14\n\tv_dot2_f32_bf16 %7, %1, %21, %15\n\t"
+            "v_dot2_f32_bf16 %8, %2, %20, %16\n\tv_dot2_f32_bf16 %9, %2, %21, %17\n\t"
+            "v_dot2_f32_bf16 %10, %3, %20, %18\n\tv_dot2_f32_bf16 %11, %3, %21, %19"
+            : "=&v"(p0[0]), "=&v"(p0[1]), "=&v"(p0[2]), "=&v"(p0[3]),
+              "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7])
+            : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]),
+              "s"(0x0000bf80u), "s"(0xbf800000u));
+    }
+    // p1 = bf16(r), r -= p1
+    __device__ __forceinline__ void phase2(uint32_t* p1) {
+        asm("v_cvt_pk_bf16_f32 %0, %4, %5\n\tv_cvt_pk_bf16_f32 %1, %6, %7\n\t"
+            "v_cvt_pk_bf16_f32 %2, %8, %9\n\tv_cvt_pk_bf16_f32 %3, %10, %11\n\t"
+            "v_dot2_f32_bf16 %4, %0, %12, %4\n\tv_dot2_f32_bf16 %5, %0, %13, %5\n\t"
+            "v_dot2_f32_bf16 %6, %1, %12, %6\n\tv_dot2_f32_bf16 %7, %1, %13, %7\n\t"
+            "v_dot2_f32_bf16 %8, %2, %12, %8\n\tv_dot2_f32_bf16 %9, %2, %13, %9\n\t"
+            "v_dot2_f32_bf16 %10, %3, %12, %10\n\tv_dot2_f32_bf16 %11, %3, %13, %11"
+            : "=&v"(p1[0]), "=&v"(p1[1]), "=&v"(p1[2]), "=&v"(p1[3]),
+              "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])
+            : "s"(0x0000bf80u), "s"(0xbf800000u));
+    }
+    // p = bf16(r): the last plane
+    __device__ __forceinline__ void phase3(uint32_t* p2) {
+        asm("v_cvt_pk_bf16_f32 %0, %4, %5\n\tv_cvt_pk_bf16_f32 %1, %6, %7\n\t"
+            "v_cvt_pk_bf16_f32 %2, %8, %9\n\tv_cvt_pk_bf16_f32 %3, %10, %11"
+            : "=&v"(p2[0]), "=&v"(p2[1]), "=&v"(p2[2]), "=&v"(p2[3])
+            : "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]), "v"(r[4]), "v"(r[5]), "v"(r[6]), "v"(r[7]));
+    }
+};
+
 template <int NP>
 __device__ __forceinline__ void split_pk(float x0, float x1, uint32_t* p) {      // p[0..NP-1]: packed bf16 pairs, plane by plane
-    p[0] = cvt_pk_bf16(x0, x1);
+    p[0] = cvt_pk_bf16(x0, x1);                                                  // (prologue tile and NP = 1 only)
     if (NP > 1) {
         float r0 = x0 - __uint_as_float(p[0] << 16);
         float r1 = x1 - __uint_as_float(p[0] & 0xffff0000u);
@@ -261,12 +308,16 @@ struct StagerP {
     float v[NV];
     __device__ __forceinline__ void load(const float* P, int ld, int m0, int k0, int tid, int rows = 128) {
         if (KMAJOR) {
-            const bool ok = (tid & 127) < rows;
-            const float* p = P + (size_t)(k0 + (tid >> 7) * NV) * ld + m0 + (ok ? (tid & 127) : 0);
+            // row base on the scalar unit (k-half is uniform per wave), the lane's column as a 32-bit offset: one
+            // global_load_dword with an SGPR base per k instead of a 64-bit VALU address each
+            const bool ok = rows >= 128 || (tid & 127) < rows;
+            const int kh = __builtin_amdgcn_readfirstlane(tid >> 7);
+            const float* base = P + (size_t)(k0 + kh * NV) * ld + m0;
+            const unsigned col = ok ? (unsigned)(tid & 127) : 0u;
 #pragma unroll
-            for (int j = 0; j < NV; ++j) { const float x = p[(size_t)j * ld]; v[j] = ok ? x : 0.f; }
+            for (int j = 0; j < NV; ++j) { const float x = (base + (size_t)j * ld)[col]; v[j] = ok ? x : 0.f; }
         } else {
-            const bool ok = (tid >> 1) < rows;
+            const bool ok = rows >= 128 || (tid >> 1) < rows;
             const float4* p = reinterpret_cast<const float4*>(P + (size_t)(m0 + (ok ? (tid >> 1) : 0)) * ld + k0 + (tid & 1) * NV);
 #pragma unroll
             for (int j = 0; j < NV / 4; ++j) {
@@ -353,7 +404,13 @@ __global__ __launch_bounds__(256, 2) void gemm_planes_kernel(GemmArgs a) {
         unsigned short* wa = dA + (cur ^ 1) * (NP * PLANE);
         unsigned short* wb = dB + (cur ^ 1) * (NP * PLANE);
         uint32_t pa[NP][NPAIR], pb[NP][NPAIR];
-        constexpr int PPG = NPAIR / 4;              // pairs per operand riding on each of the 4 MFMA groups
+        Split4 qa, qb;                              // NP >= 2 (NPAIR = 4): the phased split, riding on the MFMA groups
+        constexpr int PPG = NPAIR / 4;              // NP = 1: pairs per operand riding on each of the 4 MFMA groups
+        auto put = [&](unsigned short* w, uint32_t (*pk)[NPAIR], int pl) {
+#pragma unroll
+            for (int c = 0; c < NPAIR / 4; ++c)
+                *reinterpret_cast<uint4*>(w + pl * PLANE + c * 8) = make_uint4(pk[pl][4 * c], pk[pl][4 * c + 1], pk[pl][4 * c + 2], pk[pl][4 * c + 3]);
+        };
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
             bf16x8 af[2][NP], bf[2][NP];
@@ -370,33 +427,44 @@ __global__ __launch_bounds__(256, 2) void gemm_planes_kernel(GemmArgs a) {
                 for (int j = 0; j < 2; ++j) {           // smallest terms first
                     const int q = 2 * i + j;
                     if (NP == 3) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
-                    if (stage && ks == 0) {
+                    if (stage && NP == 1 && ks == 0) {
 #pragma unroll
                         for (int e = 0; e < PPG; ++e) { uint32_t t[NP]; split_pk<NP>(va[2 * (q * PPG + e)], va[2 * (q * PPG + e) + 1], t);
 #pragma unroll
                             for (int pl = 0; pl < NP; ++pl) pa[pl][q * PPG + e] = t[pl]; }
                     }
+                    if (stage && NP >= 2) {             // A: one phase per MFMA group; the planes go to LDS as soon as they exist
+                        __builtin_amdgcn_sched_barrier(0);      // (keep the phases BETWEEN the MFMAs: the scheduler would
+                        if (q == 0) qa.phase1(va, pa[0]);       //  otherwise hoist all MFMAs and leave the split for the end)
+                        if (q == 1) { if (NP == 3) qa.phase2(pa[1]); else { qa.phase3(pa[NP - 1]); put(wa, pa, 0); put(wa, pa, 1); } }
+                        if (q == 2 && NP == 3) { qa.phase3(pa[NP - 1]); put(wa, pa, 0); put(wa, pa, 1); }
+                        if (q == 3 && NP == 3) put(wa, pa, 2);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                     if (NP == 3) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
                     if (NP == 3) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
-                    if (stage && ks == KSTEPS - 1) {
+                    if (stage && NP == 1 && ks == KSTEPS - 1) {
 #pragma unroll
                         for (int e = 0; e < PPG; ++e) { uint32_t t[NP]; split_pk<NP>(vb[2 * (q * PPG + e)], vb[2 * (q * PPG + e) + 1], t);
 #pragma unroll
                             for (int pl = 0; pl < NP; ++pl) pb[pl][q * PPG + e] = t[pl]; }
+                    }
+                    if (stage && NP >= 2) {             // B likewise
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (q == 0) qb.phase1(vb, pb[0]);
+                        if (q == 1) { if (NP == 3) qb.phase2(pb[1]); else { qb.phase3(pb[NP - 1]); put(wb, pb, 0); put(wb, pb, 1); } }
+                        if (q == 2 && NP == 3) { qb.phase3(pb[NP - 1]); put(wb, pb, 0); put(wb, pb, 1); }
+                        if (q == 3 && NP == 3) put(wb, pb, 2);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                     if (NP >= 2) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
                     if (NP >= 2) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
                 }
         }
-        if (stage) {
+        if (stage && NP == 1) {
 #pragma unroll
-            for (int pl = 0; pl < NP; ++pl)
-#pragma unroll
-                for (int c = 0; c < NPAIR / 4; ++c) {
-                    *reinterpret_cast<uint4*>(wa + pl * PLANE + c * 8) = make_uint4(pa[pl][4 * c], pa[pl][4 * c + 1], pa[pl][4 * c + 2], pa[pl][4 * c + 3]);
-                    *reinterpret_cast<uint4*>(wb + pl * PLANE + c * 8) = make_uint4(pb[pl][4 * c], pb[pl][4 * c + 1], pb[pl][4 * c + 2], pb[pl][4 * c + 3]);
-                }
+            for (int pl = 0; pl < NP; ++pl) { put(wa, pa, pl); put(wb, pb, pl); }
         }
     };
     int kt = kt0;
