@@ -677,10 +677,12 @@ extern "C" int asr_lstm_layer_bwd(void* stream, const float* x, int B, int T, in
         if ((rc = asr_gemm_f32(stream, 0, 1, M, in_dim, H4, gates + (size_t)d * H4, ndir * H4, d ? kernel_bw : kernel_fw, H4,
                                dx, in_dim, nullptr, d > 0))) return rc;
     }
-    hipStream_t ss = side_stream();
+    // (ASR_WGRAD_INLINE=1, experiment: the weight gradients on the caller's stream, nothing next to the next layer's BPTT)
+    static const bool wg_inline = [] { const char* e = getenv("ASR_WGRAD_INLINE"); return e && e[0] == '1'; }();
+    hipStream_t ss = wg_inline ? s : side_stream();
     void* side = static_cast<void*>(ss);
     hipEvent_t e_dg = next_event();
-    if (hipEventRecord(e_dg, s) != hipSuccess || hipStreamWaitEvent(ss, e_dg, 0) != hipSuccess) return ASR_ELAUNCH;
+    if (!wg_inline && (hipEventRecord(e_dg, s) != hipSuccess || hipStreamWaitEvent(ss, e_dg, 0) != hipSuccess)) return ASR_ELAUNCH;
     // both directions of a product as ONE batched launch when the two gradient buffers sit a vector-aligned stride apart
     // (they do in the flat gradient buffer): X is then streamed once for the two dK_x instead of twice, and a launch has
     // twice the tiles (less split-K, fewer atomics)
