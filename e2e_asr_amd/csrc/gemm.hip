@@ -306,6 +306,23 @@ template <bool KMAJOR, int BKT>
 struct StagerP {
     static constexpr int NV = BKT / 2;
     float v[NV];
+    static constexpr int PIECES = KMAJOR ? NV : NV / 4;          // memory instructions per k-tile
+    // one memory instruction of load(): issued between the MFMAs of the tile before (see the kernel's pipeline comment)
+    __device__ __forceinline__ void load_piece(int j, const float* P, int ld, int m0, int k0, int tid, int rows = 128) {
+        if (KMAJOR) {
+            const bool ok = rows >= 128 || (tid & 127) < rows;
+            const int kh = __builtin_amdgcn_readfirstlane(tid >> 7);
+            const float* base = P + (size_t)(k0 + kh * NV) * ld + m0;
+            const unsigned col = ok ? (unsigned)(tid & 127) : 0u;
+            const float x = (base + (size_t)j * ld)[col];
+            v[j] = ok ? x : 0.f;
+        } else {
+            const bool ok = rows >= 128 || (tid >> 1) < rows;
+            const float4* p = reinterpret_cast<const float4*>(P + (size_t)(m0 + (ok ? (tid >> 1) : 0)) * ld + k0 + (tid & 1) * NV);
+            const float4 x = p[j];
+            v[4 * j] = ok ? x.x : 0.f; v[4 * j + 1] = ok ? x.y : 0.f; v[4 * j + 2] = ok ? x.z : 0.f; v[4 * j + 3] = ok ? x.w : 0.f;
+        }
+    }
     __device__ __forceinline__ void load(const float* P, int ld, int m0, int k0, int tid, int rows = 128) {
         if (KMAJOR) {
             // row base on the scalar unit (k-half is uniform per wave), the lane's column as a 32-bit offset: one
@@ -398,7 +415,26 @@ __global__ __launch_bounds__(256, 2) void gemm_planes_kernel(GemmArgs a) {
     stage_all(dB, sb0.v);
     __syncthreads();
     // one iteration: multiply buffer `cur`; if `stage`, split registers (va, vb) into buffer cur^1 along the way
-    auto step = [&](int cur, const float* va, const float* vb, bool stage) {
+    // The global loads of the tile after next are issued a few memory instructions per MFMA gap, from the second MFMA of this
+    // tile on, instead of in one block between the barrier and the fragment reads (stamps: that block took 260-720 cycles
+    // per k-tile, during which this wave had no MFMA in flight; dKx TN 165 -> 142 us, 4096^3 822 -> 796 us).
+    auto step = [&](int cur, const float* va, const float* vb, bool stage, auto& la, auto& lb, int kload, bool doload) {
+        int slot = 0;
+        auto ld = [&]() {                               // called after every MFMA; slot is a compile-time value after unrolling
+            constexpr int PA = StagerP<TA, BKT>::PIECES, PB = StagerP<!TB, BKT>::PIECES;
+            constexpr int NSLOT = KSTEPS * 4 * (NP == 3 ? 6 : NP == 2 ? 3 : 1);
+            constexpr int PPS = (PA + PB + NSLOT - 2) / (NSLOT - 1);            // pieces per gap
+            if (doload && slot >= 1) {
+#pragma unroll
+                for (int e = 0; e < PPS; ++e) {
+                    const int pc = (slot - 1) * PPS + e;
+                    if (pc < PA) la.load_piece(pc, a.A, a.lda, m0, kload * BKT, tid, arows);
+                    else if (pc < PA + PB) lb.load_piece(pc - PA, a.B, a.ldb, n0, kload * BKT, tid);
+                }
+                if ((slot - 1) * PPS < PA + PB) __builtin_amdgcn_sched_barrier(0);
+            }
+            ++slot;
+        };
         const unsigned short* ap = apb + cur * (NP * PLANE);
         const unsigned short* bp = bpb + cur * (NP * PLANE);
         unsigned short* wa = dA + (cur ^ 1) * (NP * PLANE);
@@ -426,7 +462,7 @@ __global__ __launch_bounds__(256, 2) void gemm_planes_kernel(GemmArgs a) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {           // smallest terms first
                     const int q = 2 * i + j;
-                    if (NP == 3) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
+                    if (NP == 3) { acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0); ld(); }
                     if (stage && NP == 1 && ks == 0) {
 #pragma unroll
                         for (int e = 0; e < PPG; ++e) { uint32_t t[NP]; split_pk<NP>(va[2 * (q * PPG + e)], va[2 * (q * PPG + e) + 1], t);
@@ -441,8 +477,8 @@ __global__ __launch_bounds__(256, 2) void gemm_planes_kernel(GemmArgs a) {
                         if (q == 3 && NP == 3) put(wa, pa, 2);
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                    if (NP == 3) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
-                    if (NP == 3) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
+                    if (NP == 3) { acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0); ld(); }
+                    if (NP == 3) { acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0); ld(); }
                     if (stage && NP == 1 && ks == KSTEPS - 1) {
 #pragma unroll
                         for (int e = 0; e < PPG; ++e) { uint32_t t[NP]; split_pk<NP>(vb[2 * (q * PPG + e)], vb[2 * (q * PPG + e) + 1], t);
@@ -457,9 +493,9 @@ __global__ __launch_bounds__(256, 2) void gemm_planes_kernel(GemmArgs a) {
                         if (q == 3 && NP == 3) put(wb, pb, 2);
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                    if (NP >= 2) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
-                    if (NP >= 2) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+                    if (NP >= 2) { acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0); ld(); }
+                    if (NP >= 2) { acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0); ld(); }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0); ld();
                 }
         }
         if (stage && NP == 1) {
@@ -470,22 +506,19 @@ __global__ __launch_bounds__(256, 2) void gemm_planes_kernel(GemmArgs a) {
     int kt = kt0;
     for (; kt + 2 < nk; kt += 2) {
         // even tile: multiply buffer 0, stage set 1 (tile kt+1) into buffer 1, load tile kt+2 into set 0
-        sa0.load(a.A, a.lda, m0, (kt + 2) * BKT, tid, arows);
-        sb0.load(a.B, a.ldb, n0, (kt + 2) * BKT, tid);
-        step(0, sa1.v, sb1.v, true);
+        step(0, sa1.v, sb1.v, true, sa0, sb0, kt + 2, true);
         __syncthreads();
         // odd tile: multiply buffer 1, stage set 0 (tile kt+2) into buffer 0, load tile kt+3 into set 1
-        if (kt + 3 < nk) { sa1.load(a.A, a.lda, m0, (kt + 3) * BKT, tid, arows); sb1.load(a.B, a.ldb, n0, (kt + 3) * BKT, tid); }
-        step(1, sa0.v, sb0.v, true);
+        step(1, sa0.v, sb0.v, true, sa1, sb1, min(kt + 3, nk - 1), true);    // (past the end: a valid tile again, unused -- no branch per load)
         __syncthreads();
     }
     // tail: one or two tiles left; buffer 0 holds tile kt, set 1 (if any) tile kt+1
     if (kt + 1 < nk) {
-        step(0, sa1.v, sb1.v, true);
+        step(0, sa1.v, sb1.v, true, sa0, sb0, 0, false);
         __syncthreads();
-        step(1, sa0.v, sb0.v, false);
+        step(1, sa0.v, sb0.v, false, sa1, sb1, 0, false);
     } else {
-        step(0, sa0.v, sb0.v, false);
+        step(0, sa0.v, sb0.v, false, sa1, sb1, 0, false);
     }
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
