@@ -314,15 +314,15 @@ struct StagerP {
             const int kh = __builtin_amdgcn_readfirstlane(tid >> 7);
             const float* base = P + (size_t)(k0 + kh * NV) * ld + m0;
             const unsigned col = ok ? (unsigned)(tid & 127) : 0u;
-            const float x = (base + (size_t)j * ld)[col];
-            v[j] = ok ? x : 0.f;
-        } else {
+            v[j] = (base + (size_t)j * ld)[col];         // rows past `rows`: a valid address, zeroed by the consumer (row_ok):
+        } else {                                         // a select here would wait for the load in the middle of the MFMAs
             const bool ok = rows >= 128 || (tid >> 1) < rows;
             const float4* p = reinterpret_cast<const float4*>(P + (size_t)(m0 + (ok ? (tid >> 1) : 0)) * ld + k0 + (tid & 1) * NV);
             const float4 x = p[j];
-            v[4 * j] = ok ? x.x : 0.f; v[4 * j + 1] = ok ? x.y : 0.f; v[4 * j + 2] = ok ? x.z : 0.f; v[4 * j + 3] = ok ? x.w : 0.f;
+            v[4 * j] = x.x; v[4 * j + 1] = x.y; v[4 * j + 2] = x.z; v[4 * j + 3] = x.w;
         }
     }
+    static __device__ __forceinline__ bool row_ok(int tid, int rows) { return rows >= 128 || (KMAJOR ? (tid & 127) : (tid >> 1)) < rows; }
     __device__ __forceinline__ void load(const float* P, int ld, int m0, int k0, int tid, int rows = 128) {
         if (KMAJOR) {
             // row base on the scalar unit (k-half is uniform per wave), the lane's column as a 32-bit offset: one
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(256, 2) void gemm_planes_kernel(GemmArgs a) {
     // The global loads of the tile after next are issued a few memory instructions per MFMA gap, from the second MFMA of this
     // tile on, instead of in one block between the barrier and the fragment reads (stamps: that block took 260-720 cycles
     // per k-tile, during which this wave had no MFMA in flight; dKx TN 165 -> 142 us, 4096^3 822 -> 796 us).
-    auto step = [&](int cur, const float* va, const float* vb, bool stage, auto& la, auto& lb, int kload, bool doload) {
+    auto step = [&](int cur, const float* va_, const float* vb, bool stage, auto& la, auto& lb, int kload, bool doload) {
         int slot = 0;
         auto ld = [&]() {                               // called after every MFMA; slot is a compile-time value after unrolling
             constexpr int PA = StagerP<TA, BKT>::PIECES, PB = StagerP<!TB, BKT>::PIECES;
@@ -440,6 +440,13 @@ __global__ __launch_bounds__(256, 2) void gemm_planes_kernel(GemmArgs a) {
         unsigned short* wa = dA + (cur ^ 1) * (NP * PLANE);
         unsigned short* wb = dB + (cur ^ 1) * (NP * PLANE);
         uint32_t pa[NP][NPAIR], pb[NP][NPAIR];
+        float xa[NV];                               // PARTM: rows past M stage zeros (the loads above fetched a valid row)
+        if (PARTM) {
+            const bool okA = StagerP<TA, BKT>::row_ok(tid, arows);
+#pragma unroll
+            for (int e = 0; e < NV; ++e) xa[e] = okA ? va_[e] : 0.f;
+        }
+        const float* va = PARTM ? xa : va_;
         Split4 qa, qb;                              // NP >= 2 (NPAIR = 4): the phased split, riding on the MFMA groups
         constexpr int PPG = NPAIR / 4;              // NP = 1: pairs per operand riding on each of the 4 MFMA groups
         auto put = [&](unsigned short* w, uint32_t (*pk)[NPAIR], int pl) {
