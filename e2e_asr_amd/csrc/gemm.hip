@@ -609,7 +609,12 @@ extern "C" int asr_gemm_f32_batched(void* stream, int transA, int transB, int M,
     // (batched only when accumulating: the split needs a pre-zeroed or live C, and only batch 1 is zeroed here)
     const int tiles_all = nwg * batch;
     if (transA && (batch == 1 || accumulate) && tiles_all < 192 && nk >= 64) {     // weight-gradient form only: forward products stay bit-reproducible
-        splits = std::min((768 + tiles_all - 1) / tiles_all, nk / 16);
+        // as many workgroups as the chip holds at once (two per CU = 512): measured stand-alone on the batched weight-gradient
+        // shapes (scripts/exp_splitk2.py), 16 x 32 slices beat 16 x 48 by 15 % and 32 x 16 beat 32 x 24 by 6 %; never fewer
+        // slices than the old 1.5-round rule gave up to 8 (128 tiles stay at 8 slices pinned to the 8 XCDs)
+        static const int wg_target = [] { const char* e = getenv("ASR_GEMM_WGTARGET"); return e ? atoi(e) : 512; }();
+        const int old_rule = (768 + tiles_all - 1) / tiles_all;
+        splits = std::min(std::max((wg_target + tiles_all - 1) / tiles_all, std::min(8, old_rule)), nk / 16);
         if (const char* e = getenv("ASR_GEMM_SPLITK")) splits = std::max(1, atoi(e));
     }
     g.splits = splits;
