@@ -545,6 +545,131 @@ __global__ __launch_bounds__(256, 2) void gemm_planes_kernel(GemmArgs a) {
         }
 }
 
+// ---------------------------------------------------------------------------------------------
+// split3 on 64x64 block tiles: the decoder's products (M = T*B = 3840 rows, N = 128..768, K = 256..1024; 60 tiles of 128x128
+// would leave three quarters of the chip idle, so they ran on the 64x64 instantiation of the fp32-input MFMA kernel: 8
+// dependent v_mfma_f32_32x32x2_f32 = 512 cycles per k-tile and wave).  Same arithmetic as gemm_planes_kernel<..., 3, 16> (six
+// bf16 products of exact three-way splits, fp32 accumulate): 6 x 32 cycles per k-tile and wave.  Four waves x 32x32; waves 0-1
+// stage the A tile, waves 2-3 the B tile (one Split4 per thread and k-tile); K need not be a multiple of 16 (V = 1000 is the
+// contraction length of dLogits . W_out^T): the last k-tile stages zeros past K.  Whole 64x64 tiles only.
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256, 4) void gemm_split3s_kernel(GemmArgs a) {
+    constexpr int BT = 64, BKT = 16, NV = 8;
+    constexpr int PITCH = BKT + 8;                  // 48-byte rows (conflict-free ds_read_b128 fragments, as the 128x128 kernel)
+    constexpr int PLANE = BT * PITCH;
+    constexpr int BUF = 3 * PLANE;
+    __shared__ __attribute__((aligned(16))) unsigned short As[2 * BUF];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[2 * BUF];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1;
+    a.A += (size_t)blockIdx.z * a.sA; a.B += (size_t)blockIdx.z * a.sB; a.C += (size_t)blockIdx.z * a.sC;
+    const int ntn = (a.N + BT - 1) / BT, ntm = (a.M + BT - 1) / BT;
+    const int nwg = ntn * ntm;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+    }
+    const int m0 = (bid / ntn) * BT, n0 = (bid % ntn) * BT;
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    const int nk = (a.K + BKT - 1) / BKT;
+    // this thread's share of the staging: waves 0-1 -> A, waves 2-3 -> B (uniform per wave); t = index among the 128 stagers
+    const bool isB = __builtin_amdgcn_readfirstlane(wid >> 1) != 0;
+    const int t = tid & 127;
+    const bool kmaj = isB ? !TB : TA;               // operand stored with the tile's row index contiguous
+    const int row = kmaj ? (t & 63) : (t >> 1), kh = kmaj ? (t >> 6) : (t & 1);
+    const float* const P = isB ? a.B : a.A;
+    const int ld = isB ? a.ldb : a.lda;
+    const int rc = min((isB ? n0 : m0) + row, (isB ? a.N : a.M) - 1);     // rows / columns past the matrix: a valid address; the
+                                                                          // epilogue never stores what they produce
+    unsigned short* const dW = (isB ? Bs : As) + row * PITCH + kh * NV;
+    const unsigned short* const apb = As + (wr * 32 + (lane & 31)) * PITCH + 8 * (lane >> 5);
+    const unsigned short* const bpb = Bs + (wc * 32 + (lane & 31)) * PITCH + 8 * (lane >> 5);
+    float x[NV];
+    // the 8 values (row, k0 + kh*8 .. +7) of this thread; k >= K reads as zero (last tile only: `tail`)
+    auto load_piece = [&](int j, int k0, bool tail) {          // j: 0..7 (row-contiguous operand) or 0..1 (k-contiguous)
+        if (kmaj) {
+            const int k = k0 + kh * NV + j;
+            const bool ok = !tail || k < a.K;
+            const float v = (P + (size_t)(ok ? k : 0) * ld)[rc];
+            x[j] = ok ? v : 0.f;
+        } else {
+            const int k = k0 + kh * NV + 4 * j;
+            const bool ok = !tail || k < a.K;                  // (K % 4 == 0 is a condition of this kernel)
+            const float4 v = *reinterpret_cast<const float4*>(P + (size_t)rc * ld + (ok ? k : 0));
+            x[4 * j] = ok ? v.x : 0.f; x[4 * j + 1] = ok ? v.y : 0.f; x[4 * j + 2] = ok ? v.z : 0.f; x[4 * j + 3] = ok ? v.w : 0.f;
+        }
+    };
+    auto load_all = [&](int k0, bool tail) {
+        if (kmaj) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) load_piece(j, k0, tail);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) load_piece(j, k0, tail);
+        }
+    };
+    auto put3 = [&](unsigned short* w, uint32_t (*pk)[4]) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<uint4*>(w + pl * PLANE) = make_uint4(pk[pl][0], pk[pl][1], pk[pl][2], pk[pl][3]);
+    };
+    {   // prologue: tile 0 -> buffer 0; tile 1 in flight in x
+        load_all(0, nk == 1);
+        uint32_t pk[3][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { uint32_t tt[3]; split_pk<3>(x[2 * j], x[2 * j + 1], tt); pk[0][j] = tt[0]; pk[1][j] = tt[1]; pk[2][j] = tt[2]; }
+        put3(dW, pk);
+        if (nk > 1) load_all(BKT, nk == 2);
+    }
+    __syncthreads();
+    // one k-tile: six MFMAs out of buffer cur; the split of tile kt+1 (registers x) rides in their gaps and lands in buffer
+    // cur^1; x is then refilled with tile kt+2
+    auto step = [&](int cur, bool stage, bool reload, int kload, bool tail) {
+        const unsigned short* ap = apb + cur * BUF;
+        const unsigned short* bp = bpb + cur * BUF;
+        unsigned short* w = dW + (cur ^ 1) * BUF;
+        bf16x8 af[3], bf[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) { af[pl] = *reinterpret_cast<const bf16x8*>(ap + pl * PLANE); bf[pl] = *reinterpret_cast<const bf16x8*>(bp + pl * PLANE); }
+        Split4 sp;
+        uint32_t pk[3][4];
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf[0], acc, 0, 0, 0);
+        if (stage) { __builtin_amdgcn_sched_barrier(0); sp.phase1(x, pk[0]); __builtin_amdgcn_sched_barrier(0); }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[2], acc, 0, 0, 0);
+        if (stage) { __builtin_amdgcn_sched_barrier(0); sp.phase2(pk[1]); __builtin_amdgcn_sched_barrier(0); }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[1], acc, 0, 0, 0);
+        if (stage) { __builtin_amdgcn_sched_barrier(0); sp.phase3(pk[2]); put3(w, pk); __builtin_amdgcn_sched_barrier(0); }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[0], acc, 0, 0, 0);
+        if (reload) { __builtin_amdgcn_sched_barrier(0); load_all(kload * BKT, tail); __builtin_amdgcn_sched_barrier(0); }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[0], acc, 0, 0, 0);
+    };
+    int kt = 0;
+    for (; kt + 3 < nk; ++kt) {                       // steady state: tile kt+2 is not the last one
+        step(kt & 1, true, true, kt + 2, false);
+        __syncthreads();
+    }
+    for (; kt + 1 < nk; ++kt) {                       // the last refill may be the partial tile (or there is none)
+        step(kt & 1, true, kt + 2 < nk, kt + 2, true);
+        __syncthreads();
+    }
+    step(kt & 1, false, false, 0, false);
+    const int n = n0 + wc * 32 + (lane & 31);
+    if (n >= a.N) return;
+    const float bv = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m >= a.M) continue;
+        float* cp = a.C + (size_t)m * a.ldc + n;
+        float v = acc[r] + bv;
+        if (a.accumulate) v += *cp;
+        *cp = v;
+    }
+}
+
 template <int NP, int BKT>
 static void launch_planes(dim3 grid, hipStream_t s, const GemmArgs& g, int transA, int transB, bool partm) {
     if (transA && partm) hipLaunchKernelGGL((gemm_planes_kernel<true, false, true, NP, BKT>), grid, dim3(256), 0, s, g);
@@ -646,6 +771,20 @@ extern "C" int asr_gemm_f32_batched(void* stream, int transA, int transB, int M,
     }
     // few output tiles and no split-K: 64x64 block tiles fill the chip 4x better (still reproducible)
     static const int small_thr = [] { const char* e = getenv("ASR_GEMM_SMALL"); return e ? atoi(e) : 160; }();
+    static const int s3s = [] { const char* e = getenv("ASR_GEMM_S3S"); return e ? atoi(e) : 1; }();
+    {
+        // split3 on 64x64 tiles (fp32-accurate, bf16 pipe): few 128x128 tiles, or edges the 128x128 kernel does not take
+        // (V = 1000 logit columns, (T-1)*B rows)
+        const int nwg64 = ((M + 63) / 64) * ((N + 63) / 64);
+        if (np == 3 && s3s && splits == 1 && ((long long)nwg * batch < small_thr || M % 128 || N % 128) && K % 4 == 0 && K >= 16 &&
+            g.vecA && g.vecB && !(transA && transB) && nwg64 >= 8) {
+            if (transA)       hipLaunchKernelGGL((gemm_split3s_kernel<true, false>), dim3(nwg64, 1, batch), dim3(256), 0, s, g);
+            else if (transB)  hipLaunchKernelGGL((gemm_split3s_kernel<false, true>), dim3(nwg64, 1, batch), dim3(256), 0, s, g);
+            else              hipLaunchKernelGGL((gemm_split3s_kernel<false, false>), dim3(nwg64, 1, batch), dim3(256), 0, s, g);
+            ASR_CHECK_LAUNCH();
+            return ASR_OK;
+        }
+    }
     if (splits == 1 && (long long)nwg * batch < small_thr) {
         nwg = ((M + 63) / 64) * ((N + 63) / 64);
         if (transA && transB)       hipLaunchKernelGGL((gemm_f32_kernel<true, true, 64>), dim3(nwg, 1, batch), dim3(256), 0, s, g);

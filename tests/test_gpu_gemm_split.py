@@ -23,7 +23,12 @@ def _run(a, b, ta, tb, split, bias=None, accumulate=False, c0=None):
 
 @pytest.mark.parametrize("form,M,N,K", [("NN", 1024, 1024, 1024), ("NN", 12800, 1024, 80 * 16), ("NT", 2048, 1024, 2048),
                                         ("TN", 1024, 1024, 12800), ("TN", 256, 1024, 25600),
-                                        ("TN", 80, 1024, 25600), ("TN", 200, 256, 12800)])
+                                        ("TN", 80, 1024, 25600), ("TN", 200, 256, 12800),
+                                        # the 64x64-tile kernel (gemm_split3s_kernel): the decoder's shapes, K = V = 1000 (not a
+                                        # multiple of the 16-wide k-tile), one- and two-tile contractions
+                                        ("NN", 3840, 256, 512), ("NT", 3840, 256, 1000), ("NN", 768, 1024, 256),
+                                        ("TN", 512, 640, 200), ("NT", 256, 256, 24), ("NN", 256, 320, 16),
+                                        ("NN", 3808, 256, 512), ("NN", 3840, 1000, 256), ("NT", 250, 1000, 36), ("TN", 100, 1000, 256)])
 @pytest.mark.parametrize("dist", ["normal", "wide"])
 def test_split_gemm_error_is_fp32_class(form, M, N, K, dist):
     rng = np.random.default_rng(hash((form, M, N, K, dist)) & 0xFFFF)
@@ -78,6 +83,10 @@ def test_split_is_the_default_and_small_products_stay_on_the_exact_kernel():
     from e2e_asr_amd import ops
     assert ops.get_gemm_split() is True
     rng = np.random.default_rng(3)
-    a = torch.from_numpy(rng.standard_normal((200, 96)).astype(np.float32)).to(DEV)      # partial tiles: exact kernel either way
-    b = torch.from_numpy(rng.standard_normal((96, 72)).astype(np.float32)).to(DEV)
+    # K not a multiple of 4 (no 16-byte rows) / fewer than 8 tiles: the fp32-input MFMA kernel either way
+    a = torch.from_numpy(rng.standard_normal((200, 98)).astype(np.float32)).to(DEV)
+    b = torch.from_numpy(rng.standard_normal((98, 72)).astype(np.float32)).to(DEV)
+    assert torch.equal(_run(a, b, False, False, True), _run(a, b, False, False, False))
+    a = torch.from_numpy(rng.standard_normal((100, 96)).astype(np.float32)).to(DEV)
+    b = torch.from_numpy(rng.standard_normal((96, 60)).astype(np.float32)).to(DEV)
     assert torch.equal(_run(a, b, False, False, True), _run(a, b, False, False, False))
