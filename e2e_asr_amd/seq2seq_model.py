@@ -29,6 +29,20 @@ def create_shifted_targets(dec_input, seq_len):
     return targets, w.reshape(-1)
 
 
+class LazyTargetWeights(dict):
+    """{task: flattened time-major length mask} (tf_utils.py:4-12), built on first access: the loss kernels mask by the
+    lengths themselves, so on the hot path nobody reads the mask and its four small launches stay off the step."""
+
+    def __init__(self, make):
+        super(LazyTargetWeights, self).__init__()
+        self._make = make
+
+    def __missing__(self, task):
+        v = self._make(task)
+        self[task] = v
+        return v
+
+
 class Seq2SeqModel(BaseParams):
     """Attention-enabled encoder-decoder with optional auxiliary-task decoders."""
 
@@ -125,10 +139,9 @@ class Seq2SeqModel(BaseParams):
         if batch is None:
             batch = self.data_iter.get_next()
         self.encoder_inputs, self.decoder_inputs, self.seq_len, self.seq_len_target = self.get_batch(batch)
-        self.targets, self.target_weights = {}, {}
-        for task in params.tasks:
-            self.targets[task], self.target_weights[task] = create_shifted_targets(
-                self.decoder_inputs[task], self.seq_len_target[task])
+        self.targets = {task: self.decoder_inputs[task][1:] for task in params.tasks}       # tf_utils.py:4-12 (a view)
+        src, lens = dict(self.decoder_inputs), dict(self.seq_len_target)
+        self.target_weights = LazyTargetWeights(lambda task: create_shifted_targets(src[task], lens[task])[1])
         self.encoder.dropout_seed = (self.global_step ^ self.rank_seed) & 0x7FFFFFFF
         self.encoder_hidden_states, self.time_major_states, self.seq_len_encs = self.encoder(
             self.encoder_inputs, self.seq_len, {t: params.num_layers[t] for t in params.tasks})
