@@ -94,7 +94,7 @@ __device__ __forceinline__ float wave_allreduce_max(float v) {
 // then stays in that XCD's L2, where the peers' L1-bypassing sc1 loads find it (measured -12 % per
 // recurrent step), instead of being written through to the fabric.  Any other placement keeps sc1.
 __device__ __forceinline__ bool group_shares_xcd(u64* slots, int G, int mem, int tid, int* err, int* lds_flag = nullptr,
-                                                 uint32_t epoch = 0) {
+                                                 uint32_t epoch = 0, int kid = 0) {
     // epoch: launches that share zeroed-once slots (segments of one decoder call) use distinct tags
     const u64 tagv = 0xA5A50000ull + (epoch & 0xFFFFu);
     __shared__ int s_same_static;
@@ -109,7 +109,7 @@ __device__ __forceinline__ bool group_shares_xcd(u64* slots, int G, int mem, int
             for (;;) {
                 const u64 x = __hip_atomic_load(slots + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if ((x >> 32) == tagv) { same = ((uint32_t)x == xcc); break; }
-                if (wall_clock64() - t0 > 200000000LL) { *err = 1; same = false; break; }
+                if (wall_clock64() - t0 > 200000000LL) { *err = 31 + 100 * kid; same = false; break; }
             }
         }
         s_same = same ? 1 : 0;

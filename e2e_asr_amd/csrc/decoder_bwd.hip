@@ -350,6 +350,7 @@ extern "C" int asr_attn_decoder_bwd(void* stream, const asr_dec_weights* w, cons
     prof_begin(ASR_PROF_DECODER_BWD, s);
     hipStream_t ss = side_stream();
     void* side = static_cast<void*>(ss);
+    hipEvent_t e_lm_bptt = nullptr;
     hipEvent_t e_fork = next_event();
     if (hipEventRecord(e_fork, s) != hipSuccess || hipStreamWaitEvent(ss, e_fork, 0) != hipSuccess) return ASR_ELAUNCH;
     // ---- hoisted data gradients: dP = dLogits.W_out^T ; dQC = dP.W_ap^T
@@ -433,6 +434,8 @@ extern "C" int asr_attn_decoder_bwd(void* stream, const asr_dec_weights* w, cons
         }
         if ((rc = asr_lstm_rec_bwd_tm(ss, ws->lm_gates, ws->lm_act, dlo, ld_dlo, w->lm_kernel + (size_t)E * 4 * lmH, ws->lm_len,
                                       bw->lm_hx, ws->err, B, T, lmH, keep_lm, seed))) return rc;
+        e_lm_bptt = next_event();
+        if (hipEventRecord(e_lm_bptt, ss) != hipSuccess) return ASR_ELAUNCH;
         if ((rc = asr_gemm_f32(side, 0, 1, TB, E, 4 * lmH, ws->lm_gates, 4 * lmH, w->lm_kernel, 4 * lmH, bw->dEH, ldEH, nullptr, 0)))
             return rc;
     }
@@ -508,6 +511,13 @@ extern "C" int asr_attn_decoder_bwd(void* stream, const asr_dec_weights* w, cons
         if (hipEventRecord(e_done, ss) != hipSuccess) return ASR_ELAUNCH;
         set_pending_join(e_done);
     }
+    // Never two persistent kernels in flight from two streams: whatever the caller launches next (the encoder's BPTT) waits for
+    // the LM chain's BPTT on the side stream.  Each needs all of its workgroups resident, and with workgroup groups spread
+    // over the XCDs (a group count that is not a multiple of 8, e.g. 30 utterances) the two starved each other's dispatch:
+    // 1 step in ~100 ended in the 2-second exchange time-out under scripts/soak_fixed.py 30 83 27.  The overlap bought
+    // nothing (both are latency-bound on the same CUs: 331 us together, ~150 + ~150 apart).
+    static const bool lm_overlap = [] { const char* e = getenv("ASR_LM_BPTT_OVERLAP"); return e && e[0] == '1'; }();   // (measurement only: UNSAFE)
+    if (e_lm_bptt && !lm_overlap && hipStreamWaitEvent(s, e_lm_bptt, 0) != hipSuccess) return ASR_ELAUNCH;
     prof_end(ASR_PROF_DECODER_BWD, s);
     return ASR_OK;
 }

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(512) void decoder_chain_fwd_kernel(ChainArgs a) {
     constexpr int NS = R * KS, NQ = R * H, NY = R * A, NE = R * G * MAXTS;
     constexpr int NPAR = NS + NQ + NY + NE;
     u64* gbase = a.gx + (size_t)grp * 2 * NPAR;
-    const bool fast = group_shares_xcd(a.xcc_slots + (size_t)grp * 16, G, mem, tid, a.err, lds_flag, (uint32_t)a.t0);
+    const bool fast = group_shares_xcd(a.xcc_slots + (size_t)grp * 16, G, mem, tid, a.err, lds_flag, (uint32_t)a.t0, 1);
 
     // ---- resident operands -----------------------------------------------------------------
     // cell matvec: DPP row -> (unit u = row % HS..., part): rows [0,16) take chunks 0..15, rows [16,32) chunks 16..31
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(512) void decoder_chain_fwd_kernel(ChainArgs a) {
                             ASR_POLL_BACKOFF();
         if ((spins & 1023) == 1023) {
                                 const long long now = wall_clock64();
-                                if (t0w == 0) t0w = now; else if (now - t0w > 200000000LL) { *a.err = 1; break; }
+                                if (t0w == 0) t0w = now; else if (now - t0w > 200000000LL) { *a.err = 51; break; }
                             }
                         }
                     }

@@ -79,7 +79,7 @@ __device__ __forceinline__ bool gather16_one(const u64* base, uint32_t epoch, fl
         if ((spins & 1023) == 1023) {
             const long long now = wall_clock64();
             if (t0 == 0) t0 = now;
-            else if (now - t0 > 200000000LL) { *err = 1; s0 = 0.f; return false; }
+            else if (now - t0 > 200000000LL) { *err = 21; s0 = 0.f; return false; }
             if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { s0 = 0.f; return false; }
         }
     }
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
     auto blenf = [&](int r) { return r ? blen1 : blen0; };
     auto rok = [&](int r) { return r < R && r0 + r < a.B; };
     u64* gbase = a.gx + (size_t)grp * 2 * NPAR;
-    const bool fast = group_shares_xcd(a.xcc_slots + (size_t)grp * 16, G, mem, tid, a.err, lds_flag);
+    const bool fast = group_shares_xcd(a.xcc_slots + (size_t)grp * 16, G, mem, tid, a.err, lds_flag, 0, 2);
 
     // ---- resident operands
     // [dh|dctx] of the EARLIER step = dG . [K_h ; WK_c]^T for my own outputs: wave w owns outputs w*OPW .. +OPW-1 (unit
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
                 if ((spins & 1023) == 1023) {
                     const long long now = wall_clock64();
                     if (t0w == 0) t0w = now;
-                    else if (now - t0w > 200000000LL) { *a.err = 1; break; }
+                    else if (now - t0w > 200000000LL) { *a.err = 52; break; }
                     if (__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
                 }
             }
@@ -454,7 +454,7 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
                 if ((spins & 1023) == 1023) {
                     const long long now = wall_clock64();
                     if (t0w == 0) t0w = now;
-                    else if (now - t0w > 200000000LL) { *a.err = 1; break; }
+                    else if (now - t0w > 200000000LL) { *a.err = 53; break; }
                     if (__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
                 }
             }
@@ -587,7 +587,7 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
                             if ((spins & 1023) == 1023) {
                                 const long long now = wall_clock64();
                                 if (t0w == 0) t0w = now;
-                                else if (now - t0w > 200000000LL) { *a.err = 1; break; }
+                                else if (now - t0w > 200000000LL) { *a.err = 54; break; }
                                 if (__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
                             }
                         }

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
     constexpr int NLM = (TRAIN ? 2 : 1) * R * LMH, NQH = 2 * R * H, NY = R * A, NE = R * G * MAXTS, NC = R * D, NP = R * H, NM = 2 * R * G;
     constexpr int NPAR = NLM + NQH + NY + NE + NC + NP + NM;
     u64* gbase = a.gx + (size_t)grp * 2 * NPAR;
-    const bool fast = group_shares_xcd(a.xcc_slots + (size_t)grp * G, G, mem, tid, a.err, lds_flag);
+    const bool fast = group_shares_xcd(a.xcc_slots + (size_t)grp * G, G, mem, tid, a.err, lds_flag, 0, 3);
 
     // ---- resident weights (registers), lane kq of a DPP row <-> float4 j of a K part at k = base + (16 j + kq) * 4
     float wlm[4][4];          // LM cell, recurrent part: K = LMH in 4 parts of 64

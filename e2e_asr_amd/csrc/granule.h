@@ -18,7 +18,7 @@ __device__ __forceinline__ bool chain_poll2(const u64* g, uint32_t epoch, float&
         if ((spins & 1023) == 1023) {
             const long long now = wall_clock64();
             if (t0 == 0) t0 = now;
-            else if (now - t0 > 200000000LL) { *err = 1; v0 = v1 = 0.f; return false; }
+            else if (now - t0 > 200000000LL) { *err = 41; v0 = v1 = 0.f; return false; }
             if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { v0 = v1 = 0.f; return false; }
         }
     }
@@ -77,7 +77,7 @@ __device__ __forceinline__ bool tagged_poll4(const uint32_t* g, uint32_t tb, flo
         if ((spins & 1023) == 1023) {
             const long long now = wall_clock64();
             if (t0 == 0) t0 = now;
-            else if (now - t0 > 200000000LL) { *err = 1; v = make_float4(0.f, 0.f, 0.f, 0.f); return false; }
+            else if (now - t0 > 200000000LL) { *err = 42; v = make_float4(0.f, 0.f, 0.f, 0.f); return false; }
             if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { v = make_float4(0.f, 0.f, 0.f, 0.f); return false; }
         }
     }

@@ -61,7 +61,7 @@ __device__ __forceinline__ bool poll_granule(const u64* g, uint32_t epoch, float
         if ((spins & 1023) == 1023) {              // bounded spin: ~2 s of wall clock
             long long now = wall_clock64();
             if (t0 == 0) t0 = now;
-            else if (now - t0 > 200000000LL) { *err = 1; val = 0.f; return false; }
+            else if (now - t0 > 200000000LL) { *err = 11; val = 0.f; return false; }
             if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { val = 0.f; return false; }
         }
     }
@@ -83,7 +83,7 @@ __device__ __forceinline__ bool poll_granule2(const u64* g, uint32_t epoch, floa
         if ((spins & 1023) == 1023) {
             long long now = wall_clock64();
             if (t0 == 0) t0 = now;
-            else if (now - t0 > 200000000LL) { *err = 1; v0 = v1 = 0.f; return false; }
+            else if (now - t0 > 200000000LL) { *err = 12; v0 = v1 = 0.f; return false; }
             if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { v0 = v1 = 0.f; return false; }
         }
     }
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(16 * HS) void lstm_rec_fwd_kernel(LstmRecArgs a) {
     const bool has_init = a.h0 != nullptr;           // uniform
     if (has_init && cell && cb < a.B) { h = a.h0[(size_t)cb * H + cj]; c = a.c0[(size_t)cb * H + cj]; }
     u64* hxg = a.hx + (size_t)grp * 2 * R * H;
-    const bool fast = group_shares_xcd(a.xcc_slots + (size_t)grp * 16, G, mem, tid, a.err, nullptr, (uint32_t)a.ep0);
+    const bool fast = group_shares_xcd(a.xcc_slots + (size_t)grp * 16, G, mem, tid, a.err, nullptr, (uint32_t)a.ep0, 4);
     // x.Kx+b of the NEXT step is loaded at the end of each cell phase (software pipelining): the
     // registers are loop-carried, never re-initialised, so the loop head needs no vmcnt wait and the
     // load latency hides under the next step's exchange.

@@ -57,7 +57,7 @@ __device__ __forceinline__ bool poll_pair(const u64* g, uint32_t epoch, float& v
         if ((spins & 1023) == 1023) {
             const long long now = wall_clock64();
             if (t0 == 0) t0 = now;
-            else if (now - t0 > 200000000LL) { *err = 1; v0 = v1 = 0.f; return false; }
+            else if (now - t0 > 200000000LL) { *err = 13; v0 = v1 = 0.f; return false; }
             if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { v0 = v1 = 0.f; return false; }
         }
     }
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(512) void lstm_rec_bwd_kernel(LstmBwdArgs a) {
     const int cj = j0 + cu;
     float dc = 0.f;
     u64* hxg = a.hx + (size_t)grp * 2 * G * G * R * HS;
-    const bool fast = group_shares_xcd(a.xcc_slots + (size_t)grp * 16, G, mem, tid, a.err);
+    const bool fast = group_shares_xcd(a.xcc_slots + (size_t)grp * 16, G, mem, tid, a.err, nullptr, 0, 5);
 
     // software-pipelined operands of the cell (loop-carried registers, no in-loop init)
     float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(R == 1 ? 4 
     float dc = 0.f;
     float4 dbs = make_float4(0.f, 0.f, 0.f, 0.f);
     uint32_t* hxg = reinterpret_cast<uint32_t*>(a.hx) + (size_t)grp * 2 * R * N;      // [2 parities][R][N] tagged floats
-    const bool fast = group_shares_xcd(a.xcc_slots + (size_t)grp * 16, G, mem, tid, a.err);
+    const bool fast = group_shares_xcd(a.xcc_slots + (size_t)grp * 16, G, mem, tid, a.err, nullptr, 0, R == 1 ? 16 : 6);
 
     // loader wave (last wave): lane l serves cell thread l
     const bool loader_wave = __builtin_amdgcn_readfirstlane(tid) >= NT - 64;
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(R == 1 ? 4 
                     if ((spins & 1023) == 1023) {
                         const long long now = wall_clock64();
                         if (t0w == 0) t0w = now;
-                        else if (now - t0w > 200000000LL) { *a.err = 1; break; }
+                        else if (now - t0w > 200000000LL) { *a.err = 55; break; }
                         if (__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
                     }
                 }

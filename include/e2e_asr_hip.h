@@ -56,7 +56,8 @@ int asr_get_gemm_split(void);
  * act [B,T,ndir,H,8] (records {i,j,f,o | c, c_prev, -, -}) and hprev [B,T,ndir,H] (undropped
  * previous hidden states); both NULL for inference.
  * keep_prob < 1 applies DropoutWrapper(output_keep_prob) (encoder.py:49-52) to `out`.
- * err_flag: device int, set non-zero if an inter-workgroup wait timed out. H in {64,128,256,512}.
+ * err_flag: device int, set non-zero if an inter-workgroup wait timed out (the value names the waiting site: 11-13 recurrent
+ * polls, 21 / 51-55 decoder chains, 41-42 granule polls, 31 + 100 * k the XCD agreement at the start of persistent kernel k). H in {64,128,256,512}.
  * kx_cat / bias_cat (optional, ndir = 2; NULL = one product per direction): the input rows of the two kernels side by side,
  * [in, 8H] = [kernel_fw[:in] | kernel_bw[:in]], and [bias_fw | bias_bw] -- the input projection of both directions then runs
  * as one product with N = 8H (asr_lstm_layer_bwd takes the same array for dX as one product with K = 8H). */

@@ -21,7 +21,11 @@ for it in range(n):
         b["logmel_len"] = np.maximum(1, (np.asarray(b["logmel_len"]) // int(rng.integers(2, 9)))); b["logmel_len"][0] = T
     losses = model.step(b)
     loss = float(losses["char"].item())
-    ops.check_device_flag(dev)
+    try:
+        ops.check_device_flag(dev)
+    except RuntimeError:
+        print("FAILED at step %d: B=%d T=%d t_dec=%d lens=%s tlens=%s" % (it, B, T, td, list(b["logmel_len"]), list(b["char_len"])), flush=True)
+        raise
     assert np.isfinite(loss), (it, B, T, td, loss)
     if it % 10 == 0:
         assert torch.isfinite(model.variables.flat).all(), it
