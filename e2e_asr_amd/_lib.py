@@ -75,6 +75,7 @@ SIGNATURES = {
     "asr_linear_wt_fwd": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int]),
     "asr_colsum_f32": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int]),
     "asr_gather_rows": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int]),
+    "asr_concat2_multi": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]),
     "asr_scatter_add_rows": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int]),
     "asr_sumsq_f32": (C.c_int, [vp, vp, C.c_size_t, vp, vp]),
     "asr_clip_adam_f32": (C.c_int, [vp, vp, vp, vp, vp, C.c_size_t, vp] + [C.c_float] * 6),

@@ -40,6 +40,20 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* table, co
     }
 }
 
+// Up to 8 row-wise concatenations dst_i[r] = [a_i[r] (wa floats) | b_i[r] (wb floats)] in ONE launch (blockIdx.y = i): the
+// encoder's per-layer [in, 8H] kernel and [8H] bias concatenations of a whole step (8 small launches otherwise).
+struct ConcatJob { const float* a; const float* b; float* dst; int rows, wa, wb, lda, ldb; };
+struct ConcatJobs { ConcatJob j[8]; };
+__global__ __launch_bounds__(256) void concat2_multi_kernel(ConcatJobs jobs) {
+    const ConcatJob j = jobs.j[blockIdx.y];
+    const int w = j.wa + j.wb;
+    const size_t n = (size_t)j.rows * w;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int r = (int)(i / w), c = (int)(i % w);
+        j.dst[i] = c < j.wa ? j.a[(size_t)r * j.lda + c] : j.b[(size_t)r * j.ldb + (c - j.wa)];
+    }
+}
+
 __global__ __launch_bounds__(256) void scatter_add_rows_kernel(float* tg, const int* idx, const float* g, int rows, int width, int ldg) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)rows * width; i += (size_t)gridDim.x * 256) {
         const int r = (int)(i / width), c = (int)(i % width);
@@ -168,6 +182,22 @@ extern "C" int asr_gather_rows(void* stream, const float* table, const int* idx,
     if (!table || !idx || !out || rows <= 0 || width <= 0 || (width & 3)) return ASR_EINVAL;
     const int grid = (int)std::min<size_t>(2048, ((size_t)rows * (width >> 2) + 255) / 256);
     hipLaunchKernelGGL(asr::gather_rows_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), table, idx, out, rows, width);
+    ASR_CHECK_LAUNCH();
+    return ASR_OK;
+}
+// n <= 8 concatenations in one launch; job i: dst[i] [rows[i], wa[i]+wb[i]] = [a[i] (row stride lda[i]) | b[i] (row stride ldb[i])]
+extern "C" int asr_concat2_multi(void* stream, int n, const float* const* a, const float* const* b, float* const* dst,
+                                 const int* rows, const int* wa, const int* wb, const int* lda, const int* ldb) {
+    if (n <= 0 || n > 8 || !a || !b || !dst || !rows || !wa || !wb || !lda || !ldb) return ASR_EINVAL;
+    asr::ConcatJobs jobs;
+    size_t most = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!a[i] || !b[i] || !dst[i] || rows[i] <= 0 || wa[i] <= 0 || wb[i] <= 0 || lda[i] < wa[i] || ldb[i] < wb[i]) return ASR_EINVAL;
+        jobs.j[i] = asr::ConcatJob{a[i], b[i], dst[i], rows[i], wa[i], wb[i], lda[i], ldb[i]};
+        most = std::max(most, (size_t)rows[i] * (wa[i] + wb[i]));
+    }
+    const int gx = (int)std::min<size_t>(512, (most + 255) / 256);
+    hipLaunchKernelGGL(asr::concat2_multi_kernel, dim3(gx, n), dim3(256), 0, static_cast<hipStream_t>(stream), jobs);
     ASR_CHECK_LAUNCH();
     return ASR_OK;
 }

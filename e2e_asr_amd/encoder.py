@@ -7,6 +7,8 @@ tensor stays batch-major [B,T,feat] end to end.  The reference's two transposes 
 (encoder.py:158,164), the fw/bw concat (:83) and the pyramid reshape (:112-115) all
 disappear: the kernel writes fw|bw halves in place and [B,T,2H] -> [B,T/2,4H] is a view.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -77,6 +79,14 @@ class Encoder(BaseParams):
         keep = params.out_prob if self.isTraining else 1.0
         save = self.isTraining
         self.saved = []
+        ahead = {}                                                 # {depth: (kx_cat, bias_cat)}: one launch for all layers
+        if x.is_cuda and params.bi_dir and ops._KXCAT >= 1 and os.environ.get("ASR_KXCAT_MULTI", "1") != "0":
+            todo = [(d,) + tuple(self._layer_weights(d)) for d in range(1, max_depth + 1)]
+            todo = [t for t in todo if t[1].shape[1] // 4 in ops.LSTM_KERNEL_H]
+            for c0 in range(0, len(todo), 4):
+                chunk = todo[c0:c0 + 4]
+                for t, kc in zip(chunk, ops.concat_kx_layers([t[1:] for t in chunk])):
+                    ahead[t[0]] = kc
         for i in range(max_depth):
             d = i + 1
             B, T, _ = x.shape
@@ -85,8 +95,9 @@ class Encoder(BaseParams):
             lens_dev = dev_i32(lens, x.device)
             kf, bf, kb, bb = self._layer_weights(d)
             seed = (self.dropout_seed * 1000003 + d * 7919) & 0x7FFFFFFF
+            kx, bc = ahead.get(d, (None, None))
             r = ops.lstm_layer_fwd(x, lens_dev, kf, bf, kb, bb, t_out=t_out, save=save,
-                                   keep_prob=keep, seed=seed)
+                                   keep_prob=keep, seed=seed, kx_cat=kx, bias_cat=bc)
             out = r[0] if save else r
             if save:
                 self.saved.append(dict(x=x, lens=lens, lens_dev=lens_dev, gates=r[1], c=r[2], hprev=r[3], kx=getattr(r[1], "kx_cat", None), out=out,

@@ -125,8 +125,32 @@ def _pad_lstm_weights(kernel, bias, IN, H, Hp):
     return kp.view(IN + Hp, 4 * Hp), bp
 
 
+def concat_kx_layers(layers):
+    """layers: [(kernel_fw, bias_fw, kernel_bw, bias_bw)] of up to four BiLSTM layers.  Returns [(kx_cat [in, 8H], bias_cat [8H])]:
+    the input rows of the two directions' kernels side by side (both directions' input projection, and dX, as ONE product)
+    -- all of them built by ONE launch (asr_concat2_multi) instead of two torch.cat launches per layer."""
+    assert 0 < len(layers) <= 4
+    dev = layers[0][0].device
+    a, b, dst, rows, wa, wb, lda, ldb, out = [], [], [], [], [], [], [], [], []
+    for kf, bf, kb, bb in layers:
+        H4 = kf.shape[1]
+        IN = kf.shape[0] - H4 // 4
+        kx = torch.empty((IN, 2 * H4), device=dev, dtype=torch.float32)
+        bc = torch.empty((2 * H4,), device=dev, dtype=torch.float32)
+        for (s0, s1, d, r, w0, w1, l0, l1) in ((_f32(kf, "kernel_fw"), _f32(kb, "kernel_bw"), kx, IN, H4, H4, H4, H4),
+                                               (_f32(bf, "bias_fw"), _f32(bb, "bias_bw"), bc, 1, H4, H4, H4, H4)):
+            a.append(s0.data_ptr()); b.append(s1.data_ptr()); dst.append(d.data_ptr())
+            rows.append(r); wa.append(w0); wb.append(w1); lda.append(l0); ldb.append(l1)
+        out.append((kx, bc))
+    n = len(a)
+    P, I = C.c_void_p * n, C.c_int * n
+    rc = _lib.lib().asr_concat2_multi(_stream(), n, P(*a), P(*b), P(*dst), I(*rows), I(*wa), I(*wb), I(*lda), I(*ldb))
+    _check(rc, "asr_concat2_multi")
+    return out
+
+
 def lstm_layer_fwd(x, seq_len, kernel_fw, bias_fw, kernel_bw=None, bias_bw=None, t_out=None,
-                   save=False, keep_prob=1.0, seed=0):
+                   save=False, keep_prob=1.0, seed=0, kx_cat=None, bias_cat=None):
     """One (Bi)LSTM layer (encoder.py:55-91).  x [B,T,in] batch-major, seq_len int32 [B].
 
     Returns out [B,t_out,ndir*H] (zeros past each length) and, when save=True, the
@@ -162,10 +186,12 @@ def lstm_layer_fwd(x, seq_len, kernel_fw, bias_fw, kernel_bw=None, bias_bw=None,
     L = _lib.lib()
     nbytes = L.asr_lstm_ws_bytes(B, H, ndir)
     hx = _hx(dev, nbytes)
-    kx_cat = bias_cat = None
     if ndir == 2 and _KXCAT >= 1:       # input rows of the two kernels side by side: both directions' projection as ONE product (N = 8H)
-        kx_cat = torch.cat([kernel_fw[:IN], kernel_bw[:IN]], 1)
-        bias_cat = torch.cat([bias_fw, bias_bw])
+        if kx_cat is None or bias_cat is None:      # (the encoder passes all its layers' concatenations, built by one launch)
+            kx_cat = torch.cat([kernel_fw[:IN], kernel_bw[:IN]], 1)
+            bias_cat = torch.cat([bias_fw, bias_bw])
+    else:
+        kx_cat = bias_cat = None
     rc = L.asr_lstm_layer_fwd(_stream(), _p(x), B, T, IN, IN, _p(seq_len), H, ndir,
                               _p(_f32(kernel_fw, "kernel_fw")), _p(_f32(bias_fw, "bias_fw")),
                               _p(_f32(kernel_bw, "kernel_bw")), _p(_f32(bias_bw, "bias_bw")),

@@ -101,6 +101,11 @@ int asr_softmax_f32(void* stream, const float* x, float* y, int n);
 int asr_colsum_f32(void* stream, const float* x, int ldx, int M, int N, float* out, int accumulate);
 /* out[r,:] = table[idx[r],:] (embedding_lookup) and table_grad[idx[r],:] += g[r,:] (its gradient). */
 int asr_gather_rows(void* stream, const float* table, const int* idx, float* out, int rows, int width);
+/* n <= 8 row-wise concatenations in ONE launch: dst[i] [rows[i], wa[i]+wb[i]] = [a[i] | b[i]] (row strides lda[i], ldb[i]; host
+ * arrays of device pointers / ints).  The encoder builds its per-layer [in,8H] kernel and [8H] bias concatenations of a step
+ * with one call (new here: the reference's graph holds the per-direction kernels, encoder.py:55-91). */
+int asr_concat2_multi(void* stream, int n, const float* const* a, const float* const* b, float* const* dst,
+                      const int* rows, const int* wa, const int* wb, const int* lda, const int* ldb);
 int asr_scatter_add_rows(void* stream, float* table_grad, const int* idx, const float* g, int rows, int width);
 
 /* tf.clip_by_global_norm + tf.train.AdamOptimizer over flat buffers (seq2seq_model.py:137-155).

@@ -182,3 +182,18 @@ def test_device_prefetcher_stages_batches_in_order():
     it = iter(DevicePrefetcher(iter(src), DEV))                   # an abandoned iterator stops its worker
     next(it)
     it.close()
+
+
+def test_concat_kx_layers_equals_torch_cat():
+    """ops.concat_kx_layers (asr_concat2_multi: every layer's [in,8H] kernel and [8H] bias concatenation in one launch) is
+    bit-equal to the two torch.cat calls per layer it replaces."""
+    from e2e_asr_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(5)
+    layers = []
+    for IN, H in ((80, 256), (1024, 256), (96, 64), (512, 128)):
+        mk = lambda *shape: torch.randn(*shape, generator=g).to(DEV)
+        layers.append((mk(IN + H, 4 * H), mk(4 * H), mk(IN + H, 4 * H), mk(4 * H)))
+    got = ops.concat_kx_layers(layers)
+    for (kf, bf, kb, bb), (kx, bc) in zip(layers, got):
+        IN = kf.shape[0] - kf.shape[1] // 4
+        assert torch.equal(kx, torch.cat([kf[:IN], kb[:IN]], 1)) and torch.equal(bc, torch.cat([bf, bb]))
