@@ -364,11 +364,9 @@ extern "C" int asr_attn_decoder_bwd(void* stream, const asr_dec_weights* w, cons
         };
         float* gw0 = const_cast<float*>(g->out_w);                       // OutputProjection
         if ((rc = wg0(H, V, TB, ws->p, H, dlogits, V, gw0))) return rc;
-        if ((rc = asr_colsum_f32(side, dlogits, V, TB, V, const_cast<float*>(g->out_b), 1))) return rc;
         gw0 = const_cast<float*>(g->ap_w);                               // AttnProjection: rows [q | ctx]
         if ((rc = wg0(H, H, TB, ws->dec_c, H, bw->dP, H, gw0))) return rc;
         if ((rc = wg0(D, H, TB, ws->ctx, D, bw->dP, H, gw0 + (size_t)H * H))) return rc;
-        if ((rc = asr_colsum_f32(side, bw->dP, H, TB, H, const_cast<float*>(g->ap_b), 1))) return rc;
     }
     if (hipMemsetAsync(bw->dc_dec, 0, sizeof(float) * B * H, s) != hipSuccess) return ASR_ELAUNCH;
     if (hipMemsetAsync(bw->dhf, 0, sizeof(float) * (size_t)B * Te * A, s) != hipSuccess) return ASR_ELAUNCH;
@@ -416,8 +414,9 @@ extern "C" int asr_attn_decoder_bwd(void* stream, const asr_dec_weights* w, cons
             return rc;
     }
     // ---- LM chain backward on the side stream: it needs only dLC[i] (all produced above) and its
-    // own carries, so it runs concurrently with the weight-gradient GEMMs below and with the
-    // encoder's BPTT that the caller launches next.  asr_side_join() orders it before the optimizer.
+    // own carries, so it runs concurrently with the data-gradient GEMMs the caller's stream does next; the caller's stream
+    // waits for its BPTT before this function returns (one persistent kernel at a time, see the end), the remaining
+    // side-stream GEMMs overlap the encoder's BPTT.  asr_side_join() orders them before the optimizer.
     hipEvent_t e_loop = next_event();
     if (hipEventRecord(e_loop, s) != hipSuccess || hipStreamWaitEvent(ss, e_loop, 0) != hipSuccess) return ASR_ELAUNCH;
     if (hipMemsetAsync(bw->dc_lm, 0, sizeof(float) * B * lmH, ss) != hipSuccess) return ASR_ELAUNCH;
@@ -483,7 +482,11 @@ extern "C" int asr_attn_decoder_bwd(void* stream, const asr_dec_weights* w, cons
         return asr_gemm_f32(stream_w, 1, 0, M, N, K, Ap, lda, Bp, ldb, C, N, nullptr, 1);
     };
     float* gw = nullptr;
-    // (OutputProjection / AttnProjection gradients were issued before the chain, see above)
+    // (OutputProjection / AttnProjection weight gradients were issued before the chain, see above; their bias column sums come
+    // here: next to the persistent chain a colsum's 1 920 small workgroups crawled for the chain's whole 770 us -- 6.8 % of the
+    // GPU time in the kernel statistics for 16 us of work -- and held back the side-stream GEMMs queued behind them)
+    if ((rc = asr_colsum_f32(stream_w, dlogits, V, TB, V, const_cast<float*>(g->out_b), 1))) return rc;
+    if ((rc = asr_colsum_f32(stream_w, bw->dP, H, TB, H, const_cast<float*>(g->ap_b), 1))) return rc;
     // Attention query projection, AttnV
     if ((rc = wgrad(H, A, TB, ws->dec_c, H, bw->dY, A, const_cast<float*>(g->attn_w)))) return rc;
     if ((rc = asr_colsum_f32(stream_w, bw->dY, A, TB, A, const_cast<float*>(g->attn_b), 1))) return rc;
