@@ -714,16 +714,19 @@ static int greedy_launch(void* stream, asr::GreedyArgs a, bool train, const floa
                                         4 * 4 * R + 4 * 8 * R + 8 * R * 16 + 32 + R * 32 + 2 * R * G + Ac + R * MAXTS * Ac +
                                         (train ? (size_t)R * lmH : 0) + (size_t)R * Te * 16);
     if (lds > 160 * 1024 - 64) return ASR_EUNSUPPORTED;
-    a.dbg = (!train && getenv("ASR_CHAIN_STAMP")) ? asr::g_lstm_dbg : nullptr;
+    a.dbg = getenv("ASR_CHAIN_STAMP") ? asr::g_lstm_dbg : nullptr;
     if (train) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asr::decoder_greedy_kernel<256, 512, 128, 256, false, true>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     else (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asr::decoder_greedy_kernel<256, 512, 128, 256>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (a.dbg) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asr::decoder_greedy_kernel<256, 512, 128, 256, true>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (a.dbg && !train) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asr::decoder_greedy_kernel<256, 512, 128, 256, true>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (a.dbg && train) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asr::decoder_greedy_kernel<256, 512, 128, 256, true, true>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     for (int g0 = 0; g0 < groups; g0 += 8) {            // 8 groups (one per XCD) = 256 workgroups per launch
         a.g0 = g0; a.ng = std::min(8, groups - g0);
-        if (train) hipLaunchKernelGGL((asr::decoder_greedy_kernel<256, 512, 128, 256, false, true>), dim3(8 * G), dim3(512), lds, s, a);
+        if (train && a.dbg) hipLaunchKernelGGL((asr::decoder_greedy_kernel<256, 512, 128, 256, true, true>), dim3(8 * G), dim3(512), lds, s, a);
+        else if (train) hipLaunchKernelGGL((asr::decoder_greedy_kernel<256, 512, 128, 256, false, true>), dim3(8 * G), dim3(512), lds, s, a);
         else if (a.dbg) hipLaunchKernelGGL((asr::decoder_greedy_kernel<256, 512, 128, 256, true>), dim3(8 * G), dim3(512), lds, s, a);
         else hipLaunchKernelGGL((asr::decoder_greedy_kernel<256, 512, 128, 256>), dim3(8 * G), dim3(512), lds, s, a);
         if (hipGetLastError() != hipSuccess) return ASR_ELAUNCH;
