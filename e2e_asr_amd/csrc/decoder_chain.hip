@@ -116,8 +116,9 @@ __global__ __launch_bounds__(512) void decoder_chain_fwd_kernel(ChainArgs a) {
     const int kq = lane & 15, row = tid >> 4;       // 32 DPP rows
     const int NG = a.ng;
     int grp, mem;
-    if ((NG & 7) == 0) { mem = (blockIdx.x >> 3) % G; grp = (blockIdx.x & 7) + 8 * (blockIdx.x / (8 * G)); }
-    else { grp = blockIdx.x / G; mem = blockIdx.x % G; }
+    if (((gridDim.x / G) & 7) == 0) { mem = (blockIdx.x >> 3) % G; grp = (blockIdx.x & 7) + 8 * (blockIdx.x / (8 * G)); }   // (grid padded to whole
+    else { grp = blockIdx.x / G; mem = blockIdx.x % G; }                                                                      //  octets of groups: lstm.hip)
+    if (grp >= NG) return;
     grp += a.g0;
     const int r0 = grp * R;
     const bool wave0 = __builtin_amdgcn_readfirstlane(tid) < 64;
@@ -492,6 +493,7 @@ template <int H, int D, int A, int R>
 static int chain_launch(hipStream_t s, asr::ChainArgs& a, int Te) {
     constexpr int G = 16;
     const int groups = a.ng;
+    const int grid_groups = (((groups + 7) & ~7) * G <= asr::resident_wg_budget()) ? ((groups + 7) & ~7) : groups;
     constexpr int KSP = (H + D + 127) / 128 * 128, KCP = KSP / 32 + 4, QP = (H + 127) / 128 * 128;
     const size_t lds = sizeof(float) * (4 + (size_t)R * 32 * KCP + 2 * (H / G) * R * 4 + R * QP + 2 * (A / G) * R + 4 + R * A +
                                         G * 32 + 32 + 8 * R * (D / G) + R * (H / G) * 4 + A + 32 * A + (size_t)R * Te * (D / G));
@@ -501,10 +503,10 @@ static int chain_launch(hipStream_t s, asr::ChainArgs& a, int Te) {
     if (H == 256 && R == 2 && a.dbg) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asr::decoder_chain_fwd_kernel<256, 512, 128, 2, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((asr::decoder_chain_fwd_kernel<256, 512, 128, 2, true>), dim3(groups * G), dim3(512), lds, s, a);
+        hipLaunchKernelGGL((asr::decoder_chain_fwd_kernel<256, 512, 128, 2, true>), dim3(grid_groups * G), dim3(512), lds, s, a);
         return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
     }
-    hipLaunchKernelGGL((asr::decoder_chain_fwd_kernel<H, D, A, R>), dim3(groups * G), dim3(512), lds, s, a);
+    hipLaunchKernelGGL((asr::decoder_chain_fwd_kernel<H, D, A, R>), dim3(grid_groups * G), dim3(512), lds, s, a);
     return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
 }
 

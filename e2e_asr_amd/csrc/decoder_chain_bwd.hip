@@ -168,8 +168,9 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
     const int kq = lane & 15, row = tid >> 4;
     const int NG = a.ng;
     int grp, mem;
-    if ((NG & 7) == 0) { mem = (blockIdx.x >> 3) % G; grp = (blockIdx.x & 7) + 8 * (blockIdx.x / (8 * G)); }
-    else { grp = blockIdx.x / G; mem = blockIdx.x % G; }
+    if (((gridDim.x / G) & 7) == 0) { mem = (blockIdx.x >> 3) % G; grp = (blockIdx.x & 7) + 8 * (blockIdx.x / (8 * G)); }   // (grid padded to whole
+    else { grp = blockIdx.x / G; mem = blockIdx.x % G; }                                                                      //  octets of groups: lstm.hip)
+    if (grp >= NG) return;
     grp += a.g0;
     const int r0 = grp * R;
     const bool wave0 = __builtin_amdgcn_readfirstlane(tid) < 64;
@@ -716,6 +717,7 @@ template <int H, int D, int A, int R>
 static int chain_bwd_launch(hipStream_t s, asr::ChainBwdArgs& a) {
     constexpr int G = 16;
     const int groups = a.ng;
+    const int grid_groups = (((groups + 7) & ~7) * G <= asr::resident_wg_budget()) ? ((groups + 7) & ~7) : groups;
     const size_t lds = asr_decoder_chain_bwd_lds_bytes(a.Te, D, A, H);
     if (lds > 160 * 1024 - 64) return ASR_EUNSUPPORTED;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asr::decoder_chain_bwd_kernel<H, D, A, R>),
@@ -723,10 +725,10 @@ static int chain_bwd_launch(hipStream_t s, asr::ChainBwdArgs& a) {
     if (H == 256 && R == 2 && a.dbg) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asr::decoder_chain_bwd_kernel<256, 512, 128, 2, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((asr::decoder_chain_bwd_kernel<256, 512, 128, 2, true>), dim3(groups * G), dim3(512), lds, s, a);
+        hipLaunchKernelGGL((asr::decoder_chain_bwd_kernel<256, 512, 128, 2, true>), dim3(grid_groups * G), dim3(512), lds, s, a);
         return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
     }
-    hipLaunchKernelGGL((asr::decoder_chain_bwd_kernel<H, D, A, R>), dim3(groups * G), dim3(512), lds, s, a);
+    hipLaunchKernelGGL((asr::decoder_chain_bwd_kernel<H, D, A, R>), dim3(grid_groups * G), dim3(512), lds, s, a);
     return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
 }
 

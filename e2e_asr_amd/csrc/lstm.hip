@@ -120,12 +120,15 @@ __global__ __launch_bounds__(16 * HS) void lstm_rec_fwd_kernel(LstmRecArgs a) {
     const int NG = (a.B + R - 1) / R;
     const int ngroups = a.ND * NG;
     int grp, mem;
-    if ((ngroups & 7) == 0) {          // members of a group share blockIdx % 8 (one XCD label)
+    // The grid holds the groups, padded by the launcher to a multiple of 8 when the budget allows: then the members of a group
+    // share blockIdx % 8 (one XCD label, the exchange stays in that XCD's L2) for ANY group count; padding workgroups leave.
+    if (((gridDim.x / G) & 7) == 0) {
         mem = (blockIdx.x >> 3) % G;
         grp = (blockIdx.x & 7) + 8 * (blockIdx.x / (8 * G));
     } else {
         grp = blockIdx.x / G; mem = blockIdx.x % G;
     }
+    if (grp >= ngroups) return;
     const int dir = grp / NG, bg = grp % NG;
     const int r0 = bg * R;
     const int u = wave * 4 + cgl;      // matvec role: unit of this DPP row
@@ -326,13 +329,20 @@ extern "C" int asr_get_gemm_precision(void);
 unsigned long long* g_lstm_dbg = nullptr;      // diagnostic stamp buffer (also read by decoder_chain_bwd.hip)
 extern "C" int asr_debug_set_buffer(void* p) { g_lstm_dbg = static_cast<unsigned long long*>(p); return ASR_OK; }
 
+}  // namespace asr
+int asr_lstm_max_wgs();
+namespace asr {
 template <int H, int R>
 static int launch_rec(hipStream_t s, const LstmRecArgs& a0) {
     constexpr int HS = 32;
     LstmRecArgs a = a0;
     a.dbg = g_lstm_dbg;
     const int NG = (a.B + R - 1) / R;
-    const int grid = a.ND * NG * (H / HS);
+    int grid = a.ND * NG * (H / HS);
+    {   // whole octets of groups (see the kernel's group mapping) when they still fit the co-residency budget
+        const int padded = ((a.ND * NG + 7) & ~7) * (H / HS);
+        if (padded <= asr_lstm_max_wgs()) grid = padded;
+    }
     // bf16 mode of the library (asr_set_gemm_precision(1)): recurrent product on the bf16 matrix pipe (H = 256 instantiation)
     static const bool mf_env = [] { const char* e = getenv("ASR_LSTM_MFMA"); return !(e && e[0] == '0'); }();
     if (H == 256 && R == 2 && g_lstm_dbg && getenv("ASR_LSTM_STAMP"))

@@ -89,8 +89,9 @@ __global__ __launch_bounds__(512) void lstm_rec_bwd_kernel(LstmBwdArgs a) {
     const int NG = (a.B + R - 1) / R;
     const int ngroups = a.ND * NG;
     int grp, mem;
-    if ((ngroups & 7) == 0) { mem = (blockIdx.x >> 3) % G; grp = (blockIdx.x & 7) + 8 * (blockIdx.x / (8 * G)); }
-    else { grp = blockIdx.x / G; mem = blockIdx.x % G; }
+    if (((gridDim.x / G) & 7) == 0) { mem = (blockIdx.x >> 3) % G; grp = (blockIdx.x & 7) + 8 * (blockIdx.x / (8 * G)); }   // (grid padded to whole
+    else { grp = blockIdx.x / G; mem = blockIdx.x % G; }                                                                      //  octets of groups: lstm.hip)
+    if (grp >= ngroups) return;
     const int dir = grp / NG, bg = grp % NG;
     const int r0 = bg * R;
     const int H4 = 4 * H;
@@ -291,8 +292,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(R == 1 ? 4 
     const int NG = (a.B + R - 1) / R;
     const int ngroups = a.ND * NG;
     int grp, mem;
-    if ((ngroups & 7) == 0) { mem = (blockIdx.x >> 3) % G; grp = (blockIdx.x & 7) + 8 * (blockIdx.x / (8 * G)); }
-    else { grp = blockIdx.x / G; mem = blockIdx.x % G; }
+    if (((gridDim.x / G) & 7) == 0) { mem = (blockIdx.x >> 3) % G; grp = (blockIdx.x & 7) + 8 * (blockIdx.x / (8 * G)); }   // (grid padded to whole
+    else { grp = blockIdx.x / G; mem = blockIdx.x % G; }                                                                      //  octets of groups: lstm.hip)
+    if (grp >= ngroups) return;
     const int dir = grp / NG, bg = grp % NG;
     const int r0 = bg * R;
     const int H4 = 4 * H;
@@ -548,10 +550,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(R == 1 ? 4 
 
 }  // namespace asr
 extern "C" int asr_get_gemm_precision(void);
+int asr_lstm_max_wgs();
 namespace asr {
 template <int H>
 static int launch_bwd_h(hipStream_t s, const LstmBwdArgs& a, int R) {
-    const int grid = a.ND * ((a.B + R - 1) / R) * (H / 32);
+    int grid = a.ND * ((a.B + R - 1) / R) * (H / 32);
+    { const int padded = ((a.ND * ((a.B + R - 1) / R) + 7) & ~7) * (H / 32); if (padded <= asr_lstm_max_wgs()) grid = padded; }
     static const bool allgather = [] { const char* e = getenv("ASR_BPTT_AG"); return !(e && e[0] == '0'); }();
     if (allgather && R <= 2) {     // more rows per group: too many granule loads per polling thread -> reduce-scatter kernel
         static const bool mf_env = [] { const char* e = getenv("ASR_LSTM_MFMA"); return !(e && e[0] == '0'); }();
