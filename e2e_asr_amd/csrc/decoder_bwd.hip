@@ -364,9 +364,6 @@ extern "C" int asr_attn_decoder_bwd(void* stream, const asr_dec_weights* w, cons
         };
         float* gw0 = const_cast<float*>(g->out_w);                       // OutputProjection
         if ((rc = wg0(H, V, TB, ws->p, H, dlogits, V, gw0))) return rc;
-        gw0 = const_cast<float*>(g->ap_w);                               // AttnProjection: rows [q | ctx]
-        if ((rc = wg0(H, H, TB, ws->dec_c, H, bw->dP, H, gw0))) return rc;
-        if ((rc = wg0(D, H, TB, ws->ctx, D, bw->dP, H, gw0 + (size_t)H * H))) return rc;
     }
     if (hipMemsetAsync(bw->dc_dec, 0, sizeof(float) * B * H, s) != hipSuccess) return ASR_ELAUNCH;
     if (hipMemsetAsync(bw->dhf, 0, sizeof(float) * (size_t)B * Te * A, s) != hipSuccess) return ASR_ELAUNCH;
@@ -482,9 +479,12 @@ extern "C" int asr_attn_decoder_bwd(void* stream, const asr_dec_weights* w, cons
         return asr_gemm_f32(stream_w, 1, 0, M, N, K, Ap, lda, Bp, ldb, C, N, nullptr, 1);
     };
     float* gw = nullptr;
-    // (OutputProjection / AttnProjection weight gradients were issued before the chain, see above; their bias column sums come
+    // (the OutputProjection weight gradient was issued before the chain, see above; the AttnProjection's and the bias column sums come
     // here: next to the persistent chain a colsum's 1 920 small workgroups crawled for the chain's whole 770 us -- 6.8 % of the
     // GPU time in the kernel statistics for 16 us of work -- and held back the side-stream GEMMs queued behind them)
+    gw = const_cast<float*>(g->ap_w);                                    // AttnProjection: rows [q | ctx] (likewise moved here)
+    if ((rc = wgrad(H, H, TB, ws->dec_c, H, bw->dP, H, gw))) return rc;
+    if ((rc = wgrad(D, H, TB, ws->ctx, D, bw->dP, H, gw + (size_t)H * H))) return rc;
     if ((rc = asr_colsum_f32(stream_w, dlogits, V, TB, V, const_cast<float*>(g->out_b), 1))) return rc;
     if ((rc = asr_colsum_f32(stream_w, bw->dP, H, TB, H, const_cast<float*>(g->ap_b), 1))) return rc;
     // Attention query projection, AttnV
