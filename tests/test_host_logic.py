@@ -109,3 +109,22 @@ def test_checkpoint_containers_roundtrip_under_tf_names(tmp_path, ext):
     np.testing.assert_array_equal(other[names[1]].numpy(), arrays[names[1]])
     assert float(other["model/rnn_decoder_phone/AttnV"].sum()) == 5.0
     assert set(checkpoint.get_matching_variables("rnn_decoder_char", path)) == {names[1], names[2]}
+
+
+def test_shifted_targets_and_lazy_weight_mask():
+    """tf_utils.py:4-12: targets = dec_input[1:], weights = time-major length mask flattened.  The model keeps the mask lazy
+    (the loss kernels mask by length themselves): it must still be the reference's mask when somebody reads it."""
+    import torch
+    from e2e_asr_amd.seq2seq_model import LazyTargetWeights, create_shifted_targets
+    ids = torch.arange(5 * 3, dtype=torch.int32).reshape(5, 3)          # [T+1, B] time-major decoder inputs
+    lens = np.array([4, 2, 0])
+    targets, w = create_shifted_targets(ids, lens)
+    assert torch.equal(targets, ids[1:])
+    expect = np.array([[1, 1, 0], [1, 1, 0], [1, 0, 0], [1, 0, 0]], np.float32).reshape(-1)
+    np.testing.assert_array_equal(w.numpy(), expect)
+    calls = []
+    lazy = LazyTargetWeights(lambda task: (calls.append(task), create_shifted_targets(ids, lens)[1])[1])
+    assert calls == [] and "char" not in lazy
+    np.testing.assert_array_equal(lazy["char"].numpy(), expect)
+    lazy["char"]
+    assert calls == ["char"]                                             # built once, on first access
