@@ -179,14 +179,102 @@ def _parse_map(buf, value_parser):
     return out
 
 
+def _uniform_float_frames(fl):
+    """FeatureList whose steps are all packed FloatLists of one length (the filterbank frames: 800 x 80 floats per utterance) ->
+    [steps, n] float32 array in one shot, or None.  Every step is then encoded with byte-identical headers at a fixed stride
+    (tag, length, Feature{tag 0x12, length, FloatList{tag 0x0A, length, 4n bytes}}); the headers of all steps are compared
+    with the first one's, so anything irregular falls back to the per-step parser.  (Per-step parsing in Python cost 2.8 ms
+    per utterance = 90 ms per batch of 32, ten times the train step; tf.data parsed in C++.)"""
+    n_total = len(fl)
+    if n_total < 12 or fl[0] != 0x0A:
+        return None
+    try:
+        ln1, p = _varint(fl, 1)                   # Feature
+        entry = p + ln1
+        if fl[p] != 0x12:
+            return None
+        ln2, p = _varint(fl, p + 1)               # FloatList
+        if fl[p] != 0x0A:
+            return None
+        ln3, p = _varint(fl, p + 1)               # packed floats
+    except IndexError:
+        return None
+    if ln3 % 4 or p + ln3 != entry or n_total % entry:
+        return None
+    a = np.frombuffer(fl, dtype=np.uint8).reshape(n_total // entry, entry)
+    if not (a[:, :p] == a[0, :p]).all():
+        return None
+    return np.ascontiguousarray(a[:, p:]).view("<f4")
+
+
+def _single_int_steps(fl):
+    """FeatureList whose steps are all Int64Lists of ONE non-negative value below 2^21 (the token id sequences) -> [steps, 1]
+    int64 array, or None (then the per-step parser runs).  The entry starts are chased in a bare loop (each entry is
+    0x0A, L, Feature{0x1A, L-2, Int64List{0x0A, L-4, varint} or {0x08, varint}}); every header byte and the varints are then
+    checked / decoded with numpy over all steps at once (the generic field walker cost 0.6 ms per utterance for ~160 tokens)."""
+    n = len(fl)
+    if n < 5:
+        return None
+    starts, pos = [], 0
+    try:
+        while pos < n:
+            starts.append(pos)
+            pos += 2 + fl[pos + 1]
+    except IndexError:
+        return None
+    if pos != n:
+        return None
+    b = np.frombuffer(fl, dtype=np.uint8)
+    s = np.asarray(starts, dtype=np.int64)
+    L = b[s + 1].astype(np.int64)
+    tag = b[s + 4]
+    if not ((b[s] == 0x0A).all() and (L < 128).all() and (L >= 4).all() and (b[s + 2] == 0x1A).all() and (b[s + 3] == L - 2).all()):
+        return None
+    if (tag == 0x0A).all():                     # packed
+        if not (b[s + 5] == L - 4).all():
+            return None
+        p0, plen = s + 6, L - 4
+    elif (tag == 0x08).all():                   # one varint per value
+        p0, plen = s + 5, L - 3
+    else:
+        return None
+    if plen.min() < 1 or plen.max() > 3:
+        return None
+    last = p0 + plen - 1
+    if (b[last] & 0x80).any():                  # the varint ends with the entry
+        return None
+    v = (b[p0] & 0x7F).astype(np.int64)
+    two, three = plen >= 2, plen == 3
+    if two.any():
+        if not (b[p0[two]] & 0x80).all():
+            return None
+        v[two] |= (b[p0[two] + 1] & 0x7F).astype(np.int64) << 7
+    if three.any():
+        if not (b[p0[three] + 1] & 0x80).all():
+            return None
+        v[three] |= (b[p0[three] + 2] & 0x7F).astype(np.int64) << 14
+    return v.reshape(-1, 1)
+
+
+def _parse_feature_list(fl):
+    """FeatureList -> [value per step]; or a 2-D array when the steps are uniform: [steps, n] float32 (packed FloatLists of n
+    values each) or [steps, 1] int64 (Int64Lists of one value each)."""
+    fast = _uniform_float_frames(fl)
+    if fast is None:
+        fast = _single_int_steps(fl)
+    if fast is not None:
+        return fast
+    return [_parse_feature(x) for f2, _, x in _fields(fl) if f2 == 1]
+
+
 def parse_sequence_example(record):
-    """-> (context: {name: array|[bytes]}, feature_lists: {name: [array|[bytes] per step]})."""
+    """-> (context: {name: array|[bytes]}, feature_lists: {name: [array|[bytes] per step] or [steps, n] float32 array})."""
     context, lists = {}, {}
     for fn, wt, v in _fields(record):
         if fn == 1:
             context = _parse_map(v, _parse_feature)
         elif fn == 2:
-            lists = _parse_map(v, lambda fl: [_parse_feature(x) for f2, _, x in _fields(fl) if f2 == 1])
+            lists = _parse_map(v, _parse_feature_list)
     return context, lists
 
 

@@ -208,3 +208,33 @@ def test_greedy_decode_wer_and_files(tmp_path):
     # without a vocabulary: token-level rate over EOS-trimmed ids
     ev2 = Eval(_FakeModel(hyp), params=Bunch(best_model_dir="", vocab_dir=""))
     assert ev2.greedy_decode([{"char": gold}]) == pytest.approx((2 + 1) / 4.0)
+
+
+def test_uniform_feature_lists_parse_in_one_shot_and_irregular_ones_fall_back():
+    """tfrecord.parse_sequence_example: filterbank frames (packed FloatLists of one length) come back as ONE [steps, n] float32
+    array and token id sequences (one non-negative value per step) as a [steps, 1] int64 array -- same values as the per-step
+    parser; anything irregular (ragged frames, negative / multi-value / huge ints, bytes) keeps the per-step form."""
+    from e2e_asr_amd import tfrecord
+    rng = np.random.default_rng(3)
+    frames = rng.standard_normal((37, 80)).astype(np.float32)
+    ids = rng.integers(0, 30000, size=25).astype(np.int64)
+    small = rng.integers(0, 100, size=9).astype(np.int64)
+    ex = tfrecord.make_sequence_example(
+        {"segment": [b"utt"], "logmel_len": np.array([37], np.int64)},
+        {"logmel": [f for f in frames], "cint": [np.array([v], np.int64) for v in ids], "pint": [np.array([v], np.int64) for v in small],
+         "ragged": [np.zeros(3, np.float32), np.zeros(5, np.float32)], "neg": [np.array([-4], np.int64), np.array([6], np.int64)],
+         "multi": [np.array([1, 2], np.int64)], "big": [np.array([1 << 40], np.int64)], "names": [[b"a"], [b"bc"]],
+         "one_frame": [np.arange(4, dtype=np.float32)]})
+    ctx, seq = tfrecord.parse_sequence_example(ex)
+    assert isinstance(seq["logmel"], np.ndarray) and seq["logmel"].dtype == np.float32 and seq["logmel"].shape == (37, 80)
+    np.testing.assert_array_equal(seq["logmel"], frames)
+    for name, want in (("cint", ids), ("pint", small)):
+        assert isinstance(seq[name], np.ndarray) and seq[name].shape == (len(want), 1) and seq[name].dtype == np.int64
+        np.testing.assert_array_equal(seq[name][:, 0], want)
+    np.testing.assert_array_equal(seq["one_frame"], np.arange(4, dtype=np.float32)[None])
+    assert isinstance(seq["ragged"], list) and [len(x) for x in seq["ragged"]] == [3, 5]
+    assert [int(x[0]) for x in seq["neg"]] == [-4, 6] and list(seq["multi"][0]) == [1, 2] and int(seq["big"][0][0]) == 1 << 40
+    assert seq["names"] == [[b"a"], [b"bc"]] and ctx["segment"] == [b"utt"] and int(ctx["logmel_len"][0]) == 37
+    # truncated / corrupted frame lists must not be mis-read by the stride shortcut
+    fl = bytes(tfrecord._ld(1, tfrecord._enc_feature(frames[0])) + tfrecord._ld(1, tfrecord._enc_feature(frames[1][:79])))
+    assert tfrecord._uniform_float_frames(memoryview(fl)) is None
