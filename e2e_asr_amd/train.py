@@ -161,7 +161,7 @@ class Train(BaseParams):
         except IOError:
             pass
         loss, current_step, lm_loss, lm_steps = 0.0, 0, 0.0, 0
-        loss_acc = None                       # device-side running mean of the step losses of this checkpoint interval
+        loss_acc = lm_loss_acc = None         # device-side running means of the step losses of this checkpoint interval
         ckpt_start = time.time()
         lm_iter = iter(lm_set) if lm_set is not None else None
         epoch = model.global_step // max(1, int(params.steps_per_epoch))              # train.py:217
@@ -182,10 +182,13 @@ class Train(BaseParams):
                         lm_model.epoch_incr()
                         lm_iter = iter(lm_set)
                         continue
-                    lm_loss += float(lm_model.step(lm_batch).item()) / params.steps_per_checkpoint
-                    ops.check_device_flag(model.device)
+                    lm_step_loss = lm_model.step(lm_batch).detach() / params.steps_per_checkpoint      # (device-side, as below)
+                    lm_loss_acc = lm_step_loss if lm_loss_acc is None else lm_loss_acc + lm_step_loss
                     lm_steps += 1
+                    if lm_steps % 16 == 0:
+                        ops.check_device_flag(model.device)
                     if lm_steps % params.steps_per_checkpoint == 0:
+                        lm_loss, lm_loss_acc = float(lm_loss_acc.item()), None
                         print("LM steps: %d, Perplexity: %f" % (lm_model.lm_global_step,
                                                                 math.exp(lm_loss) if lm_loss < 300 else float("inf")))
                         lm_loss = 0.0
