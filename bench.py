@@ -233,6 +233,11 @@ def main():
             print(json.dumps({"spawn_test": True, "n_gpus": world, "sum_of_ones": float(t.item())}))
         dist.destroy_process_group()
         return
+    # stdout carries ONE line, the JSON: libraries write there too (RCCL prints a version banner at init), so everything else
+    # of this process goes to stderr from here on and the line is written to the saved descriptor at the end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
@@ -403,7 +408,8 @@ def main():
     out["roofline_gemm"] = gemm_roofline(dev)
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
-    print(json.dumps(out))
+    sys.stdout.flush()
+    os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
 
