@@ -171,7 +171,14 @@ class Train(BaseParams):
         while epoch <= params.max_epochs:
             print("\nEpochs done: %d" % epoch)
             # (each bucket's batches are staged into HBM one batch ahead of the step: the iterator's prefetch of the reference)
-            active = [iter(DevicePrefetcher(s, self.device)) for s in buck_train_sets]       # train.py:261-266
+            prefetchers = [DevicePrefetcher(s, self.device) for s in buck_train_sets]        # train.py:261-266
+            started = {}
+
+            def bucket_iter(k):                          # reader threads start one bucket ahead of the loop (prefetch.primed)
+                if k not in started:
+                    started[k] = prefetchers[k].primed()
+                return started[k]
+            active = list(range(len(prefetchers)))
             while active:
                 if max_steps is not None and current_step >= max_steps:
                     return model
@@ -194,7 +201,10 @@ class Train(BaseParams):
                         lm_loss = 0.0
                     continue
                 try:
-                    batch = next(active[0])                                           # smallest bucket first (:295)
+                    it = bucket_iter(active[0])
+                    if len(active) > 1:
+                        bucket_iter(active[1])
+                    batch = next(it)                                                  # smallest bucket first (:295)
                 except StopIteration:
                     del active[0]                                                     # :379-383
                     continue

@@ -173,6 +173,8 @@ def test_device_prefetcher_stages_batches_in_order():
         ref = s["logmel"].cpu().numpy() if torch.is_tensor(s["logmel"]) else s["logmel"]
         np.testing.assert_array_equal((b["logmel"] * 1.0).cpu().numpy(), ref)
     assert list(DevicePrefetcher([], DEV)) == []
+    primed = DevicePrefetcher(src[:4], DEV).primed()                # reader thread already running before the first next()
+    assert [b["utt_id"] for b in primed] == [0, 1, 2, 3]
 
     def broken():
         yield src[0]
