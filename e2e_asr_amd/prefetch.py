@@ -22,13 +22,25 @@ class DevicePrefetcher(object):
 
     def __init__(self, batches, device, depth=2):
         self.batches, self.device, self.depth = batches, torch.device(device), max(1, int(depth))
+        self._workers = []
 
     def _start(self):
         pinned_q = queue.Queue(maxsize=self.depth + 1)
         free_q = queue.Queue()                              # pinned buffers whose copy has been consumed
         stop = threading.Event()
-        threading.Thread(target=self._fill, args=(pinned_q, free_q, stop), daemon=True).start()
+        worker = threading.Thread(target=self._fill, args=(pinned_q, free_q, stop), daemon=True)
+        worker.start()
+        self._workers.append((worker, stop))
         return pinned_q, free_q, stop
+
+    def close(self):
+        """Stop the reader threads this prefetcher started (an iterator that was primed but never consumed has nobody else
+        to stop its thread, and a daemon thread killed inside a pinned allocation at interpreter exit aborts the process)."""
+        for worker, stop in self._workers:
+            stop.set()
+        for worker, stop in self._workers:
+            worker.join(timeout=5.0)
+        self._workers = []
 
     def primed(self):
         """An iterator whose reader thread starts NOW (a plain iter() starts it at the first next()): the training loop primes the

@@ -109,6 +109,16 @@ class Train(BaseParams):
         return model_dev
 
     def train(self, buck_train_sets=None, dev_set=None, lm_set=None, max_steps=None):
+        """train.py:160-393.  (Wrapper: whatever way the loop ends, the reader threads it started are stopped.)"""
+        self._open_prefetchers = []
+        try:
+            return self._train(buck_train_sets, dev_set, lm_set, max_steps)
+        finally:
+            for pf in self._open_prefetchers:
+                pf.close()
+            self._open_prefetchers = []
+
+    def _train(self, buck_train_sets=None, dev_set=None, lm_set=None, max_steps=None):
         """buck_train_sets: list (shortest bucket first) of re-iterable batch sources; dev_set: a
         re-iterable of dev batches; lm_set: re-iterable of LM batches (needed when lm_prob > 0).  Left out, they are
         read from params.data_dir / params.lm_data_dir like the reference does."""
@@ -168,11 +178,14 @@ class Train(BaseParams):
         save_extra = lambda: dict(epoch=model.epoch, **(dict(
             lm_global_step=lm_model.lm_global_step, lm_learning_rate=lm_model.learning_rate, lm_epoch=lm_model.epoch)
             if lm_model is not None else {}))
+        carry = None                          # the next epoch's first bucket, its reader already running
         while epoch <= params.max_epochs:
             print("\nEpochs done: %d" % epoch)
             # (each bucket's batches are staged into HBM one batch ahead of the step: the iterator's prefetch of the reference)
             prefetchers = [DevicePrefetcher(s, self.device) for s in buck_train_sets]        # train.py:261-266
-            started = {}
+            self._open_prefetchers.extend(prefetchers)
+            started = {0: carry} if carry is not None else {}
+            carry = None
 
             def bucket_iter(k):                          # reader threads start one bucket ahead of the loop (prefetch.primed)
                 if k not in started:
@@ -204,6 +217,10 @@ class Train(BaseParams):
                     it = bucket_iter(active[0])
                     if len(active) > 1:
                         bucket_iter(active[1])
+                    elif carry is None and epoch < params.max_epochs:     # last bucket of the epoch: the next epoch's first one
+                        carry_pf = DevicePrefetcher(buck_train_sets[0], self.device)     # fills its shuffle buffer meanwhile
+                        self._open_prefetchers.append(carry_pf)                          # (0.74 -> 0.25 s per epoch change)
+                        carry = carry_pf.primed()
                     batch = next(it)                                                  # smallest bucket first (:295)
                 except StopIteration:
                     del active[0]                                                     # :379-383
