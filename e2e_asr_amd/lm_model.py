@@ -44,10 +44,18 @@ class LMModel(BaseParams):
 
     def forward(self, batch=None):
         self.encoder_inputs, self.seq_len = self.get_batch(batch)
-        self.targets, self.target_weights = create_shifted_targets(self.encoder_inputs, self.seq_len)
+        self.targets = self.encoder_inputs[1:]                                   # tf_utils.py:4-12 (a view)
+        self._target_weights = None                                              # the mask is built when somebody reads it
         self.outputs = self.encoder(self.encoder_inputs, self.seq_len)
         self.losses, self._loss_ws = LossUtils.cross_entropy_loss(self.outputs, self.targets, self.seq_len, return_ws=True)
         return self.losses
+
+    @property
+    def target_weights(self):
+        """Flattened time-major length mask (tf_utils.py:4-12); the loss kernels mask by length themselves, so it is built lazily."""
+        if self._target_weights is None:
+            self._target_weights = create_shifted_targets(self.encoder_inputs, self.seq_len)[1]
+        return self._target_weights
 
     def step(self, batch=None):
         """One sess.run([lm_model.updates, lm_model.losses]) (train.py:272-273)."""
