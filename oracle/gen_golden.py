@@ -18,10 +18,17 @@ beam_search.py imports three non-numeric modules that are absent or need
 TensorFlow (bunch, tf_utils, data_utils); they are stubbed in sys.modules with
 the minimum non-arithmetic surface (an attribute dict; the three special token
 ids 0/1/2 from data_utils.py:13-15).  BeamSearch.__new__ bypasses checkpoint
-reading; the parameter Bunches are set by hand.  BeamSearch.__call__ itself does
-not run under Python 3 (float h_size at beam_search.py:236-237), so the beam
-LOOP is not captured here -- only per-step outputs and greedy (k=1) chains that
-this script drives with the reference's own get_top_k.
+reading; the parameter Bunches are set by hand.
+
+  * beam_search.BeamSearch.__call__ -- the beam LOOP itself (beam_search.py:224-338)
+    -> tests/golden/beam_loop.npz     (`--beam-only` regenerates just these)
+    The loop is Python-2 / old-NumPy code in two places: `shape[1]/4` is a float under
+    Python 3 and np.zeros rejects it (236-243), and `np.divide(idx, k, dtype=np.int32)`
+    (306) was integer division under Python 2's NumPy.  While the reference's own
+    __call__ runs, the NAME `np` inside the imported beam_search module is bound to a
+    proxy that forwards everything to numpy except those two calls: `zeros` accepts an
+    integral float, `divide(..., dtype=<integer>)` floor-divides.  No arithmetic of the
+    reference is replaced; every other call is numpy's.
 """
 import os
 import sys
@@ -88,6 +95,86 @@ def text_fixtures():
                 sys.modules[k] = v
 
 
+class _Py2NumpyProxy(object):
+    """Stands for the name `np` inside the imported beam_search module: numpy, with the two Python-2-era behaviours
+    the beam loop relies on (see the module docstring)."""
+
+    def __getattr__(self, name):
+        return getattr(np, name)
+
+    @staticmethod
+    def zeros(shape, *a, **kw):
+        if isinstance(shape, float):
+            assert shape == int(shape)
+            shape = int(shape)
+        return np.zeros(shape, *a, **kw)
+
+    @staticmethod
+    def divide(x, y, *a, **kw):
+        dt = kw.get("dtype")
+        if dt is not None and np.issubdtype(np.dtype(dt), np.integer):
+            return np.floor_divide(x, y).astype(dt)
+        return np.divide(x, y, *a, **kw)
+
+
+BEAM_LOOP_CASES = [
+    # (variant, enc key or recipe, beam k, lm_weight, word_ins_penalty, EOS bias added to OutputProjection/bias[2])
+    ("plain", "enc_T100", 4, 0.0, 0.0, 0.0),
+    ("plain", "enc_T100", 8, 0.0, -0.2, 0.0),
+    ("plain", "enc_T100", 16, 0.1, 0.0, 0.0),
+    ("plain", "enc_T100", 4, 0.1, 0.3, 0.0),
+    ("plain", "enc_T100", 16, 0.1, 1.5, 0.0),
+    ("simple", "enc_T100", 8, 0.1, 0.0, 0.0),
+    ("simple", "enc_T7", 4, 0.0, 0.3, 0.0),
+    # hypotheses that FINISH (EOS made likelier through its output bias), so k shrinks (beam_search.py:323-327)
+    ("plain", "enc_T100", 8, 0.1, 0.3, 1.0),       # 7 of 8 finish within two steps, the survivor runs to 120 and wins
+    ("plain", "enc_T100", 16, 0.0, 1.5, 1.0),      # 12 finish
+    ("plain", "enc_T100", 16, 0.1, 0.3, 1.0),      # 10 finish
+    ("plain", "enc_T7", 4, 0.0, 0.3, 1.5),
+    ("plain", "enc_T7", 16, 0.1, 1.5, 1.5),        # 13 finish
+    ("simple", "enc_T7", 8, 0.0, 1.5, 1.0),        # all 8 finish at lengths 1..5: loop ends on k == 0, best ends in EOS
+    ("simple", "enc_T7", 8, 0.1, 1.5, 1.0),
+    ("simple", "enc_T7", 16, 0.0, 1.5, 1.0),       # all 16 finish
+    ("simple", "enc_T7", 16, 0.1, 1.5, 1.0),
+    ("plain", "enc_T100", 4, 0.0, 0.0, 3.0),       # EOS wins step 0: a one-token result
+    ("simple", "enc_T2", 8, 0.0, -0.2, 1.0),
+]
+
+
+def beam_loop_weights(g, eos_bias):
+    """Weight dicts of a beam-loop case: the committed decoder_step_<variant>.npz sets, EOS output bias raised."""
+    wd = {k[len("w_dec/"):]: np.array(g[k]) for k in g.files if k.startswith("w_dec/")}
+    wl = {k[len("w_lm/"):]: np.array(g[k]) for k in g.files if k.startswith("w_lm/")}
+    wd["model/rnn_decoder_char/rnn/OutputProjection/bias"][2] += np.float32(eos_bias)
+    return wd, wl
+
+
+def beam_loop_fixtures():
+    """(7) the reference's OWN BeamSearch.__call__ (beam_search.py:224-338) on the committed decoder_step weight sets:
+    token ids of the best hypothesis, its score, and how many hypotheses finished (the beam shrinks once per EOS)."""
+    Bunch, num_utils, basic_lstm, beam_search = _import_reference()
+    beam_search.np = _Py2NumpyProxy()
+    finished = []
+    out = {}
+    for ci, (variant, enc_key, k, lm_weight, wip, eos_bias) in enumerate(BEAM_LOOP_CASES):
+        g = np.load(os.path.join(OUT, "decoder_step_%s.npz" % variant))
+        wd, wl = beam_loop_weights(g, eos_bias)
+        bs = beam_search.BeamSearch.__new__(beam_search.BeamSearch)
+        bs.dec_params = bs.map_dec_variables(wd)
+        bs.lm_params = bs.map_lm_variables(wl)
+        bs.search_params = Bunch(beam_size=k, lm_weight=lm_weight, lm_path="", word_ins_penalty=wip, cov_penalty=0.0)
+        ids = np.asarray(bs(g[enc_key])).astype(np.int64)
+        tag = "case%02d_" % ci
+        out[tag + "ids"] = ids
+        out[tag + "variant"] = np.array(variant); out[tag + "enc_key"] = np.array(enc_key)
+        out[tag + "k"] = np.int64(k); out[tag + "lm_weight"] = np.float64(lm_weight)
+        out[tag + "word_ins_penalty"] = np.float64(wip); out[tag + "eos_bias"] = np.float64(eos_bias)
+        finished.append((ci, len(ids), int(ids[-1]) == 2))
+    out["n_cases"] = np.int64(len(BEAM_LOOP_CASES))
+    np.savez_compressed(os.path.join(OUT, "beam_loop.npz"), **out)
+    print("beam loop fixtures: (case, length, ends in EOS) =", finished)
+
+
 def make_decoder_weights(rng, E, H, lmH, D, A, V, simple):
     """Random float32 decoder weights keyed by TF variable name."""
     u = lambda *s: rng.uniform(-0.3, 0.3, s).astype(np.float32)
@@ -116,6 +203,9 @@ def main():
     text_fixtures()
     if "--text-only" in sys.argv:
         print("text fixtures written to", os.path.abspath(OUT))
+        return
+    if "--beam-only" in sys.argv:
+        beam_loop_fixtures()
         return
     Bunch, num_utils, basic_lstm, beam_search = _import_reference()
     rng = np.random.default_rng(20180201)
@@ -205,6 +295,7 @@ def main():
             out["greedy_lm%g_scores" % lm_weight] = np.asarray(scs)
         np.savez_compressed(
             os.path.join(OUT, "decoder_step_%s.npz" % ("simple" if simple else "plain")), **out)
+    beam_loop_fixtures()
     print("golden vectors written to", os.path.abspath(OUT))
 
 

@@ -16,3 +16,24 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def beam_loop_cases(golden_dir=GOLDEN):
+    """Cases of tests/golden/beam_loop.npz: outputs of the reference's OWN BeamSearch.__call__ (beam_search.py:224-338,
+    run by oracle/gen_golden.py).  Yields (id string, dict(enc, wd, wl, k, lm_weight, word_ins_penalty, ids))."""
+    import numpy as np
+    g = np.load(os.path.join(golden_dir, "beam_loop.npz"))
+    sets = {}
+    for ci in range(int(g["n_cases"])):
+        t = "case%02d_" % ci
+        variant, enc_key = str(g[t + "variant"]), str(g[t + "enc_key"])
+        if variant not in sets:
+            sets[variant] = np.load(os.path.join(golden_dir, "decoder_step_%s.npz" % variant))
+        w = sets[variant]
+        wd = {k[len("w_dec/"):]: np.array(w[k]) for k in w.files if k.startswith("w_dec/")}
+        wl = {k[len("w_lm/"):]: np.array(w[k]) for k in w.files if k.startswith("w_lm/")}
+        wd["model/rnn_decoder_char/rnn/OutputProjection/bias"][2] += np.float32(g[t + "eos_bias"])
+        case = dict(enc=w[enc_key], wd=wd, wl=wl, k=int(g[t + "k"]), lm_weight=float(g[t + "lm_weight"]),
+                    word_ins_penalty=float(g[t + "word_ins_penalty"]), ids=g[t + "ids"])
+        yield "%s-%s-k%d-lm%g-wip%g-eos%g" % (variant, enc_key, case["k"], case["lm_weight"], case["word_ins_penalty"],
+                                               float(g[t + "eos_bias"])), case

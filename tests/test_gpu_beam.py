@@ -67,3 +67,21 @@ def test_beam_device_selection_equals_host_scoring(golden_dir, monkeypatch, k, w
         monkeypatch.setenv("ASR_BEAM_HOST", "1")
         host_ids = bs(enc)
         np.testing.assert_array_equal(dev_ids, host_ids)
+
+
+def _beam_cases():
+    from conftest import beam_loop_cases
+    return [pytest.param(c, id=i) for i, c in beam_loop_cases()]
+
+
+@pytest.mark.parametrize("case", _beam_cases())
+def test_device_beam_search_equals_reference_beam_search_call(case):
+    """Device beam search (asr_beam_step + asr_beam_select) against token ids produced by the reference's OWN
+    BeamSearch.__call__ (beam_search.py:224-338; tests/golden/beam_loop.npz): bit-exact indices, k in {4,8,16},
+    lm_weight {0,0.1}, word_ins_penalty {0,0.3,-0.2,1.5}, including hypotheses that finish and shrink the beam."""
+    from e2e_asr_amd.beam_search import BeamSearch
+    sp = BeamSearch.class_params()
+    sp.beam_size = case["k"]; sp.lm_weight = case["lm_weight"]; sp.lm_path = case["wl"]
+    sp.word_ins_penalty = case["word_ins_penalty"]
+    got = BeamSearch(case["wd"], sp)(case["enc"])
+    np.testing.assert_array_equal(got, case["ids"])

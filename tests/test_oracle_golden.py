@@ -100,3 +100,27 @@ def test_tf_decoder_eval_equals_reference_greedy_chain(golden_dir, variant):
     lp = logits - np.log(np.exp(logits - logits.max(1, keepdims=True)).sum(1, keepdims=True)) \
         - logits.max(1, keepdims=True)
     np.testing.assert_allclose(lp[np.arange(n), toks], g["greedy_lm0_scores"], rtol=0, atol=1e-6)  # ref does enc.W_enc in f32
+
+
+def _beam_cases():
+    from conftest import beam_loop_cases
+    return [pytest.param(c, id=i) for i, c in beam_loop_cases()]
+
+
+@pytest.mark.parametrize("case", _beam_cases())
+def test_beam_loop_equals_reference_beam_search_call(case):
+    """The restated beam LOOP at k > 1 against token ids produced by the reference's own BeamSearch.__call__
+    (beam_search.py:224-338; oracle/gen_golden.py `beam_loop_fixtures`): word-insertion penalties of both signs, LM
+    fusion, and cases where hypotheses finish and the beam shrinks (down to k == 0)."""
+    got = O.beam_search(case["enc"], case["wd"], case["wl"], beam_size=case["k"], lm_weight=case["lm_weight"],
+                        word_ins_penalty=case["word_ins_penalty"])
+    np.testing.assert_array_equal(got, case["ids"])
+
+
+def test_beam_loop_fixtures_cover_finishing_hypotheses():
+    from conftest import beam_loop_cases
+    cases = [c for _, c in beam_loop_cases()]
+    assert len(cases) >= 15
+    assert any(c["ids"][-1] == 2 and 1 < len(c["ids"]) < 120 for c in cases)       # a finished hypothesis wins
+    assert {c["k"] for c in cases} >= {4, 8, 16}
+    assert {c["word_ins_penalty"] for c in cases} >= {0.0, 0.3, -0.2, 1.5}
