@@ -121,3 +121,9 @@ extern "C" int asr_side_join(void* stream) {
     }
     return ASR_OK;
 }
+// As asr_side_join for a THIRD stream (e.g. the stream a gradient exchange is launched from): `stream` waits for what the
+// side stream holds so far; the pending join stays pending, so the caller's own asr_side_join still orders everything.
+extern "C" int asr_side_wait(void* stream) {
+    if (asr::g_join && hipStreamWaitEvent(static_cast<hipStream_t>(stream), asr::g_join, 0) != hipSuccess) return ASR_ELAUNCH;
+    return ASR_OK;
+}

@@ -624,6 +624,12 @@ def keep_until_join(*objs):
     _keepalive.append(objs)
 
 
+def side_wait(stream):
+    """`stream` (a torch.cuda.Stream other than the current one) waits for the side-stream work queued so far; the pending
+    join is kept for the current stream's side_join() (parallel.py's tail overlap)."""
+    _check(_lib.lib().asr_side_wait(C.c_void_p(stream.cuda_stream)), "asr_side_wait")
+
+
 def side_join():
     """Order the library's side-stream work (weight/bias and LM-chain gradients) before the current
     stream; after it, buffers those kernels read may be released."""

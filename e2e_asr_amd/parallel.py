@@ -9,10 +9,21 @@ folded into the fused clip+Adam kernel.  Because loss = mean over utterances of 
 length-normalised cost (losses.py:32-35), equal shards make mean-of-means exact.
 
 xGMI is point-to-point (7 links x ~153 GB/s per GPU): a ring all-reduce is bound by ONE link,
-so fewer, larger messages win.  The flat fp32 gradient buffer (42.5 MB) is reduced in at most
-five contiguous buckets -- decoders, then encoder layers top-down -- each launched
-asynchronously as soon as its gradients are final, so the exchange hides under the encoder's
-backward-through-time.
+so fewer, larger messages win.  Default: ONE blocking all-reduce of the flat fp32 gradient buffer
+(42.5 MB) after backward.
+
+Overlap mode (`overlap=True` / ASR_DP_OVERLAP=1) obeys the rule every persistent kernel of this
+library needs (never a second resident, spinning kernel next to a persistent
+launch -- RCCL's channel kernels spin on their peers exactly as the recurrent kernels spin on their
+group, and two such kernels can starve each other's workgroup dispatch): no collective is ever in
+flight while a persistent kernel runs or can still be launched.  The only window of the backward
+pass without one is its TAIL: after the last (lowest-layer) BPTT, while that layer's weight-gradient
+GEMMs finish on the side stream.  So the buckets that are final by then -- decoders and every
+encoder layer above the lowest, ~93 % of the bytes at config 2 -- are all-reduced in that window,
+gated on (a) the main stream up to and including the last BPTT and (b) the side stream up to the
+second-lowest layer's weight gradients; the lowest layer's bucket follows after the side join.  The
+next step's first persistent kernel is ordered behind `all_reduce_grads` (the optimizer needs the
+sums), so nothing persistent can start while a collective is still running.
 """
 import torch
 import torch.distributed as dist
@@ -39,9 +50,9 @@ class TorchDistComm(object):
 class DataParallel(object):
     def __init__(self, model, process_group=None, overlap=None, comm=None, grad_dtype=None):
         """overlap=None reads ASR_DP_OVERLAP (default off): the default path is ONE blocking all-reduce of
-        the whole flat gradient after backward -- 42.5 MB, well under a millisecond of a >20 ms step,
-        and the simplest thing that is correct by construction.  overlap=True launches the per-bucket
-        all-reduces asynchronously under the encoder BPTT."""
+        the whole flat gradient after backward -- 42.5 MB, well under a millisecond of a ~9 ms step,
+        and the simplest thing that is correct by construction.  overlap=True all-reduces the buckets that
+        are final in the tail window of the backward pass (module docstring); never next to a persistent kernel."""
         import os
         if overlap is None:
             overlap = os.environ.get("ASR_DP_OVERLAP", "0") == "1"
@@ -56,8 +67,14 @@ class DataParallel(object):
         self.comm = TorchDistComm(process_group) if comm is None else comm
         self.world, self.rank = self.comm.world, self.comm.rank
         self.overlap = overlap
+        # world 1 normally skips the exchange; force_exchange (ASR_DP_FORCE_EXCHANGE=1) runs the collectives anyway, so that a
+        # one-GPU box can put real RCCL calls next to the persistent kernels (tests/test_gpu_dp_train.py)
+        self.force_exchange = os.environ.get("ASR_DP_FORCE_EXCHANGE", "0") == "1"
         self._pending = []
         self._done = set()
+        self._ready = []
+        self._reported = set()
+        self._xs = None            # stream the tail-window collectives are launched from (overlap mode, CUDA)
         self._n = model.variables.flat.numel()
         # identical initial weights everywhere (rank 0's), like a restored checkpoint
         self.comm.broadcast(model.variables.flat, src=0)
@@ -97,28 +114,69 @@ class DataParallel(object):
         order = [0] + sorted((k for k in groups if k > 0), reverse=True)
         return [(k, groups[k]) for k in order if k in groups]
 
+    def _exchange(self, flat_grad, lo, hi, async_op):
+        """All-reduce flat_grad[lo:hi] (bf16 on the wire when grad_bf16); returns the pending record."""
+        if self.grad_bf16:
+            half = flat_grad[lo:hi].to(torch.bfloat16)
+            return (self.comm.all_reduce(half, async_op=async_op), half, flat_grad[lo:hi])
+        return (self.comm.all_reduce(flat_grad[lo:hi], async_op=async_op), None, None)
+
     def grad_ready(self, key, flat_grad):
-        """Called by the model's backward when bucket `key` is final: launch its all-reduce."""
-        if not self.overlap or self.world == 1:
+        """Called by the model's backward when bucket `key` is final on the caller's + side streams: encoder layers
+        top-down (key = depth) as each layer's BPTT and weight-gradient GEMMs have been ENQUEUED, then key 0 after the side
+        join.  Overlap mode launches nothing until the lowest encoder layer reports (see the module docstring)."""
+        if not self.overlap or self.world == 1 and not self.force_exchange:
             return
-        if flat_grad.is_cuda:
-            from . import ops
-            ops.side_join()                  # weight gradients are produced on the side stream
+        if key in self._reported:
+            raise RuntimeError("gradient bucket %r reported ready twice in one step" % (key,))
+        self._reported.add(key)
+        lowest = min(k for k, _ in self.buckets if k > 0) if any(k > 0 for k, _ in self.buckets) else 0
+        cuda = flat_grad.is_cuda
+        if key > lowest:
+            # side-stream work queued so far = this layer's (and every earlier bucket's) weight gradients
+            self._ready.append(key)
+            if cuda:
+                from . import ops
+                if self._xs is None:
+                    self._xs = torch.cuda.Stream(device=flat_grad.device)
+                ops.side_wait(self._xs)
+            return
+        if key == lowest and key > 0:
+            # the last persistent kernel of the backward pass is enqueued on the caller's stream: open the tail window
+            if not self._ready:
+                return
+            ready = [0] + self._ready if any(k == 0 for k, _ in self.buckets) else list(self._ready)
+            if cuda:
+                main = torch.cuda.current_stream(flat_grad.device)
+                self._xs.wait_stream(main)                 # ... up to and including the lowest layer's BPTT
+                with torch.cuda.stream(self._xs):          # torch's process group orders the collective behind this stream
+                    for k, (lo, hi) in self.buckets:
+                        if k in ready:
+                            rec = self._exchange(flat_grad, lo, hi, True)
+                            if rec[1] is not None:
+                                rec[1].record_stream(main)
+                            self._pending.append(rec)
+            else:
+                for k, (lo, hi) in self.buckets:
+                    if k in ready:
+                        self._pending.append(self._exchange(flat_grad, lo, hi, True))
+            self._done.update(ready)
+            self._ready = []
+            return
+        # key 0 (or a model without encoder buckets): everything is final and joined on the caller's stream
         for k, (lo, hi) in self.buckets:
-            if k == key:
-                if k in self._done:
-                    raise RuntimeError("gradient bucket %r reduced twice in one step" % (k,))
-                if self.grad_bf16:
-                    half = flat_grad[lo:hi].to(torch.bfloat16)
-                    self._pending.append((self.comm.all_reduce(half, async_op=True), half, flat_grad[lo:hi]))
-                else:
-                    self._pending.append((self.comm.all_reduce(flat_grad[lo:hi], async_op=True), None, None))
+            if k not in self._done:
+                self._pending.append(self._exchange(flat_grad, lo, hi, True))
                 self._done.add(k)
+        self._ready = []
 
     def all_reduce_grads(self, flat_grad):
         """Finish the exchange; returns N so the caller scales by 1/N."""
-        if self.world > 1:
+        if self.world > 1 or self.force_exchange:
             if self._pending:
+                if self._xs is not None and flat_grad.is_cuda:
+                    # what was launched from the exchange stream (bf16 staging, a comm object that works eagerly) before the sums are read
+                    torch.cuda.current_stream(flat_grad.device).wait_stream(self._xs)
                 for w, half, dst in self._pending:
                     if w is not None:
                         w.wait()
@@ -133,7 +191,7 @@ class DataParallel(object):
                 flat_grad.copy_(half)
             else:
                 self.comm.all_reduce(flat_grad)
-        self._pending, self._done = [], set()
+        self._pending, self._done, self._ready, self._reported = [], set(), [], set()
         return self.world
 
     def all_reduce_scalar_mean(self, t):

@@ -91,7 +91,8 @@ class Seq2SeqModel(BaseParams):
             emb=dp.emb_size, hidden_dec=dp.hidden_size_dec, lm_hidden=dp.lm_hidden_size,
             attn_vec=dp.attention_vec_size, seed=seed, skip_step=ep.skip_step,
             max_scaling_down=ep.max_scaling_down, initial_res_fac=ep.initial_res_fac,
-            num_layers_dec=getattr(dp, "num_layers_dec", 1))
+            num_layers_dec=getattr(dp, "num_layers_dec", 1),
+            ind_softmax={t: bool(getattr(params.decoder_params[t], "ind_softmax", False)) for t in tasks})
         return VariableStore.from_arrays(arrays, device)
 
     def learning_rate_decay_op(self):
@@ -187,8 +188,8 @@ class Seq2SeqModel(BaseParams):
             if d not in d_states:
                 d_states[d] = torch.zeros_like(self.decoder[task].saved["enc"])
             self.decoder[task].backward(dlogits, d_states[d])
-        # the decoders' LM-chain gradients are still in flight on the library's side stream and
-        # overlap the encoder BPTT; encoder buckets all-reduce as they finish, the decoder bucket last
+        # the decoders' LM-chain gradients are still in flight on the library's side stream and overlap the encoder BPTT;
+        # data-parallel overlap mode all-reduces the finished buckets in the tail after the last BPTT (parallel.py)
         self.encoder.backward(d_states, on_layer_done=(
             (lambda depth: self.dist.grad_ready(depth, v.grad)) if self.dist is not None else None))
         ops.side_join()

@@ -52,13 +52,18 @@ def multi_cell_leaf(stack, layer, leaf):
 
 def init_weights(feat=80, hidden=256, bi_dir=True, depth=4, tasks=("char",), vocab=None,
                  emb=256, hidden_dec=256, lm_hidden=256, attn_vec=128, num_layers=None,
-                 seed=10, skip_step=2, max_scaling_down=8, initial_res_fac=1, num_layers_dec=1):
+                 seed=10, skip_step=2, max_scaling_down=8, initial_res_fac=1, num_layers_dec=1, ind_softmax=None):
     """Random-init weights of the reference architecture.
 
     Encoder kernels U(-0.075, 0.075) (encoder.py:74), biases 0 (BasicLSTMCell default),
     embedding U(-1,1) (decoder.py:97-99), everything else Glorot-uniform (TF default for
     get_variable with no initializer on scope 'model', train.py:184).  seed mirrors
     tf.set_random_seed(10) (train.py:169) in spirit; TF's RNG stream itself is not reproducible.
+
+    ind_softmax: {task: bool} (attn_decoder.py:119-125, flag 185-186).  For such a task the decoder's softmax lives in
+    `rnn/OutputProjection2/*`; `rnn/OutputProjection/*` next to it is what the char LM creates in the same scope
+    (lm_encoder.py:108-109) and what beam_search.py:75-76 reads -- it is created here too so that LMModel and
+    BeamSearch find it; without LM steps it receives zero gradients and Adam leaves it as initialised.
     """
     rng = np.random.default_rng(seed)
     vocab = vocab or {"char": 1000, "phone": 50}
@@ -71,6 +76,7 @@ def init_weights(feat=80, hidden=256, bi_dir=True, depth=4, tasks=("char",), voc
             w[enc_name(d, direction, "kernel", bi_dir)] = rng.uniform(
                 -0.075, 0.075, (in_dim + hidden, 4 * hidden)).astype(np.float32)
             w[enc_name(d, direction, "bias", bi_dir)] = np.zeros(4 * hidden, np.float32)
+    ind_tasks = []
     for task in tasks:
         V = vocab[task]
         H, lmH, E, A = hidden_dec, lm_hidden, emb, attn_vec
@@ -84,6 +90,8 @@ def init_weights(feat=80, hidden=256, bi_dir=True, depth=4, tasks=("char",), voc
         w[dec_name(task, "rnn/AttnProjection/bias")] = np.zeros(H, np.float32)
         w[dec_name(task, "rnn/OutputProjection/kernel")] = _glorot(rng, (H, V))
         w[dec_name(task, "rnn/OutputProjection/bias")] = np.zeros(V, np.float32)
+        if ind_softmax and ind_softmax.get(task):       # drawn AFTER every default variable: other seeds' streams unchanged
+            ind_tasks.append((task, H, V))
         if num_layers_dec <= 1:
             w[dec_name(task, "rnn/basic_lstm_cell/kernel")] = _glorot(rng, (E + lmH, 4 * lmH))
             w[dec_name(task, "rnn/basic_lstm_cell/bias")] = np.zeros(4 * lmH, np.float32)
@@ -101,6 +109,9 @@ def init_weights(feat=80, hidden=256, bi_dir=True, depth=4, tasks=("char",), voc
         if lmH != H:
             w[dec_name(task, "rnn/SimpleProjection/kernel")] = _glorot(rng, (lmH, H))
             w[dec_name(task, "rnn/SimpleProjection/bias")] = np.zeros(H, np.float32)
+    for task, H, V in ind_tasks:
+        w[dec_name(task, "rnn/OutputProjection2/kernel")] = _glorot(rng, (H, V))
+        w[dec_name(task, "rnn/OutputProjection2/bias")] = np.zeros(V, np.float32)
     return w
 
 

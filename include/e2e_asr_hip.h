@@ -311,6 +311,10 @@ int asr_beam_select(void* stream, const float* logits, const float* logits_lm, i
  * ordered against `stream` with events; legal under hipGraph capture).  asr_attn_decoder_bwd leaves
  * LM-chain gradient work in flight on it: call asr_side_join(stream) before reading the gradients. */
 int asr_side_join(void* stream);
+/* `stream` (a third stream, e.g. the one a gradient all-reduce is launched from) waits for the side-stream work queued so
+ * far; unlike asr_side_join the pending join is kept, so a later asr_side_join on the caller's stream still covers
+ * everything.  New (the reference is single-device): used by e2e_asr_amd/parallel.py's tail overlap. */
+int asr_side_wait(void* stream);
 /* Persistent decoder chain (csrc/decoder_chain.hip): used inside asr_attn_decoder_fwd when supported (Te <= 512).
  * asr_decoder_chain_rows: utterances per 16-workgroup group for this Te (2 up to 256 encoder positions, else 1). */
 int asr_decoder_chain_supported(int B, int Te, int D, int A, int H);

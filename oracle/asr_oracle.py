@@ -207,8 +207,12 @@ def dec_var(task, leaf):
     return "model/rnn_decoder_%s/%s" % (task, leaf)
 
 
-def decoder_weights(weights, task="char"):
-    """beam_search.py:53-98 -- name -> role mapping (AttnW squeezed to [D,A])."""
+def decoder_weights(weights, task="char", ind_softmax=False):
+    """beam_search.py:53-98 -- name -> role mapping (AttnW squeezed to [D,A]).
+    ind_softmax (attn_decoder.py:119-125): the TF-graph decoder's softmax is `rnn/OutputProjection2`, not the
+    `rnn/OutputProjection` it otherwise shares with the char LM (lm_encoder.py:108-109).  beam_search.py:75-76 reads
+    `OutputProjection` regardless, so beam search callers leave this False."""
+    out_scope = "rnn/OutputProjection2/" if ind_softmax else "rnn/OutputProjection/"
     g = lambda leaf: weights[dec_var(task, leaf)]
     opt = lambda leaf: weights.get(dec_var(task, leaf))
     multi = lambda stack, k, leaf: "rnn/multi_rnn_cell%s/cell_%d/basic_lstm_cell/%s" % ("" if stack == "lm" else "_1", k, leaf)
@@ -228,7 +232,7 @@ def decoder_weights(weights, task="char"):
         attn_dec_w=g("rnn/Attention/kernel"), attn_dec_b=g("rnn/Attention/bias"),
         inp_w=g("rnn/InputProjection/kernel"), inp_b=g("rnn/InputProjection/bias"),
         attn_proj_w=g("rnn/AttnProjection/kernel"), attn_proj_b=g("rnn/AttnProjection/bias"),
-        out_w=g("rnn/OutputProjection/kernel"), out_b=g("rnn/OutputProjection/bias"),
+        out_w=g(out_scope + "kernel"), out_b=g(out_scope + "bias"),
         simple_w=opt("rnn/SimpleProjection/kernel"), simple_b=opt("rnn/SimpleProjection/bias"),
         attn_enc_w=np.squeeze(g("AttnW")) if g("AttnW").ndim == 4 else g("AttnW"),
         attn_v=g("AttnV"), embedding=g("decoder/embedding"))
@@ -262,7 +266,7 @@ def cell_stack(x, states, stack, masks, step):
 
 def attn_decoder(dec_inp, seq_len, enc, seq_len_inp, weights, task="char",
                  is_training=False, samp_prob=0.0, lm_keep_masks=None,
-                 coin=None, sampler=None, return_aux=False, dec_keep_masks=None):
+                 coin=None, sampler=None, return_aux=False, dec_keep_masks=None, ind_softmax=False):
     """attn_decoder.py:37-172 driven by tf.nn.raw_rnn (:166).
 
     dec_inp [T_dec,B] ints; seq_len [B]; enc [B,Te,D]; seq_len_inp [B].
@@ -285,7 +289,7 @@ def attn_decoder(dec_inp, seq_len, enc, seq_len_inp, weights, task="char",
     (decoder.py:77-80); lm_keep_masks / dec_keep_masks are then lists over layers (the outer stack's masks act
     between its layers; the top layer's dropped output is discarded as before).
     """
-    p = decoder_weights(weights, task)
+    p = decoder_weights(weights, task, ind_softmax=ind_softmax)
     emb = p["embedding"]
     dt = enc.dtype
     seq_len = np.asarray(seq_len).astype(np.int64)

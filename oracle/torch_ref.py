@@ -86,7 +86,8 @@ def encoder(x_bm, seq_len, W, num_layers, bi_dir=True, skip_step=2, max_scaling_
     return att, lens
 
 
-def attn_decoder(dec_inp, seq_len, enc, seq_len_inp, W, task="char", lm_keep_masks=None, tokens=None, dec_keep_masks=None):
+def attn_decoder(dec_inp, seq_len, enc, seq_len_inp, W, task="char", lm_keep_masks=None, tokens=None, dec_keep_masks=None,
+                 ind_softmax=False):
     """attn_decoder.py:37-172 in training mode.  `tokens` [T_out,B]: the token actually fed
     at each step (teacher or sampled, taken from the product path so both follow one path).
     MultiRNNCell decoders (num_layers_dec > 1): stacks as in asr_oracle.cell_stack; the masks are then lists over layers."""
@@ -143,7 +144,8 @@ def attn_decoder(dec_inp, seq_len, enc, seq_len_inp, W, task="char", lm_keep_mas
         a = a / a.sum(1, keepdim=True)
         ctx = (a[:, :, None] * enc).sum(1)
         p = torch.cat((q, ctx), 1) @ g("rnn/AttnProjection/kernel") + g("rnn/AttnProjection/bias")
-        logits = p @ g("rnn/OutputProjection/kernel") + g("rnn/OutputProjection/bias")
+        osc = "rnn/OutputProjection2/" if ind_softmax else "rnn/OutputProjection/"       # attn_decoder.py:119-125
+        logits = p @ g(osc + "kernel") + g(osc + "bias")
         fb = fin[:, None]
         outs.append(torch.where(fb, torch.zeros_like(logits), logits))
         st = [(torch.where(fb, c0, c1), torch.where(fb, h0, h1)) for (c0, h0), (c1, h1) in zip(st, nst)]
@@ -162,8 +164,9 @@ def cross_entropy_loss(logits, targets, seq_len):
 
 
 def seq2seq_loss(batch, W, tasks=("char",), num_layers=None, bi_dir=True, avg=True, tokens=None,
-                 enc_keep_masks=None, lm_keep_masks=None, dec_keep_masks=None):
-    """seq2seq_model.py:88-144 in training mode -> (total_loss, {task: loss}, {task: logits})."""
+                 enc_keep_masks=None, lm_keep_masks=None, dec_keep_masks=None, ind_softmax=None):
+    """seq2seq_model.py:88-144 in training mode -> (total_loss, {task: loss}, {task: logits}).
+    ind_softmax: {task: bool} (attn_decoder.py:119-125)."""
     num_layers = num_layers or {"char": 4}
     x = torch.as_tensor(batch["logmel"])
     att, lens = encoder(x, batch["logmel_len"], W, {t: num_layers[t] for t in tasks}, bi_dir=bi_dir,
@@ -176,7 +179,8 @@ def seq2seq_loss(batch, W, tasks=("char",), num_layers=None, bi_dir=True, avg=Tr
         outs[task] = attn_decoder(dec_inp, dlen, att[d], lens[d], W, task,
                                   lm_keep_masks=None if lm_keep_masks is None else lm_keep_masks[task],
                                   tokens=None if tokens is None else tokens[task],
-                                  dec_keep_masks=None if dec_keep_masks is None else dec_keep_masks[task])
+                                  dec_keep_masks=None if dec_keep_masks is None else dec_keep_masks[task],
+                                  ind_softmax=bool(ind_softmax and ind_softmax.get(task)))
         T_out = int(dlen.max())
         losses[task] = cross_entropy_loss(outs[task], dec_inp[1:1 + T_out], dlen)
     total = sum(losses.values())

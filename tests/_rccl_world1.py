@@ -1,0 +1,65 @@
+"""Helper of tests/test_gpu_dp_train.py::test_rccl_world1_steps_with_and_without_overlap -- run as a child process.
+
+RCCL really initialised (backend "nccl", world size 1, 127.0.0.1) on the one GPU of the box; ASR_DP_FORCE_EXCHANGE=1 makes
+DataParallel issue its collectives although there is nobody to exchange with, so the real torch.distributed / RCCL calls
+(stream hand-over, async work handles, the exchange stream of the tail overlap) run next to the persistent kernels of a
+config-2-width train step.  A sum over one rank is the identity: weights must equal the plain model's."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", sys.argv[1] if len(sys.argv) > 1 else "29533")
+    os.environ["ASR_DP_FORCE_EXCHANGE"] = "1"
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    from e2e_asr_amd import ops
+    from e2e_asr_amd.attn_decoder import AttnDecoder
+    from e2e_asr_amd.parallel import DataParallel
+    from e2e_asr_amd.seq2seq_model import Seq2SeqModel
+    from e2e_asr_amd.weights import synthetic_batch
+
+    def params():
+        p = Seq2SeqModel.class_params()
+        p.num_layers = {"char": 4}; p.max_output = {"char": 30}
+        p.encoder_params.use_lstm = True; p.encoder_params.out_prob = 1.0
+        dp = AttnDecoder.class_params()
+        dp.out_prob_dec = 1.0; dp.samp_prob = 0.0; dp.vocab_size = 1000
+        p.decoder_params = {"char": dp}
+        return p
+    batches = [synthetic_batch(B=32, T=160 + 16 * i, F=80, t_dec=21, vocab=1000, variable_len=bool(i & 1), seed=100 + i)
+               for i in range(4)]
+    finals = {}
+    for mode in ("plain", "blocking", "overlap", "overlap_bf16"):
+        m = Seq2SeqModel(None, True, params(), device="cuda:0", feat_length=80, seed=6)
+        if mode != "plain":
+            d = DataParallel(m, overlap=mode.startswith("overlap"), grad_dtype="bf16" if mode.endswith("bf16") else "f32")
+            assert d.world == 1 and d.force_exchange and (d.overlap or mode == "blocking")
+        for b in batches:
+            m.step(b)
+        torch.cuda.synchronize()
+        ops.check_device_flag(dev)
+        finals[mode] = m.variables.flat.cpu().numpy()
+        assert np.isfinite(finals[mode]).all()
+    np.testing.assert_array_equal(finals["blocking"], finals["plain"])
+    np.testing.assert_array_equal(finals["overlap"], finals["plain"])
+    # bf16 on the wire: each gradient rounded to 8 bits once; four Adam steps stay within a few 1e-3 of the fp32 exchange
+    assert np.abs(finals["overlap_bf16"] - finals["plain"]).max() < 5e-3
+    t = torch.ones(1, device=dev)
+    dist.all_reduce(t)
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rccl world-1 ok")
+
+
+if __name__ == "__main__":
+    main()

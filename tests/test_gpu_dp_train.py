@@ -56,7 +56,7 @@ def test_two_rank_step_equals_one_global_batch_step(overlap):
     """Two half-batches through DataParallel (N = 2) must leave rank 0 with the weights of ONE step on the global batch:
     loss = mean over utterances of a length-normalised cost (losses.py:32-35), equal shards, sum of shard gradients
     scaled by 1/N inside the fused clip+Adam kernel, clip on the global-batch gradient.  overlap=True sends the
-    gradient in per-layer buckets as the encoder's backward finishes each layer."""
+    buckets that are final after the last BPTT in the tail window (from the exchange stream), the lowest layer's last."""
     from e2e_asr_amd import ops
     from e2e_asr_amd.parallel import DataParallel, shard_batch
     from e2e_asr_amd.seq2seq_model import Seq2SeqModel
@@ -92,6 +92,21 @@ def test_two_rank_step_equals_one_global_batch_step(overlap):
         np.testing.assert_allclose(np.sqrt(ranks[0]._gnorm_sq.item()) / 2.0, np.sqrt(single._gnorm_sq.item()), rtol=1e-4)
     assert ranks[0].global_step == single.global_step == 2
     assert ranks[0].rank_seed != ranks[1].rank_seed              # replicas draw their own dropout masks / sampler noise
+
+
+def test_rccl_world1_steps_with_and_without_overlap():
+    """RCCL itself next to the persistent kernels, as far as one GPU allows: a child process initialises the "nccl" backend at
+    world size 1 and runs config-2-width train steps plain, with the blocking exchange, with the tail overlap and with the
+    bf16 exchange (tests/_rccl_world1.py; ASR_DP_FORCE_EXCHANGE=1 issues the collectives although world == 1)."""
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "_rccl_world1.py"), str(port)], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0 and "rccl world-1 ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
 
 
 def test_bucket_overlap_falls_back_when_ranges_do_not_partition():

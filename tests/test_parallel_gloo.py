@@ -44,8 +44,8 @@ def _worker(rank, world, port, q, rank_mode='overlap'):
         st.ensure_grad()
         for name in st.names():
             st.grad_of(name).copy_(W[name].grad.float())
-        # bucketed async path: decoders first, then encoder layers top-down
-        dp.grad_ready(0, st.grad); dp.grad_ready(2, st.grad); dp.grad_ready(1, st.grad)
+        # the model's order (Seq2SeqModel.backward): encoder layers top-down as their BPTT is enqueued, key 0 after the join
+        dp.grad_ready(2, st.grad); dp.grad_ready(1, st.grad); dp.grad_ready(0, st.grad)
         n = dp.all_reduce_grads(st.grad)
         avg = {k: (st.grad_of(k) / n).numpy().copy() for k in st.names()}
         q.put((rank, st.to_arrays(), avg, [b for b in dp.buckets]))
