@@ -257,7 +257,7 @@ __global__ __launch_bounds__(512) void lstm_rec_bwd_kernel(LstmBwdArgs a) {
 // step; the four range partials meet in `sums` exactly where the VALU path's four DPP-row partials do.
 typedef __bf16 qbf16x8 __attribute__((ext_vector_type(8)));
 template <int H, int R, bool STAMP = false, bool MF = false>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(R == 1 ? 4 : 2, 8))) void lstm_rec_bwd_ag_kernel(LstmBwdArgs a) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 8))) void lstm_rec_bwd_ag_kernel(LstmBwdArgs a) {
     unsigned int stamp[5] = {0, 0, 0, 0, 0};
     unsigned long long tlast = STAMP ? __builtin_amdgcn_s_memtime() : 0;
 #define BPTT_STAMP(i) if (STAMP) { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); stamp[i] += (unsigned int)(t__ - tlast); tlast = t__; }

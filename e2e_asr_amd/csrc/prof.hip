@@ -2,6 +2,7 @@
 // (bench.py's roofline leg).  Disabled by default: zero overhead on the product path.
 #include "common.h"
 #include <cstdlib>
+#include <cstdio>
 #include <vector>
 
 namespace asr {
@@ -53,6 +54,11 @@ extern "C" int asr_prof_read(int tag, double* total_ms, int* launches) {
 // barrier, which is only safe when all those workgroups are resident at once: one 512-thread workgroup per compute unit
 // is guaranteed (each fits a CU's registers and LDS alone), so the budget is the CU count the runtime reports for the
 // current device -- 256 on an MI355X, fewer on a partitioned (CPX/DPX) or otherwise reduced device.
+// ASSUMPTION: the device is unmasked and owned by this process alone.  The attribute does not shrink under a CU mask
+// (HSA_CU_MASK / ROC_GLOBAL_CU_MASK) and knows nothing of another process's or stream's resident kernels; on such a device
+// set ASR_LSTM_MAXWG to the CUs really available, otherwise the only signal left is the 2-second exchange time-out.  A CU
+// mask found in the environment is refused outright below rather than trusted.  (Grid padding to whole octets of groups
+// adds workgroups that return at once, so a padded grid equal to the budget needs no more residency than the unpadded one.)
 // ---------------------------------------------------------------------------------------------
 namespace asr {
 int resident_wg_budget() {
@@ -65,9 +71,15 @@ int resident_wg_budget() {
         cus[dev] = n;
     }
     int budget = cus[dev];
-    // EXPERIMENT knob: count 2 resident workgroups per CU (true only for kernels of <= 128 VGPRs and <= 80 KB LDS)
-    if (const char* e = getenv("ASR_LSTM_WG_PER_CU")) { const int x = atoi(e); if (x == 2) budget *= 2; }
-    if (const char* e = getenv("ASR_LSTM_MAXWG")) { const int x = atoi(e); if (x > 0 && x < budget) budget = x; }
+    const char* maxwg = getenv("ASR_LSTM_MAXWG");
+    if (maxwg) { const int x = atoi(maxwg); if (x > 0 && x < budget) budget = x; }
+    else if (getenv("HSA_CU_MASK") || getenv("ROC_GLOBAL_CU_MASK")) {
+        // a CU mask the attribute does not reflect: without an explicit ASR_LSTM_MAXWG no persistent grid is known to fit
+        static bool warned = false;
+        if (!warned) { warned = true; fprintf(stderr, "e2e_asr_hip: a CU mask is set; give ASR_LSTM_MAXWG=<CUs available> "
+                                                      "(persistent kernels are refused until then)\n"); }
+        budget = 0;
+    }
     return budget;
 }
 }  // namespace asr

@@ -227,8 +227,12 @@ def _single_int_steps(fl):
     b = np.frombuffer(fl, dtype=np.uint8)
     s = np.asarray(starts, dtype=np.int64)
     L = b[s + 1].astype(np.int64)
+    # every entry must hold its 4 header bytes + 1 payload byte BEFORE any of them is gathered: a short or empty trailing
+    # Feature (e.g. `0A 00`, or a bytes-list step) passes the walk above and would index past the buffer below
+    if not ((L >= 4).all() and (L < 128).all()):
+        return None
     tag = b[s + 4]
-    if not ((b[s] == 0x0A).all() and (L < 128).all() and (L >= 4).all() and (b[s + 2] == 0x1A).all() and (b[s + 3] == L - 2).all()):
+    if not ((b[s] == 0x0A).all() and (b[s + 2] == 0x1A).all() and (b[s + 3] == L - 2).all()):
         return None
     if (tag == 0x0A).all():                     # packed
         if not (b[s + 5] == L - 4).all():

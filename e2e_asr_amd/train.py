@@ -112,7 +112,11 @@ class Train(BaseParams):
         """train.py:160-393.  (Wrapper: whatever way the loop ends, the reader threads it started are stopped.)"""
         self._open_prefetchers = []
         try:
-            return self._train(buck_train_sets, dev_set, lm_set, max_steps)
+            model = self._train(buck_train_sets, dev_set, lm_set, max_steps)
+            # whichever way the loop ended (max_steps, early stop, last epoch): a persistent-kernel time-out in the steps since
+            # the last periodic check must not leave with the returned model unnoticed
+            ops.check_device_flag(model.device)
+            return model
         finally:
             for pf in self._open_prefetchers:
                 pf.close()
@@ -217,7 +221,9 @@ class Train(BaseParams):
                     it = bucket_iter(active[0])
                     if len(active) > 1:
                         bucket_iter(active[1])
-                    elif carry is None and epoch < params.max_epochs:     # last bucket of the epoch: the next epoch's first one
+                    elif carry is None and epoch < params.max_epochs and len(buck_train_sets) > 1:
+                        # last bucket of the epoch: the next epoch's first one.  (Not with a single bucket: the carry would be a
+                        # second reader over the dataset this epoch is still iterating -- shared shuffle RNG, doubled parsing.)
                         carry_pf = DevicePrefetcher(buck_train_sets[0], self.device)     # fills its shuffle buffer meanwhile
                         self._open_prefetchers.append(carry_pf)                          # (0.74 -> 0.25 s per epoch change)
                         carry = carry_pf.primed()

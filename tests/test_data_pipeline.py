@@ -238,3 +238,20 @@ def test_uniform_feature_lists_parse_in_one_shot_and_irregular_ones_fall_back():
     # truncated / corrupted frame lists must not be mis-read by the stride shortcut
     fl = bytes(tfrecord._ld(1, tfrecord._enc_feature(frames[0])) + tfrecord._ld(1, tfrecord._enc_feature(frames[1][:79])))
     assert tfrecord._uniform_float_frames(memoryview(fl)) is None
+
+
+def test_int_step_shortcut_rejects_short_and_empty_trailing_features():
+    """tfrecord._single_int_steps gathers header bytes of every step at once: a feature list whose LAST step is an empty or
+    short Feature (`0A 00`, `0A 02 1A 00`) or a bytes list passes the entry walk and must fall back to the per-step parser
+    (None), never raise IndexError out of parse_sequence_example."""
+    from e2e_asr_amd import tfrecord
+    one = bytes(tfrecord._ld(1, tfrecord._enc_feature(np.array([7], np.int64))))
+    for tail in (b"\x0a\x00", b"\x0a\x02\x1a\x00", b"\x0a\x03\x1a\x01\x0a", bytes(tfrecord._ld(1, tfrecord._enc_feature([b"x"])))):
+        assert tfrecord._single_int_steps(memoryview(one + tail)) is None
+        assert tfrecord._single_int_steps(memoryview(tail)) is None
+    assert tfrecord._single_int_steps(memoryview(one + one))[:, 0].tolist() == [7, 7]
+    # through the public parser: an int list followed by an empty Feature step, and a bytes feature list
+    ex = tfrecord.make_sequence_example({"segment": [b"u"]}, {"cint": [np.array([3], np.int64), np.array([], np.int64)],
+                                                               "names": [[b"a"], [b""], [b"bcd"]]})
+    _, seq = tfrecord.parse_sequence_example(ex)
+    assert [list(map(int, x)) for x in seq["cint"]] == [[3], []] and seq["names"] == [[b"a"], [b""], [b"bcd"]]
