@@ -50,8 +50,9 @@ def main():
         ops.check_device_flag(dev)
         finals[mode] = m.variables.flat.cpu().numpy()
         assert np.isfinite(finals[mode]).all()
-    np.testing.assert_array_equal(finals["blocking"], finals["plain"])
-    np.testing.assert_array_equal(finals["overlap"], finals["plain"])
+    # (not bit-equal even plain vs plain: the split-K weight-gradient GEMMs sum their slices with float atomics)
+    assert np.abs(finals["blocking"] - finals["plain"]).max() < 2e-5
+    assert np.abs(finals["overlap"] - finals["plain"]).max() < 2e-5
     # bf16 on the wire: each gradient rounded to 8 bits once; four Adam steps stay within a few 1e-3 of the fp32 exchange
     assert np.abs(finals["overlap_bf16"] - finals["plain"]).max() < 5e-3
     t = torch.ones(1, device=dev)

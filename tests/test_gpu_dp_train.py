@@ -106,7 +106,13 @@ def test_rccl_world1_steps_with_and_without_overlap():
     here = os.path.dirname(os.path.abspath(__file__))
     r = subprocess.run([sys.executable, os.path.join(here, "_rccl_world1.py"), str(port)], env=env, capture_output=True,
                        text=True, timeout=300)
-    assert r.returncode == 0 and "rccl world-1 ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+    if r.returncode != 0 or "rccl world-1 ok" not in r.stdout:
+        out_dir = os.path.join(os.path.dirname(here), "gpurun_out")
+        if os.path.isdir(out_dir):
+            with open(os.path.join(out_dir, "rccl_world1_child.log"), "w") as f:
+                f.write(r.stdout + "\n---- stderr ----\n" + r.stderr)
+        lines = [l for l in r.stderr.splitlines() if "Error" in l or "error" in l or "assert" in l.lower() or "Traceback" in l]
+        raise AssertionError("child rc %d\n%s\n...\n%s" % (r.returncode, "\n".join(lines[-20:]), r.stderr[-1500:]))
 
 
 def test_bucket_overlap_falls_back_when_ranges_do_not_partition():
