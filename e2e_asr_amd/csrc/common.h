@@ -88,6 +88,36 @@ __device__ __forceinline__ float wave_allreduce_max(float v) {
 }
 
 
+// ---- packed fp32 FMA and half-wave exchange (version-2 recurrent kernels, csrc/lstm.hip / lstm_bwd.hip) ----
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// acc.lo += a.lo * b.{lo|hi}; acc.hi += a.hi * b.{lo|hi}: two fp32 FMAs per issue slot, bitwise the same as two v_fma_f32
+__device__ __forceinline__ void pk_fma_blo(f32x2& acc, f32x2 a, f32x2 b) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void pk_fma_bhi(f32x2& acc, f32x2 a, f32x2 b) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(a), "v"(b));
+}
+// acc.lo += a.{lo|hi} * b.lo; acc.hi += a.{lo|hi} * b.hi
+__device__ __forceinline__ void pk_fma_alo(f32x2& acc, f32x2 a, f32x2 b) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void pk_fma_ahi(f32x2& acc, f32x2 a, f32x2 b) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(a), "v"(b));
+}
+// lanes 32-63 of x <-> lanes 0-31 of y (v_permlane32_swap), then x + y: the lower half-wave ends with x summed over the two
+// halves, the upper half-wave with y summed over the two halves
+__device__ __forceinline__ float swap32_add(float x, float y) {
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    return __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+}
+
+// rows 1, 3 of x <-> rows 0, 2 of y (rows of 16 lanes; v_permlane16_swap), then x + y: even rows end with x summed over the
+// row pair, odd rows with y summed over the row pair
+__device__ __forceinline__ float swap16_add(float x, float y) {
+    const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    return __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+}
+
 // ---- same-XCD agreement (speed only; correctness never depends on placement) -------------------
 // Every workgroup of a group publishes its HW_REG_XCC_ID through the placement-independent sc1
 // protocol; if all G ids are equal the group's granules may be published with PLAIN stores: the line

@@ -325,6 +325,267 @@ __global__ __launch_bounds__(16 * HS) void lstm_rec_fwd_kernel(LstmRecArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Version 2 of the forward recurrence (round 3): one K-SLICE PER WAVE, consumed by SOURCE workgroup.
+//
+// The first kernel gathers all of h_{t-1} into LDS, barriers, and only then multiplies: every wave waits for the slowest
+// granule of the slowest peer, and the own workgroup's eighth of h (known locally, a full exchange round trip earlier) waits
+// with it.  Here wave w of a workgroup owns the 32 K-rows of K_h that belong to the units of ONE source workgroup
+// ((mem + w) % G; wave 0 = the own units) for all 128 gate columns of the workgroup.  A polling wave reads exactly the
+// granules its source's cell wave published with one store instruction (one 8-byte sc1 load per lane), passes them through a
+// wave-private LDS row (no barrier: LDS operations of one wave execute in order) and multiplies at once.  The cell wave
+// multiplies its own slice for the NEXT step right after publishing, in the shadow of the exchange.  ONE barrier per step
+// (partials complete), partials double-buffered by step parity; the cell thread sums the G partials in fixed order.
+// Lane map of the product: lane = 32*kh + u -- the four gate columns of unit u, K half kh (16 of the slice's 32 rows): 64
+// weight registers, and only 16 x R h values read from LDS per lane (every lane reading all 32 made the step LDS-bandwidth
+// bound: a broadcast ds_read_b128 still returns 1 KB).  The two K halves meet through v_permlane32_swap, which at the same
+// time turns (K half, unit) lanes into the cell's (row, unit) lanes: one 16-byte partial per cell thread.
+// The product runs on v_pk_fma_f32 (two fp32 FMAs per issue slot, bitwise two v_fma_f32; measured -11 % per step): with two
+// rows the pair is (row 0, row 1) x one weight, with one row (gate g, gate g+1) x one h value.
+// R*32 <= 64 (the cell is one wave): R in {1, 2}; larger batches per group keep the first kernel.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool poll_granule1(const u64* g, uint32_t epoch, float& val, int* err) {
+    long long t0 = 0;
+    for (uint32_t spins = 0;; ++spins) {
+        u64 x;
+        asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(x) : "v"(g) : "memory");
+        if ((uint32_t)(x >> 32) == epoch) { val = __uint_as_float((uint32_t)x); return true; }
+        ASR_POLL_BACKOFF();
+        if ((spins & 1023) == 1023) {
+            long long now = wall_clock64();
+            if (t0 == 0) t0 = now;
+            else if (now - t0 > 200000000LL) { *err = 13; val = 0.f; return false; }
+            if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { val = 0.f; return false; }
+        }
+    }
+}
+
+template <int H, int R, bool STAMP = false>
+__global__ __launch_bounds__(2 * H) void lstm_rec_fwd2_kernel(LstmRecArgs a) {
+    unsigned long long stamp[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long tlast = STAMP ? __builtin_amdgcn_s_memtime() : 0;
+    constexpr int HS = 32;
+    constexpr int NS = H / 32;         // K slices = waves = workgroups per group
+    constexpr int G = NS;
+    constexpr int NT = NS * 64;
+    constexpr int NCELL = R * HS;      // cell threads: the first NCELL lanes of wave 0
+    static_assert(R == 1 || R == 2, "the cell is one wave");
+    // wave-private staging of the slice's h values: K half kh at kh*HST; R = 2: (h[0][k], h[1][k]) pairs, padded so that the two
+    // halves' float4 reads fall into different banks; R = 1: 16 floats per half
+    constexpr int HST = R == 2 ? 36 : 16;
+    __shared__ __attribute__((aligned(16))) float hs[NS][2 * HST];
+    __shared__ __attribute__((aligned(16))) float4 part[2][NS][NCELL];     // partial pre-activations by step parity
+
+    __builtin_amdgcn_s_setprio(3);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int NG = (a.B + R - 1) / R;
+    const int ngroups = a.ND * NG;
+    int grp, mem;
+    if (((gridDim.x / G) & 7) == 0) {
+        mem = (blockIdx.x >> 3) % G;
+        grp = (blockIdx.x & 7) + 8 * (blockIdx.x / (8 * G));
+    } else {
+        grp = blockIdx.x / G; mem = blockIdx.x % G;
+    }
+    if (grp >= ngroups) return;
+    const int dir = grp / NG, bg = grp % NG;
+    const int r0 = bg * R;
+    const int H4 = 4 * H;
+    const int src_wg = (mem + wave) % G;           // whose units this wave multiplies (wave 0: the own ones)
+    const int u = lane & 31, kh = lane >> 5;       // product role: the four gates of unit u, K half kh of the slice
+
+    // R = 2: wp[k][p] = (gate 2p, gate 2p+1) of K row k;  R = 1: the same pairs (B operand as it is)
+    f32x2 wp[16][2];
+    {
+        const float* khp = a.kh[dir] + (size_t)(src_wg * 32 + kh * 16) * H4 + mem * HS + u;
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+#pragma unroll
+            for (int p2 = 0; p2 < 2; ++p2)
+                wp[k][p2] = f32x2{khp[(size_t)k * H4 + (2 * p2) * H], khp[(size_t)k * H4 + (2 * p2 + 1) * H]};
+    }
+    // where the h value (row r, K index k of the slice) is staged
+    auto hs_slot = [&](int r, int k) { return (k >> 4) * HST + (R == 2 ? 2 * (k & 15) + r : (k & 15)); };
+    int S = 0;
+    for (int r = 0; r < R; ++r) S = max(S, (r0 + r < a.B) ? min(a.len[r0 + r], a.T) : 0);
+
+    // cell role: wave 0, lane = cr*32 + cu
+    const bool cell_wave = wave == 0;
+    const bool cell = tid < NCELL;
+    const int cr = min(tid / HS, R - 1), cu = tid % HS;
+    const int cb = r0 + cr;
+    const int cj = mem * HS + cu;
+    const int clen = (cell && cb < a.B) ? min(a.len[cb], a.T) : 0;
+    const int cb_safe = min(cb, a.B - 1);
+    float c = 0.f, h = 0.f;
+    const bool has_init = a.h0 != nullptr;           // uniform
+    if (has_init && cell && cb < a.B) { h = a.h0[(size_t)cb * H + cj]; c = a.c0[(size_t)cb * H + cj]; }
+    u64* hxg = a.hx + (size_t)grp * 2 * R * H;
+    const bool fast = group_shares_xcd(a.xcc_slots + (size_t)grp * 16, G, mem, tid, a.err, nullptr, (uint32_t)a.ep0, 4);
+    float gx0 = 0.f, gx1 = 0.f, gx2 = 0.f, gx3 = 0.f;
+    auto prefetch = [&](int s) {
+        const int t = dir ? (clen - 1 - s) : s;
+        const int ts = min(max(t, 0), a.T - 1);
+        const float* gp_ = a.gates + (((size_t)cb_safe * a.sb + (size_t)ts * a.st) * a.ND + dir) * H4 + cj;
+        gx0 = gp_[0]; gx1 = gp_[H]; gx2 = gp_[2 * H]; gx3 = gp_[3 * H];
+    };
+    if (cell_wave) prefetch(0);
+
+    // this wave's slice of h (already in hs[wave]) times its weights -> the partial of the cell thread (row, unit)
+    auto slice_partial = [&](int par) {
+        const f32x4* hq = reinterpret_cast<const f32x4*>(&hs[wave][kh * HST]);
+        float4 out;
+        if constexpr (R == 2) {
+            f32x4 hall[8];               // all LDS reads in flight before the first FMA
+#pragma unroll
+            for (int k2 = 0; k2 < 8; ++k2) hall[k2] = hq[k2];
+            f32x2 pa[4] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};      // gate g: (row 0, row 1)
+#pragma unroll
+            for (int k2 = 0; k2 < 8; ++k2) {
+                const f32x4 hv = hall[k2];
+                const f32x2 h0 = __builtin_shufflevector(hv, hv, 0, 1), h1 = __builtin_shufflevector(hv, hv, 2, 3);
+                pk_fma_blo(pa[0], h0, wp[2 * k2][0]);
+                pk_fma_bhi(pa[1], h0, wp[2 * k2][0]);
+                pk_fma_blo(pa[2], h0, wp[2 * k2][1]);
+                pk_fma_bhi(pa[3], h0, wp[2 * k2][1]);
+                pk_fma_blo(pa[0], h1, wp[2 * k2 + 1][0]);
+                pk_fma_bhi(pa[1], h1, wp[2 * k2 + 1][0]);
+                pk_fma_blo(pa[2], h1, wp[2 * k2 + 1][1]);
+                pk_fma_bhi(pa[3], h1, wp[2 * k2 + 1][1]);
+            }
+            // K halves meet; lane (row = lane >> 5, unit) ends with the gate of ITS row
+            out = make_float4(swap32_add(pa[0].x, pa[0].y), swap32_add(pa[1].x, pa[1].y),
+                              swap32_add(pa[2].x, pa[2].y), swap32_add(pa[3].x, pa[3].y));
+        } else {
+            f32x4 hall[4];
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) hall[k4] = hq[k4];
+            f32x2 pa[2][2] = {{f32x2{0.f, 0.f}, f32x2{0.f, 0.f}}, {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}}};   // [gate pair][chain]
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) {
+                const f32x4 hv = hall[k4];
+                const f32x2 h0 = __builtin_shufflevector(hv, hv, 0, 1), h1 = __builtin_shufflevector(hv, hv, 2, 3);
+#pragma unroll
+                for (int p2 = 0; p2 < 2; ++p2) {
+                    pk_fma_alo(pa[p2][0], h0, wp[4 * k4 + 0][p2]);
+                    pk_fma_ahi(pa[p2][1], h0, wp[4 * k4 + 1][p2]);
+                    pk_fma_alo(pa[p2][0], h1, wp[4 * k4 + 2][p2]);
+                    pk_fma_ahi(pa[p2][1], h1, wp[4 * k4 + 3][p2]);
+                }
+            }
+            const f32x2 g01 = pa[0][0] + pa[0][1], g23 = pa[1][0] + pa[1][1];
+            out = make_float4(swap32_add(g01.x, g01.x), swap32_add(g01.y, g01.y), swap32_add(g23.x, g23.x), swap32_add(g23.y, g23.y));
+        }
+        if (lane < NCELL) part[par][wave][lane] = out;
+    };
+
+    if (has_init && S > 0) {          // partials of step 0 from the given initial state
+        if (lane < NCELL) {
+            const int r = lane >> 5;
+            hs[wave][hs_slot(r, lane & 31)] = (r0 + r < a.B) ? a.h0[(size_t)(r0 + r) * H + src_wg * 32 + (lane & 31)] : 0.f;
+        }
+        __builtin_amdgcn_wave_barrier();
+        slice_partial(0);
+    }
+
+    for (int s = 0; s < S; ++s) {
+        const bool live = cell && s < clen;
+        const int t = dir ? (clen - 1 - s) : s;
+        const int par = s & 1;
+        if (s > 0 || has_init) {
+            if (!cell_wave && s > 0) {
+                ASR_STAMP(0)
+                // h_{s-1} of the source's units: the 8-byte granules one store instruction of its cell wave published
+                if (lane < NCELL) {
+                    const int r = lane >> 5;
+                    float v = 0.f;
+                    if (r0 + r < a.B)
+                        poll_granule1(hxg + ((size_t)((s - 1) & 1) * R + r) * H + src_wg * 32 + (lane & 31), (uint32_t)(a.ep0 + s), v, a.err);
+                    hs[wave][hs_slot(r, lane & 31)] = v;
+                }
+                ASR_STAMP(1)
+                __builtin_amdgcn_wave_barrier();
+                slice_partial(par);
+                ASR_STAMP(2)
+            }
+            if (cell_wave) { ASR_STAMP(0) }
+            __syncthreads();          // all G partials of this step are in part[par]
+            if (cell_wave) { ASR_STAMP(1) } else { ASR_STAMP(3) }
+        }
+        if (cell_wave) {
+            float4 pre = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((s > 0 || has_init) && cell) {
+#pragma unroll
+                for (int ww = 0; ww < NS; ++ww) {
+                    const float4 p = part[par][ww][lane];
+                    pre.x += p.x; pre.y += p.y; pre.z += p.z; pre.w += p.w;
+                }
+            }
+            float gi = 0.f, gj = 0.f, gf = 0.f, go = 0.f, h_old = h, c_old = c;
+            if (live) {
+                gi = fast_sigmoid(pre.x + gx0);
+                gj = fast_tanh(pre.y + gx1);
+                gf = fast_sigmoid(pre.z + gx2 + 1.0f);   // forget bias
+                go = fast_sigmoid(pre.w + gx3);
+                c = c * gf + gi * gj;
+                h = go * fast_tanh(c);
+            }
+            const bool more = s + 1 < S;
+            if (cell && cb < a.B && more) {       // publish h_s FIRST: the critical path of every peer
+                u64* dst = hxg + ((size_t)(s & 1) * R + cr) * H + cj;
+                const u64 gv = ((u64)(uint32_t)(a.ep0 + s + 1) << 32) | __float_as_uint(h);
+                if (fast) asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(dst), "v"(gv) : "memory");
+                else __hip_atomic_store(dst, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            ASR_STAMP(2)
+            if (live) {       // bookkeeping stores, off the critical path
+                const size_t ridx = (((size_t)cb * a.sb + (size_t)t * a.st) * a.ND + dir) * H + cj;
+                float o = h;
+                if (a.keep < 1.0f)
+                    o *= keep_scale(a.seed, (uint32_t)((a.boff + cb) * a.dsb + (a.toff + t) * a.dst), (uint32_t)(dir * H + cj), a.keep);
+                a.out[((size_t)cb * a.osb + (size_t)t * a.ost) * a.ldo + dir * H + cj] = o;
+                if (a.hprev) a.hprev[ridx] = h_old;
+                if (a.act) {
+                    float4* rp = reinterpret_cast<float4*>(a.act + ridx * 8);
+                    rp[0] = make_float4(gi, gj, gf, go);
+                    rp[1] = make_float4(c, c_old, 0.f, 0.f);
+                }
+            }
+            if (more) {
+                prefetch(s + 1);
+                ASR_STAMP(3)
+                // the own units' slice for the next step, while the peers' values travel
+                if (cell) hs[0][hs_slot(cr, cu)] = (cb < a.B) ? h : 0.f;
+                __builtin_amdgcn_wave_barrier();
+                slice_partial(par ^ 1);
+                ASR_STAMP(4)
+            }
+        }
+    }
+    if (a.h_last && cell && cb < a.B) { a.h_last[(size_t)cb * H + cj] = h; a.c_last[(size_t)cb * H + cj] = c; }
+    if (STAMP && a.dbg && blockIdx.x == 0 && (tid == 0 || tid == 64)) {
+        unsigned long long* d = a.dbg + (tid == 0 ? 0 : 8);
+        for (int i = 0; i < 6; ++i) d[i] = stamp[i];
+        d[6] = (unsigned long long)S;
+    }
+    if (STAMP && a.dbg && blockIdx.x == 0 && lane == 0 && wave > 0) {       // every polling wave: exit->hit, product, barrier wait
+        a.dbg[16 + wave] = stamp[0] + stamp[1]; a.dbg[32 + wave] = stamp[2]; a.dbg[48 + wave] = stamp[3];
+    }
+    // zero output past each row's length (dynamic_rnn zero-fill; also the pyramid pad frame)
+    for (int r = 0; r < R; ++r) {
+        if (r0 + r >= a.B) break;
+        const int l = min(a.len[r0 + r], a.T);
+        const int nz = a.Tout - l;
+        for (int idx = tid; idx < nz * HS; idx += NT) {
+            const int tt = l + idx / HS, uu = idx % HS;
+            a.out[((size_t)(r0 + r) * a.osb + (size_t)tt * a.ost) * a.ldo + dir * H + mem * HS + uu] = 0.f;
+            if (a.hprev && tt < a.T)
+                a.hprev[(((size_t)(r0 + r) * a.sb + (size_t)tt * a.st) * a.ND + dir) * H + mem * HS + uu] = 0.f;
+        }
+    }
+}
+
 extern "C" int asr_get_gemm_precision(void);
 unsigned long long* g_lstm_dbg = nullptr;      // diagnostic stamp buffer (also read by decoder_chain_bwd.hip)
 extern "C" int asr_debug_set_buffer(void* p) { g_lstm_dbg = static_cast<unsigned long long*>(p); return ASR_OK; }
@@ -345,11 +606,20 @@ static int launch_rec(hipStream_t s, const LstmRecArgs& a0) {
     }
     // bf16 mode of the library (asr_set_gemm_precision(1)): recurrent product on the bf16 matrix pipe (H = 256 instantiation)
     static const bool mf_env = [] { const char* e = getenv("ASR_LSTM_MFMA"); return !(e && e[0] == '0'); }();
-    if (H == 256 && R == 2 && g_lstm_dbg && getenv("ASR_LSTM_STAMP"))
-        hipLaunchKernelGGL((lstm_rec_fwd_kernel<256, HS, 2, true>), dim3(grid), dim3(16 * HS), 0, s, a);
+    if (H == 256 && R == 2 && g_lstm_dbg && getenv("ASR_LSTM_STAMP")) {
+        const char* e2 = getenv("ASR_LSTM_V2");
+        if (e2 && e2[0] == '0') hipLaunchKernelGGL((lstm_rec_fwd_kernel<256, HS, 2, true>), dim3(grid), dim3(16 * HS), 0, s, a);
+        else hipLaunchKernelGGL((lstm_rec_fwd2_kernel<256, 2, true>), dim3(grid), dim3(512), 0, s, a);
+    }
     else if (H == 256 && mf_env && asr_get_gemm_precision() == 1)
         hipLaunchKernelGGL((lstm_rec_fwd_kernel<256, HS, R, false, true>), dim3(grid), dim3(16 * HS), 0, s, a);
-    else
+    else if constexpr (R <= 2 && H <= 256) {
+        // version 2 (slice per wave, one barrier per step) for groups of one or two rows (H = 512 would need 1024 threads at
+        // <= 128 VGPRs and spills); ASR_LSTM_V2=0 keeps version 1
+        static const bool v2 = [] { const char* e = getenv("ASR_LSTM_V2"); return !(e && e[0] == '0'); }();
+        if (v2) hipLaunchKernelGGL((lstm_rec_fwd2_kernel<H, R>), dim3(grid), dim3(2 * H), 0, s, a);
+        else hipLaunchKernelGGL((lstm_rec_fwd_kernel<H, HS, R>), dim3(grid), dim3(16 * HS), 0, s, a);
+    } else
     hipLaunchKernelGGL((lstm_rec_fwd_kernel<H, HS, R>), dim3(grid), dim3(16 * HS), 0, s, a);
     return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
 }

@@ -21,6 +21,7 @@
 // columns = 2 units x 4 gates) and each lane KG = H/32 output rows k, so the reduction over
 // columns is again 4 DPP butterflies.
 #include "common.h"
+#include "granule.h"
 #include <cstdlib>
 namespace asr { extern unsigned long long* g_lstm_dbg; }
 
@@ -548,6 +549,285 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Version 2 of the all-gather BPTT (round 3): one SOURCE SLICE PER WAVE, as csrc/lstm.hip's version 2 of the forward.
+//
+// Wave w (1 .. G-1) of a workgroup polls exactly the R x 32 tagged quads that the cell wave of source workgroup
+// (mem + w) % G published with one store instruction (one 16-byte sc1 load per lane), stages them in a wave-private LDS
+// region (no barrier) and contracts them at once with the K_h rows of the workgroup's own 32 units over that source's 128
+// gate positions; wave 0 is the cell wave and contracts the own slice for the NEXT step right after publishing; the last
+// wave is the loader of the first version (activation records one step ahead, operands of the pointwise backward handed
+// over through LDS).  ONE barrier per step; partial sums double-buffered by step parity, summed by the cell thread in fixed
+// order.  Lane map of the contraction: lane = 8*pq + ug -- units 4ug .. 4ug+3, positions 16pq .. 16pq+15 of the slice: 64 weight
+// registers and 16 x R dG values from LDS per lane (dG is 4H wide: with fewer positions per lane the LDS return path
+// binds), then a reduce-scatter over the 8 position groups inside the wave: one DPP row rotation, v_permlane16_swap and
+// v_permlane32_swap, after which every lane holds ONE finished (row, unit) value.  Products on v_pk_fma_f32 (two rows x one
+// weight, or with one row two units x one dG value).  R in {1, 2}.
+// ---------------------------------------------------------------------------------------------------------------
+template <int H, int R, bool STAMP = false>
+__global__ __launch_bounds__(2 * H + 64) void lstm_rec_bwd2_kernel(LstmBwdArgs a) {
+    unsigned int stamp[5] = {0, 0, 0, 0, 0};
+    unsigned long long tlast = STAMP ? __builtin_amdgcn_s_memtime() : 0;
+#define BPTT_STAMP(i) if (STAMP) { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); stamp[i] += (unsigned int)(t__ - tlast); tlast = t__; }
+    constexpr int HS = 32;
+    constexpr int NS = H / 32;         // source slices = contraction waves (wave 0: cell + own slice)
+    constexpr int G = NS;
+    constexpr int NT = NS * 64 + 64;   // + the loader wave
+    constexpr int N = 4 * H;
+    constexpr int NCELL = R * HS;
+    static_assert(R == 1 || R == 2, "the cell is one wave");
+    // staging of one slice's dG: position group pq (16 positions) at pq*DST; R = 2: (dG[0][p], dG[1][p]) pairs; padded so
+    // that the 8 groups' float4 reads fall into different banks
+    constexpr int DST = R == 2 ? 36 : 20;
+    __shared__ __attribute__((aligned(16))) float dgs[NS][8 * DST];
+    __shared__ __attribute__((aligned(16))) float part[2][NS][64];
+    __shared__ __attribute__((aligned(16))) float opnd[2][NCELL][8];
+
+    __builtin_amdgcn_s_setprio(3);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int NG = (a.B + R - 1) / R;
+    const int ngroups = a.ND * NG;
+    int grp, mem;
+    if (((gridDim.x / G) & 7) == 0) { mem = (blockIdx.x >> 3) % G; grp = (blockIdx.x & 7) + 8 * (blockIdx.x / (8 * G)); }
+    else { grp = blockIdx.x / G; mem = blockIdx.x % G; }
+    if (grp >= ngroups) return;
+    const int dir = grp / NG, bg = grp % NG;
+    const int r0 = bg * R;
+    const int H4 = 4 * H;
+    const int j0 = mem * HS;
+    const bool cell_wave = wave == 0;
+    const bool loader_wave = wave == NS;
+    const int src_wg = (mem + wave) % G;           // contraction waves: whose dG this wave consumes (wave 0: the own)
+    const int pq = lane >> 3, ug = lane & 7;
+
+    // K_h rows of units j0 + 4ug + i over positions 16pq + q of the slice (position = 4*unit + gate)
+    f32x2 wp[4][8];            // R = 2: wp[i][q/2] = (w[i][q], w[i][q+1]);  R = 1: wp[i/2 + 2*(q&1)][q/2] = (w[i][q], w[i+1][q]), see below
+    if (!loader_wave) {
+        const float* kh = a.kh[dir];
+        auto wv = [&](int i, int q) {
+            return kh[(size_t)(j0 + 4 * ug + i) * H4 + (q & 3) * H + src_wg * 32 + pq * 4 + (q >> 2)];
+        };
+        if constexpr (R == 2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int q2 = 0; q2 < 8; ++q2) wp[i][q2] = f32x2{wv(i, 2 * q2), wv(i, 2 * q2 + 1)};
+        } else {
+            // pairs over units: entry [2*(q & 1) + ip][q >> 1] = (w[2ip][q], w[2ip+1][q])
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+#pragma unroll
+                for (int ip = 0; ip < 2; ++ip) wp[2 * (q & 1) + ip][q >> 1] = f32x2{wv(2 * ip, q), wv(2 * ip + 1, q)};
+        }
+    }
+    int S = 0;
+    for (int r = 0; r < R; ++r) S = max(S, (r0 + r < a.B) ? min(a.len[r0 + r], a.T) : 0);
+    const bool cell = tid < NCELL;
+    const int cr = min(tid / HS, R - 1), cu = tid % HS;
+    const int cb = r0 + cr;
+    const int clen = (cell && cb < a.B) ? min(a.len[cb], a.T) : 0;
+    const int cj = j0 + cu;
+    float dc = 0.f;
+    float4 dbs = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint32_t* hxg = reinterpret_cast<uint32_t*>(a.hx) + (size_t)grp * 2 * R * N;      // [2 parities][R][N] tagged floats
+    const bool fast = group_shares_xcd(a.xcc_slots + (size_t)grp * 16, G, mem, tid, a.err, nullptr, 0, R == 1 ? 17 : 7);
+
+    // loader wave: lane l serves cell thread l
+    const int ll = lane;
+    const bool lact = loader_wave && ll < NCELL;
+    const int lcr = min(ll / HS, R - 1), lcu = ll % HS;
+    const int lcb = min(r0 + lcr, a.B - 1);
+    const int lclen = (lact && r0 + lcr < a.B) ? min(a.len[r0 + lcr], a.T) : 0;
+    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
+    float dout_v = 0.f;
+    auto prefetch = [&](int s) {
+        const int t = dir ? s : (lclen - 1 - s);
+        const int ts = min(max(t, 0), a.T - 1);
+        const float4* rp = reinterpret_cast<const float4*>(a.act + ((((size_t)lcb * a.sb + (size_t)ts * a.st) * a.ND + dir) * H + j0 + lcu) * 8);
+        ra = rp[0]; rb = rp[1];
+        dout_v = a.dout[((size_t)lcb * a.osb + (size_t)ts * a.ost) * a.ldo + dir * H + j0 + lcu];
+    };
+    auto hand_over = [&](int s) {
+        const int t = dir ? s : (lclen - 1 - s);
+        const float gi = ra.x, gj = ra.y, gf = ra.z, go = ra.w, cc = rb.x, cp = rb.y;
+        const float tc = fast_tanh(cc);
+        float dm = dout_v;
+        if (a.keep < 1.0f)
+            dm *= keep_scale(a.seed, (uint32_t)((a.boff + r0 + lcr) * a.dsb + t * a.dst), (uint32_t)(dir * H + j0 + lcu), a.keep);
+        float4* o = reinterpret_cast<float4*>(&opnd[s & 1][ll][0]);
+        o[0] = make_float4(dm, go * (1.f - tc * tc), gj * gi * (1.f - gi), gi * (1.f - gj * gj));
+        o[1] = make_float4(cp * gf * (1.f - gf), tc * go * (1.f - go), gf, 0.f);
+    };
+    if (lact) { prefetch(0); hand_over(0); if (S > 1) prefetch(1); }
+    __syncthreads();
+
+    // stage the quad (4 gates) of slice unit su, row r
+    auto stage = [&](int r, int su, float4 v) {
+        float* d = &dgs[wave][(su >> 2) * DST];
+        const int q = (su & 3) * 4;
+        if constexpr (R == 2) { d[2 * q + r] = v.x; d[2 * q + 2 + r] = v.y; d[2 * q + 4 + r] = v.z; d[2 * q + 6 + r] = v.w; }
+        else *reinterpret_cast<float4*>(d + q) = v;
+    };
+    // this wave's slice (already staged) against its weights -> partials of the own units' dh, one (row, unit) per lane
+    auto slice_partial = [&](int par) {
+        const f32x4* dq = reinterpret_cast<const f32x4*>(&dgs[wave][pq * DST]);
+        if constexpr (R == 2) {
+            f32x4 dall[8];
+#pragma unroll
+            for (int q2 = 0; q2 < 8; ++q2) dall[q2] = dq[q2];
+            f32x2 acc[4][2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i][0] = acc[i][1] = f32x2{0.f, 0.f};
+#pragma unroll
+            for (int q2 = 0; q2 < 8; ++q2) {
+                const f32x4 dv = dall[q2];
+                const f32x2 d0 = __builtin_shufflevector(dv, dv, 0, 1), d1 = __builtin_shufflevector(dv, dv, 2, 3);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { pk_fma_blo(acc[i][0], d0, wp[i][q2]); pk_fma_bhi(acc[i][1], d1, wp[i][q2]); }
+            }
+            float z[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f32x2 t2 = acc[i][0] + acc[i][1];
+                float x = t2.x, y = t2.y;                       // rows 0, 1 of unit i over this lane's 16 positions
+                x += dpp_mov<0x128>(x); y += dpp_mov<0x128>(y); // + the lane 8 further in the row of 16 (row_ror:8)
+                z[i] = swap16_add(x, y);                        // even rows of 16: row 0 of the group; odd rows: row 1
+            }
+            const float q0 = swap32_add(z[0], z[1]);            // lower half-wave: unit 0, upper: unit 1
+            const float q1 = swap32_add(z[2], z[3]);            //                  unit 2,        unit 3
+            const int b3 = (lane >> 3) & 1, b4 = (lane >> 4) & 1, b5 = lane >> 5;
+            part[par][wave][b4 * 32 + 4 * ug + 2 * b3 + b5] = b3 ? q1 : q0;
+        } else {
+            f32x4 dall[4];
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) dall[q4] = dq[q4];
+            f32x2 acc[2][2];       // [unit pair][chain]
+            acc[0][0] = acc[0][1] = acc[1][0] = acc[1][1] = f32x2{0.f, 0.f};
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const f32x4 dv = dall[q4];
+                const f32x2 d01 = __builtin_shufflevector(dv, dv, 0, 1), d23 = __builtin_shufflevector(dv, dv, 2, 3);
+#pragma unroll
+                for (int ip = 0; ip < 2; ++ip) {        // position q = 4q4 + e: weight entry [2*(q & 1) + ip][q >> 1]
+                    pk_fma_alo(acc[ip][0], d01, wp[ip][2 * q4]);
+                    pk_fma_ahi(acc[ip][1], d01, wp[2 + ip][2 * q4]);
+                    pk_fma_alo(acc[ip][0], d23, wp[ip][2 * q4 + 1]);
+                    pk_fma_ahi(acc[ip][1], d23, wp[2 + ip][2 * q4 + 1]);
+                }
+            }
+            float v[4];
+#pragma unroll
+            for (int ip = 0; ip < 2; ++ip) {
+                const f32x2 t2 = acc[ip][0] + acc[ip][1];
+                v[2 * ip] = t2.x + dpp_mov<0x128>(t2.x);
+                v[2 * ip + 1] = t2.y + dpp_mov<0x128>(t2.y);
+            }
+            const float z0 = swap16_add(v[0], v[1]);            // even rows: unit 0, odd rows: unit 1
+            const float z1 = swap16_add(v[2], v[3]);            //            unit 2,           unit 3
+            const float qq = swap32_add(z0, z1);                // lower half-wave keeps z0, upper z1
+            const int b3 = (lane >> 3) & 1, b4 = (lane >> 4) & 1, b5 = lane >> 5;
+            if (!b3) part[par][wave][4 * ug + 2 * b5 + b4] = qq;
+        }
+    };
+
+    for (int s = 0; s < S; ++s) {
+        const bool live = cell && s < clen;
+        const int t = dir ? s : (clen - 1 - s);
+        const int par = s & 1;
+        if (s > 0) {
+            if (loader_wave) {
+                if (lact) { hand_over(s); if (s + 1 < S) prefetch(s + 1); }
+            } else if (!cell_wave) {
+                BPTT_STAMP(0)
+                if (lane < NCELL) {
+                    const int r = lane >> 5, su = lane & 31;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (r0 + r < a.B)
+                        tagged_poll4(hxg + ((size_t)((s - 1) & 1) * R + r) * N + 4 * (src_wg * 32 + su), tag_bit(s - 1), v, a.err);
+                    stage(r, su, v);
+                }
+                BPTT_STAMP(1)
+                __builtin_amdgcn_wave_barrier();
+                slice_partial(par);
+                BPTT_STAMP(2)
+            }
+            if (cell_wave) { BPTT_STAMP(0) }
+            __syncthreads();
+            if (cell_wave) { BPTT_STAMP(1) } else if (!loader_wave) { BPTT_STAMP(3) }
+        }
+        if (cell_wave) {
+            float4 dg = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (cell) {
+                const float4 oa = *reinterpret_cast<const float4*>(&opnd[par][tid][0]);   // {dout*mask, A, Ki, Kj}
+                const float4 ob = *reinterpret_cast<const float4*>(&opnd[par][tid][4]);   // {Kf, Ko, f, -}
+                float dh = oa.x;
+                if (s > 0) {
+                    float rec = 0.f;
+#pragma unroll
+                    for (int ww = 0; ww < NS; ++ww) rec += part[par][ww][tid];
+                    dh += rec;
+                }
+                if (live) {
+                    const float dct = fmaf(dh, oa.y, dc);
+                    dg = make_float4(dct * oa.z, dct * oa.w, dct * ob.x, dh * ob.y);
+                    dc = dct * ob.z;
+                    dbs.x += dg.x; dbs.y += dg.y; dbs.z += dg.z; dbs.w += dg.w;      // bias gradient: sum of dG over time
+                }
+                // the value everyone (the owner included) consumes is the tagged, truncated one
+                const uint32_t tb = tag_bit(s);
+                typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
+                const u32x4s g0 = {(__float_as_uint(dg.x) & ~1u) | tb, (__float_as_uint(dg.y) & ~1u) | tb,
+                                   (__float_as_uint(dg.z) & ~1u) | tb, (__float_as_uint(dg.w) & ~1u) | tb};
+                if (cb < a.B && s + 1 < S) {       // publish dG_s of this unit FIRST: one tagged quad
+                    uint32_t* dst = hxg + ((size_t)par * R + cr) * N + 4 * cj;
+                    if (fast) asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(dst), "v"(g0) : "memory");
+                    else {
+                        __hip_atomic_store(dst + 0, g0.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(dst + 1, g0.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(dst + 2, g0.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(dst + 3, g0.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                BPTT_STAMP(2)
+                if (live) {       // bookkeeping, off the critical path
+                    float* gp = a.gates + (((size_t)cb * a.sb + (size_t)t * a.st) * a.ND + dir) * H4 + cj;
+                    gp[0] = dg.x; gp[H] = dg.y; gp[2 * H] = dg.z; gp[3 * H] = dg.w;
+                }
+                if (s + 1 < S)    // own slice of the next step's contraction: the truncated values the peers will read
+                    stage(cr, cu, make_float4(__uint_as_float(g0.x & ~1u), __uint_as_float(g0.y & ~1u),
+                                              __uint_as_float(g0.z & ~1u), __uint_as_float(g0.w & ~1u)));
+            }
+            if (s + 1 < S) {
+                BPTT_STAMP(3)
+                __builtin_amdgcn_wave_barrier();
+                slice_partial(par ^ 1);
+                BPTT_STAMP(4)
+            }
+        }
+    }
+    if (a.db_part && cell && cb < a.B) {        // one row per utterance and direction: summed over the batch by a tiny colsum
+        float* dp = a.db_part + ((size_t)(a.boff + cb) * a.ND + dir) * H4 + cj;
+        dp[0] = dbs.x; dp[H] = dbs.y; dp[2 * H] = dbs.z; dp[3 * H] = dbs.w;
+    }
+    if (STAMP && a.dbg && blockIdx.x == 0 && (tid == 0 || tid == 64)) {
+        for (int i = 0; i < 5; ++i) atomicAdd(a.dbg + 32 + (tid == 0 ? 0 : 8) + i, (unsigned long long)stamp[i]);
+        if (tid == 0) atomicAdd(a.dbg + 32 + 7, (unsigned long long)S);
+    }
+#undef BPTT_STAMP
+    // dG = 0 past each row's length (the weight/input GEMMs read every row)
+    for (int r = 0; r < R; ++r) {
+        if (r0 + r >= a.B) break;
+        const int l = min(a.len[r0 + r], a.T);
+        const int nz = a.T - l;
+        for (int idx = tid; idx < nz * 4 * HS; idx += NT) {
+            const int tt = l + idx / (4 * HS), q = idx % (4 * HS);
+            a.gates[(((size_t)(r0 + r) * a.sb + (size_t)tt * a.st) * a.ND + dir) * H4 + (q / HS) * H + j0 + (q % HS)] = 0.f;
+        }
+    }
+}
+
 }  // namespace asr
 extern "C" int asr_get_gemm_precision(void);
 int asr_lstm_max_wgs();
@@ -559,10 +839,16 @@ static int launch_bwd_h(hipStream_t s, const LstmBwdArgs& a, int R) {
     static const bool allgather = [] { const char* e = getenv("ASR_BPTT_AG"); return !(e && e[0] == '0'); }();
     if (allgather && R <= 2) {     // more rows per group: too many granule loads per polling thread -> reduce-scatter kernel
         static const bool mf_env = [] { const char* e = getenv("ASR_LSTM_MFMA"); return !(e && e[0] == '0'); }();
+        static const bool v2 = [] { const char* e = getenv("ASR_LSTM_V2"); return !(e && e[0] == '0'); }();
         if (H == 256 && mf_env && !a.dbg && asr_get_gemm_precision() == 1) {      // bf16 mode: contraction on the bf16 matrix pipe
             if (R == 1) hipLaunchKernelGGL((lstm_rec_bwd_ag_kernel<256, 1, false, true>), dim3(grid), dim3(512), 0, s, a);
             else hipLaunchKernelGGL((lstm_rec_bwd_ag_kernel<256, 2, false, true>), dim3(grid), dim3(512), 0, s, a);
         }
+        else if (H <= 256 && v2 && !a.dbg) {       // version 2: slice per wave, one barrier per step (ASR_LSTM_V2=0 keeps version 1)
+            if (R == 1) hipLaunchKernelGGL((lstm_rec_bwd2_kernel<(H <= 256 ? H : 256), 1>), dim3(grid), dim3(2 * H + 64), 0, s, a);
+            else hipLaunchKernelGGL((lstm_rec_bwd2_kernel<(H <= 256 ? H : 256), 2>), dim3(grid), dim3(2 * H + 64), 0, s, a);
+        }
+        else if (H == 256 && R == 2 && v2 && a.dbg) hipLaunchKernelGGL((lstm_rec_bwd2_kernel<256, 2, true>), dim3(grid), dim3(576), 0, s, a);
         else if (R == 1) hipLaunchKernelGGL((lstm_rec_bwd_ag_kernel<H, 1>), dim3(grid), dim3(512), 0, s, a);
         else if (H == 256 && a.dbg) hipLaunchKernelGGL((lstm_rec_bwd_ag_kernel<256, 2, true>), dim3(grid), dim3(512), 0, s, a);
         else hipLaunchKernelGGL((lstm_rec_bwd_ag_kernel<H, 2>), dim3(grid), dim3(512), 0, s, a);

@@ -12,15 +12,18 @@ dev = torch.device("cuda:0")
 dbg = torch.zeros(64, dtype=torch.int64, device=dev)
 _lib.lib().asr_debug_set_buffer(dbg.data_ptr())
 names = ["poll (gather dG)", "barrier 1", "matvec + DPP", "barrier 2", "cell + publish"]
+V1 = os.environ.get("ASR_LSTM_V2") == "0"
+names_cell = names if V1 else ["own slice -> barrier arrive", "barrier wait", "sum partials + cell + publish", "bookkeeping + own staging", "own slice contraction"]
+names_poll = names if V1 else ["barrier exit -> poll start", "poll until hit + staging", "contraction + reduce-scatter", "barrier wait", "-"]
 
 
 def report(tag):
     d = dbg.cpu().numpy()
     steps = float(d[32 + 7])
-    for who, off in (("cell wave (thread 0)", 32), ("polling wave (thread 511)", 40)):
+    for who, off, nm in (("cell wave (thread 0)", 32, names_cell), ("polling wave (thread 511; version 2: thread 64)", 40, names_poll)):
         v = d[off:off + 5].astype(float)
         print("%s, %s: %.0f cycles per step" % (tag, who, v.sum() / steps))
-        print("   " + "  ".join("%s %.0f" % (n, x / steps) for n, x in zip(names, v)))
+        print("   " + "  ".join("%s %.0f" % (n, x / steps) for n, x in zip(nm, v)))
 
 
 # (a) alone: one BiLSTM layer, B=32, T=400
