@@ -545,11 +545,12 @@ __global__ __launch_bounds__(2 * H) void lstm_rec_fwd2_kernel(LstmRecArgs a) {
                 if (a.keep < 1.0f)
                     o *= keep_scale(a.seed, (uint32_t)((a.boff + cb) * a.dsb + (a.toff + t) * a.dst), (uint32_t)(dir * H + cj), a.keep);
                 a.out[((size_t)cb * a.osb + (size_t)t * a.ost) * a.ldo + dir * H + cj] = o;
-                if (a.hprev) a.hprev[ridx] = h_old;
+                // saved for the backward pass, not read again before it: streaming stores (measured -0.05 us per step)
+                if (a.hprev) __builtin_nontemporal_store(h_old, a.hprev + ridx);
                 if (a.act) {
-                    float4* rp = reinterpret_cast<float4*>(a.act + ridx * 8);
-                    rp[0] = make_float4(gi, gj, gf, go);
-                    rp[1] = make_float4(c, c_old, 0.f, 0.f);
+                    f32x4* rp = reinterpret_cast<f32x4*>(a.act + ridx * 8);
+                    __builtin_nontemporal_store(f32x4{gi, gj, gf, go}, rp);
+                    __builtin_nontemporal_store(f32x4{c, c_old, 0.f, 0.f}, rp + 1);
                 }
             }
             if (more) {

@@ -21,7 +21,7 @@ names = ["prefetch", "poll+lds-write", "barrier1", "matvec+dpp+sums", "barrier2"
 roles = (("cell wave (tid 0)", 0, names), ("polling wave (last tid)", 8, names))
 if not v1:       # version 2 (slice per wave): stamps of tid 0 (cell wave) and tid 64 (first polling wave)
     roles = (("cell wave (tid 0)", 0, ["own slice -> barrier arrive", "barrier wait", "sum partials + cell + publish", "bookkeeping + prefetch",
-                                       "own slice matvec", "-"]),
+                                       "own slice matvec", "(one stamp, back to back)"]),
              ("polling wave 1 (tid 64)", 8, ["barrier exit -> poll start", "poll until hit + lds write", "lds hop + matvec + swap + write",
                                              "barrier wait", "-", "-"]))
 for who, off, nm in roles:
