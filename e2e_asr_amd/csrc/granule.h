@@ -83,23 +83,4 @@ __device__ __forceinline__ bool tagged_poll4(const uint32_t* g, uint32_t tb, flo
     }
 }
 
-// ---- LDS-DMA loads for a prefetch ring: no register destination (a destination written after the asm statement ended would be
-// invisible to the compiler), exact vmcnt counts by the caller (vm_wait<N>), wave-uniform LDS base in M0 + lane * size.
-// EVERY wave that used them must vm_wait<0>() before it ends: a straggler would land in the next workgroup's LDS.
-__device__ __forceinline__ void glds4(const void* gsrc, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-template <int N>
-__device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N) : "memory"); }
-__device__ __forceinline__ unsigned lds_addr(const void* p) {      // wave-uniform LDS byte address for M0
-    return __builtin_amdgcn_readfirstlane((unsigned)(size_t)p);
-}
-
 }  // namespace asr

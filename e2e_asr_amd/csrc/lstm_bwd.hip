@@ -556,29 +556,24 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
 // Wave w (1 .. G-1) of a workgroup polls exactly the R x 32 tagged quads that the cell wave of source workgroup
 // (mem + w) % G published with one store instruction (one 16-byte sc1 load per lane), stages them in a wave-private LDS
 // region (no barrier) and contracts them at once with the K_h rows of the workgroup's own 32 units over that source's 128
-// gate positions; wave 0 is the cell wave and contracts the own slice for the NEXT step right after publishing.  ONE barrier
-// per step; partial sums double-buffered by step parity, summed by the cell thread in fixed order.
-// Lane map of the contraction: lane = 8*pq + ug -- units 4ug .. 4ug+3, positions 16pq .. 16pq+15 of the slice: 64 weight
+// gate positions; wave 0 is the cell wave and contracts the own slice for the NEXT step right after publishing; the last
+// wave is the loader of the first version (activation records one step ahead, operands of the pointwise backward handed
+// over through LDS).  ONE barrier per step; partial sums double-buffered by step parity, summed by the cell thread in fixed
+// order.  Lane map of the contraction: lane = 8*pq + ug -- units 4ug .. 4ug+3, positions 16pq .. 16pq+15 of the slice: 64 weight
 // registers and 16 x R dG values from LDS per lane (dG is 4H wide: with fewer positions per lane the LDS return path
 // binds), then a reduce-scatter over the 8 position groups inside the wave: one DPP row rotation, v_permlane16_swap and
 // v_permlane32_swap, after which every lane holds ONE finished (row, unit) value.  Products on v_pk_fma_f32 (two rows x one
 // weight, or with one row two units x one dG value).  R in {1, 2}.
-// No loader wave: the cell wave prefetches the activation record and dout of step s+2 by LDS-DMA (no register
-// destinations) into a ring of three slots right after publishing, and forms the operands of step s+1's pointwise backward
-// (everything that does not depend on dh / dc) after its own slice, behind a COUNTED wait -- vmcnt(3) leaves exactly the three
-// youngest loads in flight, so the wave never drains its queue in the critical part of a step.  Eight waves at <= 160
-// registers leave each SIMD 184 free: one workgroup of the side stream's weight-gradient GEMMs fits next to the recurrence
-// (with nine waves at 162 nothing did, and the GEMMs of a whole layer ran AFTER the last BPTT: 0.64 ms of exposed tail).
 // ---------------------------------------------------------------------------------------------------------------
 template <int H, int R, bool STAMP = false>
-__global__ __launch_bounds__(2 * H) void lstm_rec_bwd2_kernel(LstmBwdArgs a) {
+__global__ __launch_bounds__(2 * H + 64) void lstm_rec_bwd2_kernel(LstmBwdArgs a) {
     unsigned int stamp[5] = {0, 0, 0, 0, 0};
     unsigned long long tlast = STAMP ? __builtin_amdgcn_s_memtime() : 0;
 #define BPTT_STAMP(i) if (STAMP) { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); stamp[i] += (unsigned int)(t__ - tlast); tlast = t__; }
     constexpr int HS = 32;
-    constexpr int NS = H / 32;         // source slices = waves (wave 0: cell + own slice)
+    constexpr int NS = H / 32;         // source slices = contraction waves (wave 0: cell + own slice)
     constexpr int G = NS;
-    constexpr int NT = NS * 64;
+    constexpr int NT = NS * 64 + 64;   // + the loader wave
     constexpr int N = 4 * H;
     constexpr int NCELL = R * HS;
     static_assert(R == 1 || R == 2, "the cell is one wave");
@@ -587,10 +582,7 @@ __global__ __launch_bounds__(2 * H) void lstm_rec_bwd2_kernel(LstmBwdArgs a) {
     constexpr int DST = R == 2 ? 36 : 20;
     __shared__ __attribute__((aligned(16))) float dgs[NS][8 * DST];
     __shared__ __attribute__((aligned(16))) float part[2][NS][64];
-    // the cell wave's prefetch ring (LDS-DMA): activation record {i,j,f,o | c, c_prev, -, -} and dout of step s in slot s % 3
-    __shared__ __attribute__((aligned(16))) float4 ringa[3][64];
-    __shared__ __attribute__((aligned(16))) float4 ringb[3][64];
-    __shared__ __attribute__((aligned(16))) float ringd[3][64];
+    __shared__ __attribute__((aligned(16))) float opnd[2][NCELL][8];
 
     __builtin_amdgcn_s_setprio(3);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -606,12 +598,13 @@ __global__ __launch_bounds__(2 * H) void lstm_rec_bwd2_kernel(LstmBwdArgs a) {
     const int H4 = 4 * H;
     const int j0 = mem * HS;
     const bool cell_wave = wave == 0;
-    const int src_wg = (mem + wave) % G;           // whose dG this wave consumes (wave 0: the own)
+    const bool loader_wave = wave == NS;
+    const int src_wg = (mem + wave) % G;           // contraction waves: whose dG this wave consumes (wave 0: the own)
     const int pq = lane >> 3, ug = lane & 7;
 
     // K_h rows of units j0 + 4ug + i over positions 16pq + q of the slice (position = 4*unit + gate)
-    f32x2 wp[4][8];            // R = 2: wp[i][q/2] = (w[i][q], w[i][q+1]);  R = 1: wp[2*(q & 1) + ip][q >> 1] = (w[2ip][q], w[2ip+1][q])
-    {
+    f32x2 wp[4][8];            // R = 2: wp[i][q/2] = (w[i][q], w[i][q+1]);  R = 1: wp[i/2 + 2*(q&1)][q/2] = (w[i][q], w[i+1][q]), see below
+    if (!loader_wave) {
         const float* kh = a.kh[dir];
         auto wv = [&](int i, int q) {
             return kh[(size_t)(j0 + 4 * ug + i) * H4 + (q & 3) * H + src_wg * 32 + pq * 4 + (q >> 2)];
@@ -622,6 +615,7 @@ __global__ __launch_bounds__(2 * H) void lstm_rec_bwd2_kernel(LstmBwdArgs a) {
 #pragma unroll
                 for (int q2 = 0; q2 < 8; ++q2) wp[i][q2] = f32x2{wv(i, 2 * q2), wv(i, 2 * q2 + 1)};
         } else {
+            // pairs over units: entry [2*(q & 1) + ip][q >> 1] = (w[2ip][q], w[2ip+1][q])
 #pragma unroll
             for (int q = 0; q < 16; ++q)
 #pragma unroll
@@ -633,7 +627,6 @@ __global__ __launch_bounds__(2 * H) void lstm_rec_bwd2_kernel(LstmBwdArgs a) {
     const bool cell = tid < NCELL;
     const int cr = min(tid / HS, R - 1), cu = tid % HS;
     const int cb = r0 + cr;
-    const int cb_safe = min(cb, a.B - 1);
     const int clen = (cell && cb < a.B) ? min(a.len[cb], a.T) : 0;
     const int cj = j0 + cu;
     float dc = 0.f;
@@ -641,36 +634,34 @@ __global__ __launch_bounds__(2 * H) void lstm_rec_bwd2_kernel(LstmBwdArgs a) {
     uint32_t* hxg = reinterpret_cast<uint32_t*>(a.hx) + (size_t)grp * 2 * R * N;      // [2 parities][R][N] tagged floats
     const bool fast = group_shares_xcd(a.xcc_slots + (size_t)grp * 16, G, mem, tid, a.err, nullptr, 0, R == 1 ? 17 : 7);
 
-    // cell wave: three LDS-DMA loads of step s into ring slot s % 3
+    // loader wave: lane l serves cell thread l
+    const int ll = lane;
+    const bool lact = loader_wave && ll < NCELL;
+    const int lcr = min(ll / HS, R - 1), lcu = ll % HS;
+    const int lcb = min(r0 + lcr, a.B - 1);
+    const int lclen = (lact && r0 + lcr < a.B) ? min(a.len[r0 + lcr], a.T) : 0;
+    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
+    float dout_v = 0.f;
     auto prefetch = [&](int s) {
-        const int t = dir ? s : (clen - 1 - s);
+        const int t = dir ? s : (lclen - 1 - s);
         const int ts = min(max(t, 0), a.T - 1);
-        const float4* rp = reinterpret_cast<const float4*>(a.act + ((((size_t)cb_safe * a.sb + (size_t)ts * a.st) * a.ND + dir) * H + cj) * 8);
-        const int slot = s % 3;
-        glds16(rp, lds_addr(&ringa[slot][0]));
-        glds16(rp + 1, lds_addr(&ringb[slot][0]));
-        glds4(a.dout + ((size_t)cb_safe * a.osb + (size_t)ts * a.ost) * a.ldo + dir * H + cj, lds_addr(&ringd[slot][0]));
+        const float4* rp = reinterpret_cast<const float4*>(a.act + ((((size_t)lcb * a.sb + (size_t)ts * a.st) * a.ND + dir) * H + j0 + lcu) * 8);
+        ra = rp[0]; rb = rp[1];
+        dout_v = a.dout[((size_t)lcb * a.osb + (size_t)ts * a.ost) * a.ldo + dir * H + j0 + lcu];
     };
-    // Everything of the pointwise backward of step s that does not depend on dh / dc, from the ring, into registers:
-    //   dct = dc + dh*A;  dG = {dct*Ki, dct*Kj, dct*Kf, dh*Ko};  dc' = dct*f   with dh = dout*mask + recurrent part
-    float4 oa = make_float4(0.f, 0.f, 0.f, 0.f), ob = oa;      // {dout*mask, A, Ki, Kj}, {Kf, Ko, f, -}
-    auto operands = [&](int s) {
-        const int t = dir ? s : (clen - 1 - s);
-        const int slot = s % 3;
-        const float4 ra = ringa[slot][lane], rb = ringb[slot][lane];
+    auto hand_over = [&](int s) {
+        const int t = dir ? s : (lclen - 1 - s);
         const float gi = ra.x, gj = ra.y, gf = ra.z, go = ra.w, cc = rb.x, cp = rb.y;
         const float tc = fast_tanh(cc);
-        float dm = ringd[slot][lane];
+        float dm = dout_v;
         if (a.keep < 1.0f)
-            dm *= keep_scale(a.seed, (uint32_t)((a.boff + cb) * a.dsb + t * a.dst), (uint32_t)(dir * H + cj), a.keep);
-        oa = make_float4(dm, go * (1.f - tc * tc), gj * gi * (1.f - gi), gi * (1.f - gj * gj));
-        ob = make_float4(cp * gf * (1.f - gf), tc * go * (1.f - go), gf, 0.f);
+            dm *= keep_scale(a.seed, (uint32_t)((a.boff + r0 + lcr) * a.dsb + t * a.dst), (uint32_t)(dir * H + j0 + lcu), a.keep);
+        float4* o = reinterpret_cast<float4*>(&opnd[s & 1][ll][0]);
+        o[0] = make_float4(dm, go * (1.f - tc * tc), gj * gi * (1.f - gi), gi * (1.f - gj * gj));
+        o[1] = make_float4(cp * gf * (1.f - gf), tc * go * (1.f - go), gf, 0.f);
     };
-    if (cell_wave) {
-        if (cell && S > 0) { prefetch(0); if (S > 1) prefetch(1); }
-        if (S > 1) vm_wait<3>(); else vm_wait<0>();
-        if (cell && S > 0) operands(0);
-    }
+    if (lact) { prefetch(0); hand_over(0); if (S > 1) prefetch(1); }
+    __syncthreads();
 
     // stage the quad (4 gates) of slice unit su, row r
     auto stage = [&](int r, int su, float4 v) {
@@ -683,29 +674,23 @@ __global__ __launch_bounds__(2 * H) void lstm_rec_bwd2_kernel(LstmBwdArgs a) {
     auto slice_partial = [&](int par) {
         const f32x4* dq = reinterpret_cast<const f32x4*>(&dgs[wave][pq * DST]);
         if constexpr (R == 2) {
-            f32x4 dall[8];             // two batches of four reads in flight
+            f32x4 dall[8];
 #pragma unroll
-            for (int q2 = 0; q2 < 4; ++q2) dall[q2] = dq[q2];
-            f32x2 acc[4];              // four chains, revisited every fourth instruction (a second set would cost 8 registers)
+            for (int q2 = 0; q2 < 8; ++q2) dall[q2] = dq[q2];
+            f32x2 acc[4][2];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i] = f32x2{0.f, 0.f};
+            for (int i = 0; i < 4; ++i) acc[i][0] = acc[i][1] = f32x2{0.f, 0.f};
 #pragma unroll
             for (int q2 = 0; q2 < 8; ++q2) {
-                if (q2 == 2) {
-#pragma unroll
-                    for (int j = 4; j < 8; ++j) dall[j] = dq[j];
-                }
                 const f32x4 dv = dall[q2];
                 const f32x2 d0 = __builtin_shufflevector(dv, dv, 0, 1), d1 = __builtin_shufflevector(dv, dv, 2, 3);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) pk_fma_blo(acc[i], d0, wp[i][q2]);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) pk_fma_bhi(acc[i], d1, wp[i][q2]);
+                for (int i = 0; i < 4; ++i) { pk_fma_blo(acc[i][0], d0, wp[i][q2]); pk_fma_bhi(acc[i][1], d1, wp[i][q2]); }
             }
             float z[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const f32x2 t2 = acc[i];
+                const f32x2 t2 = acc[i][0] + acc[i][1];
                 float x = t2.x, y = t2.y;                       // rows 0, 1 of unit i over this lane's 16 positions
                 x += dpp_mov<0x128>(x); y += dpp_mov<0x128>(y); // + the lane 8 further in the row of 16 (row_ror:8)
                 z[i] = swap16_add(x, y);                        // even rows of 16: row 0 of the group; odd rows: row 1
@@ -752,7 +737,9 @@ __global__ __launch_bounds__(2 * H) void lstm_rec_bwd2_kernel(LstmBwdArgs a) {
         const int t = dir ? s : (clen - 1 - s);
         const int par = s & 1;
         if (s > 0) {
-            if (!cell_wave) {
+            if (loader_wave) {
+                if (lact) { hand_over(s); if (s + 1 < S) prefetch(s + 1); }
+            } else if (!cell_wave) {
                 BPTT_STAMP(0)
                 if (lane < NCELL) {
                     const int r = lane >> 5, su = lane & 31;
@@ -768,11 +755,13 @@ __global__ __launch_bounds__(2 * H) void lstm_rec_bwd2_kernel(LstmBwdArgs a) {
             }
             if (cell_wave) { BPTT_STAMP(0) }
             __syncthreads();
-            if (cell_wave) { BPTT_STAMP(1) } else { BPTT_STAMP(3) }
+            if (cell_wave) { BPTT_STAMP(1) } else if (!loader_wave) { BPTT_STAMP(3) }
         }
         if (cell_wave) {
             float4 dg = make_float4(0.f, 0.f, 0.f, 0.f);
             if (cell) {
+                const float4 oa = *reinterpret_cast<const float4*>(&opnd[par][tid][0]);   // {dout*mask, A, Ki, Kj}
+                const float4 ob = *reinterpret_cast<const float4*>(&opnd[par][tid][4]);   // {Kf, Ko, f, -}
                 float dh = oa.x;
                 if (s > 0) {
                     float rec = 0.f;
@@ -793,8 +782,7 @@ __global__ __launch_bounds__(2 * H) void lstm_rec_bwd2_kernel(LstmBwdArgs a) {
                                    (__float_as_uint(dg.z) & ~1u) | tb, (__float_as_uint(dg.w) & ~1u) | tb};
                 if (cb < a.B && s + 1 < S) {       // publish dG_s of this unit FIRST: one tagged quad
                     uint32_t* dst = hxg + ((size_t)par * R + cr) * N + 4 * cj;
-                    // (s_nop 1: the data registers of an asm x4 store must not be rewritten before the store has read them)
-                    if (fast) asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" :: "v"(dst), "v"(g0) : "memory");
+                    if (fast) asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(dst), "v"(g0) : "memory");
                     else {
                         __hip_atomic_store(dst + 0, g0.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         __hip_atomic_store(dst + 1, g0.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -807,7 +795,6 @@ __global__ __launch_bounds__(2 * H) void lstm_rec_bwd2_kernel(LstmBwdArgs a) {
                     float* gp = a.gates + (((size_t)cb * a.sb + (size_t)t * a.st) * a.ND + dir) * H4 + cj;
                     gp[0] = dg.x; gp[H] = dg.y; gp[2 * H] = dg.z; gp[3 * H] = dg.w;
                 }
-                if (s + 2 < S) prefetch(s + 2);
                 if (s + 1 < S)    // own slice of the next step's contraction: the truncated values the peers will read
                     stage(cr, cu, make_float4(__uint_as_float(g0.x & ~1u), __uint_as_float(g0.y & ~1u),
                                               __uint_as_float(g0.z & ~1u), __uint_as_float(g0.w & ~1u)));
@@ -816,14 +803,10 @@ __global__ __launch_bounds__(2 * H) void lstm_rec_bwd2_kernel(LstmBwdArgs a) {
                 BPTT_STAMP(3)
                 __builtin_amdgcn_wave_barrier();
                 slice_partial(par ^ 1);
-                // step s+1's record and dout (issued one step ago) have landed when only the three youngest loads are left
-                if (s + 2 < S) vm_wait<3>(); else vm_wait<0>();
-                if (cell) operands(s + 1);
                 BPTT_STAMP(4)
             }
         }
     }
-    if (cell_wave) vm_wait<0>();       // LDS-DMA must never outlive the workgroup
     if (a.db_part && cell && cb < a.B) {        // one row per utterance and direction: summed over the batch by a tiny colsum
         float* dp = a.db_part + ((size_t)(a.boff + cb) * a.ND + dir) * H4 + cj;
         dp[0] = dbs.x; dp[H] = dbs.y; dp[2 * H] = dbs.z; dp[3 * H] = dbs.w;
@@ -862,10 +845,10 @@ static int launch_bwd_h(hipStream_t s, const LstmBwdArgs& a, int R) {
             else hipLaunchKernelGGL((lstm_rec_bwd_ag_kernel<256, 2, false, true>), dim3(grid), dim3(512), 0, s, a);
         }
         else if (H <= 256 && v2 && !a.dbg) {       // version 2: slice per wave, one barrier per step (ASR_LSTM_V2=0 keeps version 1)
-            if (R == 1) hipLaunchKernelGGL((lstm_rec_bwd2_kernel<(H <= 256 ? H : 256), 1>), dim3(grid), dim3(2 * H), 0, s, a);
-            else hipLaunchKernelGGL((lstm_rec_bwd2_kernel<(H <= 256 ? H : 256), 2>), dim3(grid), dim3(2 * H), 0, s, a);
+            if (R == 1) hipLaunchKernelGGL((lstm_rec_bwd2_kernel<(H <= 256 ? H : 256), 1>), dim3(grid), dim3(2 * H + 64), 0, s, a);
+            else hipLaunchKernelGGL((lstm_rec_bwd2_kernel<(H <= 256 ? H : 256), 2>), dim3(grid), dim3(2 * H + 64), 0, s, a);
         }
-        else if (H == 256 && R == 2 && v2 && a.dbg) hipLaunchKernelGGL((lstm_rec_bwd2_kernel<256, 2, true>), dim3(grid), dim3(512), 0, s, a);
+        else if (H == 256 && R == 2 && v2 && a.dbg) hipLaunchKernelGGL((lstm_rec_bwd2_kernel<256, 2, true>), dim3(grid), dim3(576), 0, s, a);
         else if (R == 1) hipLaunchKernelGGL((lstm_rec_bwd_ag_kernel<H, 1>), dim3(grid), dim3(512), 0, s, a);
         else if (H == 256 && a.dbg) hipLaunchKernelGGL((lstm_rec_bwd_ag_kernel<256, 2, true>), dim3(grid), dim3(512), 0, s, a);
         else hipLaunchKernelGGL((lstm_rec_bwd_ag_kernel<H, 2>), dim3(grid), dim3(512), 0, s, a);

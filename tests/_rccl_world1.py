@@ -38,23 +38,35 @@ def main():
         return p
     batches = [synthetic_batch(B=32, T=160 + 16 * i, F=80, t_dec=21, vocab=1000, variable_len=bool(i & 1), seed=100 + i)
                for i in range(4)]
-    finals = {}
+    grads, losses = {}, {}
     for mode in ("plain", "blocking", "overlap", "overlap_bf16"):
         m = Seq2SeqModel(None, True, params(), device="cuda:0", feat_length=80, seed=6)
+        d = None
         if mode != "plain":
             d = DataParallel(m, overlap=mode.startswith("overlap"), grad_dtype="bf16" if mode.endswith("bf16") else "f32")
             assert d.world == 1 and d.force_exchange and (d.overlap or mode == "blocking")
-        for b in batches:
-            m.step(b)
+        # the gradient after the exchange of the FIRST step (identical weights in every mode): a sum over one rank is the identity
+        m.forward(batches[0]); m.backward()
+        if d is not None:
+            d.all_reduce_grads(m.variables.grad)
+        torch.cuda.synchronize()
+        grads[mode] = m.variables.grad.cpu().numpy().copy()
+        m.apply_gradients()
+        # and a few whole steps: real RCCL calls next to the persistent kernels, no time-out, no hang
+        ls = []
+        for b in batches[1:]:
+            ls.append(m.step(b)["char"].item())
         torch.cuda.synchronize()
         ops.check_device_flag(dev)
-        finals[mode] = m.variables.flat.cpu().numpy()
-        assert np.isfinite(finals[mode]).all()
+        losses[mode] = ls
+        assert np.isfinite(m.variables.flat.cpu().numpy()).all()
+    scale = np.abs(grads["plain"]).max()
     # (not bit-equal even plain vs plain: the split-K weight-gradient GEMMs sum their slices with float atomics)
-    assert np.abs(finals["blocking"] - finals["plain"]).max() < 2e-5
-    assert np.abs(finals["overlap"] - finals["plain"]).max() < 2e-5
-    # bf16 on the wire: each gradient rounded to 8 bits once; four Adam steps stay within a few 1e-3 of the fp32 exchange
-    assert np.abs(finals["overlap_bf16"] - finals["plain"]).max() < 5e-3
+    assert np.abs(grads["blocking"] - grads["plain"]).max() < 1e-5 * scale
+    assert np.abs(grads["overlap"] - grads["plain"]).max() < 1e-5 * scale
+    assert np.abs(grads["overlap_bf16"] - grads["plain"]).max() < 1e-2 * scale      # bfloat16 on the wire: 8 significand bits
+    for mode in ("blocking", "overlap", "overlap_bf16"):
+        np.testing.assert_allclose(losses[mode], losses["plain"], rtol=2e-2)
     t = torch.ones(1, device=dev)
     dist.all_reduce(t)
     dist.barrier()
