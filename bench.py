@@ -36,11 +36,37 @@ PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: matrix/vector FP32 peak
 PEAK_HBM_GBS = 8000.0
 
 
-def build_model(dev, training=True):
+def build_model(dev, training=True, multitask_depth=None):
+    """Config 2 (default) or, with multitask_depth = d, BASELINE config 4: + an auxiliary phone decoder (V = 50, up to 250
+    output steps, main.py:127-129) on the encoder states of depth d (`-nlp`; BASELINE says layer 2)."""
     from e2e_asr_amd.seq2seq_model import Seq2SeqModel
     p = Seq2SeqModel.class_params()
     p.encoder_params.use_lstm = True          # the reference CLI always sets it (encoder.py:187)
+    if multitask_depth is not None:
+        from e2e_asr_amd.attn_decoder import AttnDecoder
+        p.tasks = ["char", "phone"]
+        p.num_layers = {"char": 4, "phone": int(multitask_depth)}
+        dp = AttnDecoder.class_params(); dp.vocab_size = V_PHONE
+        p.decoder_params = {"char": AttnDecoder.class_params(), "phone": dp}
     return Seq2SeqModel(None, isTraining=training, params=p, device=dev, feat_length=F, seed=10)
+
+
+V_PHONE, TDEC_PHONE = 50, 251
+
+
+def config4_batch(variable_len=False, seed=1234):
+    from e2e_asr_amd.weights import synthetic_batch
+    b = synthetic_batch(B=B, T=T, F=F, t_dec=TDEC, vocab=V, variable_len=variable_len, seed=seed, tasks=("char",))
+    bp = synthetic_batch(B=B, T=T, F=F, t_dec=TDEC_PHONE, vocab=V_PHONE, variable_len=variable_len, seed=seed + 77, tasks=("phone",))
+    b["phone"], b["phone_len"] = bp["phone"], bp["phone_len"]
+    return b
+
+
+def decoder_flop_fwd(te, steps, vocab, D=512, A=128, E=256, Hd=256):
+    """Algorithmic forward FLOPs of one attention decoder over a batch: per step and utterance the two
+    cells, InputProjection, query projection, scores, context, AttnProjection, OutputProjection; + hf = enc.AttnW once."""
+    per_step = 2 * (E + Hd) * 4 * Hd * 2 + 2 * (Hd + D) * E + 2 * Hd * A + 2 * te * A + 2 * te * D + 2 * (Hd + D) * Hd + 2 * Hd * vocab
+    return B * (steps * per_step + 2 * te * D * A)
 
 
 def gemm_roofline(dev):
@@ -108,7 +134,7 @@ def _usable_cpus():
     return max(1, n)
 
 
-def cpu_baseline(budget_s=90.0):
+def cpu_baseline(budget_s=90.0, multitask_depth=None):
     """CPU 'port' baseline, SURVEY 8(d) protocol: the torch twin of the oracle (oracle/torch_ref.py: per-timestep
     BasicLSTMCell loops with masking exactly as dynamic_rnn/raw_rnn run them, float32, autograd backward, TF clip +
     Adam arithmetic) doing full train steps on a bounded sample of the same workload -- the full batch of 32 utterances,
@@ -121,7 +147,9 @@ def cpu_baseline(budget_s=90.0):
     import torch as th
     from e2e_asr_amd.weights import init_weights, synthetic_batch
     from oracle import torch_ref as R
-    w = {k: v.astype(np.float32) for k, v in init_weights(seed=10).items()}
+    tasks = ("char",) if multitask_depth is None else ("char", "phone")
+    nl = {"char": 4} if multitask_depth is None else {"char": 4, "phone": int(multitask_depth)}
+    w = {k: v.astype(np.float32) for k, v in init_weights(seed=10, tasks=tasks, vocab={"char": V, "phone": V_PHONE}).items()}
     ncpu = _usable_cpus()
     prev_threads = th.get_num_threads()
     t_start = time.perf_counter()
@@ -129,13 +157,16 @@ def cpu_baseline(budget_s=90.0):
     def run(nthreads, Ts, tdec, iters, leg_budget):
         th.set_num_threads(nthreads)
         batch = synthetic_batch(B=B, T=Ts, F=F, t_dec=tdec, vocab=V)
+        if multitask_depth is not None:                       # phone targets: twice the char length (250 vs 120 at full size)
+            bp = synthetic_batch(B=B, T=Ts, F=F, t_dec=2 * tdec, vocab=V_PHONE, seed=99, tasks=("phone",))
+            batch["phone"], batch["phone_len"] = bp["phone"], bp["phone_len"]
         W = R.weights_to_torch(w, dtype=th.float32)          # conversion outside the timer
         times, t_leg = [], time.perf_counter()
         for it in range(iters + 1):                          # iteration 0 = warm-up
             t0 = time.perf_counter()
             for p in W.values():
                 p.grad = None
-            total, _, _ = R.seq2seq_loss(batch, W)
+            total, _, _ = R.seq2seq_loss(batch, W, tasks=tasks, num_layers=nl)
             total.backward()
             with th.no_grad():      # clip_by_global_norm + Adam (cost only; arithmetic as seq2seq_model.py:137-155)
                 gn = th.sqrt(sum((p.grad.double() ** 2).sum() for p in W.values()))
@@ -169,13 +200,78 @@ def cpu_baseline(budget_s=90.0):
     allc = [r for r in runs if r["threads"] == ncpu][0]
     return dict(value=best["frames_per_s"], unit="frames/s", cores=best["threads"], kind="port",
                 sample="full train steps (fwd+bwd+clip+Adam; float32 torch twin of the oracle, per-timestep loops) on 32 "
-                       "utterances x 96 frames x 80 mel, 15 target tokens; 1 warm-up + up to 3 timed iterations, median; "
-                       "value = faster of {1 thread, all usable cores}",
+                       "utterances x 96 frames x 80 mel, 15 target tokens%s; 1 warm-up + up to 3 timed iterations, median; "
+                       "value = faster of {1 thread, all usable cores}" % ("" if multitask_depth is None else " (+ 31 phone tokens on depth %d)" % multitask_depth),
                 cpu_model=_cpu_model(), host_cores=os.cpu_count(), usable_cores=ncpu,
                 threads_1_frames_per_s=one["frames_per_s"], threads_all_frames_per_s=allc["frames_per_s"],
                 runs=runs, flatness_check=flat,
                 per_frame_cost_ratio_T192_vs_T96=((flat["min_s"] / flat["frames"]) / (best["min_s"] / best["frames"])) if flat else None,
                 flatness_note="ratio of the fastest iterations (host noise only ever adds time); 1.0 = per-frame cost independent of T")
+
+
+def run_config5(args, real_stdout):
+    """BASELINE config 5: batch-1 beam search, width 16, LM shallow fusion (beam_search.py:224-338), one MI355X.  One "step" =
+    one utterance decoded on the device from encoder states resident in HBM ([100, 512], 120 emitted tokens with random
+    weights).  `value` = utterances / s.  cpu_baseline = the float64 NumPy oracle's beam search, 1 thread, ONE utterance
+    (the reference's own loop is pure Python over NumPy, 1 thread)."""
+    from e2e_asr_amd import ops
+    from e2e_asr_amd.beam_search import BeamSearch
+    from e2e_asr_amd.weights import init_weights
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(0)
+    wd = {k: v for k, v in init_weights(seed=3).items() if "rnn_decoder_char" in k}
+    wl = {k: v for k, v in init_weights(seed=4).items() if "rnn_decoder_char" in k}
+    sp = BeamSearch.class_params()
+    sp.beam_size = 16; sp.lm_weight = 0.1; sp.lm_path = wl
+    bs = BeamSearch(wd, sp)
+    te, D = 100, 512
+    encs = [torch.as_tensor((rng.standard_normal((te, D)) * 0.3).astype(np.float32)).to(dev) for _ in range(max(args.steps, 1))]
+    for i in range(max(args.warmup, 1)):
+        bs(encs[i % len(encs)])
+    torch.cuda.synchronize(); ops.check_device_flag(dev)
+    t0 = time.perf_counter()
+    outs = [bs(e) for e in encs[:args.steps]]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ops.check_device_flag(dev)
+    tokens = sum(len(o) for o in outs)
+    us_per_token = dt / max(tokens, 1) * 1e6
+    # per emitted token the k = 16 live hypotheses read every decoder and LM weight once (two cells of each model, the
+    # projections, the output softmax) and the utterance's enc / hf once: the algorithmic bytes of one beam step
+    E, Hd, A, lmH = 256, 256, 128, 256
+    wbytes = 4 * ((E + lmH) * 4 * lmH * 2 + (E + Hd) * 4 * Hd + (lmH + D) * E + Hd * A + (Hd + D) * Hd + Hd * V * 2)
+    step_bytes = wbytes + 4 * te * (D + A)
+    out = {
+        "metric": "beam-search utterances/sec (beam 16, LM shallow fusion lm_weight 0.1, batch 1)", "value": args.steps / dt,
+        "unit": "utterances/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "replicas only (beam_search.py is batch 1; BASELINE north_star keeps it single-GPU)",
+        "vs_baseline": None, "dtype": "f32 step kernels; float64 scoring and selection on the device (beam_search.py computes in float64)",
+        "data": "synthetic",
+        "config": {"workload": "config5: batch-1 beam search width 16 + LM shallow fusion (lm_weight 0.1, separate LM weight set), encoder "
+                               "states [100, 512] resident in HBM, %d emitted tokens per utterance" % (tokens // max(len(outs), 1)),
+                   "mode": "decode", "global_batch": 1, "parallelism": "single GPU"},
+        "us_per_emitted_token": us_per_token,
+        "roofline": {"bound": "hbm", "kernel": "asr_beam_step + asr_beam_select (ten step launches + selection per emitted token)",
+                     "achieved": step_bytes / (us_per_token * 1e-6) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                     "frac": step_bytes / (us_per_token * 1e-6) / 1e9 / PEAK_HBM_GBS, "traffic": None,
+                     "algorithmic_bytes_per_step": step_bytes,
+                     "note": "latency-bound chain of ~13 dependent launches per token at batch 16: the byte rate is reported, the bound "
+                             "is launch latency (DESIGN section 10)"},
+    }
+    if not args.no_cpu_baseline:
+        from oracle import asr_oracle as O
+        torch.set_num_threads(1)
+        enc0 = encs[0].cpu().numpy()
+        t1 = time.perf_counter()
+        ref = O.beam_search(enc0, wd, wl, beam_size=16, lm_weight=0.1)
+        dtc = time.perf_counter() - t1
+        sys.stderr.write("[bench cpu_baseline] oracle beam search: %.1f s for one utterance\n" % dtc)
+        out["cpu_baseline"] = {"value": 1.0 / dtc, "unit": "utterances/s", "cores": 1, "kind": "port",
+                               "sample": "ONE utterance ([100,512] states, beam 16, lm_weight 0.1, %d tokens) through the float64 NumPy "
+                                         "oracle of beam_search.py:224-338, 1 thread" % len(ref),
+                               "cpu_model": _cpu_model(), "seconds_per_utterance": dtc,
+                               "ids_equal_device": bool(np.array_equal(ref, outs[0]))}
+    os.write(real_stdout, (json.dumps(out) + "\n").encode())
 
 
 def spawn_ranks(args):
@@ -213,7 +309,13 @@ def main():
                     help="PCIe-inclusive variant (never the headline value): the filterbank batch starts every step in pinned "
                          "host memory and is copied to HBM inside the timed region")
     ap.add_argument("--graph", action="store_true", help="EXPERIMENT: replay one captured step as a hipGraph (step-varying scalars frozen)")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5],
+                    help="BASELINE.json configs: 2 = the headline line (default, unchanged); 3 = the same model with --dtype bf16; "
+                         "4 = multitask (+ phone decoder on encoder depth --nlp); 5 = batch-1 beam search 16 + LM fusion")
+    ap.add_argument("--nlp", type=int, default=2, help="config 4: encoder depth the phone decoder reads (BASELINE: layer 2; reference default 3)")
     args = ap.parse_args()
+    if args.config == 3:
+        args.dtype = "bf16"
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args)                                  # does not return
@@ -240,6 +342,12 @@ def main():
     os.dup2(2, 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if args.config == 5:
+        if world > 1:
+            raise SystemExit("bench.py --config 5: beam search is single-GPU (replicas only)")
+        run_config5(args, real_stdout)
+        return
+    mt = args.nlp if args.config == 4 else None
     dist = None
     if world > 1 or os.environ.get("ASR_FORCE_DIST") == "1":      # (ASR_FORCE_DIST: rehearse the RCCL calls on one GPU under torchrun)
         import torch.distributed as dist
@@ -249,14 +357,15 @@ def main():
     from e2e_asr_amd.weights import synthetic_batch
     ops.set_gemm_precision(args.dtype)
     ops.set_gemm_split(args.gemm == "split3")
-    model = build_model(dev, training=args.mode != "eval")
+    model = build_model(dev, training=args.mode != "eval", multitask_depth=mt)
     has_train = hasattr(model, "step")
     mode = args.mode if args.mode != "auto" else ("train" if has_train else "fwd")
     if world > 1:
         from e2e_asr_amd.parallel import DataParallel
         # broadcast weights, hook the grad all-reduce (config 3 = bf16: the exchange carries bfloat16, fp32 master gradient)
         DataParallel(model, grad_dtype="bf16" if args.dtype == "bf16" else "f32")
-    batch = synthetic_batch(B=B, T=T, F=F, t_dec=TDEC, vocab=V, variable_len=args.variable_len, seed=1234 + rank)
+    batch = (synthetic_batch(B=B, T=T, F=F, t_dec=TDEC, vocab=V, variable_len=args.variable_len, seed=1234 + rank) if mt is None
+             else config4_batch(args.variable_len, seed=1234 + rank))
     # inputs resident in HBM before the timed region
     batch = {k: (torch.as_tensor(v).to(dev) if k == "logmel" else v) for k, v in batch.items()}
 
@@ -336,6 +445,7 @@ def main():
     rec_ms, rec_n = ops.prof_read("lstm_rec_fwd")
     recb_ms, recb_n = ops.prof_read("lstm_rec_bwd")
     decf_ms, decf_n = ops.prof_read("decoder_fwd")
+    decb_ms, decb_n = ops.prof_read("decoder_bwd")
     ops.prof_enable(False)
     if rank != 0:
         if dist is not None:
@@ -344,19 +454,35 @@ def main():
     ms_step = dt / args.steps * 1e3
     frames = world * B * T
     value = frames / (dt / args.steps)
-    flop_per_frame = (REC_FLOP_FWD + PROJ_FLOP_FWD + 14.25e9) / (B * T) * (3 if mode == "train" else 1)
+    dec_flop = 14.25e9 if mt is None else 14.25e9 + decoder_flop_fwd(T >> (mt - 1), TDEC_PHONE - 1, V_PHONE)
+    flop_per_frame = (REC_FLOP_FWD + PROJ_FLOP_FWD + dec_flop) / (B * T) * (3 if mode == "train" else 1)
     # dominant kernel family by GPU time: the persistent recurrent LSTM pair (4 launches/step each,
     # T=800/400/200/100); report the slower of the two.  Same algorithmic FLOPs (h.K_h resp. dG.K_h^T).
     rec_per_step_ms = rec_ms / args.steps
     recb_per_step_ms = recb_ms / args.steps
     use_bwd = mode == "train" and recb_per_step_ms > rec_per_step_ms
     dom_ms = recb_per_step_ms if use_bwd else rec_per_step_ms
-    dom_name = "lstm_rec_bwd_ag_kernel<256,2> (persistent BPTT)" if use_bwd else "lstm_rec_fwd_kernel<256,32,2> (persistent recurrent LSTM)"
+    v2 = os.environ.get("ASR_LSTM_V2", "1") != "0"
+    dom_name = (("lstm_rec_bwd2_kernel<256,2> (persistent BPTT, version 2)" if v2 else "lstm_rec_bwd_ag_kernel<256,2> (persistent BPTT)") if use_bwd else
+                ("lstm_rec_fwd2_kernel<256,2> (persistent recurrent LSTM, version 2)" if v2 else "lstm_rec_fwd_kernel<256,32,2> (persistent recurrent LSTM)"))
     achieved = REC_FLOP_FWD / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else None
+    dom_launches, dom_flop, chain_steps = 4.0, REC_FLOP_FWD, sum(ENC_LAYER_T)
+    if mt is not None and mode == "train":
+        # config 4: the two decoders' persistent chains outweigh each recurrent kernel -- report the larger decoder family
+        # (decoder_fwd = both training-graph decoders; decoder_bwd = both backward chains incl. their GEMMs)
+        dec_fwd_step, dec_bwd_step = decf_ms / args.steps, decb_ms / args.steps
+        if max(dec_fwd_step, dec_bwd_step) > dom_ms:
+            use_dec_bwd = dec_bwd_step > dec_fwd_step
+            dom_ms = dec_bwd_step if use_dec_bwd else dec_fwd_step
+            dom_flop = dec_flop * (2 if use_dec_bwd else 1)
+            dom_name = ("asr_attn_decoder_bwd (persistent backward chains of the char and phone decoders + their GEMMs)" if use_dec_bwd else
+                        "asr_attn_decoder_fwd (char: one-launch training decoder; phone: persistent segment chains, Te = %d)" % (T >> (mt - 1)))
+            achieved = dom_flop / (dom_ms * 1e-3) / 1e12
+            dom_launches, chain_steps = 2.0, (TDEC - 1) + (TDEC_PHONE - 1)
     # HBM traffic per launch cannot be read by the process that is being timed (the PMC passes are separate rocprofv3
     # runs, MI355X_MICROARCH.md): the committed summary of those passes is quoted, and its provenance is stated.
     traffic, traffic_source = None, None
-    for name in ("traffic_r02.json", "traffic_r01.json"):
+    for name in (() if mt is not None else ("traffic_r03.json", "traffic_r02.json", "traffic_r01.json")):
         tp = os.path.join(ROOT, "profiles", name)
         if os.path.exists(tp):
             try:
@@ -366,17 +492,19 @@ def main():
             except Exception:
                 traffic = None
     out = {
-        "metric": "encoder+decoder frames/sec at batch32x800frx80mel", "value": value, "unit": "frames/s",
+        "metric": "encoder+decoder frames/sec at batch32x800frx80mel" + ("" if mt is None else " (config 4: multitask)"), "value": value, "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": ("f32" if args.dtype == "f32" else "bf16 MFMA operands in the GEMMs (%s); fp32 accumulate, recurrences, attention, loss, Adam" % (
-            "one plane" if args.dtype == "bf16" else "two planes, three products")),
+            "one operand plane in the encoder's products, two in the decoder's" if args.dtype == "bf16" else "two planes, three products")),
         "gemm_path": (args.dtype if args.dtype != "f32" else
                       "split3: fp32 in / fp32 out / fp32-accurate, evaluated on the bf16 MFMA pipe by exact 3-way operand "
                       "splitting (tests/test_gpu_gemm_split.py holds its error to the v_mfma_f32_32x32x2_f32 kernel's)"
                       if args.gemm == "split3" else "exact: v_mfma_f32_32x32x2_f32"),
         "data": "synthetic",
-        "config": {"workload": ("config2" if args.dtype == "f32" else "config3 (per-GPU)") + ": 4-layer pyramidal BiLSTM(256)+attn decoder(256), V=1000, per-GPU batch "
+        "config": {"workload": (("config2" if args.dtype == "f32" else "config3 (per-GPU)") if mt is None else
+                                "config4 (per-GPU; + phone decoder V=50, 250 steps, on encoder depth %d = %d positions)" % (mt, T >> (mt - 1))) +
+                               ": 4-layer pyramidal BiLSTM(256)+attn decoder(256), V=1000, per-GPU batch "
                                "32x800x80, %s step%s" % (
                                    "full train (fwd+bwd+clip+Adam%s)" % ("+RCCL all-reduce" if world > 1 else "")
                                    if mode == "train" else ("forward-only (training graph incl. loss)" if mode == "fwd" else
@@ -388,11 +516,11 @@ def main():
                      "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": (achieved / PEAK_F32_MFMA_TFLOPS) if achieved else None, "traffic": traffic,
                      "traffic_source": traffic_source,
-                     "avg_launch_ms": dom_ms / 4.0, "launches": (recb_n if use_bwd else rec_n),
-                     "serial_chain_steps": sum(ENC_LAYER_T), "us_per_recurrent_step": dom_ms * 1e3 / sum(ENC_LAYER_T),
-                     "note": "latency-bound serial chain of 1500 dependent steps; fp32 VALU/MFMA peak is the same 157.3 TF"},
+                     "avg_launch_ms": dom_ms / dom_launches, "launches": (recb_n if use_bwd else rec_n) if dom_launches == 4.0 else int(2 * args.steps),
+                     "serial_chain_steps": chain_steps, "us_per_recurrent_step": dom_ms * 1e3 / chain_steps,
+                     "note": "latency-bound serial chain of %d dependent steps; fp32 VALU/MFMA peak is the same 157.3 TF" % chain_steps},
         "phases_ms_per_step": {"lstm_rec_fwd": rec_per_step_ms, "lstm_rec_bwd": recb_ms / args.steps,
-                               "decoder_fwd": decf_ms / args.steps},
+                               "decoder_fwd": decf_ms / args.steps, "decoder_bwd": decb_ms / args.steps},
     }
     sum_len = int(np.sum(batch["logmel_len"])) * world
     out["frames_true_sum_len_per_s"] = sum_len / (dt / args.steps)      # rate on the true sum of lengths next to padded B*T
@@ -407,7 +535,7 @@ def main():
         out["comm"] = comm
     out["roofline_gemm"] = gemm_roofline(dev)
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline()
+        out["cpu_baseline"] = cpu_baseline(multitask_depth=mt)
     sys.stdout.flush()
     os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist is not None:

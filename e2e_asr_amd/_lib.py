@@ -96,6 +96,8 @@ SIGNATURES = {
     "asr_attn_cell_bwd": (C.c_int, [vp] * 11 + [vp, C.c_int] + [vp] * 6 + [vp, C.c_int, vp] + [C.c_int] * 5),
     "asr_side_join": (C.c_int, [vp]),
     "asr_side_wait": (C.c_int, [vp]),
+    "asr_set_lstm_mfma": (C.c_int, [C.c_int]),
+    "asr_get_lstm_mfma": (C.c_int, []),
     "asr_decoder_chain_supported": (C.c_int, [C.c_int] * 5),
     "asr_decoder_chain_rows": (C.c_int, [C.c_int]),
     "asr_decoder_greedy_supported": (C.c_int, [C.c_int] * 8),

@@ -588,6 +588,14 @@ __global__ __launch_bounds__(2 * H) void lstm_rec_fwd2_kernel(LstmRecArgs a) {
 }
 
 extern "C" int asr_get_gemm_precision(void);
+// bf16 mode only: recurrent products of the FIRST-version kernels on the bf16 matrix pipe (round 2).  Off by default since
+// round 3 (the fp32 version-2 recurrences are faster and exact); ASR_LSTM_MFMA=1 or asr_set_lstm_mfma(1) selects them.
+static int g_lstm_mfma = -1;
+extern "C" int asr_get_lstm_mfma(void) {
+    if (g_lstm_mfma < 0) { const char* e = getenv("ASR_LSTM_MFMA"); g_lstm_mfma = (e && e[0] == '1') ? 1 : 0; }
+    return g_lstm_mfma;
+}
+extern "C" int asr_set_lstm_mfma(int on) { g_lstm_mfma = on ? 1 : 0; return ASR_OK; }
 unsigned long long* g_lstm_dbg = nullptr;      // diagnostic stamp buffer (also read by decoder_chain_bwd.hip)
 extern "C" int asr_debug_set_buffer(void* p) { g_lstm_dbg = static_cast<unsigned long long*>(p); return ASR_OK; }
 
@@ -606,7 +614,7 @@ static int launch_rec(hipStream_t s, const LstmRecArgs& a0) {
         if (padded <= asr_lstm_max_wgs()) grid = padded;
     }
     // bf16 mode of the library (asr_set_gemm_precision(1)): recurrent product on the bf16 matrix pipe (H = 256 instantiation)
-    static const bool mf_env = [] { const char* e = getenv("ASR_LSTM_MFMA"); return !(e && e[0] == '0'); }();
+    const bool mf_env = asr_get_lstm_mfma() != 0;      // opt-in since round 3: the fp32 version-2 kernels are faster
     if (H == 256 && R == 2 && g_lstm_dbg && getenv("ASR_LSTM_STAMP")) {
         const char* e2 = getenv("ASR_LSTM_V2");
         if (e2 && e2[0] == '0') hipLaunchKernelGGL((lstm_rec_fwd_kernel<256, HS, 2, true>), dim3(grid), dim3(16 * HS), 0, s, a);

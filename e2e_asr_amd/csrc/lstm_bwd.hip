@@ -830,6 +830,7 @@ __global__ __launch_bounds__(2 * H + 64) void lstm_rec_bwd2_kernel(LstmBwdArgs a
 
 }  // namespace asr
 extern "C" int asr_get_gemm_precision(void);
+extern "C" int asr_get_lstm_mfma(void);
 int asr_lstm_max_wgs();
 namespace asr {
 template <int H>
@@ -838,7 +839,7 @@ static int launch_bwd_h(hipStream_t s, const LstmBwdArgs& a, int R) {
     { const int padded = ((a.ND * ((a.B + R - 1) / R) + 7) & ~7) * (H / 32); if (padded <= asr_lstm_max_wgs()) grid = padded; }
     static const bool allgather = [] { const char* e = getenv("ASR_BPTT_AG"); return !(e && e[0] == '0'); }();
     if (allgather && R <= 2) {     // more rows per group: too many granule loads per polling thread -> reduce-scatter kernel
-        static const bool mf_env = [] { const char* e = getenv("ASR_LSTM_MFMA"); return !(e && e[0] == '0'); }();
+        const bool mf_env = asr_get_lstm_mfma() != 0;      // opt-in since round 3 (csrc/lstm.hip)
         static const bool v2 = [] { const char* e = getenv("ASR_LSTM_V2"); return !(e && e[0] == '0'); }();
         if (H == 256 && mf_env && !a.dbg && asr_get_gemm_precision() == 1) {      // bf16 mode: contraction on the bf16 matrix pipe
             if (R == 1) hipLaunchKernelGGL((lstm_rec_bwd_ag_kernel<256, 1, false, true>), dim3(grid), dim3(512), 0, s, a);

@@ -343,6 +343,11 @@ int asr_zero_finished_rows(void* stream, float* logits, const int* len, int T, i
  * larger batches run as consecutive launches, and a shape whose smallest group does not fit returns ASR_EUNSUPPORTED
  * (-3) -- or selects the per-step launch path -- instead of waiting for workgroups that can never be scheduled. */
 int asr_resident_wg_budget(void);
+/* bf16 mode (asr_set_gemm_precision(1)) only: 1 = recurrent products of the first-version recurrent kernels on the bf16
+ * matrix pipe (round 2's config-3 path); 0 (default since round 3) = the fp32 version-2 recurrences in every mode.
+ * New (the reference has one precision); the environment variable ASR_LSTM_MFMA=1 sets the initial value. */
+int asr_set_lstm_mfma(int on);
+int asr_get_lstm_mfma(void);
 
 /* Optional per-kernel HIP-event timing on the launch stream (bench.py roofline leg).
  * tag: 0 lstm recurrent fwd, 1 lstm recurrent bwd, 2 gemm, 3 decoder fwd, 4 decoder bwd, 5 optimizer.

@@ -121,15 +121,19 @@ def test_model_bf16_logits_and_gradients_close_to_fp64_oracle():
         assert cos > 0.995, (n, cos)
 
 
-@pytest.mark.parametrize("prec,tol", [("bf16", 5e-3), ("bf16x2", 1e-3)])
+@pytest.mark.parametrize("prec,tol", [("bf16", 1e-3), ("bf16-one-plane-everywhere", 5e-3), ("bf16x2", 1e-3)])
 def test_config3_full_size_logits_vs_oracle(prec, tol):
-    """BASELINE config 3's per-GPU workload at FULL size (B = 32, T = 800): logits against the float64 oracle.  One bf16 plane:
-    within 5e-3 absolute (measured 1.3e-3: above the north star's fp32 tolerance of 1e-3, stated in the module docstring) and
-    the loss within 1 %.  bf16x2 (two planes, three products): within the north star's 1e-3."""
+    """BASELINE config 3's per-GPU workload at FULL size (B = 32, T = 800): logits against the float64 oracle.
+    "bf16" = the mode `bench.py --config 3` runs: one bf16 operand plane in the encoder's products (91 % of the GEMM FLOPs), two
+    in the decoder's (ops._decoder_precision), fp32 recurrences: WITHIN THE NORTH STAR'S 1e-3 (measured 0.82e-3), loss within
+    1 %.  One plane everywhere: 1.22e-3 (asserted < 5e-3; each half of the model alone carries ~0.85e-3).  bf16x2 everywhere
+    (two planes, three products): 2.4e-6."""
     from tests.test_gpu_model import _model, _f64
     from e2e_asr_amd import ops
     from e2e_asr_amd.weights import synthetic_batch
     from oracle import asr_oracle as O
+    ops.set_decoder_bf16_planes(1 if prec == "bf16-one-plane-everywhere" else 2)
+    prec = prec.split("-")[0]
     ops.set_gemm_precision(prec)
     m = _model(feat=80, vocab={"char": 1000}, params_update=dict(max_output={"char": 120}), seed=17)
     b = synthetic_batch(B=32, T=800, F=80, t_dec=121, vocab=1000, variable_len=True, seed=4321)
@@ -140,6 +144,7 @@ def test_config3_full_size_logits_vs_oracle(prec, tol):
     b64 = dict(b); b64["logmel"] = b["logmel"].astype(np.float64)
     r = O.seq2seq_forward(b64, w, is_training=True)
     err = np.abs(out - r["outputs"]["char"]).max()
+    ops.set_decoder_bf16_planes(2)
     assert (1e-5 if prec == "bf16" else 0.0) < err < tol, err
     assert abs(m.total_loss.item() - r["total_loss"]) < 1e-2 * abs(r["total_loss"])
     print("config-3 (%s operands) full size: max |logit diff| = %.3g" % (prec, err))
@@ -180,8 +185,12 @@ def test_recurrent_product_on_the_bf16_matrix_pipe():
     bz = torch.zeros(4 * H)
     lens = np.array([32, 20, 1, 31])
     ops.set_gemm_precision("bf16")
-    got = ops.lstm_layer_fwd(x.to(DEV), torch.from_numpy(lens.astype(np.int32)).to(DEV), kf.to(DEV), bz.to(DEV), kb.to(DEV),
-                             bz.to(DEV)).cpu().double()
+    ops.set_lstm_mfma(True)          # (opt-in since round 3: by default bf16 mode keeps the fp32 version-2 recurrences)
+    try:
+        got = ops.lstm_layer_fwd(x.to(DEV), torch.from_numpy(lens.astype(np.int32)).to(DEV), kf.to(DEV), bz.to(DEV), kb.to(DEV),
+                                 bz.to(DEV)).cpu().double()
+    finally:
+        ops.set_lstm_mfma(False)
     ops.check_device_flag(torch.device(DEV))
     rb = lambda v: v.to(torch.bfloat16).double()
     ident = lambda v: v.double()
@@ -212,12 +221,14 @@ def test_bptt_contraction_on_the_bf16_matrix_pipe_close_to_fp32_path():
         res = {}
         for prec in ("f32", "bf16"):
             ops.set_gemm_precision(prec)
+            ops.set_lstm_mfma(prec == "bf16")
             out, gates, act, hp = ops.lstm_layer_fwd(x, ln, k[0], bz, k[1], bz, save=True)
             dk = [torch.zeros_like(k[0]) for _ in range(2)]; db = [torch.zeros_like(bz) for _ in range(2)]
             dx = ops.lstm_layer_bwd(x, ln, k[0], k[1], dout, gates, act, hp, dk[0], db[0], dk[1], db[1], need_dx=True,
                                     kx_cat=getattr(gates, "kx_cat", None))
             ops.check_device_flag(torch.device(DEV))
             res[prec] = [dx.cpu().double()] + [t.cpu().double() for t in dk + db]
+        ops.set_lstm_mfma(False)
         for g32, g16 in zip(res["f32"], res["bf16"]):
             cos = float((g32 * g16).sum() / (g32.norm() * g16.norm() + 1e-30))
             err = float((g32 - g16).abs().max() / g32.abs().max())
