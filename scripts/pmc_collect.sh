@@ -1,9 +1,9 @@
 #!/bin/bash
-# rocprofv3 evidence for profiles/ (round 2).  One counter group per pass (MI355X_MICROARCH.md: SQ 8 slots, TCC 4 -- FETCH_SIZE
+# rocprofv3 evidence for profiles/ (rounds 2, 3).  One counter group per pass (MI355X_MICROARCH.md: SQ 8 slots, TCC 4 -- FETCH_SIZE
 # and WRITE_SIZE do not fit one pass; GRBM independent), --kernel-trace only, the program directly after `--`.
 # usage (on the GPU box, from the repo root):  bash scripts/pmc_collect.sh <outdir under gpurun_out>
 set -e
-OUT=${1:-gpurun_out/pmc_r02}
+OUT=${1:-gpurun_out/pmc_r03}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 RP="rocprofv3 --kernel-trace --output-format csv"
