@@ -916,7 +916,10 @@ extern "C" int asr_lstm_layer_bwd(void* stream, const float* x, int B, int T, in
     a.B = B; a.T = T; a.Tout = Tout; a.ND = ndir; a.boff = 0; a.keep = keep_prob; a.seed = seed;
     a.sb = T; a.st = 1; a.osb = Tout; a.ost = 1; a.ldo = ndir * H; a.dsb = Tout; a.dst = 1;
     a.dbg = getenv("ASR_LSTM_STAMP") ? asr::g_lstm_dbg : nullptr;
-    const int R = asr_lstm_pick_rows(B, ndir, G);
+    int R = asr_lstm_pick_rows(B, ndir, G);
+    // H = 512: the reduce-scatter kernel for four or eight rows per group spills (256 registers + 200-768 bytes of scratch: 9.6 us
+    // per step at B = 32); two rows per group through the all-gather kernel in twice the launches are 4.0 us per step of a layer
+    if (H == 512 && R > 2 && !getenv("ASR_LSTM_R")) R = 2;
     // the all-gather kernel (R <= 2) sums dG over time per utterance itself: the bias gradient is then a colsum over B rows
     // instead of over B*T rows of dG (0.4 GB of side-stream reads per step at config 2)
     static const bool ag_env = [] { const char* e = getenv("ASR_BPTT_AG"); return !(e && e[0] == '0'); }();

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from e2e_asr_amd import ops
 dev = torch.device("cuda:0")
-B, H = 32, 256
+B, H = 32, int(os.environ.get("H", 256))
 ops.set_gemm_precision(os.environ.get("PREC", "f32"))      # PREC=bf16: recurrent products on the bf16 matrix pipe
 flush = torch.zeros(1 << 28, device=dev)       # 1 GiB of floats
 for T, IN in ((800, 80), (400, 1024), (100, 1024)):
