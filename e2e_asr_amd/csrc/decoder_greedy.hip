@@ -141,14 +141,17 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
     const bool fast = group_shares_xcd(a.xcc_slots + (size_t)grp * G, G, mem, tid, a.err, lds_flag, 0, 3);
 
     // ---- resident weights (registers), lane kq of a DPP row <-> float4 j of a K part at k = base + (16 j + kq) * 4
-    float wlm[4][4];          // LM cell, recurrent part: K = LMH in 4 parts of 64
+    // (gates (i, j) and (f, o) of one K row as register PAIRS: the two matvecs below run on v_pk_fma_f32 -- two fp32 FMAs per
+    //  issue slot, bitwise two v_fma_f32 -- with the h / input value broadcast to both halves; round 3, as csrc/lstm.hip)
+    f32x2 wlm[4][2];          // LM cell, recurrent part: K = LMH in 4 parts of 64
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int k = part * 64 + kq * 4 + e;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) wlm[e][g] = a.lm_kh[(size_t)k * L4 + g * LMH + mem * LS + u8];
+        for (int g2 = 0; g2 < 2; ++g2)
+            wlm[e][g2] = f32x2{a.lm_kh[(size_t)k * L4 + (2 * g2) * LMH + mem * LS + u8], a.lm_kh[(size_t)k * L4 + (2 * g2 + 1) * LMH + mem * LS + u8]};
     }
-    float wdec[16][4];        // outer cell: K = KD in 4 parts of 256
+    f32x2 wdec[16][2];        // outer cell: K = KD in 4 parts of 256
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
             const int k = part * 256 + (j * 16 + kq) * 4 + e;
             const float* wr = (k < LMH) ? a.wk + (size_t)k * H4 : (k < LMH + H ? a.dec_kh + (size_t)(k - LMH) * H4 : a.wk + (size_t)(k - H) * H4);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) wdec[j * 4 + e][g] = wr[g * H + mem * HS + u8];
+            for (int g2 = 0; g2 < 2; ++g2) wdec[j * 4 + e][g2] = f32x2{wr[(2 * g2) * H + mem * HS + u8], wr[(2 * g2 + 1) * H + mem * HS + u8]};
         }
     const int ycol = row & 3, ypart = (row >> 2) & 3;
     const bool yact = row < 16;
@@ -309,23 +312,31 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
         GREEDY_STAMP()
         {
             float acc[R][4];
+            f32x2 ap2[R][2];
+#pragma unroll
+            for (int r = 0; r < R; ++r) ap2[r][0] = ap2[r][1] = f32x2{0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x2 xlo[R], xhi[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const f32x4 x = *reinterpret_cast<const f32x4*>(v_dec + r * KD + part * 256 + kq * 4 + j * 64);
+                    xlo[r] = __builtin_shufflevector(x, x, 0, 1); xhi[r] = __builtin_shufflevector(x, x, 2, 3);
+                }
+                // eight independent accumulators in rotation
+#pragma unroll
+                for (int r = 0; r < R; ++r) { pk_fma_alo(ap2[r][0], xlo[r], wdec[j * 4 + 0][0]); pk_fma_alo(ap2[r][1], xlo[r], wdec[j * 4 + 0][1]); }
+#pragma unroll
+                for (int r = 0; r < R; ++r) { pk_fma_ahi(ap2[r][0], xlo[r], wdec[j * 4 + 1][0]); pk_fma_ahi(ap2[r][1], xlo[r], wdec[j * 4 + 1][1]); }
+#pragma unroll
+                for (int r = 0; r < R; ++r) { pk_fma_alo(ap2[r][0], xhi[r], wdec[j * 4 + 2][0]); pk_fma_alo(ap2[r][1], xhi[r], wdec[j * 4 + 2][1]); }
+#pragma unroll
+                for (int r = 0; r < R; ++r) { pk_fma_ahi(ap2[r][0], xhi[r], wdec[j * 4 + 3][0]); pk_fma_ahi(ap2[r][1], xhi[r], wdec[j * 4 + 3][1]); }
+            }
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                acc[r][0] = acc[r][1] = acc[r][2] = acc[r][3] = 0.f;
-                const float* sv = v_dec + r * KD + part * 256 + kq * 4;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float4 x = *reinterpret_cast<const float4*>(sv + j * 64);
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        acc[r][g] = fmaf(x.x, wdec[j * 4 + 0][g], acc[r][g]);
-                        acc[r][g] = fmaf(x.y, wdec[j * 4 + 1][g], acc[r][g]);
-                        acc[r][g] = fmaf(x.z, wdec[j * 4 + 2][g], acc[r][g]);
-                        acc[r][g] = fmaf(x.w, wdec[j * 4 + 3][g], acc[r][g]);
-                    }
-                }
-#pragma unroll
-                for (int g = 0; g < 4; ++g) acc[r][g] = row16_allreduce_sum(acc[r][g]);
+                acc[r][0] = row16_allreduce_sum(ap2[r][0].x); acc[r][1] = row16_allreduce_sum(ap2[r][0].y);
+                acc[r][2] = row16_allreduce_sum(ap2[r][1].x); acc[r][3] = row16_allreduce_sum(ap2[r][1].y);
             }
             if (kq == 0) {
 #pragma unroll
@@ -339,12 +350,15 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
                 float al[R][4];
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    const float4 x = *reinterpret_cast<const float4*>(v_lmh + r * LMH + part * 64 + kq * 4);
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        al[r][g] = fmaf(x.x, wlm[0][g], fmaf(x.y, wlm[1][g], fmaf(x.z, wlm[2][g], x.w * wlm[3][g])));
-                        al[r][g] = row16_allreduce_sum(al[r][g]);
-                    }
+                    const f32x4 x = *reinterpret_cast<const f32x4*>(v_lmh + r * LMH + part * 64 + kq * 4);
+                    const f32x2 xlo = __builtin_shufflevector(x, x, 0, 1), xhi = __builtin_shufflevector(x, x, 2, 3);
+                    f32x2 t0 = f32x2{0.f, 0.f}, t1 = t0;
+                    pk_fma_alo(t0, xlo, wlm[0][0]); pk_fma_alo(t1, xlo, wlm[0][1]);
+                    pk_fma_ahi(t0, xlo, wlm[1][0]); pk_fma_ahi(t1, xlo, wlm[1][1]);
+                    pk_fma_alo(t0, xhi, wlm[2][0]); pk_fma_alo(t1, xhi, wlm[2][1]);
+                    pk_fma_ahi(t0, xhi, wlm[3][0]); pk_fma_ahi(t1, xhi, wlm[3][1]);
+                    al[r][0] = row16_allreduce_sum(t0.x); al[r][1] = row16_allreduce_sum(t0.y);
+                    al[r][2] = row16_allreduce_sum(t1.x); al[r][3] = row16_allreduce_sum(t1.y);
                 }
                 if (kq == 0) {
 #pragma unroll
@@ -597,12 +611,15 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
                 float al[R][4];
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    const float4 x = *reinterpret_cast<const float4*>(v_dec + r * KD + part * 64 + kq * 4);
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        al[r][g] = fmaf(x.x, wlm[0][g], fmaf(x.y, wlm[1][g], fmaf(x.z, wlm[2][g], x.w * wlm[3][g])));
-                        al[r][g] = row16_allreduce_sum(al[r][g]);
-                    }
+                    const f32x4 x = *reinterpret_cast<const f32x4*>(v_dec + r * KD + part * 64 + kq * 4);
+                    const f32x2 xlo = __builtin_shufflevector(x, x, 0, 1), xhi = __builtin_shufflevector(x, x, 2, 3);
+                    f32x2 t0 = f32x2{0.f, 0.f}, t1 = t0;
+                    pk_fma_alo(t0, xlo, wlm[0][0]); pk_fma_alo(t1, xlo, wlm[0][1]);
+                    pk_fma_ahi(t0, xlo, wlm[1][0]); pk_fma_ahi(t1, xlo, wlm[1][1]);
+                    pk_fma_alo(t0, xhi, wlm[2][0]); pk_fma_alo(t1, xhi, wlm[2][1]);
+                    pk_fma_ahi(t0, xhi, wlm[3][0]); pk_fma_ahi(t1, xhi, wlm[3][1]);
+                    al[r][0] = row16_allreduce_sum(t0.x); al[r][1] = row16_allreduce_sum(t0.y);
+                    al[r][2] = row16_allreduce_sum(t1.x); al[r][3] = row16_allreduce_sum(t1.y);
                 }
                 if (kq == 0) {
 #pragma unroll
