@@ -279,12 +279,22 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
             const uint32_t* tL = reinterpret_cast<const uint32_t*>(gbase + (size_t)(step & 1) * NPAR);
             const uint32_t tbs = tag_bit(step);
             if (TRAIN) {
-                for (int p = tid - 64; p < NLM / 4; p += NPOLL) {       // a quad = (dropped, plain) outputs of two adjacent units
-                    const int r = (2 * p) / LMH, k = (2 * p) % LMH;
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (rok(r)) tagged_poll4(tL + 4 * p, tbs, v, a.err);
-                    *reinterpret_cast<float2*>(v_dec + r * KD + k) = make_float2(v.x, v.z);
-                    *reinterpret_cast<float2*>(v_lmh + r * LMH + k) = make_float2(v.y, v.w);
+                // a quad = (dropped, plain) outputs of two adjacent units; NLM / 4 = 512 quads over 384 threads: both of a thread's
+                // quads in flight at once (granule.h tagged_poll4_many)
+                static_assert(NLM / 4 <= 2 * NPOLL, "two quads per polling thread");
+                const int p0 = tid - 64, p1 = p0 + NPOLL;
+                const int pp[2] = {p0, p1 < NLM / 4 ? p1 : p0};
+                const uint32_t* ptr[2] = {tL + 4 * pp[0], tL + 4 * pp[1]};
+                bool need[2] = {rok((2 * pp[0]) / LMH), p1 < NLM / 4 && rok((2 * pp[1]) / LMH)};
+                const uint32_t tbb[2] = {tbs, tbs};
+                float4 v[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+                tagged_poll4_many<2>(ptr, need, tbb, v, a.err);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (j == 1 && p1 >= NLM / 4) break;
+                    const int r = (2 * pp[j]) / LMH, k = (2 * pp[j]) % LMH;
+                    *reinterpret_cast<float2*>(v_dec + r * KD + k) = make_float2(v[j].x, v[j].z);
+                    *reinterpret_cast<float2*>(v_lmh + r * LMH + k) = make_float2(v[j].y, v[j].w);
                 }
             } else {
                 for (int p = tid - 64; p < NLM / 4; p += NPOLL) {
@@ -392,12 +402,21 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
         }
         // ---- (3) gather (q_i, h_i); y slice = q . W_att[:, slice] + b
         if (poller) {
-            for (int p = tid - 64; p < NQH / 4; p += NPOLL) {       // a quad = (q, h) of two adjacent units
-                const int r = (2 * p) / H, k = (2 * p) % H;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (rok(r)) tagged_poll4(tQH + 4 * p, tb, v, a.err);
-                *reinterpret_cast<float2*>(v_ap + r * KA + k) = make_float2(v.x, v.z);
-                *reinterpret_cast<float2*>(v_dec + r * KD + LMH + k) = make_float2(v.y, v.w);
+            // a quad = (q, h) of two adjacent units; 512 quads over 384 threads: both of a thread's quads in flight
+            static_assert(NQH / 4 <= 2 * NPOLL, "two quads per polling thread");
+            const int p0 = tid - 64, p1 = p0 + NPOLL;
+            const int pp[2] = {p0, p1 < NQH / 4 ? p1 : p0};
+            const uint32_t* ptr[2] = {tQH + 4 * pp[0], tQH + 4 * pp[1]};
+            bool need[2] = {rok((2 * pp[0]) / H), p1 < NQH / 4 && rok((2 * pp[1]) / H)};
+            const uint32_t tbb[2] = {tb, tb};
+            float4 v[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+            tagged_poll4_many<2>(ptr, need, tbb, v, a.err);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (j == 1 && p1 >= NQH / 4) break;
+                const int r = (2 * pp[j]) / H, k = (2 * pp[j]) % H;
+                *reinterpret_cast<float2*>(v_ap + r * KA + k) = make_float2(v[j].x, v[j].z);
+                *reinterpret_cast<float2*>(v_dec + r * KD + LMH + k) = make_float2(v[j].y, v[j].w);
             }
         }
         __syncthreads();
@@ -531,14 +550,50 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
         }
         // ---- (6) gather ctx_i; AttnProjection slice
         if (poller) {
-            for (int p = tid - 64; p < NC / 4; p += NPOLL) {
-                const int idx = 4 * p, r = idx / D, k = idx % D;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (rok(r)) tagged_poll4(tC + idx, tb, v, a.err);
-                *reinterpret_cast<float4*>(v_ap + r * KA + H + k) = v;
-                *reinterpret_cast<float4*>(v_dec + r * KD + LMH + H + k) = v;
+            // 512 context quads over 384 threads, and in the training graph the 512 quads of the early LM output of step i+1
+            // (published right after this step's outer cell): all of a thread's up to four quads in flight at once
+            static_assert(NC / 4 <= 2 * NPOLL, "two context quads per polling thread");
+            const int p0 = tid - 64, p1 = p0 + NPOLL;
+            const int pc[2] = {p0, p1 < NC / 4 ? p1 : p0};
+            if (TRAIN && early) {
+                const uint32_t* tL = reinterpret_cast<const uint32_t*>(gbase + (size_t)((i + 1) & 1) * NPAR);
+                const uint32_t tbs = tag_bit(i + 1);
+                const int pl[2] = {p0, p1 < NLM / 4 ? p1 : p0};
+                const uint32_t* ptr[4] = {tC + 4 * pc[0], tC + 4 * pc[1], tL + 4 * pl[0], tL + 4 * pl[1]};
+                bool need[4] = {rok((4 * pc[0]) / D), p1 < NC / 4 && rok((4 * pc[1]) / D),
+                                rok((2 * pl[0]) / LMH), p1 < NLM / 4 && rok((2 * pl[1]) / LMH)};
+                const uint32_t tbb[4] = {tb, tb, tbs, tbs};
+                float4 v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                tagged_poll4_many<4>(ptr, need, tbb, v, a.err);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (!(j == 1 && p1 >= NC / 4)) {
+                        const int idx = 4 * pc[j], r = idx / D, k = idx % D;
+                        *reinterpret_cast<float4*>(v_ap + r * KA + H + k) = v[j];
+                        *reinterpret_cast<float4*>(v_dec + r * KD + LMH + H + k) = v[j];
+                    }
+                    if (!(j == 1 && p1 >= NLM / 4)) {
+                        const int r = (2 * pl[j]) / LMH, k = (2 * pl[j]) % LMH;
+                        *reinterpret_cast<float2*>(v_dec + r * KD + k) = make_float2(v[2 + j].x, v[2 + j].z);
+                        *reinterpret_cast<float2*>(v_lmh + r * LMH + k) = make_float2(v[2 + j].y, v[2 + j].w);
+                    }
+                }
+            } else {
+                const uint32_t* ptr[2] = {tC + 4 * pc[0], tC + 4 * pc[1]};
+                bool need[2] = {rok((4 * pc[0]) / D), p1 < NC / 4 && rok((4 * pc[1]) / D)};
+                const uint32_t tbb[2] = {tb, tb};
+                float4 v[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+                tagged_poll4_many<2>(ptr, need, tbb, v, a.err);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (j == 1 && p1 >= NC / 4) break;
+                    const int idx = 4 * pc[j], r = idx / D, k = idx % D;
+                    *reinterpret_cast<float4*>(v_ap + r * KA + H + k) = v[j];
+                    *reinterpret_cast<float4*>(v_dec + r * KD + LMH + H + k) = v[j];
+                }
             }
-            if (early) lm_gather(i + 1);        // published right after this step's outer cell: long since there
         }
         __syncthreads();
         GREEDY_STAMP()

@@ -83,4 +83,42 @@ __device__ __forceinline__ bool tagged_poll4(const uint32_t* g, uint32_t tb, flo
     }
 }
 
+// Several tagged quads per thread with ALL of the thread's loads in flight (one asm statement: loads + wait, "=&v" outputs), re-polled
+// together until every needed one carries its tag bit.  The decoder kernels polled a thread's quads one after the other: a phase
+// that gathers 512 quads with 384 polling threads paid two L2 round trips, the context + early-LM gather four.
+// p[j]: 16-byte aligned; a slot with need[j] == false is not judged (point it at any valid quad); tb[j]: expected bit of slot j.
+template <int N>
+__device__ __forceinline__ bool tagged_poll4_many(const uint32_t* const* p, bool* need, const uint32_t* tb, float4* v, int* err) {
+    static_assert(N == 2 || N == 4, "two or four quads per thread");
+    long long t0 = 0;
+    for (uint32_t spins = 0;; ++spins) {
+        u32x4c x[N];
+        if constexpr (N == 2)
+            asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+                         : "=&v"(x[0]), "=&v"(x[1]) : "v"(p[0]), "v"(p[1]) : "memory");
+        else
+            asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\t"
+                         "global_load_dwordx4 %2, %6, off sc1\n\tglobal_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
+                         : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]) : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]) : "memory");
+        bool pending = false;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            if (!need[j]) continue;
+            if ((x[j].x & 1u) + (x[j].y & 1u) + (x[j].z & 1u) + (x[j].w & 1u) == 4u * tb[j]) {
+                v[j] = make_float4(__uint_as_float(x[j].x & ~1u), __uint_as_float(x[j].y & ~1u), __uint_as_float(x[j].z & ~1u),
+                                   __uint_as_float(x[j].w & ~1u));
+                need[j] = false;
+            } else pending = true;
+        }
+        if (!pending) return true;
+        ASR_POLL_BACKOFF();
+        if ((spins & 1023) == 1023) {
+            const long long now = wall_clock64();
+            if (t0 == 0) t0 = now;
+            else if (now - t0 > 200000000LL) { *err = 43; return false; }
+            if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
+        }
+    }
+}
+
 }  // namespace asr

@@ -18,6 +18,30 @@ def golden_dir():
     return GOLDEN
 
 
+def _usable_cpus():
+    """CPUs this process may really use: the affinity mask capped by the cgroup CPU quota (a GPU box gives a 16-CPU share of a
+    256-CPU host; torch's default thread count would oversubscribe it 16 times and the float64 twins of the gradient tests ran
+    2-3x slower on some boxes)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        txt = open("/sys/fs/cgroup/cpu.max").read().split()
+        if txt[0] != "max":
+            n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+    except (OSError, ValueError, IndexError):
+        pass
+    return max(1, n)
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _torch_threads():
+    try:
+        import torch
+        torch.set_num_threads(min(16, _usable_cpus()))
+    except Exception:
+        pass
+    yield
+
+
 def beam_loop_cases(golden_dir=GOLDEN):
     """Cases of tests/golden/beam_loop.npz: outputs of the reference's OWN BeamSearch.__call__ (beam_search.py:224-338,
     run by oracle/gen_golden.py).  Yields (id string, dict(enc, wd, wl, k, lm_weight, word_ins_penalty, ids))."""

@@ -60,12 +60,14 @@ def _batch(seed, B, T, F, tdec, vocab, lens=None, tasks=("char",)):
     return b
 
 
-def _grad_check(m, b, tol=2e-3, **kw):
+def _grad_check(m, b, tol=2e-3, outs=None, **kw):
     from oracle import torch_ref as R
     w = _f64(m.variables.to_arrays())
     W = R.weights_to_torch(w)
     b64 = dict(b); b64["logmel"] = b["logmel"].astype(np.float64)
-    total, _, _ = R.seq2seq_loss(b64, W, **kw)
+    total, losses, logits = R.seq2seq_loss(b64, W, **kw)
+    if outs is not None:           # the twin's forward (pinned to the NumPy oracle to 1e-12 by tests/test_oracle_torch_ref.py)
+        outs.update(losses={t: float(v.item()) for t, v in losses.items()}, outputs={t: v.detach().numpy() for t, v in logits.items()})
     total.backward()
     worst = 0.0
     for name in m.variables.names():
@@ -98,18 +100,23 @@ def test_config4_phone_decoder_on_layer2_states_real_widths(Te):
     for t in tasks:
         assert m.decoder[t].saved["ws"].get("chain_ws") is not None                    # the persistent chains really ran
     ops.check_device_flag(torch.device(DEV))
-    w = _f64(m.variables.to_arrays())
-    b64 = dict(b); b64["logmel"] = b["logmel"].astype(np.float64)
-    r = O.seq2seq_forward(b64, w, tasks=tasks, num_layers=nl, is_training=True)
     assert m.encoder_hidden_states[2].shape[1] == Te
-    for t in tasks:
-        err = np.abs(m.outputs[t].cpu().numpy() - r["outputs"][t]).max()
-        assert err < 1e-3, (t, err)                                                    # north-star tolerance
-        np.testing.assert_allclose(m.losses[t].item(), r["losses"][t], rtol=2e-5)
-    np.testing.assert_allclose(m.total_loss.item(), r["total_loss"], rtol=2e-5)
+    got = {t: m.outputs[t].cpu().numpy() for t in tasks}
+    got_loss = {t: m.losses[t].item() for t in tasks}
     m.backward()
     ops.check_device_flag(torch.device(DEV))
-    loss, worst = _grad_check(m, b, tasks=tasks, num_layers=nl)
+    if Te == 260:      # the NumPy oracle itself; at Te = 400 its float64 torch twin (one pass over the 800 frames instead of two)
+        w = _f64(m.variables.to_arrays())
+        b64 = dict(b); b64["logmel"] = b["logmel"].astype(np.float64)
+        r = O.seq2seq_forward(b64, w, tasks=tasks, num_layers=nl, is_training=True)
+        loss, worst = _grad_check(m, b, tasks=tasks, num_layers=nl)
+    else:
+        r = {}
+        loss, worst = _grad_check(m, b, outs=r, tasks=tasks, num_layers=nl)
+    for t in tasks:
+        err = np.abs(got[t] - r["outputs"][t]).max()
+        assert err < 1e-3, (t, err)                                                    # north-star tolerance
+        np.testing.assert_allclose(got_loss[t], r["losses"][t], rtol=2e-5)
     np.testing.assert_allclose(m.total_loss.item(), loss, rtol=2e-5)
     print("config 4, Te=%d: worst relative gradient error %.2e" % (Te, worst))
 
