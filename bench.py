@@ -255,8 +255,10 @@ def run_config5(args, real_stdout):
                      "achieved": step_bytes / (us_per_token * 1e-6) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                      "frac": step_bytes / (us_per_token * 1e-6) / 1e9 / PEAK_HBM_GBS, "traffic": None,
                      "algorithmic_bytes_per_step": step_bytes,
-                     "note": "latency-bound chain of ~13 dependent launches per token at batch 16: the byte rate is reported, the bound "
-                             "is launch latency (DESIGN section 10)"},
+                     "note": "a chain of ~11 dependent small kernels per token at batch 16 (rocprofv3: their own durations sum to ~72 of "
+                             "the 80 us -- scoring 14, merge 12, attention 10, five skinny GEMV launches 5-8 each; every kernel starts "
+                             "with dependent memory round trips): the byte rate is reported, the bound is dependent-access latency "
+                             "(DESIGN section 10)"},
     }
     if not args.no_cpu_baseline:
         from oracle import asr_oracle as O

@@ -112,6 +112,8 @@ SIGNATURES = {
     "asr_beam_step_sel": (C.c_int, [vp] * 14),
     "asr_beam_gather": (C.c_int, [vp, vp, C.c_int, vp, vp] + [C.c_int] * 4),
     "asr_beam_select": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, vp]),
+    "asr_beam_decode_ws_floats": (C.c_size_t, [vp, C.c_int, C.c_int]),
+    "asr_beam_decode": (C.c_int, [vp] * 8 + [C.c_size_t, C.c_int, C.c_int, C.c_double, C.c_double, vp, vp, vp]),
     "asr_set_gemm_precision": (C.c_int, [C.c_int]),
     "asr_get_gemm_precision": (C.c_int, []),
     "asr_set_gemm_split": (C.c_int, [C.c_int]),

@@ -208,7 +208,23 @@ class BeamSearch(BaseParams):
         cd = _lib.DecDims(kmax, Te, D, A, H, lmH, E, V, 1)
         st = ops._stream()
         in_place = self.dec_params.simple_w is None and self.lm_params.simple_w is None
-        for s in range(max_steps):
+        # ASR_BEAM_PERSIST=1: one persistent launch for the whole utterance (asr_beam_decode, csrc/beam.hip) -- bit-identical
+        # to the loop below (same tile bodies; tests/test_gpu_beam.py) but SLOWER on MI355X (108 vs 80 us per token: every
+        # hand-over between XCDs costs fabric round trips), so the step-by-step loop is the default
+        persistent = False
+        if in_place and os.environ.get("ASR_BEAM_PERSIST", "0") == "1":
+            barrier = torch.zeros(1, dtype=torch.int32, device=dev)
+            n_ws = int(L.asr_beam_decode_ws_floats(C.byref(cd), extH, max_steps))
+            ws = getattr(get_top_k, "ring", None)
+            if ws is None or ws.numel() < n_ws:
+                ws = get_top_k.ring = torch.empty(n_ws, dtype=torch.float32, device=dev)
+            rc = L.asr_beam_decode(st, C.byref(cw), C.byref(clm), C.byref(cd), ops._p(hf), ops._p(enc), ops._p(ln), ops._p(ws), n_ws,
+                                   max_steps, data_utils.EOS_ID, float(sp.lm_weight), float(sp.word_ins_penalty), C.byref(book),
+                                   ops._p(barrier), ops._p(ops._Flag.get(dev)))
+            if rc != -3:                      # ASR_EUNSUPPORTED: keep the step-by-step loop
+                ops._check(rc, "asr_beam_decode")
+                persistent = True
+        for s in range(0 if not persistent else max_steps, max_steps):
             if in_place:       # the step kernels read the parents' rows of the previous step's output in place: ping-pong
                 a, b = (0, 1) if s % 2 == 0 else (1, 0)
                 ops._check(L.asr_beam_step_sel(st, C.byref(cw), C.byref(clm), C.byref(cd), ops._p(hf), ops._p(enc), ops._p(ln),
@@ -228,6 +244,9 @@ class BeamSearch(BaseParams):
         n_live, _, n_fin, n_steps = [int(x) for x in state.cpu().numpy()]
         ops.check_device_flag(dev)
         bp_h, fin_h, fin_s, cum_h = bp.cpu().numpy(), fin.cpu().numpy(), fin_score.cpu().numpy(), cum.cpu().numpy()
+        # what the loop left behind, for tests that compare the persistent launch with the step-by-step loop bit for bit
+        self.last_book = dict(persistent=persistent, n_live=n_live, n_fin=n_fin, n_steps=n_steps, bp=bp_h[:n_steps].copy(),
+                              fin=fin_h[:n_fin].copy(), fin_score=fin_s[:n_fin].copy(), cum=cum_h[:n_live].copy())
 
         def backtrack(step, row):                  # tokens of the hypothesis that entered step `step + 1` as row `row`
             seq = []

@@ -118,6 +118,43 @@ __device__ __forceinline__ float swap16_add(float x, float y) {
     return __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
 }
 
+// ---- agent-scope accesses -------------------------------------------------------------------------------------------
+// A kernel whose phases run in workgroups of different XCDs WITHOUT a kernel boundary between them (csrc/beam.hip) cannot
+// use plain loads and stores for what one phase hands to the next: the L2s of two XCDs are not coherent for them.  Relaxed
+// agent-scope atomics compile to `sc1` loads (served by the coherence point, never by a stale line) and `sc1` write-through
+// stores.  Mode COH of the tile bodies:
+//   0  plain accesses (the launch-per-step kernels: a kernel boundary orders everything);
+//   1  every hand-over load and store agent-scope (correct for buffers that are REWRITTEN in place; slow: an uncached
+//      4-byte request per lane and word -- 15 us per phase of the beam kernel);
+//   2  write-once buffers: DATA (activations, states, logits) is stored agent-scope to an address nobody has read before
+//      (a ring slot per token) and loaded PLAIN -- no L1 or L2 can hold a stale copy of a line that was never read --
+//      while the few CONTROL words that live at fixed addresses (tokens, parent rows, counters) stay agent-scope.
+template <int COH> __device__ __forceinline__ float ld_data(const float* p) {
+    if constexpr (COH == 1) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else return *p;
+}
+template <int COH> __device__ __forceinline__ float4 ld_data4(const float* p) {
+    if constexpr (COH == 1) return make_float4(ld_data<1>(p), ld_data<1>(p + 1), ld_data<1>(p + 2), ld_data<1>(p + 3));
+    else return *reinterpret_cast<const float4*>(p);
+}
+template <int COH> __device__ __forceinline__ float ld_f(const float* p) {
+    if constexpr (COH != 0) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else return *p;
+}
+template <int COH> __device__ __forceinline__ int ld_i(const int* p) {
+    if constexpr (COH != 0) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else return *p;
+}
+template <int COH> __device__ __forceinline__ double ld_d(const double* p) {
+    if constexpr (COH != 0) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else return *p;
+}
+template <int COH> __device__ __forceinline__ void st_f(float* p, float v) {
+    if constexpr (COH != 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v;
+}
+template <int COH> __device__ __forceinline__ void st_i(int* p, int v) {
+    if constexpr (COH != 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v;
+}
+template <int COH> __device__ __forceinline__ void st_d(double* p, double v) {
+    if constexpr (COH != 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v;
+}
+
 // ---- same-XCD agreement (speed only; correctness never depends on placement) -------------------
 // Every workgroup of a group publishes its HW_REG_XCC_ID through the placement-independent sc1
 // protocol; if all G ids are equal the group's granules may be published with PLAIN stores: the line

@@ -570,6 +570,10 @@ __global__ __launch_bounds__(2 * H + 64) void lstm_rec_bwd2_kernel(LstmBwdArgs a
     unsigned int stamp[5] = {0, 0, 0, 0, 0};
     unsigned long long tlast = STAMP ? __builtin_amdgcn_s_memtime() : 0;
 #define BPTT_STAMP(i) if (STAMP) { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); stamp[i] += (unsigned int)(t__ - tlast); tlast = t__; }
+    // STAMP: every wave's busy time between two step barriers (exit of one to arrival at the next) -> dbg[48 + wave]: the wave
+    // with the largest sum is the one the others wait for
+    unsigned long long busy = 0, texit = 0;
+#define BPTT_BAR() { if (STAMP) busy += __builtin_amdgcn_s_memtime() - texit; __syncthreads(); if (STAMP) texit = __builtin_amdgcn_s_memtime(); }
     constexpr int HS = 32;
     constexpr int NS = H / 32;         // source slices = contraction waves (wave 0: cell + own slice)
     constexpr int G = NS;
@@ -662,6 +666,7 @@ __global__ __launch_bounds__(2 * H + 64) void lstm_rec_bwd2_kernel(LstmBwdArgs a
     };
     if (lact) { prefetch(0); hand_over(0); if (S > 1) prefetch(1); }
     __syncthreads();
+    if (STAMP) texit = __builtin_amdgcn_s_memtime();
 
     // stage the quad (4 gates) of slice unit su, row r
     auto stage = [&](int r, int su, float4 v) {
@@ -754,7 +759,7 @@ __global__ __launch_bounds__(2 * H + 64) void lstm_rec_bwd2_kernel(LstmBwdArgs a
                 BPTT_STAMP(2)
             }
             if (cell_wave) { BPTT_STAMP(0) }
-            __syncthreads();
+            BPTT_BAR()
             if (cell_wave) { BPTT_STAMP(1) } else if (!loader_wave) { BPTT_STAMP(3) }
         }
         if (cell_wave) {
@@ -815,7 +820,9 @@ __global__ __launch_bounds__(2 * H + 64) void lstm_rec_bwd2_kernel(LstmBwdArgs a
         for (int i = 0; i < 5; ++i) atomicAdd(a.dbg + 32 + (tid == 0 ? 0 : 8) + i, (unsigned long long)stamp[i]);
         if (tid == 0) atomicAdd(a.dbg + 32 + 7, (unsigned long long)S);
     }
+    if (STAMP && a.dbg && blockIdx.x == 0 && lane == 0) atomicAdd(a.dbg + 48 + wave, busy);
 #undef BPTT_STAMP
+#undef BPTT_BAR
     // dG = 0 past each row's length (the weight/input GEMMs read every row)
     for (int r = 0; r < R; ++r) {
         if (r0 + r >= a.B) break;

@@ -87,7 +87,8 @@ def check_device_flag(dev):
         f.zero_()
         where = {11: "lstm_rec_fwd poll", 12: "lstm_rec_fwd pair poll", 13: "lstm_rec_bwd poll", 21: "decoder_chain_bwd poll",
                  41: "granule pair poll", 42: "quad poll", 51: "decoder_chain wait", 52: "decoder_chain_bwd wait a",
-                 53: "decoder_chain_bwd wait b", 54: "decoder_chain_bwd wait c", 55: "lstm_rec_bwd wait"}.get(code)
+                 53: "decoder_chain_bwd wait b", 54: "decoder_chain_bwd wait c", 55: "lstm_rec_bwd wait",
+                 61: "beam_persist grid barrier"}.get(code)
         if where is None and code % 100 == 31:
             where = "XCC agreement at the start of " + {0: "?", 1: "decoder_chain_fwd", 2: "decoder_chain_bwd", 3: "decoder_greedy / train",
                                                         4: "lstm_rec_fwd", 5: "lstm_rec_bwd (reduce-scatter)", 6: "lstm_rec_bwd (all-gather)"}.get(code // 100, "?")

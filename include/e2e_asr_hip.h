@@ -306,6 +306,19 @@ typedef struct {
 } asr_beam_book;
 int asr_beam_select(void* stream, const float* logits, const float* logits_lm, int V, int kmax, int max_steps,
                     int eos_id, double lm_weight, double word_ins_penalty, const asr_beam_book* book);
+/* The whole loop of beam_search.py:255-337 for one utterance in ONE persistent launch (csrc/beam.hip): the tile bodies of
+ * asr_beam_step_sel and asr_beam_select run as eight phases per token behind grid barriers, results handed from phase to
+ * phase through write-once ring slots (no host round trip, no launch chain).  Initial conditions as for the step calls:
+ * d->B = beam, book->state = {1, beam, 0, 0}, book->cum = 0, book->ints[0] = GO.  `ws`: asr_beam_decode_ws_floats(d,
+ * lm->H, max_steps) floats, 128-byte aligned (token slots: states, projections, both logit vectors of every step);
+ * `barrier`: one zeroed 32-bit word; `err_flag`: the device error word (0 = clean, 61 = a grid barrier timed out).  On
+ * return `book` is what the step-by-step loop would have left (bit-identical).  ASR_EUNSUPPORTED -> use the step calls:
+ * a SimpleProjection is present, V > 1024, beam > 16, LM vocabulary differs. */
+size_t asr_beam_decode_ws_floats(const asr_dec_dims* d, int extH, int max_steps);
+int asr_beam_decode(void* stream, const asr_dec_weights* w, const asr_lm_weights* lm, const asr_dec_dims* d,
+                    const float* hf, const float* enc, const int* enc_len, float* ws, size_t ws_floats,
+                    int max_steps, int eos_id, double lm_weight, double word_ins_penalty,
+                    const asr_beam_book* book, unsigned* barrier, int* err_flag);
 
 /* The decoder entry points run the LM cell chain on a library-owned side stream (forked from and
  * ordered against `stream` with events; legal under hipGraph capture).  asr_attn_decoder_bwd leaves

@@ -19,7 +19,8 @@ __device__ __forceinline__ void bounce(unsigned* mine, unsigned* theirs, int ite
             if (++guard > 2000000) { if (first) *out = 0; return; }       // never hang the box
             if (LOAD == 0) asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(x) : "v"(theirs) : "memory");
             else if (LOAD == 1) asm volatile("global_load_dword %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(x) : "v"(theirs) : "memory");
-            else asm volatile("global_load_dword %0, %1, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(x) : "v"(theirs) : "memory");
+            else if (LOAD == 2) asm volatile("global_load_dword %0, %1, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(x) : "v"(theirs) : "memory");
+            else { unsigned sx; asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(sx) : "s"(theirs) : "memory"); x = sx; }
         } while ((int)x < i);
         if (!first) {
             if (STORE == 0) asm volatile("global_store_dword %0, %1, off" :: "v"(mine), "v"(i) : "memory");
@@ -41,11 +42,11 @@ int main() {
     (void)hipMalloc(&buf, 4096); (void)hipMallocManaged(&out, 64); (void)hipMallocManaged(&xcc, 64);
     const int iters = 2000;
     const char* sn[3] = {"plain store", "sc0 sc1 store", "atomic swap"};
-    const char* ln[3] = {"sc1 load", "sc0 sc1 load", "sc0 load"};
+    const char* ln[4] = {"sc1 load", "sc0 sc1 load", "sc0 load", "scalar glc load"};
     for (int peer : {8, 1}) {
 #define RUN(S, L) { (void)hipMemset(buf, 0, 4096); k<S, L><<<16, 64>>>(buf, peer, iters, out, xcc); (void)hipDeviceSynchronize(); \
         printf("peer %d (xcc %u vs %u)  %-14s %-13s  %.0f ticks per one-way hand-over\n", peer, xcc[0], xcc[1], sn[S], ln[L], (double)*out / iters / 2); fflush(stdout); }
-        RUN(0, 0) RUN(1, 0) RUN(2, 0) RUN(0, 1) RUN(1, 1)
+        RUN(0, 0) RUN(1, 0) RUN(2, 0) RUN(0, 1) RUN(1, 1) RUN(0, 3) RUN(1, 3)
     }
     return 0;
 }

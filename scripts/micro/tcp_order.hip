@@ -5,12 +5,19 @@
 // hipcc --offload-arch=gfx950 -O3 scripts/micro/tcp_order.hip -o scripts/micro/tcp_order
 #include <hip/hip_runtime.h>
 #include <cstdio>
-__global__ __launch_bounds__(128) void k(const unsigned* big, size_t nbig, unsigned* hot, int mode, int iters, unsigned long long* out, volatile int* stop) {
+__global__ __launch_bounds__(128) void k(const unsigned* big, size_t nbig, unsigned* hot, int mode, int spoll, int iters, unsigned long long* out, volatile int* stop) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (wave == 1) {
         unsigned long long t0 = __builtin_amdgcn_s_memtime();
         unsigned x = 0;
         for (int i = 0; i < iters; ++i) {
+            if (spoll) {           // the measuring wave polls by SCALAR loads (glc: served by L2, not by the scalar cache)
+                const unsigned* p = hot + (__builtin_amdgcn_readfirstlane(x) & 1);
+                unsigned sx;
+                asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(sx) : "s"(p) : "memory");
+                x = sx;
+                continue;
+            }
             const unsigned* p = hot + (x & 1);
             asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(x) : "v"(p) : "memory");
         }
@@ -39,10 +46,11 @@ int main() {
     (void)hipMalloc(&big, nbig * 4); (void)hipMemset(big, 0, nbig * 4); (void)hipMalloc(&hot, 4096); (void)hipMemset(hot, 0, 4096);
     (void)hipMallocManaged(&out, 64); (void)hipMallocManaged(&stop, 4);
     const char* nm[4] = {"other wave idle", "other wave: vector loads missing to HBM", "other wave: SCALAR loads missing to HBM", "other wave: vector loads hitting L2"};
+    for (int spoll = 0; spoll < 2; ++spoll)
     for (int mode = 0; mode < 4; ++mode) {
         *stop = 0; (void)hipDeviceSynchronize();
-        k<<<1, 128>>>(big, nbig, hot, mode, 20000, out, stop); (void)hipDeviceSynchronize();
-        printf("%-42s  %.0f ticks per dependent sc1 load\n", nm[mode], (double)out[0] / 20000); fflush(stdout);
+        k<<<1, 128>>>(big, nbig, hot, mode, spoll, 20000, out, stop); (void)hipDeviceSynchronize();
+        printf("%-42s  %.0f ticks per dependent %s load\n", nm[mode], (double)out[0] / 20000, spoll ? "scalar glc" : "sc1"); fflush(stdout);
     }
     return 0;
 }

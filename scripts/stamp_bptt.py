@@ -24,6 +24,9 @@ def report(tag):
         v = d[off:off + 5].astype(float)
         print("%s, %s: %.0f cycles per step" % (tag, who, v.sum() / steps))
         print("   " + "  ".join("%s %.0f" % (n, x / steps) for n, x in zip(nm, v)))
+    if not V1:
+        print("   busy cycles per step between barriers, waves 0..8 (0 cell, 1-7 contraction, 8 loader): " +
+              " ".join("%.0f" % (x / steps) for x in d[48:57].astype(float)))
 
 
 # (a) alone: one BiLSTM layer, B=32, T=400

@@ -85,3 +85,33 @@ def test_device_beam_search_equals_reference_beam_search_call(case):
     sp.word_ins_penalty = case["word_ins_penalty"]
     got = BeamSearch(case["wd"], sp)(case["enc"])
     np.testing.assert_array_equal(got, case["ids"])
+
+
+def _run_beam(case, persist, monkeypatch):
+    from e2e_asr_amd.beam_search import BeamSearch
+    monkeypatch.setenv("ASR_BEAM_PERSIST", persist)
+    sp = BeamSearch.class_params()
+    sp.beam_size = case["k"]; sp.lm_weight = case["lm_weight"]; sp.lm_path = case["wl"]
+    sp.word_ins_penalty = case["word_ins_penalty"]
+    bs = BeamSearch(case["wd"], sp)
+    ids = bs(case["enc"])
+    book = dict(bs.last_book)
+    book["supported"] = bs.dec_params.simple_w is None and bs.lm_params.simple_w is None
+    return ids, book
+
+
+@pytest.mark.parametrize("case", _beam_cases())
+def test_persistent_beam_launch_equals_step_loop_bit_for_bit(case, monkeypatch):
+    """asr_beam_decode (one persistent launch: the step kernels' tile bodies as phases behind grid barriers, agent-scope
+    hand-over between XCDs) against the loop of asr_beam_step_sel + asr_beam_select: the same ids, back-pointers, finished
+    list and float64 scores, bit for bit, twice in a row (a stale line in some XCD's L2 would show as a different score)."""
+    ids0, b0 = _run_beam(case, "0", monkeypatch)
+    assert not b0["persistent"]
+    for _ in range(2):
+        ids1, b1 = _run_beam(case, "1", monkeypatch)
+        assert b1["persistent"] == b1["supported"]          # a SimpleProjection keeps the step loop (ASR_EUNSUPPORTED)
+        np.testing.assert_array_equal(ids1, ids0)
+        for key in ("n_live", "n_fin", "n_steps"):
+            assert b1[key] == b0[key], key
+        for key in ("bp", "fin", "fin_score", "cum"):
+            np.testing.assert_array_equal(b1[key], b0[key], err_msg=key)
