@@ -23,12 +23,14 @@ class DevicePrefetcher(object):
     def __init__(self, batches, device, depth=2):
         self.batches, self.device, self.depth = batches, torch.device(device), max(1, int(depth))
         self._workers = []
+        self._exhausted = None                              # set when the newest reader thread has read its last batch
 
     def _start(self):
         pinned_q = queue.Queue(maxsize=self.depth + 1)
         free_q = queue.Queue()                              # pinned buffers whose copy has been consumed
         stop = threading.Event()
-        worker = threading.Thread(target=self._fill, args=(pinned_q, free_q, stop), daemon=True)
+        self._exhausted = threading.Event()
+        worker = threading.Thread(target=self._fill, args=(pinned_q, free_q, stop, self._exhausted), daemon=True)
         worker.start()
         self._workers.append((worker, stop))
         return pinned_q, free_q, stop
@@ -41,6 +43,14 @@ class DevicePrefetcher(object):
         for worker, stop in self._workers:
             worker.join(timeout=5.0)
         self._workers = []
+
+    def reader_finished(self):
+        """True once the newest reader thread has no more input to read: it has iterated `batches` to the end, or `batches`
+        reports `files_exhausted` (a SpeechDataset whose last record has been parsed: only its shuffle buffer still drains).
+        From then on a second pass over the same dataset does not read and parse beside this one."""
+        if self._exhausted is None:
+            return False
+        return self._exhausted.is_set() or bool(getattr(self.batches, "files_exhausted", False))
 
     def primed(self):
         """An iterator whose reader thread starts NOW (a plain iter() starts it at the first next()): the training loop primes the
@@ -115,7 +125,7 @@ class DevicePrefetcher(object):
                 continue
         return False
 
-    def _fill(self, pinned_q, free_q, stop):
+    def _fill(self, pinned_q, free_q, stop, exhausted=None):
         try:
             made = 0
             for b in self.batches:
@@ -148,6 +158,8 @@ class DevicePrefetcher(object):
                                                              # out over the intra-op pool and crowd the launching thread)
                 if not self._put(pinned_q, stop, (dict(b), view, pinned)):
                     return
+            if exhausted is not None:
+                exhausted.set()
             self._put(pinned_q, stop, _END)
         except BaseException as e:                            # surfaces in the consumer, not in a dead thread
             self._put(pinned_q, stop, e)

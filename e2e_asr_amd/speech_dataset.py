@@ -8,6 +8,7 @@ reference's `sess.run(data_iter.initializer)`; exhaustion = its `OutOfRangeError
 (`padded_batch`, :54-58; the last batch may be smaller).  Batches are the dicts `Seq2SeqModel.get_batch` consumes:
 logmel [B,T,F] f32, char/phone [B,L] int64 (batch-major, like the iterator of the reference), *_len [B], utt_id [B].
 """
+import threading
 import numpy as np
 
 from . import tfrecord
@@ -46,7 +47,12 @@ class SpeechDataset(object):
         self.is_training = isTraining
         self.data_files = list(data_files)
         self.verify_crc = verify_crc
-        self._rng = np.random.default_rng(seed)
+        # every pass over the dataset shuffles with its OWN generator, the n-th child of the seed: the training loop starts the
+        # next epoch's reader while this epoch's shuffle buffer is still draining (train.py), and two passes drawing from one
+        # generator would make the order depend on thread timing
+        self._seed_seq = np.random.SeedSequence(seed)
+        self._spawn_lock = threading.Lock()
+        self.files_exhausted = False              # the newest pass has read its last record (its shuffle buffer may still drain)
 
     def get_instance(self, proto):
         """One parsed utterance (speech_dataset.py:13-45)."""
@@ -69,9 +75,11 @@ class SpeechDataset(object):
                 "phone_len": int(ctx["pint_len"][0]), "utt_id": ctx["segment"][0]}
 
     def _instances(self):
+        self.files_exhausted = False
         for fn in self.data_files:
             for rec in tfrecord.read_records(fn, verify_payload=self.verify_crc):
                 yield self.get_instance(rec)
+        self.files_exhausted = True
 
     def collate(self, insts):
         F = self.params.feat_length
@@ -86,7 +94,9 @@ class SpeechDataset(object):
     def __iter__(self):
         src = self._instances()
         if self.is_training:
-            src = shuffle_buffer(src, self.SHUFFLE_BUFFER, self._rng)
+            with self._spawn_lock:
+                rng = np.random.default_rng(self._seed_seq.spawn(1)[0])
+            src = shuffle_buffer(src, self.SHUFFLE_BUFFER, rng)
         batch = []
         for inst in src:
             batch.append(inst)

@@ -187,8 +187,10 @@ class Train(BaseParams):
             print("\nEpochs done: %d" % epoch)
             # (each bucket's batches are staged into HBM one batch ahead of the step: the iterator's prefetch of the reference)
             prefetchers = [DevicePrefetcher(s, self.device) for s in buck_train_sets]        # train.py:261-266
-            self._open_prefetchers.extend(prefetchers)
-            started = {0: carry} if carry is not None else {}
+            started = {}
+            if carry is not None:                 # bucket 0 of this epoch is the reader that was primed during the last one
+                prefetchers[0], started[0] = carry
+            self._open_prefetchers.extend(p for p in prefetchers if p not in self._open_prefetchers)
             carry = None
 
             def bucket_iter(k):                          # reader threads start one bucket ahead of the loop (prefetch.primed)
@@ -221,12 +223,15 @@ class Train(BaseParams):
                     it = bucket_iter(active[0])
                     if len(active) > 1:
                         bucket_iter(active[1])
-                    elif carry is None and epoch < params.max_epochs and len(buck_train_sets) > 1:
-                        # last bucket of the epoch: the next epoch's first one.  (Not with a single bucket: the carry would be a
-                        # second reader over the dataset this epoch is still iterating -- shared shuffle RNG, doubled parsing.)
+                    elif carry is None and epoch < params.max_epochs and (
+                            len(buck_train_sets) > 1 or prefetchers[active[0]].reader_finished()):
+                        # last bucket of the epoch: the next epoch's first one.  With a single bucket that is the dataset this
+                        # epoch is still iterating (its files would be parsed twice at once), so the carry starts only when
+                        # this epoch's reader has parsed its last record -- the loop then still has the shuffle buffer (4 000
+                        # utterances) to consume, and every pass shuffles with its own generator (speech_dataset.py).
                         carry_pf = DevicePrefetcher(buck_train_sets[0], self.device)     # fills its shuffle buffer meanwhile
                         self._open_prefetchers.append(carry_pf)                          # (0.74 -> 0.25 s per epoch change)
-                        carry = carry_pf.primed()
+                        carry = (carry_pf, carry_pf.primed())
                     batch = next(it)                                                  # smallest bucket first (:295)
                 except StopIteration:
                     del active[0]                                                     # :379-383

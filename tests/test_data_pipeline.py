@@ -108,6 +108,21 @@ def test_training_shuffle_is_a_buffered_permutation(tmp_path):
     ds = SpeechDataset(Bunch(batch_size=7, feat_length=8), [f], isTraining=True, seed=3)
     ids = [u for b in ds for u in b["utt_id"]]
     assert sorted(ids) == sorted(u["utt_id"] for u in utts) and ids != [u["utt_id"] for u in utts]
+    # every pass has its own generator (the n-th child of the seed): a second pass is another permutation, a second dataset
+    # with the same seed repeats both passes exactly -- also when the passes overlap in time, as in the training loop, which
+    # starts the next epoch's reader once `files_exhausted` says this pass has parsed its last record
+    ids2 = [u for b in ds for u in b["utt_id"]]
+    assert sorted(ids2) == sorted(ids) and ids2 != ids
+    ds_b = SpeechDataset(Bunch(batch_size=7, feat_length=8), [f], isTraining=True, seed=3)
+    it1 = iter(ds_b)
+    first = next(it1)                                  # 40 utterances < the shuffle buffer: everything is parsed before the first batch
+    assert ds_b.files_exhausted
+    it2 = iter(ds_b)                                   # the next pass starts while the first one still drains
+    second_pass_first = next(it2)
+    assert not ds_b.files_exhausted or len(utts) <= ds_b.SHUFFLE_BUFFER
+    rest1 = [u for b in it1 for u in b["utt_id"]]
+    rest2 = [u for b in it2 for u in b["utt_id"]]
+    assert list(first["utt_id"]) + rest1 == ids and list(second_pass_first["utt_id"]) + rest2 == ids2
     # tf.data semantics: with buffer k, the element emitted at position i comes from the first i+k inputs
     out = list(shuffle_buffer(range(100), 10, np.random.default_rng(0)))
     assert sorted(out) == list(range(100)) and all(v < i + 10 for i, v in enumerate(out))

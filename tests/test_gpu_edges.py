@@ -184,6 +184,21 @@ def test_device_prefetcher_stages_batches_in_order():
     it = iter(DevicePrefetcher(iter(src), DEV))                   # an abandoned iterator stops its worker
     next(it)
     it.close()
+    # reader_finished(): false before a reader exists and while it still has batches to read, true once it has read the last
+    # one -- the moment the single-bucket training loop starts the next epoch's reader over the same dataset (train.py)
+    import time
+    pf = DevicePrefetcher(src, DEV, depth=1)
+    assert not pf.reader_finished()
+    it = pf.primed()
+    first = next(it)
+    assert first["utt_id"] == 0 and not pf.reader_finished()      # 6+ batches, queue depth 2 + ring: the reader is still blocked
+    rest = list(it)
+    assert [b["utt_id"] for b in rest] == list(range(1, len(src)))
+    for _ in range(100):
+        if pf.reader_finished():
+            break
+        time.sleep(0.01)
+    assert pf.reader_finished()
 
 
 def test_concat_kx_layers_equals_torch_cat():
