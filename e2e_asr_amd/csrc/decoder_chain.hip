@@ -218,8 +218,14 @@ __global__ __launch_bounds__(512) void decoder_chain_fwd_kernel(ChainArgs a) {
 
     const int nsteps = a.t1 - a.t0;
     if (STAMP) { sph = 15; CHAINF_STAMP() }
+    const int tid_outer = tid;
     for (int s = 0; s < nsteps; ++s) {
         sph = 0;
+        // thread indices re-derived per step from an opaque copy (csrc/decoder_greedy.hip): fewer loop-invariant addresses held
+        int tz;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(tz));
+        const int tid = tid_outer + tz, lane = tid & 63;
+        const int kq = lane & 15, row = tid >> 4;
         const int i = a.t0 + s;
         const uint32_t ep = (uint32_t)(a.t0 + s + 1);      // tags unique over the segments of one call (workspace zeroed once)
         u64* gpar = gbase + (size_t)(s & 1) * NPAR;

@@ -276,8 +276,15 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
     __syncthreads();
 
     if (STAMP) tlast = __builtin_amdgcn_s_memtime();
+    const int tid_outer = tid;
     for (int s = 0; s < a.T; ++s) {
         sph = 0;
+        // thread indices re-derived per step from an opaque copy: addresses built from them are then not hoisted out of the loop
+        // and spilled (csrc/decoder_greedy.hip has the measurement: scratch reloads in front of the critical stores)
+        int tz;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(tz));
+        const int tid = tid_outer + tz, lane = tid & 63;
+        const int kq = lane & 15, row = tid >> 4;
         float* const pfl = pfl_base + (s & 1) * nitemsP;
         float* const yl = pfl;                            // y_i [R][A]
         float* const alf = yl + R * A;                    // alpha_i [R][TeP]
