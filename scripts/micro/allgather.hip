@@ -30,9 +30,10 @@ __device__ __forceinline__ unsigned or16(u16v a) {
 // lane to four streaming lines (the BPTT's dG bookkeeping); bit 2: the loader's lines were touched 8 steps earlier by
 // scalar loads of a tenth wave.
 template <int SCALAR, int NOISE>
-__global__ __launch_bounds__(640) void k(unsigned* buf, unsigned* big, size_t nbig, int steps, unsigned long long* out, int* err) {
+__global__ __launch_bounds__(640) void k(unsigned* buf, unsigned* big, size_t nbig, int steps, unsigned long long* out, int* err, int gs) {
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    const int group = xcd * 4 + (idx >> 3), member = idx & 7;
+    // gs = workgroups per group (8, or 4: twice the groups, three peers to hear from instead of seven)
+    const int group = gs == 8 ? xcd * 4 + (idx >> 3) : xcd * 8 + (idx >> 2), member = gs == 8 ? (idx & 7) : (idx & 3);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     unsigned* gb = buf + (size_t)group * 2 * 8 * 64;
     unsigned acc = 0;
@@ -94,8 +95,8 @@ __global__ __launch_bounds__(640) void k(unsigned* buf, unsigned* big, size_t nb
                 if (s & 1) { acc += oa[0] + ob[1] + od; fetch(s + 2, oa, ob, od); }
                 else { acc += ea[0] + eb[1] + ed; fetch(s + 2, ea, eb, ed); }
             }
-        } else if (!dead) {
-            const int src = (member + wave) & 7;
+        } else if (!dead && wave < gs) {
+            const int src = (member + wave) & (gs - 1);
             const unsigned* p = slot + src * 64;
             int guard = 0;
             if (SCALAR == 1) {
@@ -135,12 +136,12 @@ __global__ __launch_bounds__(640) void k(unsigned* buf, unsigned* big, size_t nb
 int main() {
     const size_t nbig = (size_t)1 << 30;     // 4 GiB of unsigned
     unsigned *buf, *big; unsigned long long* out; int* err;
-    (void)hipMalloc(&buf, 32 * 2 * 8 * 64 * 4); (void)hipMalloc(&big, nbig * 4); (void)hipMemset(big, 0, nbig * 4);
+    (void)hipMalloc(&buf, 64 * 2 * 8 * 64 * 4); (void)hipMalloc(&big, nbig * 4); (void)hipMemset(big, 0, nbig * 4);
     (void)hipMallocManaged(&out, 64); (void)hipMallocManaged(&err, 4);
     const int steps = 2000;        // streaming region: 256 workgroups x 2016 steps x 4 KB = 2.1 GB... halves of `big` (4 GiB)
-#define RUN(S, N) { (void)hipMemset(buf, 0, 32 * 2 * 8 * 64 * 4); *err = 0; (void)hipDeviceSynchronize(); \
-        k<S, N><<<256, 640>>>(buf, big, nbig, steps, out, err); (void)hipDeviceSynchronize(); \
-        printf("%-18s %-70s %6.0f ticks per step%s\n", pn[S], nm[N], (double)out[0] / steps, *err ? "  (SPIN GUARD HIT)" : ""); fflush(stdout); }
+#define RUN(S, N) { (void)hipMemset(buf, 0, 64 * 2 * 8 * 64 * 4); *err = 0; (void)hipDeviceSynchronize(); \
+        k<S, N><<<256, 640>>>(buf, big, nbig, steps, out, err, GS); (void)hipDeviceSynchronize(); \
+        printf("groups of %d  %-18s %-70s %6.0f ticks per step%s\n", GS, pn[S], nm[N], (double)out[0] / steps, *err ? "  (SPIN GUARD HIT)" : ""); fflush(stdout); }
     const char* nm[128] = {};
     const char* pn[4] = {"vector sc1 polls", "scalar glc polls", "buffer_inv sc1 + plain", "vector sc0 sc1 polls"};
     nm[0] = ""; nm[1] = "+ loader stream"; nm[2] = "+ bookkeeping stores"; nm[3] = "+ loader stream + bookkeeping stores";
@@ -149,6 +150,7 @@ int main() {
     nm[8] = "+ loader stream never waited for";
     nm[65] = "+ loader stream over a 64 KB window (L1 misses, L2 hits)";
     nm[32] = "+ loader stream in bursts: 8 steps' records every 8th step";
-    for (int rep = 0; rep < 1; ++rep) { RUN(0, 0) RUN(3, 0) RUN(1, 0) RUN(2, 0) RUN(0, 2) RUN(0, 65) RUN(0, 1) RUN(0, 8) RUN(0, 32) RUN(0, 5) RUN(0, 21) }
+    int GS = 8;
+    for (int rep = 0; rep < 2; ++rep, GS = 4) { RUN(0, 0) RUN(3, 0) RUN(1, 0) RUN(2, 0) RUN(0, 2) RUN(0, 65) RUN(0, 1) RUN(0, 8) RUN(0, 32) RUN(0, 5) RUN(0, 21) }
     return 0;
 }
