@@ -68,9 +68,11 @@ __global__ __launch_bounds__(512) void chain_relayout_kernel(const float* wh, co
 // STAMP: diagnostic instantiation (ASR_CHAIN_STAMP=1 + asr_debug_set_buffer): s_memtime totals of wave 0 of workgroup 0
 // per phase (code between two consecutive barriers of a step; slot 15 = prologue), accumulated over the launches of a call;
 // never used for timing claims.
-// R: utterances per group.  R = 2 holds up to 16 encoder positions per workgroup (Te <= 256); R = 1 trades the second row for
-// 32 positions per workgroup (Te <= 512, the depth-2 tap of the phone decoder): R * MAXTS = 32 = the DPP rows of a workgroup.
-template <int H, int D, int A, int R = 2, bool STAMP = false>
+// R: utterances per group, MAXTS: encoder positions per workgroup (Te <= 16 * MAXTS).  R * MAXTS (utterance, position) pairs are
+// scored by the 32 DPP rows of a workgroup in R * MAXTS / 32 passes: (2, 16) for Te <= 256; (1, 32) up to 512 positions; and
+// (2, 32), two passes, wherever the LDS still holds two utterances' enc / hf slices (Te <= 432 at config-2 widths: the depth-2
+// tap of the phone decoder, 400 positions -- ONE launch for 32 utterances instead of two launches of 16, round 3).
+template <int H, int D, int A, int R = 2, bool STAMP = false, int MAXTS_ = 32 / R>
 __global__ __launch_bounds__(512) void decoder_chain_fwd_kernel(ChainArgs a) {
     unsigned int stamp[16] = {0};
     unsigned long long tlast = STAMP ? __builtin_amdgcn_s_memtime() : 0;
@@ -87,7 +89,9 @@ __global__ __launch_bounds__(512) void decoder_chain_fwd_kernel(ChainArgs a) {
     constexpr int KCP = KC + 4;          // padded chunk stride in LDS
     constexpr int QP = (H + 127) / 128 * 128;     // padded query length
     constexpr int QC = QP / 32;          // q values per lane in the y matvec
-    constexpr int MAXTS = 32 / R;        // encoder positions per workgroup (Te <= 16 * MAXTS)
+    constexpr int MAXTS = MAXTS_;        // encoder positions per workgroup (Te <= 16 * MAXTS)
+    constexpr int PASSES = R * MAXTS / 32;
+    static_assert(R * MAXTS == 32 * PASSES && (PASSES == 1 || PASSES == 2) && R * MAXTS <= 64, "(utterance, position) pairs per workgroup");
     static_assert(HS * G == H && AS * G == A && DS * G == D && HS <= 16 && AS <= 8, "sizes");
     static_assert(KC % 4 == 0 && QC % 4 == 0 && KS % 2 == 0 && H % 2 == 0 && A % 2 == 0, "mapping");
     constexpr int H4 = 4 * H;
@@ -102,8 +106,8 @@ __global__ __launch_bounds__(512) void decoder_chain_fwd_kernel(ChainArgs a) {
     float* ysum = ql + R * QP;                      // [2 parts][AS][R]
     float* yl = ysum + 2 * AS * R + 4;              // y [R][A]
     float* el = yl + R * A;                         // e / alpha [R][G*MAXTS]
-    float* eout = el + R * G * MAXTS;               // [32] scores of this workgroup
-    float* cpart = eout + 32;                       // [8][R][DS]
+    float* eout = el + R * G * MAXTS;               // [R * MAXTS] scores of this workgroup
+    float* cpart = eout + 32 * PASSES;              // [8][R][DS]
     float* pgl = cpart + 8 * R * DS;                // preG of the current step for my units [R][HS][4]
     float* vl = pgl + R * HS * 4;                   // v [A]
     float* hfl = vl + A;                            // hf slice [R][TS][A]
@@ -346,34 +350,38 @@ __global__ __launch_bounds__(512) void decoder_chain_fwd_kernel(ChainArgs a) {
         __syncthreads();
         CHAINF_STAMP()
         {
-            // DPP row -> (tl = row % MAXTS, r = row / MAXTS); lane kq -> A/16 consecutive a (float4 steps)
-            const int tl = row % MAXTS, r = row / MAXTS;
-            float sc = 0.f;
-            if (tl < TS) {
-                constexpr int AL = A / 16;
-                const float* hrow = hfl + (r * MAXTS + tl) * A;
-                const float* yrow = yl + r * A;
-                if (AL % 4 == 0) {       // float4 chunks 64 columns apart: conflict-free across the 16 lanes of the DPP row
+            // DPP row (+ 32 per pass) -> (tl = pair % MAXTS, r = pair / MAXTS); lane kq -> A/16 consecutive a (float4 steps)
 #pragma unroll
-                    for (int c = 0; c < AL / 4; ++c) {
-                        const int a0 = c * 64 + kq * 4;
-                        const float4 h4 = *reinterpret_cast<const float4*>(hrow + a0);
-                        const float4 y4 = *reinterpret_cast<const float4*>(yrow + a0);
-                        const float4 v4 = *reinterpret_cast<const float4*>(vl + a0);
-                        sc = fmaf(v4.x, fast_tanh(h4.x + y4.x), sc); sc = fmaf(v4.y, fast_tanh(h4.y + y4.y), sc);
-                        sc = fmaf(v4.z, fast_tanh(h4.z + y4.z), sc); sc = fmaf(v4.w, fast_tanh(h4.w + y4.w), sc);
+            for (int pass = 0; pass < PASSES; ++pass) {
+                const int pair = row + 32 * pass;
+                const int tl = pair % MAXTS, r = pair / MAXTS;
+                float sc = 0.f;
+                if (tl < TS) {
+                    constexpr int AL = A / 16;
+                    const float* hrow = hfl + (r * MAXTS + tl) * A;
+                    const float* yrow = yl + r * A;
+                    if (AL % 4 == 0) {       // float4 chunks 64 columns apart: conflict-free across the 16 lanes of the DPP row
+#pragma unroll
+                        for (int c = 0; c < AL / 4; ++c) {
+                            const int a0 = c * 64 + kq * 4;
+                            const float4 h4 = *reinterpret_cast<const float4*>(hrow + a0);
+                            const float4 y4 = *reinterpret_cast<const float4*>(yrow + a0);
+                            const float4 v4 = *reinterpret_cast<const float4*>(vl + a0);
+                            sc = fmaf(v4.x, fast_tanh(h4.x + y4.x), sc); sc = fmaf(v4.y, fast_tanh(h4.y + y4.y), sc);
+                            sc = fmaf(v4.z, fast_tanh(h4.z + y4.z), sc); sc = fmaf(v4.w, fast_tanh(h4.w + y4.w), sc);
+                        }
+                    } else {
+#pragma unroll
+                        for (int q4 = 0; q4 < AL; ++q4) sc = fmaf(vl[kq * AL + q4], fast_tanh(hrow[kq * AL + q4] + yrow[kq * AL + q4]), sc);
                     }
-                } else {
-#pragma unroll
-                    for (int q4 = 0; q4 < AL; ++q4) sc = fmaf(vl[kq * AL + q4], fast_tanh(hrow[kq * AL + q4] + yrow[kq * AL + q4]), sc);
                 }
+                sc = row16_allreduce_sum(sc);
+                if (kq == 0) eout[pair] = sc;
             }
-            sc = row16_allreduce_sum(sc);
-            if (kq == 0) eout[row] = sc;
         }
         __syncthreads();
         CHAINF_STAMP()
-        if (wave0 && tid < 32) {
+        if (wave0 && tid < R * MAXTS) {
             const int tl = tid % MAXTS, r = tid / MAXTS;
             if (tl < TS && r0 + r < a.B)
                 chain_publish(gE + (size_t)r * G * MAXTS + mem * MAXTS + tl, ep, eout[tid], fast);
@@ -478,14 +486,31 @@ extern "C" int asr_decoder_chain_supported(int B, int Te, int D, int A, int H) {
     return (H == 256 && D == 512 && A == 128) || (H == 64 && D == 128 && A == 16);
 }
 
-// granule area of one call: [groups][2 parities][S | Q | Y | E] + [groups][16] XCC slots, for R rows per group
-static size_t chain_npar(int R, int D, int A, int H) { return (size_t)R * (H + D) + (size_t)R * H + (size_t)R * A + 16 * 32; }
-static size_t chain_gran_bytes_r(int B, int D, int A, int H, int R) {
-    const size_t groups = ((size_t)B + R - 1) / R;
-    return (groups * 2 * chain_npar(R, D, A, H) * sizeof(u64) + groups * 16 * sizeof(u64) + 255) / 256 * 256;
+// LDS of one workgroup of the forward kernel (floats), for R utterances per group and MAXTS positions per workgroup
+static size_t chain_fwd_lds_floats(int H, int D, int A, int R, int MAXTS, int Te) {
+    const int G = 16, KSP = (H + D + 127) / 128 * 128, KCP = KSP / 32 + 4, QP = (H + 127) / 128 * 128;
+    return 4 + (size_t)R * 32 * KCP + 2 * (H / G) * R * 4 + R * QP + 2 * (A / G) * R + 4 + R * A + (size_t)R * G * MAXTS + R * MAXTS +
+           8 * R * (D / G) + R * (H / G) * 4 + A + (size_t)R * MAXTS * A + (size_t)R * Te * (D / G);
 }
-static size_t chain_gran_bytes(int B, int D, int A, int H) {      // the workspace serves either decomposition
-    return std::max(chain_gran_bytes_r(B, D, A, H, 1), chain_gran_bytes_r(B, D, A, H, 2));
+static const size_t kChainLdsMax = 160 * 1024 - 64;
+// The forward chain's decomposition for this Te: two utterances per group wherever their slices fit the LDS (16 positions per
+// workgroup up to 256 positions, 32 -- two score passes -- beyond), else one.  (asr_decoder_chain_rows is the BACKWARD
+// chain's: its LDS also holds dhf, so it drops to one utterance per group above 256 positions.)
+static void chain_fwd_mode(int Te, int H, int D, int A, int* R, int* MAXTS) {
+    if (Te <= 256) { *R = 2; *MAXTS = 16; return; }
+    const char* e = getenv("ASR_CHAIN_FWD_R2");          // =0: one utterance per group above 256 positions, as before round 3
+    const bool two = !(e && e[0] == '0');
+    if (two && chain_fwd_lds_floats(H, D, A, 2, 32, Te) * sizeof(float) <= kChainLdsMax) { *R = 2; *MAXTS = 32; return; }
+    *R = 1; *MAXTS = 32;
+}
+// granule area of one call: [groups][2 parities][S | Q | Y | E] + [groups][16] XCC slots, for R rows per group
+static size_t chain_npar(int R, int MAXTS, int D, int A, int H) { return (size_t)R * (H + D) + (size_t)R * H + (size_t)R * A + (size_t)R * 16 * MAXTS; }
+static size_t chain_gran_bytes_r(int B, int D, int A, int H, int R, int MAXTS) {
+    const size_t groups = ((size_t)B + R - 1) / R;
+    return (groups * 2 * chain_npar(R, MAXTS, D, A, H) * sizeof(u64) + groups * 16 * sizeof(u64) + 255) / 256 * 256;
+}
+static size_t chain_gran_bytes(int B, int D, int A, int H) {      // the workspace serves every decomposition
+    return std::max(std::max(chain_gran_bytes_r(B, D, A, H, 1, 32), chain_gran_bytes_r(B, D, A, H, 2, 16)), chain_gran_bytes_r(B, D, A, H, 2, 32));
 }
 static size_t chain_relayout_bytes(int D, int H) {
     const size_t KC = ((size_t)(H + D) + 127) / 128 * 128 / 32;
@@ -495,24 +520,22 @@ extern "C" size_t asr_decoder_chain_ws_bytes(int B, int D, int A, int H) {
     return chain_gran_bytes(B, D, A, H) + chain_relayout_bytes(D, H);      // granules + XCC slots | re-laid weights
 }
 
-template <int H, int D, int A, int R>
+template <int H, int D, int A, int R, int MAXTS>
 static int chain_launch(hipStream_t s, asr::ChainArgs& a, int Te) {
     constexpr int G = 16;
     const int groups = a.ng;
     const int grid_groups = (((groups + 7) & ~7) * G <= asr::resident_wg_budget()) ? ((groups + 7) & ~7) : groups;
-    constexpr int KSP = (H + D + 127) / 128 * 128, KCP = KSP / 32 + 4, QP = (H + 127) / 128 * 128;
-    const size_t lds = sizeof(float) * (4 + (size_t)R * 32 * KCP + 2 * (H / G) * R * 4 + R * QP + 2 * (A / G) * R + 4 + R * A +
-                                        G * 32 + 32 + 8 * R * (D / G) + R * (H / G) * 4 + A + 32 * A + (size_t)R * Te * (D / G));
-    if (lds > 160 * 1024 - 64) return ASR_EUNSUPPORTED;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asr::decoder_chain_fwd_kernel<H, D, A, R>),
+    const size_t lds = sizeof(float) * chain_fwd_lds_floats(H, D, A, R, MAXTS, Te);
+    if (lds > kChainLdsMax) return ASR_EUNSUPPORTED;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asr::decoder_chain_fwd_kernel<H, D, A, R, false, MAXTS>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (H == 256 && R == 2 && a.dbg) {
+    if (H == 256 && R == 2 && MAXTS == 16 && a.dbg) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asr::decoder_chain_fwd_kernel<256, 512, 128, 2, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((asr::decoder_chain_fwd_kernel<256, 512, 128, 2, true>), dim3(grid_groups * G), dim3(512), lds, s, a);
         return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
     }
-    hipLaunchKernelGGL((asr::decoder_chain_fwd_kernel<H, D, A, R>), dim3(grid_groups * G), dim3(512), lds, s, a);
+    hipLaunchKernelGGL((asr::decoder_chain_fwd_kernel<H, D, A, R, false, MAXTS>), dim3(grid_groups * G), dim3(512), lds, s, a);
     return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
 }
 
@@ -527,7 +550,8 @@ int asr_decoder_chain_fwd(void* stream, float* gates, const float* wh, const flo
     if (!asr_decoder_chain_supported(B, Te, D, A, H) || t1 <= t0) return ASR_EUNSUPPORTED;
     hipStream_t s = static_cast<hipStream_t>(stream);
     // NOTE: all batch rows of a launch share the [T][B][.] row stride B, so chunking is by group range only
-    const int R = asr_decoder_chain_rows(Te);
+    int R, MAXTS;
+    chain_fwd_mode(Te, H, D, A, &R, &MAXTS);
     const size_t bytes = chain_gran_bytes(B, D, A, H);
     float4* wrl = reinterpret_cast<float4*>(static_cast<char*>(ws) + bytes);
     if (t0 == 0) {                                                                          // once per sequence
@@ -542,15 +566,15 @@ int asr_decoder_chain_fwd(void* stream, float* gates, const float* wh, const flo
     a.gx = static_cast<u64*>(ws);
     a.wrl = wrl;
     const size_t groups = ((size_t)B + R - 1) / R;
-    a.xcc_slots = a.gx + groups * 2 * chain_npar(R, D, A, H);
+    a.xcc_slots = a.gx + groups * 2 * chain_npar(R, MAXTS, D, A, H);
     a.err = err; a.B = B; a.Te = Te; a.t0 = t0; a.t1 = t1;
     a.dbg = getenv("ASR_CHAIN_STAMP") ? asr::g_lstm_dbg : nullptr;
     const int gpl = std::min(16, asr::resident_wg_budget() / 16);     // groups per launch: all of them co-resident
     for (int g0 = 0; g0 < (int)groups; g0 += gpl) {
         a.g0 = g0; a.ng = std::min<int>(gpl, (int)groups - g0);
         int rc;
-        if (H == 256) rc = R == 2 ? chain_launch<256, 512, 128, 2>(s, a, Te) : chain_launch<256, 512, 128, 1>(s, a, Te);
-        else rc = R == 2 ? chain_launch<64, 128, 16, 2>(s, a, Te) : chain_launch<64, 128, 16, 1>(s, a, Te);
+        if (H == 256) rc = R == 1 ? chain_launch<256, 512, 128, 1, 32>(s, a, Te) : MAXTS == 16 ? chain_launch<256, 512, 128, 2, 16>(s, a, Te) : chain_launch<256, 512, 128, 2, 32>(s, a, Te);
+        else rc = R == 1 ? chain_launch<64, 128, 16, 1, 32>(s, a, Te) : MAXTS == 16 ? chain_launch<64, 128, 16, 2, 16>(s, a, Te) : chain_launch<64, 128, 16, 2, 32>(s, a, Te);
         if (rc) return rc;
     }
     return ASR_OK;

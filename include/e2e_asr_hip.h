@@ -329,7 +329,8 @@ int asr_side_join(void* stream);
  * everything.  New (the reference is single-device): used by e2e_asr_amd/parallel.py's tail overlap. */
 int asr_side_wait(void* stream);
 /* Persistent decoder chain (csrc/decoder_chain.hip): used inside asr_attn_decoder_fwd when supported (Te <= 512).
- * asr_decoder_chain_rows: utterances per 16-workgroup group for this Te (2 up to 256 encoder positions, else 1). */
+ * asr_decoder_chain_rows: utterances per 16-workgroup group of the BACKWARD chain for this Te (2 up to 256 encoder positions,
+ * else 1; the forward chain keeps 2 wherever both utterances' slices fit the LDS, up to 432 positions at config-2 widths). */
 int asr_decoder_chain_supported(int B, int Te, int D, int A, int H);
 int asr_decoder_chain_rows(int Te);
 /* Inference graph (mode 1) as one persistent launch (csrc/decoder_greedy.hip): argmax feedback, LM cell, attention,

@@ -497,12 +497,16 @@ def test_decoder_chain_path_vs_oracle_and_autograd():
         assert err < 2e-3, (name, err)
 
 
+@pytest.mark.parametrize("fwd_r2", ["1", "0"])
 @pytest.mark.parametrize("nb,T", [(5, 700), (19, 523)])
-def test_decoder_chain_long_encoder_one_row_groups(monkeypatch, nb, T):
-    """More than 256 encoder positions (the depth-2 tap: T/2 frames): the chain kernels run as one utterance per group
-    with 32 positions per workgroup (asr_decoder_chain_rows(Te) == 1); 19 utterances = two launches (16 + 3 groups).
-    Logits vs the float64 oracle, and logits, sampled tokens and every gradient vs the per-step launch path."""
+def test_decoder_chain_long_encoder_one_row_groups(monkeypatch, nb, T, fwd_r2):
+    """More than 256 encoder positions (the depth-2 tap: T/2 frames): 32 positions per workgroup.  The BACKWARD chain runs one
+    utterance per group (asr_decoder_chain_rows(Te) == 1; 19 utterances = two launches, 16 + 3 groups); the FORWARD chain keeps
+    two utterances per group, scored in two passes, wherever their slices fit the LDS (round 3; ASR_CHAIN_FWD_R2=0: one per
+    group, as the backward).  Logits vs the float64 oracle, and logits, sampled tokens and every gradient vs the per-step launch
+    path, for both forward decompositions."""
     from e2e_asr_amd import _lib, ops
+    monkeypatch.setenv("ASR_CHAIN_FWD_R2", fwd_r2)
     L = _lib.lib()
     Te = (T + 1) // 2
     assert L.asr_decoder_chain_rows(Te) == 1 and L.asr_decoder_chain_rows(256) == 2
