@@ -1,5 +1,5 @@
 """Soak of the multitask model (char depth 4 + phone decoder on depth `nlp`) over random ragged batch shapes: every step
-must finish without an exchange time-out.  soak_multi.py seed steps nlp"""
+must finish without an exchange time-out.  soak_multi.py seed steps nlp [Tmax]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -12,6 +12,7 @@ from e2e_asr_amd.weights import synthetic_batch
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 nlp = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+tmax = int(sys.argv[4]) if len(sys.argv) > 4 else 600      # depth 2 and Tmax = 900: the forward chain's two-pass groups (Te 257..432) and beyond
 dev = torch.device("cuda:0")
 p = Seq2SeqModel.class_params()
 p.encoder_params.use_lstm = True
@@ -23,7 +24,7 @@ model = Seq2SeqModel(None, isTraining=True, params=p, device=dev, feat_length=80
 rng = np.random.default_rng(seed)
 t0 = time.time()
 for it in range(n):
-    B = int(rng.integers(1, 41)); T = int(rng.integers(40, 601)); td = int(rng.integers(4, 41)); tp = int(rng.integers(4, 90))
+    B = int(rng.integers(1, 41)); T = int(rng.integers(40, tmax + 1)); td = int(rng.integers(4, 41)); tp = int(rng.integers(4, 90))
     b = synthetic_batch(B=B, T=T, F=80, t_dec=td, vocab=1000, variable_len=True, seed=int(rng.integers(1 << 30)), tasks=("char",))
     bp = synthetic_batch(B=B, T=T, F=80, t_dec=tp, vocab=50, variable_len=True, seed=int(rng.integers(1 << 30)), tasks=("phone",))
     b["phone"], b["phone_len"] = bp["phone"], bp["phone_len"]
