@@ -465,8 +465,11 @@ def main():
     use_bwd = mode == "train" and recb_per_step_ms > rec_per_step_ms
     dom_ms = recb_per_step_ms if use_bwd else rec_per_step_ms
     v2 = os.environ.get("ASR_LSTM_V2", "1") != "0"
-    dom_name = (("lstm_rec_bwd2_kernel<256,2> (persistent BPTT, version 2)" if v2 else "lstm_rec_bwd_ag_kernel<256,2> (persistent BPTT)") if use_bwd else
-                ("lstm_rec_fwd2_kernel<256,2> (persistent recurrent LSTM, version 2)" if v2 else "lstm_rec_fwd_kernel<256,32,2> (persistent recurrent LSTM)"))
+    g4 = v2 and os.environ.get("ASR_LSTM_G4", "1") != "0" and 2 * B * 4 <= 256       # csrc/lstm.hip: groups of four workgroups when the batch fits
+    dom_name = (("lstm_rec_bwd4_kernel (persistent BPTT, groups of four workgroups)" if g4 else
+                 "lstm_rec_bwd2_kernel<256,2> (persistent BPTT, version 2)" if v2 else "lstm_rec_bwd_ag_kernel<256,2> (persistent BPTT)") if use_bwd else
+                ("lstm_rec_fwd4_kernel (persistent recurrent LSTM, groups of four workgroups)" if g4 else
+                 "lstm_rec_fwd2_kernel<256,2> (persistent recurrent LSTM, version 2)" if v2 else "lstm_rec_fwd_kernel<256,32,2> (persistent recurrent LSTM)"))
     achieved = REC_FLOP_FWD / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else None
     dom_launches, dom_flop, chain_steps = 4.0, REC_FLOP_FWD, sum(ENC_LAYER_T)
     if mt is not None and mode == "train":

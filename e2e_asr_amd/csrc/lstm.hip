@@ -591,6 +591,156 @@ extern "C" int asr_get_gemm_precision(void);
 // bf16 mode only: recurrent products of the FIRST-version kernels on the bf16 matrix pipe (round 2).  Off by default since
 // round 3 (the fp32 version-2 recurrences are faster and exact); ASR_LSTM_MFMA=1 or asr_set_lstm_mfma(1) selects them.
 static int g_lstm_mfma = -1;
+// ---------------------------------------------------------------------------------------------------------------
+// Groups of FOUR workgroups (H = 256: 64 units each, one batch row per group) -- the `HS = 64` candidate of the round-2 review,
+// priced by scripts/micro/allgather.hip at -9 % of the bare exchange (three peers to hear from instead of seven).  Wave w
+// multiplies K half (w & 1) of the 64-unit slice of source workgroup (mem + (w >> 1)) % 4: lane = own unit, 32 K rows x 4 gates
+// = 128 weight registers, the 32 h values broadcast from a wave-private LDS row -- no cross-lane reduction at all; the cell
+// wave (wave 0) sums the eight partials.  Wave 0 takes the first half of the own slice straight from its registers, wave 1
+// polls the second half of the own slice like any other source.  Forward 1.19 -> 1.08 us per step at B = 32, T = 800 (round 3).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void lstm_rec_fwd4_kernel(LstmRecArgs a) {
+    constexpr int H = 256, HS = 64, G = 4, NW = 8, NT = 512, H4 = 4 * H;
+    __shared__ __attribute__((aligned(16))) float hs[NW][32];
+    __shared__ __attribute__((aligned(16))) float4 part[2][NW][HS];
+
+    __builtin_amdgcn_s_setprio(3);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int NG = a.B;
+    const int ngroups = a.ND * NG;
+    int grp, mem;
+    if (((gridDim.x / G) & 7) == 0) { mem = (blockIdx.x >> 3) % G; grp = (blockIdx.x & 7) + 8 * (blockIdx.x / (8 * G)); }
+    else { grp = blockIdx.x / G; mem = blockIdx.x % G; }
+    if (grp >= ngroups) return;
+    const int dir = grp / NG, cb = grp % NG;
+    const int src_wg = (mem + (wave >> 1)) % G, khh = wave & 1;
+    const int kbase = src_wg * HS + khh * 32;          // first K row (= hidden unit of the source) of this wave's half slice
+
+    f32x2 wp[32][2];                                   // wp[k][p] = (gate 2p, gate 2p+1) of K row kbase + k for unit mem*64 + lane
+    {
+        const float* khp = a.kh[dir] + (size_t)kbase * H4 + mem * HS + lane;
+#pragma unroll
+        for (int k = 0; k < 32; ++k)
+#pragma unroll
+            for (int p2 = 0; p2 < 2; ++p2)
+                wp[k][p2] = f32x2{khp[(size_t)k * H4 + (2 * p2) * H], khp[(size_t)k * H4 + (2 * p2 + 1) * H]};
+    }
+    const int S = min(a.len[cb], a.T);
+    const bool cell_wave = wave == 0;
+    const int cj = mem * HS + lane;
+    float c = 0.f, h = 0.f;
+    const bool has_init = a.h0 != nullptr;
+    if (has_init && cell_wave) { h = a.h0[(size_t)cb * H + cj]; c = a.c0[(size_t)cb * H + cj]; }
+    u64* hxg = a.hx + (size_t)grp * 2 * H;             // [2 parities][H] granules
+    const bool fast = group_shares_xcd(a.xcc_slots + (size_t)grp * 16, G, mem, tid, a.err, nullptr, (uint32_t)a.ep0, 4);
+    float gx0 = 0.f, gx1 = 0.f, gx2 = 0.f, gx3 = 0.f;
+    auto prefetch = [&](int s) {
+        const int t = dir ? (S - 1 - s) : s;
+        const int ts = min(max(t, 0), a.T - 1);
+        const float* gp_ = a.gates + (((size_t)cb * a.sb + (size_t)ts * a.st) * a.ND + dir) * H4 + cj;
+        gx0 = gp_[0]; gx1 = gp_[H]; gx2 = gp_[2 * H]; gx3 = gp_[3 * H];
+    };
+    if (cell_wave) prefetch(0);
+
+    auto slice_partial = [&](int par) {
+        const f32x4* hq = reinterpret_cast<const f32x4*>(&hs[wave][0]);
+        f32x4 hall[8];
+#pragma unroll
+        for (int k4 = 0; k4 < 8; ++k4) hall[k4] = hq[k4];
+        f32x2 pa[2][2] = {{f32x2{0.f, 0.f}, f32x2{0.f, 0.f}}, {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}}};   // [gate pair][chain]
+#pragma unroll
+        for (int k4 = 0; k4 < 8; ++k4) {
+            const f32x4 hv = hall[k4];
+            const f32x2 h0 = __builtin_shufflevector(hv, hv, 0, 1), h1 = __builtin_shufflevector(hv, hv, 2, 3);
+#pragma unroll
+            for (int p2 = 0; p2 < 2; ++p2) {
+                pk_fma_alo(pa[p2][0], h0, wp[4 * k4 + 0][p2]);
+                pk_fma_ahi(pa[p2][1], h0, wp[4 * k4 + 1][p2]);
+                pk_fma_alo(pa[p2][0], h1, wp[4 * k4 + 2][p2]);
+                pk_fma_ahi(pa[p2][1], h1, wp[4 * k4 + 3][p2]);
+            }
+        }
+        const f32x2 g01 = pa[0][0] + pa[0][1], g23 = pa[1][0] + pa[1][1];
+        part[par][wave][lane] = make_float4(g01.x, g01.y, g23.x, g23.y);
+    };
+
+    if (has_init && S > 0) {
+        if (lane < 32) hs[wave][lane] = a.h0[(size_t)cb * H + kbase + lane];
+        __builtin_amdgcn_wave_barrier();
+        slice_partial(0);
+    }
+    for (int s = 0; s < S; ++s) {
+        const int t = dir ? (S - 1 - s) : s;
+        const int par = s & 1;
+        if (s > 0 || has_init) {
+            if (!cell_wave && s > 0) {
+                if (lane < 32) {
+                    float v = 0.f;
+                    poll_granule1(hxg + (size_t)((s - 1) & 1) * H + kbase + lane, (uint32_t)(a.ep0 + s), v, a.err);
+                    hs[wave][lane] = v;
+                }
+                __builtin_amdgcn_wave_barrier();
+                slice_partial(par);
+            }
+            __syncthreads();
+        }
+        if (cell_wave) {
+            float4 pre = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (s > 0 || has_init) {
+#pragma unroll
+                for (int ww = 0; ww < NW; ++ww) {
+                    const float4 p = part[par][ww][lane];
+                    pre.x += p.x; pre.y += p.y; pre.z += p.z; pre.w += p.w;
+                }
+            }
+            const float h_old = h, c_old = c;
+            const float gi = fast_sigmoid(pre.x + gx0);
+            const float gj = fast_tanh(pre.y + gx1);
+            const float gf = fast_sigmoid(pre.z + gx2 + 1.0f);
+            const float go = fast_sigmoid(pre.w + gx3);
+            c = c * gf + gi * gj;
+            h = go * fast_tanh(c);
+            const bool more = s + 1 < S;
+            if (more) {
+                u64* dst = hxg + (size_t)(s & 1) * H + cj;
+                const u64 gv = ((u64)(uint32_t)(a.ep0 + s + 1) << 32) | __float_as_uint(h);
+                if (fast) asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(dst), "v"(gv) : "memory");
+                else __hip_atomic_store(dst, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            {
+                const size_t ridx = (((size_t)cb * a.sb + (size_t)t * a.st) * a.ND + dir) * H + cj;
+                float o = h;
+                if (a.keep < 1.0f)
+                    o *= keep_scale(a.seed, (uint32_t)((a.boff + cb) * a.dsb + (a.toff + t) * a.dst), (uint32_t)(dir * H + cj), a.keep);
+                a.out[((size_t)cb * a.osb + (size_t)t * a.ost) * a.ldo + dir * H + cj] = o;
+                if (a.hprev) __builtin_nontemporal_store(h_old, a.hprev + ridx);
+                if (a.act) {
+                    f32x4* rp = reinterpret_cast<f32x4*>(a.act + ridx * 8);
+                    __builtin_nontemporal_store(f32x4{gi, gj, gf, go}, rp);
+                    __builtin_nontemporal_store(f32x4{c, c_old, 0.f, 0.f}, rp + 1);
+                }
+            }
+            if (more) {
+                prefetch(s + 1);
+                if (lane < 32) hs[0][lane] = h;          // the first half of the own slice, for the next step
+                __builtin_amdgcn_wave_barrier();
+                slice_partial(par ^ 1);
+            }
+        }
+    }
+    if (a.h_last && cell_wave) { a.h_last[(size_t)cb * H + cj] = h; a.c_last[(size_t)cb * H + cj] = c; }
+    {   // zero output past the row's length (dynamic_rnn zero-fill; also the pyramid pad frame)
+        const int nz = a.Tout - S;
+        for (int idx = tid; idx < nz * HS; idx += NT) {
+            const int tt = S + idx / HS, uu = idx % HS;
+            a.out[((size_t)cb * a.osb + (size_t)tt * a.ost) * a.ldo + dir * H + mem * HS + uu] = 0.f;
+            if (a.hprev && tt < a.T)
+                a.hprev[(((size_t)cb * a.sb + (size_t)tt * a.st) * a.ND + dir) * H + mem * HS + uu] = 0.f;
+        }
+    }
+}
+
 extern "C" int asr_get_lstm_mfma(void) {
     if (g_lstm_mfma < 0) { const char* e = getenv("ASR_LSTM_MFMA"); g_lstm_mfma = (e && e[0] == '1') ? 1 : 0; }
     return g_lstm_mfma;
@@ -706,6 +856,23 @@ extern "C" int asr_lstm_layer_fwd(void* stream, const float* x, int B, int T, in
     a.B = B; a.T = T; a.Tout = Tout; a.ND = ndir; a.keep = keep_prob; a.seed = seed;
     a.sb = T; a.st = 1; a.osb = Tout; a.ost = 1; a.ldo = ndir * H; a.dsb = Tout; a.dst = 1; a.toff = 0;
     a.h0 = a.c0 = nullptr; a.h_last = a.c_last = nullptr; a.ep0 = 0;
+    {   // groups of four workgroups, one row per group (lstm_rec_fwd4_kernel), when the whole batch is resident at once:
+        // 1.19 -> 1.08 us per step at B = 32 (ASR_LSTM_G4=0: the eight-workgroup groups of version 2)
+        const char* e = getenv("ASR_LSTM_G4");
+        const char* v2e = getenv("ASR_LSTM_V2");
+        if (!(e && e[0] == '0') && !(v2e && v2e[0] == '0') && !(g_lstm_dbg && getenv("ASR_LSTM_STAMP")) &&
+            !(asr_get_lstm_mfma() != 0 && asr_get_gemm_precision() == 1) && H == 256 && ndir * B * 4 <= asr_lstm_max_wgs()) {
+            a.dbg = nullptr;
+            const int groups = ndir * B;
+            const int padded = ((groups + 7) & ~7) * 4;
+            const int grid = padded <= asr_lstm_max_wgs() ? padded : groups * 4;
+            prof_begin(ASR_PROF_LSTM_REC_FWD, s);
+            hipLaunchKernelGGL(asr::lstm_rec_fwd4_kernel, dim3(grid), dim3(512), 0, s, a);
+            prof_end(ASR_PROF_LSTM_REC_FWD, s);
+            ASR_CHECK_LAUNCH();
+            return ASR_OK;
+        }
+    }
     const int R = asr_lstm_pick_rows(B, ndir, H / 32);
     // batches too large for one resident grid run as consecutive launches over row ranges
     const int max_groups = asr_lstm_max_wgs() / (H / 32) / ndir;

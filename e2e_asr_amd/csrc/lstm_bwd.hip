@@ -835,6 +835,172 @@ __global__ __launch_bounds__(2 * H + 64) void lstm_rec_bwd2_kernel(LstmBwdArgs a
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Groups of FOUR workgroups (H = 256: 64 units each, one batch row per group), as lstm_rec_fwd4_kernel of csrc/lstm.hip.
+// Wave w contracts the 32 tagged quads (128 dG positions) that source workgroup (mem + (w >> 1)) % 4 published for half (w & 1)
+// of its units with the K_h rows of the workgroup's own 64 units: lane = own unit, 128 weight registers, the dG values
+// broadcast from a wave-private LDS row, no cross-lane reduction; the cell wave (wave 0) sums the eight partials.  Eight
+// waves only: with a ninth (loader) wave the register file allows 168 per wave, less than the weights + operands; the cell
+// wave itself fetches the activation record of the NEXT step and turns it into the pointwise operands in the slack after its
+// own contraction (it never polls, so its loads delay nobody's polls), one step ahead as the loader wave did.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void lstm_rec_bwd4_kernel(LstmBwdArgs a) {
+    constexpr int H = 256, HS = 64, G = 4, NW = 8, NT = 512, H4 = 4 * H, N = 4 * H;
+    __shared__ __attribute__((aligned(16))) float dgs[NW][128];
+    __shared__ __attribute__((aligned(16))) float part[2][NW][HS];
+    __shared__ __attribute__((aligned(16))) float opnd[2][HS][8];
+
+    __builtin_amdgcn_s_setprio(3);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int NG = a.B;
+    const int ngroups = a.ND * NG;
+    int grp, mem;
+    if (((gridDim.x / G) & 7) == 0) { mem = (blockIdx.x >> 3) % G; grp = (blockIdx.x & 7) + 8 * (blockIdx.x / (8 * G)); }
+    else { grp = blockIdx.x / G; mem = blockIdx.x % G; }
+    if (grp >= ngroups) return;
+    const int dir = grp / NG, cb = grp % NG;
+    const int j0 = mem * HS, cj = j0 + lane;
+    const bool cell_wave = wave == 0;
+    const int sbase = ((mem + (wave >> 1)) % G) * HS + (wave & 1) * 32;      // first source unit of this wave's half slice
+
+    // K_h row of the own unit cj over the wave's 128 positions q = 4*su + gate (column gate*H + sbase + su), as pairs
+    f32x2 wq[64];
+    {
+        const float* kr = a.kh[dir] + (size_t)cj * H4 + sbase;
+#pragma unroll
+        for (int su = 0; su < 32; ++su) {
+            wq[2 * su] = f32x2{kr[su], kr[H + su]};
+            wq[2 * su + 1] = f32x2{kr[2 * H + su], kr[3 * H + su]};
+        }
+    }
+    const int S = min(a.len[cb], a.T);
+    float dc = 0.f;
+    float4 dbs = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint32_t* hxg = reinterpret_cast<uint32_t*>(a.hx) + (size_t)grp * 2 * N;           // [2 parities][N] tagged floats
+    const bool fast = group_shares_xcd(a.xcc_slots + (size_t)grp * 16, G, mem, tid, a.err, nullptr, 0, 17);
+
+    // cell wave: the record of step s (time t) -> registers; then -> the operands of the pointwise backward in LDS
+    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f);
+    float rc_ = 0.f, rcp = 0.f, dout_v = 0.f;
+    auto prefetch = [&](int s) {
+        const int t = dir ? s : (S - 1 - s);
+        const int ts = min(max(t, 0), a.T - 1);
+        const float4* rp = reinterpret_cast<const float4*>(a.act + ((((size_t)cb * a.sb + (size_t)ts * a.st) * a.ND + dir) * H + cj) * 8);
+        ra = rp[0];
+        const float2 cc2 = *reinterpret_cast<const float2*>(rp + 1);
+        rc_ = cc2.x; rcp = cc2.y;
+        dout_v = a.dout[((size_t)cb * a.osb + (size_t)ts * a.ost) * a.ldo + dir * H + cj];
+    };
+    auto hand_over = [&](int s) {
+        const int t = dir ? s : (S - 1 - s);
+        const float gi = ra.x, gj = ra.y, gf = ra.z, go = ra.w;
+        const float tc = fast_tanh(rc_);
+        float dm = dout_v;
+        if (a.keep < 1.0f)
+            dm *= keep_scale(a.seed, (uint32_t)((a.boff + cb) * a.dsb + t * a.dst), (uint32_t)(dir * H + cj), a.keep);
+        float4* o = reinterpret_cast<float4*>(&opnd[s & 1][lane][0]);
+        o[0] = make_float4(dm, go * (1.f - tc * tc), gj * gi * (1.f - gi), gi * (1.f - gj * gj));
+        o[1] = make_float4(rcp * gf * (1.f - gf), tc * go * (1.f - go), gf, 0.f);
+    };
+    if (cell_wave && S > 0) { prefetch(0); hand_over(0); if (S > 1) prefetch(1); }
+    __syncthreads();
+
+    // this wave's half slice (staged in dgs[wave]) against its weights -> the partial of dh of the own unit
+    auto slice_partial = [&](int par) {
+        const f32x4* dq = reinterpret_cast<const f32x4*>(&dgs[wave][0]);
+        f32x2 acc[4] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            f32x4 dv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dv[i] = dq[8 * c + i];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const f32x2 d01 = __builtin_shufflevector(dv[i], dv[i], 0, 1), d23 = __builtin_shufflevector(dv[i], dv[i], 2, 3);
+                asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc[(2 * i) & 3]) : "v"(d01), "v"(wq[2 * (8 * c + i)]));
+                asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc[(2 * i + 1) & 3]) : "v"(d23), "v"(wq[2 * (8 * c + i) + 1]));
+            }
+        }
+        const f32x2 t2 = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        part[par][wave][lane] = t2.x + t2.y;
+    };
+
+    for (int s = 0; s < S; ++s) {
+        const int t = dir ? s : (S - 1 - s);
+        const int par = s & 1;
+        if (s > 0) {
+            if (!cell_wave) {
+                if (lane < 32) {
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    tagged_poll4(hxg + (size_t)((s - 1) & 1) * N + 4 * (sbase + lane), tag_bit(s - 1), v, a.err);
+                    *reinterpret_cast<float4*>(&dgs[wave][4 * lane]) = v;
+                }
+                __builtin_amdgcn_wave_barrier();
+                slice_partial(par);
+            }
+            __syncthreads();
+        }
+        if (cell_wave) {
+            const float4 oa = *reinterpret_cast<const float4*>(&opnd[par][lane][0]);   // {dout*mask, A, Ki, Kj}
+            const float4 ob = *reinterpret_cast<const float4*>(&opnd[par][lane][4]);   // {Kf, Ko, f, -}
+            float dh = oa.x;
+            if (s > 0) {
+                float rec = 0.f;
+#pragma unroll
+                for (int ww = 0; ww < NW; ++ww) rec += part[par][ww][lane];
+                dh += rec;
+            }
+            const float dct = fmaf(dh, oa.y, dc);
+            const float4 dg = make_float4(dct * oa.z, dct * oa.w, dct * ob.x, dh * ob.y);
+            dc = dct * ob.z;
+            dbs.x += dg.x; dbs.y += dg.y; dbs.z += dg.z; dbs.w += dg.w;
+            const uint32_t tb = tag_bit(s);
+            typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
+            const u32x4s g0 = {(__float_as_uint(dg.x) & ~1u) | tb, (__float_as_uint(dg.y) & ~1u) | tb,
+                               (__float_as_uint(dg.z) & ~1u) | tb, (__float_as_uint(dg.w) & ~1u) | tb};
+            const bool more = s + 1 < S;
+            if (more) {       // publish dG_s of this unit FIRST: one tagged quad
+                uint32_t* dst = hxg + (size_t)par * N + 4 * cj;
+                if (fast) asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(dst), "v"(g0) : "memory");
+                else {
+                    __hip_atomic_store(dst + 0, g0.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(dst + 1, g0.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(dst + 2, g0.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(dst + 3, g0.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            {       // bookkeeping, off the critical path
+                float* gp = a.gates + (((size_t)cb * a.sb + (size_t)t * a.st) * a.ND + dir) * H4 + cj;
+                gp[0] = dg.x; gp[H] = dg.y; gp[2 * H] = dg.z; gp[3 * H] = dg.w;
+            }
+            if (more) {
+                // first half of the own slice for the next step: the truncated values the peers will read
+                if (lane < 32)
+                    *reinterpret_cast<float4*>(&dgs[0][4 * lane]) = make_float4(__uint_as_float(g0.x & ~1u), __uint_as_float(g0.y & ~1u),
+                                                                                __uint_as_float(g0.z & ~1u), __uint_as_float(g0.w & ~1u));
+                __builtin_amdgcn_wave_barrier();
+                slice_partial(par ^ 1);
+                // the next step's operands (its record was requested one step ago), then the request for the step after it
+                hand_over(s + 1);
+                if (s + 2 < S) prefetch(s + 2);
+            }
+        }
+    }
+    if (a.db_part && cell_wave) {        // one row per utterance and direction: summed over the batch by a tiny colsum
+        float* dp = a.db_part + ((size_t)(a.boff + cb) * a.ND + dir) * H4 + cj;
+        dp[0] = dbs.x; dp[H] = dbs.y; dp[2 * H] = dbs.z; dp[3 * H] = dbs.w;
+    }
+    {   // dG = 0 past the row's length (the weight/input GEMMs read every row)
+        const int nz = a.T - S;
+        for (int idx = tid; idx < nz * 4 * HS; idx += NT) {
+            const int tt = S + idx / (4 * HS), q = idx % (4 * HS);
+            a.gates[(((size_t)cb * a.sb + (size_t)tt * a.st) * a.ND + dir) * H4 + (q / HS) * H + j0 + (q % HS)] = 0.f;
+        }
+    }
+}
+
 }  // namespace asr
 extern "C" int asr_get_gemm_precision(void);
 extern "C" int asr_get_lstm_mfma(void);
@@ -935,6 +1101,26 @@ extern "C" int asr_lstm_layer_bwd(void* stream, const float* x, int B, int T, in
     const int max_groups = asr_lstm_max_wgs() / G / ndir;
     if (max_groups < 1) return ASR_EUNSUPPORTED;      // one group (both directions) cannot be co-resident on this device
     const int rows_per_launch = max_groups * R;
+    // groups of four workgroups, one row per group (lstm_rec_bwd4_kernel), when the whole batch is resident at once
+    // (ASR_LSTM_G4=0: the eight-workgroup groups of version 2)
+    bool g4 = false;
+    {
+        const char* e = getenv("ASR_LSTM_G4");
+        const char* v2e = getenv("ASR_LSTM_V2");
+        g4 = !(e && e[0] == '0') && !(v2e && v2e[0] == '0') && ag_env && !a.dbg && !(asr_get_lstm_mfma() != 0 && asr_get_gemm_precision() == 1) &&
+             H == 256 && R <= 2 && ndir * B * 4 <= asr_lstm_max_wgs();
+    }
+    if (g4) {
+        if (hipMemsetAsync(hx_ws, 0, lstm_bwd_sync_bytes(B, H, ndir), s) != hipSuccess) return ASR_ELAUNCH;
+        const int groups = ndir * B;
+        const int padded = ((groups + 7) & ~7) * 4;
+        const int grid = padded <= asr_lstm_max_wgs() ? padded : groups * 4;
+        a.boff = 0;
+        prof_begin(ASR_PROF_LSTM_REC_BWD, s);
+        hipLaunchKernelGGL(asr::lstm_rec_bwd4_kernel, dim3(grid), dim3(512), 0, s, a);
+        prof_end(ASR_PROF_LSTM_REC_BWD, s);
+        if (hipGetLastError() != hipSuccess) return ASR_ELAUNCH;
+    } else
     for (int b0 = 0; b0 < B; b0 += rows_per_launch) {
         if (hipMemsetAsync(hx_ws, 0, lstm_bwd_sync_bytes(B, H, ndir), s) != hipSuccess) return ASR_ELAUNCH;
         LstmBwdArgs c = a;

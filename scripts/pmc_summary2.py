@@ -102,8 +102,8 @@ traffic = {
             "WRITE_SIZE passes (--kernel-trace only) over `bench.py --steps 3 --warmup 2 --no-cpu-baseline`; FETCH_SIZE doubled per "
             "MI355X_MICROARCH.md (gfx950 reports 1/2 of wide coalesced reads; mixed access widths are uncalibrated).  Average "
             "over the 4 launches per step (T = 800/400/200/100).",
-    "lstm_rec_bwd_bytes_per_launch": per_launch("lstm_rec_bwd2_kernel<256, 2") or per_launch("lstm_rec_bwd_ag_kernel<256, 2") or per_launch("lstm_rec_bwd_ag_kernel<256, 1"),
-    "lstm_rec_fwd_bytes_per_launch": per_launch("lstm_rec_fwd2_kernel<256, 2") or per_launch("lstm_rec_fwd_kernel<256, 32, 2") or per_launch("lstm_rec_fwd_kernel<256, 32, 1"),
+    "lstm_rec_bwd_bytes_per_launch": per_launch("lstm_rec_bwd4_kernel") or per_launch("lstm_rec_bwd2_kernel<256, 2") or per_launch("lstm_rec_bwd_ag_kernel<256, 2") or per_launch("lstm_rec_bwd_ag_kernel<256, 1"),
+    "lstm_rec_fwd_bytes_per_launch": per_launch("lstm_rec_fwd4_kernel") or per_launch("lstm_rec_fwd2_kernel<256, 2") or per_launch("lstm_rec_fwd_kernel<256, 32, 2") or per_launch("lstm_rec_fwd_kernel<256, 32, 1"),
     "algorithmic_bytes_per_launch": {"lstm_rec_bwd": steps * B * 2 * 13 * H * 4 // 4, "lstm_rec_fwd": steps * B * 2 * 14 * H * 4 // 4},
 }
 json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic_%s.json" % tag), "w"), indent=1)

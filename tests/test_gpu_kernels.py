@@ -58,8 +58,14 @@ def _lstm_case(rng, B, Tn, IN, H, bi, lens):
     (9, 16, 32, 512, True, [16] * 9, None),                      # H=512, B not a multiple of R
     (70, 12, 16, 256, True, None, None),                         # batch larger than one resident grid
 ])
-def test_lstm_layer_fwd(dev, B, Tn, IN, H, bi, lens, tout):
+@pytest.mark.parametrize("g4", ["1", "0"])
+def test_lstm_layer_fwd(dev, monkeypatch, B, Tn, IN, H, bi, lens, tout, g4):
+    """g4: H = 256 batches that are resident at once run in groups of FOUR workgroups, one row per group (lstm_rec_fwd4_kernel);
+    ASR_LSTM_G4=0 keeps the eight-workgroup groups of version 2 for them (other shapes are unaffected by the switch)."""
     from e2e_asr_amd import ops
+    if g4 == "0" and H != 256:
+        pytest.skip("the switch only matters at H = 256")
+    monkeypatch.setenv("ASR_LSTM_G4", g4)
     rng = np.random.default_rng(B * 1000 + Tn)
     if lens is None:
         lens = rng.integers(1, Tn + 1, B); lens[0] = Tn
@@ -239,10 +245,16 @@ def test_next_token_argmax_first_max(dev):
     (9, 10, 32, 512, True, None, 1.0),                        # H = 512, R = 2 (all-gather kernel, 32 positions per lane)
     (40, 9, 16, 128, True, None, 0.9),                        # H = 128, R = 2, dropout
     (20, 7, 16, 256, False, None, 1.0),                       # uni-directional, R = 1
+    (8, 15, 16, 256, True, [15, 9, 1, 15, 7, 3, 11, 2], 0.9),  # H = 256, ragged, dropout: groups of four workgroups
 ])
-def test_lstm_layer_bwd_vs_autograd(dev, B, Tn, IN, H, bi, lens, keep):
-    """BPTT kernel + dX/dK/db GEMMs against torch autograd (float64) on the oracle twin."""
+@pytest.mark.parametrize("g4", ["1", "0"])
+def test_lstm_layer_bwd_vs_autograd(dev, monkeypatch, B, Tn, IN, H, bi, lens, keep, g4):
+    """BPTT kernel + dX/dK/db GEMMs against torch autograd (float64) on the oracle twin.  g4: as in test_lstm_layer_fwd
+    (lstm_rec_bwd4_kernel vs the version-2 all-gather BPTT at H = 256)."""
     from e2e_asr_amd import ops
+    if g4 == "0" and H != 256:
+        pytest.skip("the switch only matters at H = 256")
+    monkeypatch.setenv("ASR_LSTM_G4", g4)
     from oracle import torch_ref as R
     rng = np.random.default_rng(B * 31 + Tn)
     if lens is None:
