@@ -5,12 +5,17 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from e2e_asr_amd import ops
 dev = torch.device("cuda:0")
-B, H = 32, int(os.environ.get("H", 256))
+B, H = int(os.environ.get("B", 32)), int(os.environ.get("H", 256))
 ops.set_gemm_precision(os.environ.get("PREC", "f32"))      # PREC=bf16: recurrent products on the bf16 matrix pipe
 flush = torch.zeros(1 << 28, device=dev)       # 1 GiB of floats
 for T, IN in ((800, 80), (400, 1024), (100, 1024)):
     x = torch.randn(B, T, IN, device=dev) * 0.3
     ln = torch.full((B,), T, dtype=torch.int32, device=dev)
+    if os.environ.get("RAGGED") == "1":          # lengths U[T/2, T], the longest first (as bench.py --variable-len)
+        g = torch.Generator().manual_seed(5)
+        ln = torch.randint(T // 2, T + 1, (B,), generator=g, dtype=torch.int32)
+        ln[0] = T
+        ln = ln.to(dev)
     k = [torch.randn(IN + H, 4 * H, device=dev) * 0.05 for _ in range(2)]
     bz = [torch.zeros(4 * H, device=dev) for _ in range(2)]
     dk = [torch.zeros_like(k[0]) for _ in range(2)]

@@ -57,6 +57,7 @@ def _lstm_case(rng, B, Tn, IN, H, bi, lens):
     (3, 20, 1024, 256, True, [20, 11, 7], None),                 # C2 layer-2 input width
     (9, 16, 32, 512, True, [16] * 9, None),                      # H=512, B not a multiple of R
     (70, 12, 16, 256, True, None, None),                         # batch larger than one resident grid
+    (45, 9, 16, 256, True, None, None),                          # two launches of the groups-of-four kernel (32 + 13 rows)
 ])
 @pytest.mark.parametrize("g4", ["1", "0"])
 def test_lstm_layer_fwd(dev, monkeypatch, B, Tn, IN, H, bi, lens, tout, g4):
@@ -246,6 +247,7 @@ def test_next_token_argmax_first_max(dev):
     (40, 9, 16, 128, True, None, 0.9),                        # H = 128, R = 2, dropout
     (20, 7, 16, 256, False, None, 1.0),                       # uni-directional, R = 1
     (8, 15, 16, 256, True, [15, 9, 1, 15, 7, 3, 11, 2], 0.9),  # H = 256, ragged, dropout: groups of four workgroups
+    (45, 8, 16, 256, True, None, 0.9),                        # ... in two launches (32 + 13 rows), dropout counters offset by the row base
 ])
 @pytest.mark.parametrize("g4", ["1", "0"])
 def test_lstm_layer_bwd_vs_autograd(dev, monkeypatch, B, Tn, IN, H, bi, lens, keep, g4):

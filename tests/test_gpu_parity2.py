@@ -388,10 +388,11 @@ def test_arbitrary_hidden_size_vs_oracle_and_autograd(H, bi):
 
 def test_persistent_grid_that_cannot_be_coresident_is_refused(monkeypatch):
     """The persistent kernels need every workgroup of a group resident at once.  The budget is the device's CU count
-    (hipDeviceAttributeMultiprocessorCount), lowered here through ASR_LSTM_MAXWG to stand in for a partitioned device:
-    a BiLSTM(256) group needs 2 x 8 workgroups, so a budget of 8 must be refused with ValueError (ASR_EUNSUPPORTED), not
-    run into the 2-second exchange timeout; the uni-directional layer fits (one group per launch) and stays correct; the
-    decoder falls back to the per-step launch path below 16 workgroups."""
+    (hipDeviceAttributeMultiprocessorCount), lowered here through ASR_LSTM_MAXWG to stand in for a partitioned device.  With
+    8 workgroups a BiLSTM(256) still runs -- one row per launch in groups of four workgroups per direction (round 3; before,
+    its 2 x 8-workgroup group had to be refused) -- and stays correct, as does the uni-directional layer; with 3 workgroups
+    not even one group fits and both must be refused with ValueError (ASR_EUNSUPPORTED), not run into the 2-second exchange
+    timeout; the decoder falls back to the per-step launch path below 16 workgroups."""
     from e2e_asr_amd import _lib, ops
     L = _lib.lib()
     full = L.asr_resident_wg_budget()
@@ -403,13 +404,22 @@ def test_persistent_grid_that_cannot_be_coresident_is_refused(monkeypatch):
     bz = torch.zeros(4 * H, device=DEV)
     ln = torch.tensor([12, 7, 1], dtype=torch.int32, device=DEV)
     want_uni = ops.lstm_layer_fwd(x, ln, k, bz)
+    want_bi = ops.lstm_layer_fwd(x, ln, k, bz, k, bz)
     monkeypatch.setenv("ASR_LSTM_MAXWG", "8")
     assert L.asr_resident_wg_budget() == 8
+    got_bi = ops.lstm_layer_fwd(x, ln, k, bz, k, bz)           # 2 directions x 4 workgroups = one row per launch, three launches
+    got_uni = ops.lstm_layer_fwd(x, ln, k, bz)
+    ops.check_device_flag(torch.device(DEV))
+    assert torch.allclose(got_uni, want_uni, atol=1e-6) and torch.allclose(got_bi, want_bi, atol=1e-6)
+    monkeypatch.setenv("ASR_LSTM_G4", "0")                     # the eight-workgroup groups: the BiLSTM group does not fit
     with pytest.raises(ValueError):
         ops.lstm_layer_fwd(x, ln, k, bz, k, bz)
-    got_uni = ops.lstm_layer_fwd(x, ln, k, bz)                 # 8 workgroups = one group per launch, three launches
-    ops.check_device_flag(torch.device(DEV))
-    assert torch.allclose(got_uni, want_uni, atol=1e-6)
+    monkeypatch.delenv("ASR_LSTM_G4")
+    monkeypatch.setenv("ASR_LSTM_MAXWG", "3")
+    for args in ((x, ln, k, bz, k, bz), (x, ln, k, bz)):
+        with pytest.raises(ValueError):
+            ops.lstm_layer_fwd(*args)
+    monkeypatch.setenv("ASR_LSTM_MAXWG", "8")
     assert L.asr_decoder_chain_supported(4, 10, 512, 128, 256) == 0 and L.asr_decoder_greedy_supported(4, 10, 512, 128, 256, 256, 256, 1000) == 0
     monkeypatch.delenv("ASR_LSTM_MAXWG")
     assert L.asr_resident_wg_budget() == full and L.asr_decoder_chain_supported(4, 10, 512, 128, 256) == 1
