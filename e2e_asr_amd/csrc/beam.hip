@@ -226,16 +226,23 @@ template <int COH>
 __device__ __forceinline__ void beam_score_body(const BeamSelArgs& a, const int row, const int tid, BeamScoreShared& sh) {
     constexpr int VPL = 4, KM = 16;
     const int lane = tid & 63, wave = tid >> 6;
-    const int n_rows = ld_i<COH>(a.state), k = ld_i<COH>(a.state + 1);
-    const bool act = row < n_rows && k > 0;
+    // every load of the kernel is requested before the first one is looked at: the row's logits and carried score do not wait
+    // for the live-row count (a row beyond it reads valid memory and is masked afterwards) -- one memory round trip, not three
     const int V = a.V;
     float x[VPL], xl[VPL];
-    float m = -INFINITY, ml = -INFINITY;
 #pragma unroll
     for (int j = 0; j < VPL; ++j) {
         const int v = tid + 256 * j;
-        x[j] = (act && v < V) ? ld_data<COH>(a.logits + (size_t)row * V + v) : -INFINITY;
-        xl[j] = (act && v < V) ? ld_data<COH>(a.logits_lm + (size_t)row * V + v) : -INFINITY;
+        x[j] = v < V ? ld_data<COH>(a.logits + (size_t)row * V + v) : -INFINITY;
+        xl[j] = v < V ? ld_data<COH>(a.logits_lm + (size_t)row * V + v) : -INFINITY;
+    }
+    const double c0 = ld_d<COH>(a.cum + row);
+    const int n_rows = ld_i<COH>(a.state), k = ld_i<COH>(a.state + 1);
+    const bool act = row < n_rows && k > 0;
+    float m = -INFINITY, ml = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+        if (!act) { x[j] = -INFINITY; xl[j] = -INFINITY; }
         m = fmaxf(m, x[j]); ml = fmaxf(ml, xl[j]);
     }
     m = wave_allreduce_max(m); ml = wave_allreduce_max(ml);
@@ -257,33 +264,56 @@ __device__ __forceinline__ void beam_score_body(const BeamSelArgs& a, const int 
     sum = (sh.ssum[0][0] + sh.ssum[0][1]) + (sh.ssum[0][2] + sh.ssum[0][3]);
     suml = (sh.ssum[1][0] + sh.ssum[1][1]) + (sh.ssum[1][2] + sh.ssum[1][3]);
     if (act) {
-        const double c0 = ld_d<COH>(a.cum + row);
         double sc[VPL];
 #pragma unroll
         for (int j = 0; j < VPL; ++j) {
             const bool ok = tid + 256 * j < V;
             sc[j] = ok ? (log(e[j] / sum) + a.lm_weight * log(el[j] / suml)) + c0 : -INFINITY;
         }
-        for (int it = 0; it < k; ++it) {           // top-k of this wave's quarter
-            double bv = -INFINITY; int bi = 0x7fffffff;
+        // top-k of this wave's quarter.  Each lane first sorts its four scores (descending, ties by token), so that an
+        // iteration is ONE wave-wide maximum over the lanes' heads and a pop in the winning lane (before: four compare-selects to
+        // find the lane's best and four compares to knock the winner out, every iteration)
+        int id[VPL];
 #pragma unroll
-            for (int j = 0; j < VPL; ++j) dmax_take(bv, bi, sc[j], tid + 256 * j);
+        for (int j = 0; j < VPL; ++j) id[j] = (tid + 256 * j < V) ? tid + 256 * j : 0x7fffffff;
+        auto cswap = [&](int x, int y) {       // after: (sc[x], id[x]) is the better of the two
+            const bool sw = sc[y] > sc[x] || (sc[y] == sc[x] && id[y] < id[x]);
+            const double tv = sw ? sc[y] : sc[x], uv = sw ? sc[x] : sc[y];
+            const int ti = sw ? id[y] : id[x], ui = sw ? id[x] : id[y];
+            sc[x] = tv; sc[y] = uv; id[x] = ti; id[y] = ui;
+        };
+        cswap(0, 1); cswap(2, 3); cswap(0, 2); cswap(1, 3); cswap(1, 2);
+        for (int it = 0; it < k; ++it) {
+            double bv = sc[0]; int bi = id[0];
             wave_argmax(bv, bi);
             if (lane == 0) { sh.cs[wave][it] = bv; sh.ci[wave][it] = bi; }
-#pragma unroll
-            for (int j = 0; j < VPL; ++j) if (tid + 256 * j == bi) sc[j] = -INFINITY;
+            if (id[0] == bi && bi != 0x7fffffff) {
+                sc[0] = sc[1]; id[0] = id[1]; sc[1] = sc[2]; id[1] = id[2]; sc[2] = sc[3]; id[2] = id[3];
+                sc[3] = -INFINITY; id[3] = 0x7fffffff;
+            }
         }
     }
     __syncthreads();
-    if (act && wave == 0) {                    // top-k of the hypothesis (:214) from the 4 * k quarter winners
-        const bool ok = lane < 4 * k;
-        double cv = ok ? sh.cs[lane / k][lane % k] : -INFINITY;
-        const int cx = ok ? sh.ci[lane / k][lane % k] : 0x7fffffff;
+    if (act && wave == 0) {
+        // top-k of the hypothesis (:214): a four-way MERGE of the quarters' sorted lists on lanes 0..3 (score descending, ties by
+        // token -- tokens interleave between the quarters, so the tie is broken on the token, not on the quarter)
+        const int w = lane & 3;
+        const bool mine = lane < 4;
+        int hp = 0;
+        double hv = mine ? sh.cs[w][0] : -INFINITY;
+        int ht = mine ? sh.ci[w][0] : 0x7fffffff;
         for (int it = 0; it < k; ++it) {
-            double bv = cv; int bi = cx;
-            wave_argmax(bv, bi);
-            if (lane == 0) { st_d<COH>(a.cand + row * KM + it, bv); st_i<COH>(a.cand_idx + row * KM + it, bi); }
-            if (cx == bi) cv = -INFINITY;
+            double m = hv;
+            m = fmax(m, dpp_mov_f64<0xB1>(m)); m = fmax(m, dpp_mov_f64<0x4E>(m));          // over the quad: lanes 0..3 hold the heads
+            int tm = (mine && hv == m) ? ht : 0x7fffffff;
+            tm = min(tm, __builtin_amdgcn_update_dpp(0x7fffffff, tm, 0xB1, 0xF, 0xF, false));
+            tm = min(tm, __builtin_amdgcn_update_dpp(0x7fffffff, tm, 0x4E, 0xF, 0xF, false));
+            if (mine && hv == m && ht == tm) {
+                st_d<COH>(a.cand + row * KM + it, hv); st_i<COH>(a.cand_idx + row * KM + it, ht);
+                ++hp;
+                hv = hp < k ? sh.cs[w][hp] : -INFINITY;
+                ht = hp < k ? sh.ci[w][hp] : 0x7fffffff;
+            }
         }
     }
 }
@@ -293,34 +323,56 @@ __global__ __launch_bounds__(256) void beam_score_kernel(BeamSelArgs a) {
 }
 
 // top-k over the n_rows * k continuations, candidate c = row * k + it (:294-306), and the bookkeeping (:306-327).  One wave.
-struct BeamMergeShared { double wsc[16]; int wr[16], wv[16]; };
+struct BeamMergeShared { double wsc[16]; int wr[16], wv[16]; double cs[16][16]; int ct[16][16]; };
+// max over the 16 lanes of a DPP row, 64-bit values (the four row steps of wave_max_f64)
+__device__ __forceinline__ double row16_max_f64(double v) {
+    v = fmax(v, dpp_mov_f64<0xB1>(v));
+    v = fmax(v, dpp_mov_f64<0x4E>(v));
+    v = fmax(v, dpp_mov_f64<0x141>(v));
+    v = fmax(v, dpp_mov_f64<0x140>(v));
+    return v;
+}
+// Every hypothesis' candidates arrive sorted (score descending, ties by token: beam_score_body emits them in that order), so the
+// top-k of the n_rows * k continuations in the order (score descending, candidate c = row * k + it ascending) is a k-way MERGE of
+// sorted lists: lane r of the first DPP row holds the head of list r, an iteration is one 16-lane maximum (ties: lowest row) and
+// one LDS read for the winner's next head -- no division, no 64-lane reduction, no knock-out pass (round 3: the 16 serial
+// wave-wide argmax iterations over 256 candidates were ~5 of the kernel's 12 us).
 template <int COH>
 __device__ __forceinline__ void beam_merge_body(const BeamSelArgs& a, const int lane, BeamMergeShared& sh) {
     constexpr int KM = 16;
-    const int n_rows = ld_i<COH>(a.state), k = ld_i<COH>(a.state + 1), s = ld_i<COH>(a.state + 3);
-    if (n_rows <= 0 || k <= 0) return;
-    double cv[4]; int cc[4], ctok[4];
+    // all 16 x 16 slots of the candidate arrays, requested together with the counters (one memory round trip); slots beyond
+    // row n_rows / rank k hold stale values and are masked
+    double cvq[4]; int ctq[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const int c = lane + 64 * q;
-        const bool ok = c < n_rows * k;
-        cv[q] = ok ? ld_d<COH>(a.cand + (c / k) * KM + c % k) : -INFINITY;
-        cc[q] = ok ? c : 0x7fffffff;
-        ctok[q] = ok ? ld_i<COH>(a.cand_idx + (c / k) * KM + c % k) : -1;      // the candidate's token: no dependent load per winner
+        const int c = lane + 64 * q, r = c >> 4, it = c & 15;
+        cvq[q] = r < a.kmax ? ld_d<COH>(a.cand + r * KM + it) : -INFINITY;
+        ctq[q] = r < a.kmax ? ld_i<COH>(a.cand_idx + r * KM + it) : -1;
     }
+    const int n_rows = ld_i<COH>(a.state), k = ld_i<COH>(a.state + 1), s = ld_i<COH>(a.state + 3);
+    if (n_rows <= 0 || k <= 0) return;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c = lane + 64 * q, r = c >> 4, it = c & 15;
+        const bool ok = r < n_rows && it < k;
+        sh.cs[r][it] = ok ? cvq[q] : -INFINITY;
+        sh.ct[r][it] = ok ? ctq[q] : -1;
+    }
+    __builtin_amdgcn_wave_barrier();
+    int hp = 0;                                               // head of my list (lanes 0..15: list = lane)
+    double hv = (lane < n_rows) ? sh.cs[lane & 15][0] : -INFINITY;
     for (int it = 0; it < k; ++it) {
-        double bv = -INFINITY; int bi = 0x7fffffff;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) dmax_take(bv, bi, cv[q], cc[q]);
-        wave_argmax(bv, bi);
-        if (lane == 0) {
-            const bool ok = bi != 0x7fffffff;
-            sh.wsc[it] = bv; sh.wr[it] = ok ? bi / k : 0;
-            if (!ok) sh.wv[it] = -1;
+        const double m = row16_max_f64(lane < 16 ? hv : -INFINITY);       // (lanes 16..63 idle along)
+        const unsigned long long mask = __ballot(lane < 16 && hv == m && hv > -INFINITY);
+        const int win = mask ? __ffsll((long long)mask) - 1 : -1;           // ties: the lowest row = the lowest candidate index
+        if (lane == win) {
+            sh.wsc[it] = hv; sh.wr[it] = lane; sh.wv[it] = sh.ct[lane][hp];
+            ++hp;
+            hv = hp < k ? sh.cs[lane][hp] : -INFINITY;
         }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) if (cc[q] == bi && bi != 0x7fffffff) { sh.wv[it] = ctok[q]; cv[q] = -INFINITY; }
+        if (win < 0 && lane == 0) { sh.wsc[it] = -INFINITY; sh.wr[it] = 0; sh.wv[it] = -1; }
     }
+    __builtin_amdgcn_wave_barrier();
     if (lane == 0) {
         int live = 0, nfin = ld_i<COH>(a.state + 2);
         for (int j = 0; j < k; ++j) {
