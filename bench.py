@@ -255,8 +255,8 @@ def run_config5(args, real_stdout):
                      "achieved": step_bytes / (us_per_token * 1e-6) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                      "frac": step_bytes / (us_per_token * 1e-6) / 1e9 / PEAK_HBM_GBS, "traffic": None,
                      "algorithmic_bytes_per_step": step_bytes,
-                     "note": "a chain of ~11 dependent small kernels per token at batch 16 (rocprofv3: their own durations sum to ~64 of "
-                             "the 71 us -- scoring 13, merge 7, attention 10, five skinny GEMV launches 5-10 each; every kernel starts "
+                     "note": "a chain of ~11 dependent small kernels per token at batch 16 (rocprofv3: their own durations sum to ~59 of "
+                             "the 61 us -- scoring 13, merge 7, attention 10, five skinny GEMV launches 5-7 each; every kernel starts "
                              "with dependent memory round trips): the byte rate is reported, the bound is dependent-access latency "
                              "(DESIGN section 10)"},
     }

@@ -110,6 +110,8 @@ SIGNATURES = {
     "asr_beam_scratch_floats": (C.c_size_t, [C.c_int] * 5),
     "asr_beam_step": (C.c_int, [vp] * 13),
     "asr_beam_step_sel": (C.c_int, [vp] * 14),
+    "asr_beam_step_perm": (C.c_int, [vp] * 17),
+    "asr_lstm_kernel_tile_order": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
     "asr_beam_gather": (C.c_int, [vp, vp, C.c_int, vp, vp] + [C.c_int] * 4),
     "asr_beam_select": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, vp]),
     "asr_beam_decode_ws_floats": (C.c_size_t, [vp, C.c_int, C.c_int]),

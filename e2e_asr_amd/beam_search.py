@@ -182,6 +182,23 @@ class BeamSearch(BaseParams):
         get_top_k.structs = (cw, clm, cst, (Te, D, A, H, lmH, E, V, extH))
         return get_top_k
 
+    def _tile_ordered_kernels(self):
+        """The three LSTM kernels in the column order the step's tiles read them in (asr_lstm_kernel_tile_order), once per
+        weight set: the weights are constants of this object (ASR_BEAM_TILED=0: the TF column order, as before round 3)."""
+        if os.environ.get("ASR_BEAM_TILED", "1") == "0":
+            return (None, None, None)
+        if getattr(self, "_tiled", None) is None:
+            L = _lib.lib()
+            out = []
+            for w in (self.dec_params.lm_lstm_w, self.lm_params.lstm_w, self.dec_params.dec_lstm_w):
+                w = w.contiguous()
+                t = torch.empty_like(w)
+                ops._check(L.asr_lstm_kernel_tile_order(ops._stream(), ops._p(w), w.shape[0], w.shape[1] // 4, ops._p(t)),
+                           "asr_lstm_kernel_tile_order")
+                out.append(t)
+            self._tiled = tuple(out)
+        return self._tiled
+
     def _decode_on_device(self, get_top_k, max_steps=120):
         """The loop of beam_search.py:255-337 with scoring, selection and bookkeeping on the device."""
         sp = self.search_params
@@ -208,6 +225,7 @@ class BeamSearch(BaseParams):
         cd = _lib.DecDims(kmax, Te, D, A, H, lmH, E, V, 1)
         st = ops._stream()
         in_place = self.dec_params.simple_w is None and self.lm_params.simple_w is None
+        tiled = self._tile_ordered_kernels() if in_place else (None, None, None)
         # ASR_BEAM_PERSIST=1: one persistent launch for the whole utterance (asr_beam_decode, csrc/beam.hip) -- bit-identical
         # to the loop below (same tile bodies; tests/test_gpu_beam.py) but SLOWER on MI355X (108 vs 80 us per token: every
         # hand-over between XCDs costs fabric round trips), so the step-by-step loop is the default
@@ -227,9 +245,10 @@ class BeamSearch(BaseParams):
         for s in range(0 if not persistent else max_steps, max_steps):
             if in_place:       # the step kernels read the parents' rows of the previous step's output in place: ping-pong
                 a, b = (0, 1) if s % 2 == 0 else (1, 0)
-                ops._check(L.asr_beam_step_sel(st, C.byref(cw), C.byref(clm), C.byref(cd), ops._p(hf), ops._p(enc), ops._p(ln),
-                                               ops._p(ints), ops._p(ints[kmax:]) if s else None, C.byref(cst[a]), C.byref(cst[b]),
-                                               ops._p(scratch), ops._p(logits[0]), ops._p(logits[1])), "asr_beam_step_sel")
+                ops._check(L.asr_beam_step_perm(st, C.byref(cw), C.byref(clm), C.byref(cd), ops._p(hf), ops._p(enc), ops._p(ln),
+                                                ops._p(ints), ops._p(ints[kmax:]) if s else None, C.byref(cst[a]), C.byref(cst[b]),
+                                                ops._p(scratch), ops._p(logits[0]), ops._p(logits[1]),
+                                                ops._p(tiled[0]), ops._p(tiled[1]), ops._p(tiled[2])), "asr_beam_step_perm")
             else:
                 if s:
                     ops._check(L.asr_beam_gather(st, ops._p(ints[kmax:]), kmax, C.byref(cst[1]), C.byref(cst[0]), H, lmH, extH, D),

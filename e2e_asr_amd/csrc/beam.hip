@@ -12,6 +12,11 @@
 #include <cstdlib>
 #include "../../include/e2e_asr_hip.h"
 
+extern "C" int asr_beam_step_perm(void* stream, const asr_dec_weights* w, const asr_lm_weights* lm, const asr_dec_dims* d,
+                                  const float* hf, const float* enc, const int* enc_len, const int* tokens, const int* sel,
+                                  const asr_beam_state* in, const asr_beam_state* out, float* scratch,
+                                  float* logits, float* logits_lm, const float* lm_kernel_t, const float* ext_kernel_t,
+                                  const float* dec_kernel_t);
 extern "C" int asr_beam_step_sel(void* stream, const asr_dec_weights* w, const asr_lm_weights* lm, const asr_dec_dims* d,
                                  const float* hf, const float* enc, const int* enc_len, const int* tokens, const int* sel,
                                  const asr_beam_state* in, const asr_beam_state* out, float* scratch,
@@ -29,6 +34,17 @@ extern "C" int asr_beam_step_sel(void* stream, const asr_dec_weights* w, const a
                                  const float* hf, const float* enc, const int* enc_len, const int* tokens, const int* sel,
                                  const asr_beam_state* in, const asr_beam_state* out, float* scratch,
                                  float* logits, float* logits_lm) {
+    return asr_beam_step_perm(stream, w, lm, d, hf, enc, enc_len, tokens, sel, in, out, scratch, logits, logits_lm, nullptr, nullptr, nullptr);
+}
+// ... with the three LSTM kernels ALSO given in tile order (asr_lstm_kernel_tile_order: column 16*tile + 4*unit + gate next to each
+// other, the order the skinny LSTM tiles read them in), or NULL: a tile's 16 weight columns of a K row are then ONE 64-byte
+// segment instead of four 16-byte pieces a gate block apart -- the two LM cells 9.8 -> 5.9 us, the outer cell 7.7 -> 5.0 us per
+// token (same values, same arithmetic: results are bit-identical).  The weights are constants of a decode: permute once.
+extern "C" int asr_beam_step_perm(void* stream, const asr_dec_weights* w, const asr_lm_weights* lm, const asr_dec_dims* d,
+                                  const float* hf, const float* enc, const int* enc_len, const int* tokens, const int* sel,
+                                  const asr_beam_state* in, const asr_beam_state* out, float* scratch,
+                                  float* logits, float* logits_lm, const float* lm_kernel_t, const float* ext_kernel_t,
+                                  const float* dec_kernel_t) {
     if (!w || !lm || !d || !hf || !enc || !enc_len || !tokens || !in || !out || !scratch || !logits || !logits_lm) return ASR_EINVAL;
     if (sel && (w->simple_w || lm->simple_w)) return ASR_EUNSUPPORTED;
     const int k = d->B, Te = d->Te, D = d->D, A = d->A, H = d->H, lmH = d->lmH, E = d->E, V = d->V;
@@ -46,10 +62,12 @@ extern "C" int asr_beam_step_sel(void* stream, const asr_dec_weights* w, const a
     if (paired) {
         asr::SkinnyArgs c0{}, c1{};
         c0.x1 = w->embedding; c0.ld1 = E; c0.K1 = E; c0.gather1 = tokens; c0.x2 = in->dlh; c0.ld2 = lmH; c0.K2 = lmH; c0.gather2 = sel;
-        c0.W = w->lm_kernel; c0.ldw = 4 * lmH; c0.bias = w->lm_bias; c0.M = k; c0.N = 4 * lmH; c0.H = lmH;
+        c0.W = lm_kernel_t ? lm_kernel_t : w->lm_kernel; c0.wperm = lm_kernel_t != nullptr;
+        c0.ldw = 4 * lmH; c0.bias = w->lm_bias; c0.M = k; c0.N = 4 * lmH; c0.H = lmH;
         c0.c_prev = in->dlc; c0.c_out = out->dlc; c0.h_out = out->dlh; c0.keep = 1.0f;
         c1.x1 = lm->embedding; c1.ld1 = lm->E; c1.K1 = lm->E; c1.gather1 = tokens; c1.x2 = in->lh; c1.ld2 = lm->H; c1.K2 = lm->H; c1.gather2 = sel;
-        c1.W = lm->lstm_kernel; c1.ldw = 4 * lm->H; c1.bias = lm->lstm_bias; c1.M = k; c1.N = 4 * lm->H; c1.H = lm->H;
+        c1.W = ext_kernel_t ? ext_kernel_t : lm->lstm_kernel; c1.wperm = ext_kernel_t != nullptr;
+        c1.ldw = 4 * lm->H; c1.bias = lm->lstm_bias; c1.M = k; c1.N = 4 * lm->H; c1.H = lm->H;
         c1.c_prev = in->lc; c1.c_out = out->lc; c1.h_out = out->lh; c1.keep = 1.0f;
         if ((rc = asr::skinny_launch_pair(static_cast<hipStream_t>(stream), true, c0, c1))) return rc;
         asr::SkinnyArgs p0{}, p1{};
@@ -72,7 +90,8 @@ extern "C" int asr_beam_step_sel(void* stream, const asr_dec_weights* w, const a
     {
         asr::SkinnyArgs oc{};
         oc.x1 = x; oc.ld1 = E; oc.K1 = E; oc.x2 = in->dh; oc.ld2 = H; oc.K2 = H; oc.gather2 = sel;
-        oc.W = w->dec_kernel; oc.ldw = 4 * H; oc.bias = w->dec_bias; oc.M = k; oc.N = 4 * H; oc.H = H;
+        oc.W = dec_kernel_t ? dec_kernel_t : w->dec_kernel; oc.wperm = dec_kernel_t != nullptr;
+        oc.ldw = 4 * H; oc.bias = w->dec_bias; oc.M = k; oc.N = 4 * H; oc.H = H;
         oc.c_prev = in->dc; oc.c_out = out->dc; oc.h_out = out->dh; oc.keep = 1.0f;
         if ((rc = asr::skinny_launch(static_cast<hipStream_t>(stream), true, oc))) return rc;
     }
@@ -92,6 +111,22 @@ extern "C" int asr_beam_step_sel(void* stream, const asr_dec_weights* w, const a
         lo = lsp; LP = lm->P;
     }
     return asr_linear_fwd(stream, lo, LP, LP, nullptr, nullptr, 0, 0, lm->out_w, lm->V, lm->out_b, logits_lm, lm->V, k, lm->V, nullptr, 0);
+}
+
+namespace asr {
+// out[k][16*tile + 4*unit + gate] = W[k][gate*H + 4*tile + unit]: the column order of the skinny LSTM tiles (csrc/skinny_body.h)
+__global__ __launch_bounds__(256) void lstm_kernel_tile_order_kernel(const float* W, float* out, int K, int H) {
+    const int n = blockIdx.x * 256 + threadIdx.x, k = blockIdx.y;
+    if (n >= 4 * H || k >= K) return;
+    const int tile = n >> 4, nl = n & 15;
+    out[(size_t)k * 4 * H + n] = W[(size_t)k * 4 * H + (nl & 3) * H + 4 * tile + (nl >> 2)];
+}
+}  // namespace asr
+extern "C" int asr_lstm_kernel_tile_order(void* stream, const float* W, int K, int H, float* out) {
+    if (!W || !out || K <= 0 || H <= 0 || (H & 3)) return ASR_EINVAL;
+    hipLaunchKernelGGL(asr::lstm_kernel_tile_order_kernel, dim3((4 * H + 255) / 256, K), dim3(256), 0, static_cast<hipStream_t>(stream), W, out, K, H);
+    ASR_CHECK_LAUNCH();
+    return ASR_OK;
 }
 
 extern "C" size_t asr_beam_scratch_floats(int k, int Te, int H, int E, int lmP) {

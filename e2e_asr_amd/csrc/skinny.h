@@ -16,6 +16,7 @@ struct SkinnyArgs {
     // LSTM mode (H > 0)
     int H; const float* c_prev; float* c_out; float* h_out; float* hdrop_out; float* gates_out;
     float keep; uint32_t seed; uint32_t step;
+    int wperm;                            // LSTM mode: W's columns are already in tile order (column 16*tile + 4*unit + gate)
 };
 
 // Two independent problems of the same mode (both LSTM cells, or both plain linears) in ONE launch: blockIdx.x first

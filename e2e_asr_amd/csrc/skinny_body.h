@@ -19,7 +19,7 @@ __device__ __forceinline__ void skinny_body(const SkinnyArgs& a, const int bx, c
     const int K = a.K1 + a.K2;
     // column of W feeding output row nl of the MFMA tile
     int colW; bool colok;
-    if (LSTM) { const int j = bx * 4 + (nl >> 2); colW = (nl & 3) * a.H + j; colok = j < a.H; }
+    if (LSTM) { const int j = bx * 4 + (nl >> 2); colW = a.wperm ? bx * 16 + nl : (nl & 3) * a.H + j; colok = j < a.H; }
     else      { colW = bx * 16 + nl; colok = colW < a.N; }
     const int brow = by * 16 + nl;      // batch row this lane supplies as MFMA B operand
     const bool rowok = brow < a.M;

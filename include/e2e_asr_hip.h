@@ -289,6 +289,16 @@ int asr_beam_step_sel(void* stream, const asr_dec_weights* w, const asr_lm_weigh
                       const float* hf, const float* enc, const int* enc_len, const int* tokens, const int* sel,
                       const asr_beam_state* in, const asr_beam_state* out, float* scratch,
                       float* logits, float* logits_lm);
+/* asr_beam_step_sel with the three LSTM kernels (decoder's inner LM cell, external LM cell, outer cell) additionally given in the
+ * column order the step's tiles read them in (asr_lstm_kernel_tile_order, once per weight set; any of them may be NULL): the
+ * cells' weight reads become contiguous, results are bit-identical.  New (the reference has no such call). */
+int asr_beam_step_perm(void* stream, const asr_dec_weights* w, const asr_lm_weights* lm, const asr_dec_dims* d,
+                       const float* hf, const float* enc, const int* enc_len, const int* tokens, const int* sel,
+                       const asr_beam_state* in, const asr_beam_state* out, float* scratch,
+                       float* logits, float* logits_lm, const float* lm_kernel_t, const float* ext_kernel_t,
+                       const float* dec_kernel_t);
+/* out[k][16*tile + 4*unit + gate] = W[k][gate*H + 4*tile + unit] for a TF LSTM kernel W [K, 4H] (H a multiple of 4). */
+int asr_lstm_kernel_tile_order(void* stream, const float* W, int K, int H, float* out);
 /* Device-resident scoring, selection and bookkeeping of one beam step (beam_search.py:196-214, 290-327): float64
  * log-softmax of both logit vectors, score = log p_dec + lm_weight*log p_lm + carried, top-k per hypothesis then over
  * the continuations, parent = candidate / k, EOS -> finished list and k -= 1.  With asr_beam_gather (sel = ints + kmax)
