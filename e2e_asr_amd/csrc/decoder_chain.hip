@@ -442,13 +442,21 @@ __global__ __launch_bounds__(512) void decoder_chain_fwd_kernel(ChainArgs a) {
             float cs = 0.f;
             if (tp < NTP) {
                 const int L = blenf(r);
+                float c1 = 0.f, c2 = 0.f, c3 = 0.f;
                 for (int m = tp; m < G; m += NTP) {
                     const float* ap = el + r * G * MAXTS + m * MAXTS;
                     const float* xp = encl + ((size_t)r * Te + m * TS) * DS + dd;
                     const int nt = min(TS, L - m * TS);
-                    for (int tl = 0; tl < nt; ++tl) cs = fmaf(ap[tl], xp[tl * DS], cs);
+                    // four independent chains, loads ahead of the FMAs (one serial "load, load, fma" chain over up to 32 positions before)
+                    int tl = 0;
+                    for (; tl + 4 <= nt; tl += 4) {
+                        const float4 a4 = *reinterpret_cast<const float4*>(ap + tl);
+                        const float x0 = xp[tl * DS], x1 = xp[(tl + 1) * DS], x2 = xp[(tl + 2) * DS], x3 = xp[(tl + 3) * DS];
+                        cs = fmaf(a4.x, x0, cs); c1 = fmaf(a4.y, x1, c1); c2 = fmaf(a4.z, x2, c2); c3 = fmaf(a4.w, x3, c3);
+                    }
+                    for (; tl < nt; ++tl) cs = fmaf(ap[tl], xp[tl * DS], cs);
                 }
-                cpart[(tp * R + r) * DS + dd] = cs;
+                cpart[(tp * R + r) * DS + dd] = (cs + c1) + (c2 + c3);
             }
         }
         __syncthreads();

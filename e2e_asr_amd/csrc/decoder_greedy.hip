@@ -539,15 +539,23 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
             // alpha is exactly zero past the length and in unused slots (tl >= TS), so every thread runs the same loops
             // (positions past Te are clamped onto the last row: alpha = 0 there)
             const int dd = tid & 15, r = (tid >> 4) & 3, tp = tid >> 6;
-            float cs = 0.f;
+            float cs = 0.f, cs2 = 0.f;
+            static_assert(MAXTS == 8, "two float4 of alpha per source workgroup");
 #pragma unroll
             for (int mm = 0; mm < G / 8; ++mm) {
                 const int m = tp + 8 * mm;
                 const float* ap = el + r * G * MAXTS + m * MAXTS;
                 const float* xr = encl + (size_t)r * Te * DS + dd;
-                for (int tl = 0; tl < TS; ++tl) cs = fmaf(ap[tl], xr[min(m * TS + tl, Te - 1) * DS], cs);   // (unrolling to 8 spills)
+                // all MAXTS slots, loads first (slots >= TS hold alpha = 0; their position is clamped onto a valid row): the serial
+                // "load, load, fma" chain over TS positions was 11 % of the step; the unrolled form spilled until round 3 freed registers
+                const float4 a0 = *reinterpret_cast<const float4*>(ap), a1 = *reinterpret_cast<const float4*>(ap + 4);
+                float xv[MAXTS];
+#pragma unroll
+                for (int tl = 0; tl < MAXTS; ++tl) xv[tl] = xr[min(m * TS + min(tl, TS - 1), Te - 1) * DS];
+                cs = fmaf(a0.x, xv[0], cs); cs2 = fmaf(a0.y, xv[1], cs2); cs = fmaf(a0.z, xv[2], cs); cs2 = fmaf(a0.w, xv[3], cs2);
+                cs = fmaf(a1.x, xv[4], cs); cs2 = fmaf(a1.y, xv[5], cs2); cs = fmaf(a1.z, xv[6], cs); cs2 = fmaf(a1.w, xv[7], cs2);
             }
-            cpart[(tp * R + r) * DS + dd] = cs;
+            cpart[(tp * R + r) * DS + dd] = cs + cs2;
         }
         __syncthreads();
         GREEDY_STAMP()
