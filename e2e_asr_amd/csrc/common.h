@@ -71,10 +71,22 @@ __device__ __forceinline__ float row16_allreduce_sum(float v) {
     v += dpp_mov<0x140>(v);   // row_mirror           (joins the two halves of the 16)
     return v;
 }
+// The value the lane 16 (32) away holds -- what `__shfl_xor(v, 16)` / `(v, 32)` return -- by v_permlane16_swap / v_permlane32_swap
+// (gfx950) instead of ds_bpermute: two VALU instructions, no trip through the LDS crossbar (round 3: the cross-row steps of the
+// wave-wide reductions below were two dependent ds_bpermute round trips each; the softmax phases of the decoder kernels pay
+// two such reductions per step).  Same operands meet, so sums and maxima are bit-identical to the shuffle form.
+__device__ __forceinline__ float lane_xor16(float v) {
+    const auto s = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(((__lane_id() >> 4) & 1) ? s[0] : s[1]);      // odd rows find the even neighbour in s[0], even rows the odd one in s[1]
+}
+__device__ __forceinline__ float lane_xor32(float v) {
+    const auto s = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(__lane_id() >= 32 ? s[0] : s[1]);
+}
 __device__ __forceinline__ float wave_allreduce_sum(float v) {
     v = row16_allreduce_sum(v);
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
+    v += lane_xor16(v);
+    v += lane_xor32(v);
     return v;
 }
 __device__ __forceinline__ float wave_allreduce_max(float v) {
@@ -82,8 +94,8 @@ __device__ __forceinline__ float wave_allreduce_max(float v) {
     v = fmaxf(v, dpp_mov<0x4E>(v));
     v = fmaxf(v, dpp_mov<0x141>(v));
     v = fmaxf(v, dpp_mov<0x140>(v));
-    v = fmaxf(v, __shfl_xor(v, 16));
-    v = fmaxf(v, __shfl_xor(v, 32));
+    v = fmaxf(v, lane_xor16(v));
+    v = fmaxf(v, lane_xor32(v));
     return v;
 }
 

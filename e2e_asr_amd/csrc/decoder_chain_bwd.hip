@@ -426,7 +426,7 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
                 }
             }
             // reduce the 32 lanes of each half-wave: this workgroup's partial of S = dctx_tot . ctx_i, gathered with dctx_tot
-            sprt += __shfl_xor(sprt, 16); sprt = row16_allreduce_sum(sprt);
+            sprt += lane_xor16(sprt); sprt = row16_allreduce_sum(sprt);
             if (dd0 == 0 && rok(r)) pubg(g1 + (size_t)r * D1 + D + mem, ep, sprt, fast);
         }
         // ---- gather dctx_tot of both rows over all D columns (+ the G partials of S): waves 1-3, all loads in flight
