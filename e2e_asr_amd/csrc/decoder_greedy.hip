@@ -501,9 +501,11 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
         }
         // ---- (5) gather all scores, softmax over tau < len (replicated), context slice
         if (poller) {
-            const int nq = (TS + 3) / 4;                        // quads per (utterance, source workgroup)
+            const int nq = (TS + 3) / 4;                        // quads per (utterance, source workgroup): 1 or 2 (MAXTS = 8)
+            const int lq = nq - 1;                              // ... so the index arithmetic is shifts, not four runtime divisions
+            static_assert(MAXTS == 8 && G == 32, "nq in {1, 2}; r = p >> (5 + lq)");
             for (int p = tid - 64; p < R * G * nq; p += NPOLL) {
-                const int r = p / (G * nq), rem = p % (G * nq), m = rem / nq, q = rem % nq;
+                const int r = p >> (5 + lq), rem = p & ((G << lq) - 1), m = rem >> lq, q = rem & lq;
                 const int off = r * G * MAXTS + m * MAXTS + 4 * q;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (rok(r)) tagged_poll4(tE + off, tb, v, a.err);
