@@ -50,6 +50,10 @@ struct LstmRecArgs {
     int ep0;               // granule tag base: tags are ep0 + step + 1 (segments of one call share a workspace zeroed once)
     const float* h0; const float* c0;      // [B][H] initial state (ND = 1) or nullptr = zeros
     float* h_last; float* c_last;          // [B][H] final state (ND = 1) or nullptr
+    // lstm_rec_fwd4_kernel<IK > 0>: the input projection inside the recurrent kernel (`gates` is then not read): x [B][T][ldx],
+    // kx[dir] = the input rows [in_dim][4H] of the TF kernel, bias[dir] [4H]
+    const float* __restrict__ x; int ldx;
+    const float* kx[2]; const float* bias[2];
 };
 
 __device__ __forceinline__ bool poll_granule(const u64* g, uint32_t epoch, float& val, int* err) {
@@ -599,8 +603,15 @@ static int g_lstm_mfma = -1;
 // wave (wave 0) sums the eight partials.  Wave 0 takes the first half of the own slice straight from its registers, wave 1
 // polls the second half of the own slice like any other source.  Forward 1.19 -> 1.08 us per step at B = 32, T = 800 (round 3).
 // ---------------------------------------------------------------------------------------------------------------
+// IK > 0: the INPUT PROJECTION runs in here too (in_dim = 8 * IK; the first encoder layer, 80 log-mel inputs).  Wave w holds the
+// K_x rows of inputs [w*IK, (w+1)*IK) for its lanes' units (4 * IK registers) and adds x_t . K_x to its partial; x_t is the same
+// for the whole workgroup and is fetched one step ahead with scalar loads.  The product costs a wave 2 * IK packed FMAs in
+// front of its poll, where it would only wait; what it saves is the 25 600 x 2 048 projection GEMM (K = 80: 89 us, bound by
+// writing 210 MB of gates) and the recurrence's own reading them back -- the streaming operand that costs the exchange most.
+template <int IK = 0>
 __global__ __launch_bounds__(512) void lstm_rec_fwd4_kernel(LstmRecArgs a) {
     constexpr int H = 256, HS = 64, G = 4, NW = 8, NT = 512, H4 = 4 * H;
+    constexpr bool XIN = IK > 0;
     __shared__ __attribute__((aligned(16))) float hs[NW][32];
     __shared__ __attribute__((aligned(16))) float4 part[2][NW][HS];
 
@@ -629,6 +640,40 @@ __global__ __launch_bounds__(512) void lstm_rec_fwd4_kernel(LstmRecArgs a) {
     const int S = min(a.len[cb], a.T);
     const bool cell_wave = wave == 0;
     const int cj = mem * HS + lane;
+    f32x2 wx[XIN ? IK : 1][2];                         // wx[k][p] = (gate 2p, gate 2p+1) of input row wave*IK + k for unit cj
+    float xb[XIN ? IK : 1];                            // x_t of the NEXT product, inputs [wave*IK, wave*IK + IK)
+    if constexpr (XIN) {
+        const float* kxp = a.kx[dir] + (size_t)(wave * IK) * H4 + cj;
+#pragma unroll
+        for (int k = 0; k < IK; ++k)
+#pragma unroll
+            for (int p2 = 0; p2 < 2; ++p2)
+                wx[k][p2] = f32x2{kxp[(size_t)k * H4 + (2 * p2) * H], kxp[(size_t)k * H4 + (2 * p2 + 1) * H]};
+    }
+    // x row of step s (uniform over the workgroup: scalar loads)
+    auto load_x = [&](int s) {
+        if constexpr (XIN) {
+            const int t = dir ? (S - 1 - s) : s;
+            const int ts = min(max(t, 0), a.T - 1);
+            const float* xp = a.x + ((size_t)cb * a.T + ts) * a.ldx + wave * IK;
+#pragma unroll
+            for (int k = 0; k < IK; ++k) xb[k] = xp[k];
+        }
+    };
+    // x part of a step's pre-activations (two chains per gate pair, as the h part)
+    auto x_partial = [&](f32x2 (&pa)[2][2]) {
+        if constexpr (XIN) {
+#pragma unroll
+            for (int k = 0; k + 1 < IK + 1; k += 2) {
+                const f32x2 x2 = f32x2{xb[k], k + 1 < IK ? xb[k + 1] : 0.f};
+#pragma unroll
+                for (int p2 = 0; p2 < 2; ++p2) {
+                    pk_fma_alo(pa[p2][0], x2, wx[k][p2]);
+                    if (k + 1 < IK) pk_fma_ahi(pa[p2][1], x2, wx[k + 1][p2]);
+                }
+            }
+        }
+    };
     float c = 0.f, h = 0.f;
     const bool has_init = a.h0 != nullptr;
     if (has_init && cell_wave) { h = a.h0[(size_t)cb * H + cj]; c = a.c0[(size_t)cb * H + cj]; }
@@ -636,12 +681,16 @@ __global__ __launch_bounds__(512) void lstm_rec_fwd4_kernel(LstmRecArgs a) {
     const bool fast = group_shares_xcd(a.xcc_slots + (size_t)grp * 16, G, mem, tid, a.err, nullptr, (uint32_t)a.ep0, 4);
     float gx0 = 0.f, gx1 = 0.f, gx2 = 0.f, gx3 = 0.f;
     auto prefetch = [&](int s) {
+        if constexpr (XIN) return;            // (gx = the bias, loaded once below)
         const int t = dir ? (S - 1 - s) : s;
         const int ts = min(max(t, 0), a.T - 1);
         const float* gp_ = a.gates + (((size_t)cb * a.sb + (size_t)ts * a.st) * a.ND + dir) * H4 + cj;
         gx0 = gp_[0]; gx1 = gp_[H]; gx2 = gp_[2 * H]; gx3 = gp_[3 * H];
     };
-    if (cell_wave) prefetch(0);
+    if (cell_wave) {
+        if constexpr (XIN) { const float* bp = a.bias[dir] + cj; gx0 = bp[0]; gx1 = bp[H]; gx2 = bp[2 * H]; gx3 = bp[3 * H]; }
+        else prefetch(0);
+    }
 
     auto slice_partial = [&](int par) {
         const f32x4* hq = reinterpret_cast<const f32x4*>(&hs[wave][0]);
@@ -649,6 +698,7 @@ __global__ __launch_bounds__(512) void lstm_rec_fwd4_kernel(LstmRecArgs a) {
 #pragma unroll
         for (int k4 = 0; k4 < 8; ++k4) hall[k4] = hq[k4];
         f32x2 pa[2][2] = {{f32x2{0.f, 0.f}, f32x2{0.f, 0.f}}, {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}}};   // [gate pair][chain]
+        x_partial(pa);
 #pragma unroll
         for (int k4 = 0; k4 < 8; ++k4) {
             const f32x4 hv = hall[k4];
@@ -664,16 +714,24 @@ __global__ __launch_bounds__(512) void lstm_rec_fwd4_kernel(LstmRecArgs a) {
         const f32x2 g01 = pa[0][0] + pa[0][1], g23 = pa[1][0] + pa[1][1];
         part[par][wave][lane] = make_float4(g01.x, g01.y, g23.x, g23.y);
     };
+    auto x_only_partial = [&](int par) {      // step 0 without an initial state: the pre-activations are x_0 . K_x alone
+        f32x2 pa[2][2] = {{f32x2{0.f, 0.f}, f32x2{0.f, 0.f}}, {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}}};
+        x_partial(pa);
+        const f32x2 g01 = pa[0][0] + pa[0][1], g23 = pa[1][0] + pa[1][1];
+        part[par][wave][lane] = make_float4(g01.x, g01.y, g23.x, g23.y);
+    };
 
+    if (S > 0) load_x(0);
     if (has_init && S > 0) {
         if (lane < 32) hs[wave][lane] = a.h0[(size_t)cb * H + kbase + lane];
         __builtin_amdgcn_wave_barrier();
         slice_partial(0);
-    }
+    } else if (XIN && S > 0) x_only_partial(0);
+    if (XIN && S > 1) load_x(1);          // xb always holds the x row of the NEXT product
     for (int s = 0; s < S; ++s) {
         const int t = dir ? (S - 1 - s) : s;
         const int par = s & 1;
-        if (s > 0 || has_init) {
+        if (s > 0 || has_init || XIN) {
             if (!cell_wave && s > 0) {
                 if (lane < 32) {
                     float v = 0.f;
@@ -682,12 +740,13 @@ __global__ __launch_bounds__(512) void lstm_rec_fwd4_kernel(LstmRecArgs a) {
                 }
                 __builtin_amdgcn_wave_barrier();
                 slice_partial(par);
+                if (XIN && s + 1 < S) load_x(s + 1);
             }
             __syncthreads();
         }
         if (cell_wave) {
             float4 pre = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (s > 0 || has_init) {
+            if (s > 0 || has_init || XIN) {
 #pragma unroll
                 for (int ww = 0; ww < NW; ++ww) {
                     const float4 p = part[par][ww][lane];
@@ -726,6 +785,7 @@ __global__ __launch_bounds__(512) void lstm_rec_fwd4_kernel(LstmRecArgs a) {
                 if (lane < 32) hs[0][lane] = h;          // the first half of the own slice, for the next step
                 __builtin_amdgcn_wave_barrier();
                 slice_partial(par ^ 1);
+                if (XIN && s + 2 < S) load_x(s + 2);
             }
         }
     }
@@ -833,8 +893,22 @@ extern "C" int asr_lstm_layer_fwd(void* stream, const float* x, int B, int T, in
     if (hx_bytes < asr_lstm_ws_bytes(B, H, ndir)) return ASR_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int H4 = 4 * H;
+    // groups of four workgroups (lstm_rec_fwd4_kernel) -- and with 80 inputs (the first encoder layer) the input projection
+    // inside that kernel: no projection GEMM, no gates written or read (ASR_LSTM_XIN=0: the GEMM, as for every other width)
+    bool g4 = false, xin = false;
+    {
+        const char* e = getenv("ASR_LSTM_G4");
+        const char* v2e = getenv("ASR_LSTM_V2");
+        const char* ce = getenv("ASR_LSTM_G4_CHUNKS");
+        const char* xe = getenv("ASR_LSTM_XIN");
+        const int rpl = asr_lstm_max_wgs() / (4 * ndir);
+        g4 = !(e && e[0] == '0') && !(v2e && v2e[0] == '0') && !(g_lstm_dbg && getenv("ASR_LSTM_STAMP")) &&
+             !(asr_get_lstm_mfma() != 0 && asr_get_gemm_precision() == 1) && H == 256 && rpl >= 1 && (B + rpl - 1) / rpl <= (ce ? atoi(ce) : 4);
+        xin = g4 && in_dim == 80 && !(xe && xe[0] == '0');
+    }
     // input projection for all timesteps: gates[b,t,dir,:] = x[b,t,:] . K_x + bias
-    if (ndir == 2 && kx_cat && bias_cat) {
+    if (xin) {
+    } else if (ndir == 2 && kx_cat && bias_cat) {
         // both directions as ONE product with N = 8H: gates rows are [fw 4H | bw 4H] and the caller supplies the input rows of
         // the two kernels side by side ([in, 8H]) -- twice the tiles per launch (less tile quantisation: 1 600 instead of
         // 2 x 800 on 512 resident slots at layer 2) and X streamed once
@@ -856,38 +930,33 @@ extern "C" int asr_lstm_layer_fwd(void* stream, const float* x, int B, int T, in
     a.B = B; a.T = T; a.Tout = Tout; a.ND = ndir; a.keep = keep_prob; a.seed = seed;
     a.sb = T; a.st = 1; a.osb = Tout; a.ost = 1; a.ldo = ndir * H; a.dsb = Tout; a.dst = 1; a.toff = 0;
     a.h0 = a.c0 = nullptr; a.h_last = a.c_last = nullptr; a.ep0 = 0;
-    {   // groups of four workgroups, one row per group (lstm_rec_fwd4_kernel), when the whole batch is resident at once:
-        // 1.19 -> 1.08 us per step at B = 32 (ASR_LSTM_G4=0: the eight-workgroup groups of version 2)
-        const char* e = getenv("ASR_LSTM_G4");
-        const char* v2e = getenv("ASR_LSTM_V2");
-        // larger batches: consecutive launches over ranges of 32 rows; measured against the first-version kernels with four /
-        // eight rows per group: B = 64 2.25 vs 2.69 us per step of a layer, B = 128 4.85 vs 4.97 (ASR_LSTM_G4_CHUNKS, default 4)
+    a.x = nullptr; a.ldx = 0; a.kx[0] = a.kx[1] = nullptr; a.bias[0] = a.bias[1] = nullptr;
+    if (g4) {   // one row per group; larger batches as consecutive launches over ranges of 32 rows (measured against the first-version
+                // kernels with four / eight rows per group: B = 64 2.25 vs 2.69 us per step of a layer, B = 128 4.85 vs 4.97)
         const int rpl = asr_lstm_max_wgs() / (4 * ndir);
-        const char* ce = getenv("ASR_LSTM_G4_CHUNKS");
-        const int max_chunks = ce ? atoi(ce) : 4;
-        if (!(e && e[0] == '0') && !(v2e && v2e[0] == '0') && !(g_lstm_dbg && getenv("ASR_LSTM_STAMP")) &&
-            !(asr_get_lstm_mfma() != 0 && asr_get_gemm_precision() == 1) && H == 256 && rpl >= 1 && (B + rpl - 1) / rpl <= max_chunks) {
-            a.dbg = nullptr;
-            for (int b0 = 0; b0 < B; b0 += rpl) {
-                LstmRecArgs c = a;
-                c.B = (B - b0 < rpl) ? (B - b0) : rpl;
-                c.gates = a.gates + (size_t)b0 * T * ndir * H4;
-                c.len = len + b0;
-                c.out = out + (size_t)b0 * Tout * ndir * H;
-                c.act = act ? act + (size_t)b0 * T * ndir * H * 8 : nullptr;
-                c.hprev = hprev ? hprev + (size_t)b0 * T * ndir * H : nullptr;
-                c.boff = b0;
-                const int groups = ndir * c.B;
-                const int padded = ((groups + 7) & ~7) * 4;
-                const int grid = padded <= asr_lstm_max_wgs() ? padded : groups * 4;
-                prof_begin(ASR_PROF_LSTM_REC_FWD, s);
-                hipLaunchKernelGGL(asr::lstm_rec_fwd4_kernel, dim3(grid), dim3(512), 0, s, c);
-                prof_end(ASR_PROF_LSTM_REC_FWD, s);
-                ASR_CHECK_LAUNCH();
-                if (b0 + rpl < B && hipMemsetAsync(hx_ws, 0, asr_lstm_ws_bytes(B, H, ndir), s) != hipSuccess) return ASR_ELAUNCH;
-            }
-            return ASR_OK;
+        a.dbg = nullptr;
+        a.x = x; a.ldx = ldx; a.kx[0] = kernel_fw; a.kx[1] = kernel_bw; a.bias[0] = bias_fw; a.bias[1] = bias_bw;
+        for (int b0 = 0; b0 < B; b0 += rpl) {
+            LstmRecArgs c = a;
+            c.B = (B - b0 < rpl) ? (B - b0) : rpl;
+            c.gates = a.gates + (size_t)b0 * T * ndir * H4;
+            c.x = x + (size_t)b0 * T * ldx;
+            c.len = len + b0;
+            c.out = out + (size_t)b0 * Tout * ndir * H;
+            c.act = act ? act + (size_t)b0 * T * ndir * H * 8 : nullptr;
+            c.hprev = hprev ? hprev + (size_t)b0 * T * ndir * H : nullptr;
+            c.boff = b0;
+            const int groups = ndir * c.B;
+            const int padded = ((groups + 7) & ~7) * 4;
+            const int grid = padded <= asr_lstm_max_wgs() ? padded : groups * 4;
+            prof_begin(ASR_PROF_LSTM_REC_FWD, s);
+            if (xin) hipLaunchKernelGGL(asr::lstm_rec_fwd4_kernel<10>, dim3(grid), dim3(512), 0, s, c);
+            else hipLaunchKernelGGL(asr::lstm_rec_fwd4_kernel<0>, dim3(grid), dim3(512), 0, s, c);
+            prof_end(ASR_PROF_LSTM_REC_FWD, s);
+            ASR_CHECK_LAUNCH();
+            if (b0 + rpl < B && hipMemsetAsync(hx_ws, 0, asr_lstm_ws_bytes(B, H, ndir), s) != hipSuccess) return ASR_ELAUNCH;
         }
+        return ASR_OK;
     }
     const int R = asr_lstm_pick_rows(B, ndir, H / 32);
     // batches too large for one resident grid run as consecutive launches over row ranges
@@ -945,6 +1014,7 @@ int asr_lstm_rec_fwd_tm(hipStream_t s, const float* gates, const float* kh, cons
     a.B = B; a.T = T; a.Tout = T; a.ND = 1; a.boff = 0; a.keep = keep; a.seed = seed;
     a.sb = 1; a.st = B; a.osb = 1; a.ost = B; a.ldo = ldo; a.dsb = 1; a.dst = B; a.toff = toff;
     a.h0 = h0; a.c0 = c0; a.h_last = h_last; a.c_last = c_last; a.ep0 = toff;
+    a.x = nullptr; a.ldx = 0; a.kx[0] = a.kx[1] = nullptr; a.bias[0] = a.bias[1] = nullptr;
     const int R = asr_lstm_pick_rows(B, 1, H / 32);
     switch (H) {
         case 64: return launch_rec_h<64>(s, a, R);
