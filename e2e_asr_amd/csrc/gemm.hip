@@ -18,6 +18,8 @@
 #include "common.h"
 #include <algorithm>
 #include <cstdlib>
+#include <map>
+#include <mutex>
 
 namespace asr {
 
@@ -31,6 +33,7 @@ struct GemmArgs {
     int vecA, vecB;   // 16-B vector loads legal for this operand
     int xcd_split;    // split-K with one 1-D grid: K slice s runs entirely on XCD s % 8 (splits is a multiple of 8)
     long long sA, sB, sC;   // batch strides (elements); batch index = blockIdx.z
+    float* sk_ws; int* sk_flag; int sk_epoch;   // gemm_planes_kernel<..., SK = true>: one partial tile ([256 threads][64 accumulators]) and one flag per workgroup
 };
 
 // Load 4 consecutive floats p[0..3] where element i is valid iff i < nvalid.
@@ -347,7 +350,16 @@ struct StagerP {
 
 // PARTM: M is not a multiple of 128 -- the A operand stages zeros for the rows past M (only that instantiation pays the
 // selects) and the epilogue skips them.
-template <bool TA, bool TB, bool PARTM, int NP, int BKT>
+// SK ("stream-K", Osama et al. 2023 restated for this kernel): the grid is what the chip holds at once (two workgroups per CU) and
+// every workgroup multiplies the SAME number of k-tiles (+-1) -- a contiguous run of the (tile, k-tile) sequence, so a run covers
+// a tail of one output tile, some whole tiles and a head of another.  With whole tiles per workgroup, T tiles on 512 slots cost
+// ceil(T / 512) rounds (the encoder's products have 25 * 2^n tiles: 1 600 -> 4 rounds for 3.125 of work, 200 -> 1 for 0.39).  A
+// workgroup whose run ends inside a tile leaves its accumulators in a workspace slot and raises a flag; the workgroup that
+// reaches the tile's last k-tile adds the slots of the (lower-numbered, hence earlier dispatched: no circular wait) workgroups
+// before it in ascending order and writes C -- a FIXED summation order: results are reproducible run to run, like the
+// whole-tile kernel's.  Each XCD's 64 workgroups share one eighth of the tiles (blockIdx & 7 = XCD under round-robin
+// dispatch), so no run crosses XCDs and operand tiles stay in one L2 as before.
+template <bool TA, bool TB, bool PARTM, int NP, int BKT, bool SK = false>
 __global__ __launch_bounds__(256, 2) void gemm_planes_kernel(GemmArgs a) {
     constexpr int BM = 128, BN = 128;
     constexpr int PITCH = BKT + 8;                  // bf16 elements: 48- / 80-byte rows, conflict-free ds_read_b128 fragments
@@ -362,13 +374,33 @@ __global__ __launch_bounds__(256, 2) void gemm_planes_kernel(GemmArgs a) {
     const int ntn = a.N / BN, ntm = (a.M + BM - 1) / BM;
     const int nwg = ntn * ntm;
     int bid = blockIdx.x, ksl = blockIdx.y;
-    if (a.xcd_split) {          // weight-gradient form: whole K slices per XCD (see gemm_f32_kernel)
+    const int nk_all = a.K / BKT;
+    // SK: this workgroup's run of units [su, su1) of its XCD's share (unit = one k-tile of one tile; tiles in order)
+    const int sk_g8 = gridDim.x >> 3, sk_li = blockIdx.x >> 3;
+    const long long sk_u8 = (long long)(nwg >> 3) * nk_all;
+    int su = 0, su1 = 0;
+    if (SK) {
+        su = (int)(sk_u8 * sk_li / sk_g8); su1 = (int)(sk_u8 * (sk_li + 1) / sk_g8);
+        ksl = 0;
+    } else if (a.xcd_split) {          // weight-gradient form: whole K slices per XCD (see gemm_f32_kernel)
         const int xcd = bid & 7, idx = bid >> 3;
         ksl = xcd + 8 * (idx / nwg);
         bid = idx % nwg;
     } else {
         const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
         bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+    }
+    bool sk_first = true;
+    do {
+    int sk_kt0 = 0, sk_nk = 0, sk_tl = 0;
+    if (SK) {       // next segment of the run, LAST FIRST: (tile, [kt0, nk)).  The head of a tile this run ends in is what another
+        if (su >= su1) break;                   // workgroup waits for, so it is multiplied first; the tail of the tile the run
+        sk_tl = (su1 - 1) / nk_all;             // begins in -- where this workgroup waits for others -- comes last
+        sk_nk = su1 - sk_tl * nk_all; sk_kt0 = max(su - sk_tl * nk_all, 0);
+        su1 -= sk_nk - sk_kt0;
+        bid = (blockIdx.x & 7) * (nwg >> 3) + sk_tl;
+        if (!sk_first) __syncthreads();          // the last tile's fragment reads are done before the planes are overwritten
+        sk_first = false;
     }
     const int m0 = (bid / ntn) * BM, n0 = (bid % ntn) * BN;
     f32x16 acc[2][2];
@@ -384,10 +416,9 @@ __global__ __launch_bounds__(256, 2) void gemm_planes_kernel(GemmArgs a) {
     // loads of tile t+2 are issued at the top.  Two register sets (sa0/sb0, sa1/sb1) alternate, hence the loop unrolled by 2.
     StagerP<TA, BKT> sa0, sa1;       // A natural [M,K]: k contiguous unless transposed
     StagerP<!TB, BKT> sb0, sb1;      // B natural [K,N]: n contiguous unless transposed
-    const int nk_all = a.K / BKT;
     const int per = (nk_all + a.splits - 1) / a.splits;
-    const int kt0 = ksl * per, nk = min(nk_all, kt0 + per);
-    if (kt0 >= nk) return;
+    const int kt0 = SK ? sk_kt0 : ksl * per, nk = SK ? sk_nk : min(nk_all, kt0 + per);
+    if (!SK && kt0 >= nk) return;
     const int arows = PARTM ? a.M - m0 : 128;   // >= 128 except in the last row of tiles of a partial-M product
     const int rowA = TA ? (tid & 127) : (tid >> 1), khA = TA ? (tid >> 7) : (tid & 1);
     const int rowB = !TB ? (tid & 127) : (tid >> 1), khB = !TB ? (tid >> 7) : (tid & 1);
@@ -527,6 +558,53 @@ __global__ __launch_bounds__(256, 2) void gemm_planes_kernel(GemmArgs a) {
     } else {
         step(0, sa0.v, sb0.v, false, sa1, sb1, 0, false);
     }
+    // Slots and flags cross workgroups (possibly XCDs) inside one launch: agent-scope accesses (sc1: stores write through, loads
+    // are served from the coherent level) instead of fences -- a buffer_inv / buffer_wbl2 costs every workgroup of the XCD its
+    // L2 contents (first version, with acquire polls: +150 us per launch).  A store is acknowledged (vmcnt) once it is there.
+    typedef float f32x4s __attribute__((ext_vector_type(4)));
+    if (SK && nk < nk_all) {            // the run ends inside this tile: accumulators -> this workgroup's slot, then the flag
+        float* wp = a.sk_ws + (size_t)blockIdx.x * (BM * BN) + tid * 64;          // 256 B per thread: one base, immediate offsets
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const f32x4s v = {acc[q >> 1][q & 1][4 * r], acc[q >> 1][q & 1][4 * r + 1], acc[q >> 1][q & 1][4 * r + 2], acc[q >> 1][q & 1][4 * r + 3]};
+                asm volatile("global_store_dwordx4 %0, %1, off offset:%2 sc1" :: "v"(wp), "v"(v), "n"((q * 4 + r) * 16) : "memory");
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(a.sk_flag + blockIdx.x, a.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        continue;
+    }
+    if (SK && kt0 > 0) {                // the tile began in earlier workgroups of this XCD's share: add their slots, lowest first
+        const long long ub = (long long)sk_tl * nk_all;         // the tile's first unit
+        int c = sk_li - 1;
+        while (sk_u8 * c / sk_g8 > ub) --c;
+        for (; c < sk_li; ++c) {
+            const int cb = c * 8 + (blockIdx.x & 7);
+            if (tid == 0) {
+                int guard = 0;
+                while (__hip_atomic_load(a.sk_flag + cb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.sk_epoch && ++guard < (1 << 24))
+                    __builtin_amdgcn_s_sleep(8);
+            }
+            __syncthreads();
+            const float* rp = a.sk_ws + (size_t)cb * (BM * BN) + tid * 64;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4s v0, v1, v2, v3;
+                asm volatile("global_load_dwordx4 %0, %4, off offset:%5 sc1\n\tglobal_load_dwordx4 %1, %4, off offset:%6 sc1\n\t"
+                             "global_load_dwordx4 %2, %4, off offset:%7 sc1\n\tglobal_load_dwordx4 %3, %4, off offset:%8 sc1\n\t"
+                             "s_waitcnt vmcnt(0)"
+                             : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3)
+                             : "v"(rp), "n"(q * 64), "n"(q * 64 + 16), "n"(q * 64 + 32), "n"(q * 64 + 48) : "memory");
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[q >> 1][q & 1][e] += v0[e]; acc[q >> 1][q & 1][4 + e] += v1[e];
+                    acc[q >> 1][q & 1][8 + e] += v2[e]; acc[q >> 1][q & 1][12 + e] += v3[e];
+                }
+            }
+        }
+    }
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -543,6 +621,7 @@ __global__ __launch_bounds__(256, 2) void gemm_planes_kernel(GemmArgs a) {
                 else { if (a.accumulate) v += *cp; *cp = v; }
             }
         }
+    } while (SK);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -670,6 +749,30 @@ __global__ __launch_bounds__(256, 4) void gemm_split3s_kernel(GemmArgs a) {
     }
 }
 
+// workspace of the stream-K launches of one stream: a partial tile and a flag per workgroup (allocated at the stream's first use)
+struct SkWorkspace { float* ws; int* flag; int* epoch; };      // epoch: launches so far (a flag is raised by writing the launch's number: no clearing)
+constexpr int SK_MAX_WGS = 1024;
+static SkWorkspace sk_workspace(hipStream_t s) {
+    static std::mutex mu;
+    static std::map<hipStream_t, SkWorkspace> all;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = all.find(s);
+    if (it != all.end()) return it->second;
+    SkWorkspace w{nullptr, nullptr, nullptr};
+    if (hipMalloc(&w.ws, (size_t)SK_MAX_WGS * 128 * 128 * sizeof(float)) != hipSuccess ||
+        hipMalloc(&w.flag, SK_MAX_WGS * sizeof(int)) != hipSuccess ||
+        hipMemset(w.flag, 0, SK_MAX_WGS * sizeof(int)) != hipSuccess) { w.ws = nullptr; w.flag = nullptr; (void)hipGetLastError(); return w; }
+    w.epoch = new int(0);
+    all[s] = w;
+    return w;
+}
+
+template <int NP, int BKT>
+static void launch_planes_sk(dim3 grid, hipStream_t s, const GemmArgs& g, int transB) {
+    if (transB) hipLaunchKernelGGL((gemm_planes_kernel<false, true, false, NP, BKT, true>), grid, dim3(256), 0, s, g);
+    else        hipLaunchKernelGGL((gemm_planes_kernel<false, false, false, NP, BKT, true>), grid, dim3(256), 0, s, g);
+}
+
 template <int NP, int BKT>
 static void launch_planes(dim3 grid, hipStream_t s, const GemmArgs& g, int transA, int transB, bool partm) {
     if (transA && partm) hipLaunchKernelGGL((gemm_planes_kernel<true, false, true, NP, BKT>), grid, dim3(256), 0, s, g);
@@ -722,6 +825,7 @@ extern "C" int asr_gemm_f32_batched(void* stream, int transA, int transB, int M,
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.accumulate = accumulate;
     g.sA = strideA; g.sB = strideB; g.sC = strideC;
+    g.sk_ws = nullptr; g.sk_flag = nullptr; g.sk_epoch = 0;
     g.vecA = ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && (lda % 4 == 0) && (strideA % 4 == 0);
     g.vecB = ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && (ldb % 4 == 0) && (strideB % 4 == 0);
     int nwg = ((M + 127) / 128) * ((N + 127) / 128);
@@ -761,6 +865,38 @@ extern "C" int asr_gemm_f32_batched(void* stream, int transA, int transB, int M,
             g.splits = (splits + 4) / 8 * 8;
             g.xcd_split = 1;
             grid = dim3(nwg * g.splits, 1, batch);
+        }
+        // Stream-K (see the kernel): forward / data-gradient forms whose tiles fill the last round of workgroup slots badly.
+        // OPT-IN (ASR_GEMM_SK=1), measured and not adopted: stand-alone it is 0-6 % ahead on the encoder's products with >= 800
+        // tiles and 14 % behind at 400 (a lone workgroup on a CU multiplies a k-tile in 0.77 us, two sharing it in 0.73 us
+        // each: the "rounds" a partial last round wastes are mostly not there to win back), and inside the train step the runs
+        // that wait for a slot of a workgroup still queued behind the other stream's GEMM cost +0.19 ms (7.99 vs 7.80 ms).
+        const char* sk_e = getenv("ASR_GEMM_SK");
+        const int sk_on = sk_e ? atoi(sk_e) : 0;
+        static const int sk_slots = [] {
+            int dev = 0, cus = 256;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+            return std::min(2 * cus, SK_MAX_WGS) & ~7;
+        }();
+        const int bkt = (np == 1 && K % 32 == 0) ? 32 : 16;
+        const int nkp = K / bkt;
+        if (sk_on && !transA && !partm && splits == 1 && batch == 1 && nwg % 8 == 0 && nkp >= 8 && sk_slots >= 8) {
+            const int rounds = (nwg + sk_slots - 1) / sk_slots;
+            const double waste = 1.0 - (double)nwg / ((double)rounds * sk_slots);
+            const long long units = (long long)nwg * nkp;
+            const int G = (int)std::min<long long>(sk_slots, (units / 8) & ~7LL);          // at least 8 k-tiles per workgroup
+            if (waste >= 0.1 && G >= 8) {
+                const SkWorkspace w = sk_workspace(s);
+                if (w.ws) {
+                    g.sk_ws = w.ws; g.sk_flag = w.flag; g.sk_epoch = ++*w.epoch;
+                    if (np == 3)        launch_planes_sk<3, 16>(dim3(G), s, g, transB);
+                    else if (np == 2)   launch_planes_sk<2, 16>(dim3(G), s, g, transB);
+                    else if (bkt == 32) launch_planes_sk<1, 32>(dim3(G), s, g, transB);
+                    else                launch_planes_sk<1, 16>(dim3(G), s, g, transB);
+                    ASR_CHECK_LAUNCH();
+                    return ASR_OK;
+                }
+            }
         }
         if (np == 3)                      launch_planes<3, 16>(grid, s, g, transA, transB, partm);
         else if (np == 2)                 launch_planes<2, 16>(grid, s, g, transA, transB, partm);

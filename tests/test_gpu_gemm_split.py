@@ -90,3 +90,48 @@ def test_split_is_the_default_and_small_products_stay_on_the_exact_kernel():
     a = torch.from_numpy(rng.standard_normal((100, 96)).astype(np.float32)).to(DEV)
     b = torch.from_numpy(rng.standard_normal((96, 60)).astype(np.float32)).to(DEV)
     assert torch.equal(_run(a, b, False, False, True), _run(a, b, False, False, False))
+
+
+@pytest.mark.parametrize("form,M,N,K,prec", [
+    ("NN", 12800, 2048, 1024, 0),       # config-2 layer-2 input projection: 1 600 tiles, 3.125 per workgroup slot
+    ("NN", 6400, 1024, 1024, 0),        # 400 tiles: less than one round, runs shorter than a tile (middle contributors)
+    ("NT", 3200, 1024, 2048, 0),        # data gradient of the top layer: 200 tiles, 128 k-tiles each, three or four workgroups per tile
+    ("NT", 12800, 1024, 2048, 0),       # ... of layer 2: 800 tiles
+    ("NN", 6400, 1024, 1024, 1),        # one bf16 plane (BK = 32)
+    ("NN", 3200, 2048, 1024, 2),        # two planes
+    ("NN", 1024 + 128, 1024, 256, 0),   # 72 tiles: 9 per XCD, 16 k-tiles -> at most 18 workgroups per XCD ... few units per run
+])
+def test_stream_k_equals_whole_tile_kernel_and_is_reproducible(monkeypatch, form, M, N, K, prec):
+    """gemm_planes_kernel<..., SK> (every workgroup an equal run of k-tiles, partial tiles summed in a fixed order) against the
+    whole-tile launch of the same kernel (ASR_GEMM_SK=0) and float64: same error class, bit-identical from run to run, bias and
+    accumulation applied once."""
+    from e2e_asr_amd import ops
+    rng = np.random.default_rng(M + N + K + prec)
+    ta, tb = form[0] == "T", form[1] == "T"
+    a = rng.standard_normal((M, K)).astype(np.float32); b = rng.standard_normal((N, K) if tb else (K, N)).astype(np.float32)
+    bias = rng.standard_normal((N,)).astype(np.float32)
+    c0 = rng.standard_normal((M, N)).astype(np.float32)
+    at, bt, biast, c0t = (torch.from_numpy(x).to(DEV) for x in (a, b, bias, c0))
+    prev = ops.get_gemm_precision()
+    ops.set_gemm_precision({0: "f32", 1: "bf16", 2: "bf16x2"}[prec])
+    try:
+        monkeypatch.setenv("ASR_GEMM_SK", "1")
+        sk1 = _run(at, bt, ta, tb, True, biast)
+        sk2 = _run(at, bt, ta, tb, True, biast)
+        sk_acc = _run(at, bt, ta, tb, True, biast, accumulate=True, c0=c0t)
+        monkeypatch.setenv("ASR_GEMM_SK", "0")
+        wt = _run(at, bt, ta, tb, True, biast)
+    finally:
+        ops.set_gemm_precision(prev)
+    torch.cuda.synchronize()
+    assert torch.equal(sk1, sk2)
+    B64 = (b.T if tb else b).astype(np.float64)
+    ref = a.astype(np.float64) @ B64 + bias
+    scale = np.abs(a).astype(np.float64) @ np.abs(B64) + np.abs(bias)
+    e_sk = (np.abs(sk1.cpu().numpy() - ref) / scale).max(); e_wt = (np.abs(wt.cpu().numpy() - ref) / scale).max()
+    tol = {0: 8 * np.sqrt(K) * 2.0 ** -24, 1: 2.0 ** -7, 2: 2.0 ** -14}[prec]
+    assert e_sk < tol and e_wt < tol, (e_sk, e_wt)
+    assert e_sk < 3 * e_wt + 2.0 ** -22, (e_sk, e_wt)
+    # the two differ by summation order in the tiles several workgroups share, nowhere by more than fp32 rounding of the terms
+    np.testing.assert_allclose(sk1.cpu().numpy(), wt.cpu().numpy(), rtol=0, atol=float(16 * 2.0 ** -24 * scale.max()))
+    np.testing.assert_allclose(sk_acc.cpu().numpy(), sk1.cpu().numpy() + c0, rtol=0, atol=float(4 * 2.0 ** -24 * (scale.max() + np.abs(c0).max())))
