@@ -58,6 +58,9 @@ def _lstm_case(rng, B, Tn, IN, H, bi, lens):
     (9, 16, 32, 512, True, [16] * 9, None),                      # H=512, B not a multiple of R
     (70, 12, 16, 256, True, None, None),                         # batch larger than one resident grid
     (45, 9, 16, 256, True, None, None),                          # two launches of the groups-of-four kernel (32 + 13 rows)
+    (45, 11, 80, 256, True, None, 12),                           # ... with the projection inside (x rows offset by the launch's first row), pad frame
+    (7, 3, 80, 256, False, [3, 1, 2, 3, 1, 2, 2], None),         # ... lengths 1 and 2 (the x row is fetched a step ahead), one direction
+    (1, 1, 80, 256, True, [1], None),                            # one row, one frame
 ])
 @pytest.mark.parametrize("g4", ["1", "0", "1-gemm"])
 def test_lstm_layer_fwd(dev, monkeypatch, B, Tn, IN, H, bi, lens, tout, g4):
@@ -251,6 +254,9 @@ def test_next_token_argmax_first_max(dev):
     (20, 7, 16, 256, False, None, 1.0),                       # uni-directional, R = 1
     (8, 15, 16, 256, True, [15, 9, 1, 15, 7, 3, 11, 2], 0.9),  # H = 256, ragged, dropout: groups of four workgroups
     (45, 8, 16, 256, True, None, 0.9),                        # ... in two launches (32 + 13 rows), dropout counters offset by the row base
+    (45, 11, 80, 256, True, None, 1.0),                       # 80 inputs (forward: projection inside the kernel), two launches
+    (7, 3, 80, 256, False, [3, 1, 2, 3, 1, 2, 2], 1.0),       # lengths 1 and 2, one direction
+    (1, 1, 80, 256, True, [1], 1.0),                          # one row, one frame
 ])
 @pytest.mark.parametrize("g4", ["1", "0"])
 def test_lstm_layer_bwd_vs_autograd(dev, monkeypatch, B, Tn, IN, H, bi, lens, keep, g4):
