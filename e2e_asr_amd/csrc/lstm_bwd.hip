@@ -1063,6 +1063,7 @@ extern "C" size_t asr_lstm_bwd_ws_bytes(int B, int H, int ndir) {
 // Backward of asr_lstm_layer_fwd.  act/hprev are the forward's saved tensors; gates (the
 // forward's input-projection buffer) is overwritten with dG.  dx [B,T,in] (may be NULL for the first layer) receives the input
 // gradient; dkernel_*/dbias_* are ACCUMULATED into (TF layout [in+H,4H] / [4H]).
+int asr_colsum_pair_f32(hipStream_t s, const float* x, int ldx, int M, int N, float* out0, float* out1);
 extern "C" int asr_lstm_layer_bwd(void* stream, const float* x, int B, int T, int in_dim, int ldx,
                                   const int* len, int H, int ndir,
                                   const float* kernel_fw, const float* kernel_bw,
@@ -1157,6 +1158,10 @@ extern "C" int asr_lstm_layer_bwd(void* stream, const float* x, int B, int T, in
     }
     // bias gradient from the per-utterance partials: B rows, on the caller's stream (the workspace is reused by the next
     // layer's BPTT, so it must not wait in the side stream's queue)
+    if (db_part && ndir == 2) {           // both directions in one launch
+        int rc;
+        if ((rc = asr_colsum_pair_f32(s, db_part, 2 * H4, B, H4, dbias_fw, dbias_bw))) return rc;
+    } else
     for (int d = 0; d < ndir && db_part; ++d) {
         int rc;
         if ((rc = asr_colsum_f32(stream, db_part + (size_t)d * H4, ndir * H4, B, H4, d ? dbias_bw : dbias_fw, 1))) return rc;

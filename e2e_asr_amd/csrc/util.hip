@@ -7,7 +7,9 @@ namespace asr {
 
 // out[n] += sum_m x[m][n].  Block = 64 columns x 4 row-strips of its blockIdx.y slab; slabs
 // meet through one float atomic per column (out is pre-zeroed by the host when not accumulating).
-__global__ __launch_bounds__(256) void colsum_kernel(const float* x, int ldx, int M, int N, float* out, int rows_per_slab) {
+// (columns from `split` on go to out2 + (c - split): the two directions' bias gradients of a BiLSTM layer in one launch)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* x, int ldx, int M, int N, float* out, int rows_per_slab,
+                                                     int split = 0x7fffffff, float* out2 = nullptr) {
     __shared__ float part[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), strip = threadIdx.x >> 6;
     const int s0 = blockIdx.y * rows_per_slab, s1 = min(M, s0 + rows_per_slab);
@@ -28,7 +30,8 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* x, int ldx, in
     __syncthreads();
     if (strip == 0 && c < N) {
         const float t = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
-        if (gridDim.y == 1) out[c] += t; else atomicAdd(out + c, t);
+        float* o = c >= split ? out2 + (c - split) : out + c;
+        if (gridDim.y == 1) *o += t; else atomicAdd(o, t);
     }
 }
 
@@ -175,6 +178,18 @@ extern "C" int asr_colsum_f32(void* stream, const float* x, int ldx, int M, int 
     slabs = (M + rows_per_slab - 1) / rows_per_slab;
     if (M == 0) return ASR_OK;
     hipLaunchKernelGGL(asr::colsum_kernel, dim3(nx, slabs), dim3(256), 0, s, x, ldx, M, N, out, rows_per_slab);
+    ASR_CHECK_LAUNCH();
+    return ASR_OK;
+}
+// out0[n] += sum_m x[m][n], out1[n] += sum_m x[m][N + n] for n < N (x rows of 2N columns): internal, used by asr_lstm_layer_bwd
+int asr_colsum_pair_f32(hipStream_t s, const float* x, int ldx, int M, int N, float* out0, float* out1) {
+    if (!x || !out0 || !out1 || M < 0 || N <= 0 || ldx < 2 * N) return ASR_EINVAL;
+    if (M == 0) return ASR_OK;
+    const int nx = (2 * N + 63) / 64;
+    int slabs = std::max(1, std::min(M / 32, (2048 + nx - 1) / nx));
+    const int rows_per_slab = (M + slabs - 1) / slabs;
+    slabs = (M + rows_per_slab - 1) / rows_per_slab;
+    hipLaunchKernelGGL(asr::colsum_kernel, dim3(nx, slabs), dim3(256), 0, s, x, ldx, M, 2 * N, out0, rows_per_slab, N, out1);
     ASR_CHECK_LAUNCH();
     return ASR_OK;
 }

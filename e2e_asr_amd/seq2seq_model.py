@@ -179,7 +179,9 @@ class Seq2SeqModel(BaseParams):
         v = self.variables
         v.ensure_grad()
         v.grad.zero_()
-        gscale = torch.full((1,), 1.0 / len(params.tasks) if params.avg else 1.0, device=self.device)
+        if getattr(self, "_gscale", None) is None:          # d total_loss / d task loss: constant for the model's life
+            self._gscale = torch.full((1,), 1.0 / len(params.tasks) if params.avg else 1.0, device=self.device)
+        gscale = self._gscale
         d_states = {}
         for task in params.tasks:
             lw = self._loss_ws[task]
