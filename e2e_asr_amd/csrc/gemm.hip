@@ -368,6 +368,7 @@ __global__ __launch_bounds__(256, 2) void gemm_planes_kernel(GemmArgs a) {
     constexpr int KSTEPS = BKT / 16;
     __shared__ __attribute__((aligned(16))) unsigned short As[2 * NP * PLANE];
     __shared__ __attribute__((aligned(16))) unsigned short Bs[2 * NP * PLANE];
+    __shared__ int sk_lost;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid >> 1, wc = wid & 1;
     a.A += (size_t)blockIdx.z * a.sA; a.B += (size_t)blockIdx.z * a.sB; a.C += (size_t)blockIdx.z * a.sC;
@@ -586,8 +587,16 @@ __global__ __launch_bounds__(256, 2) void gemm_planes_kernel(GemmArgs a) {
                 int guard = 0;
                 while (__hip_atomic_load(a.sk_flag + cb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.sk_epoch && ++guard < (1 << 24))
                     __builtin_amdgcn_s_sleep(8);
+                sk_lost = guard >= (1 << 24);       // (seconds: the slot never came -- the tile is written as NaN, never silently short)
             }
             __syncthreads();
+            if (sk_lost) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[q >> 1][q & 1][e] = __builtin_nanf("");
+                break;
+            }
             const float* rp = a.sk_ws + (size_t)cb * (BM * BN) + tid * 64;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
