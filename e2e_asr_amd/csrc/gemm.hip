@@ -590,7 +590,9 @@ __global__ __launch_bounds__(256, 2) void gemm_planes_kernel(GemmArgs a) {
                 sk_lost = guard >= (1 << 24);       // (seconds: the slot never came -- the tile is written as NaN, never silently short)
             }
             __syncthreads();
-            if (sk_lost) {
+            const bool lost = sk_lost != 0;
+            __syncthreads();                        // (thread 0 writes the word again for the next slot)
+            if (lost) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
 #pragma unroll
