@@ -79,6 +79,22 @@ extern "C" int asr_attn_decoder_fwd(void* stream, const asr_dec_weights* w, cons
     // hf = enc . AttnW   (attn_decoder.py:70-73)
     if ((rc = asr_gemm_f32(stream, 0, 0, B * Te, A, D, enc, D, w->attn_enc_w, A, ws->hf, A, nullptr, 0))) return rc;
     const int P = w->simple_w ? H : lmH;
+    // WK = W_inp . K_x and b' = b_inp . K_x + b_dec of the one-launch decoders: weights only -- on the side stream, next to the hf
+    // product above (three small launches in a row are three launch latencies; side by side they are one)
+    // (ASR_DEC_SIDE_SMALL=0: everything on the caller's stream, as before round 3's last day)
+    static const bool side_small = [] { const char* e = getenv("ASR_DEC_SIDE_SMALL"); return !(e && e[0] == '0'); }();
+    void* small_s = side_small ? side : stream;
+    auto fold_input_projection = [&](float* wk, float* bprime) -> int {
+        int r;
+        if ((r = asr_gemm_f32(small_s, 0, 0, lmH + D, 4 * H, E, w->inp_w, E, w->dec_kernel, 4 * H, wk, 4 * H, nullptr, 0))) return r;
+        if ((r = asr_gemm_f32(small_s, 0, 0, 1, 4 * H, E, w->inp_b, E, w->dec_kernel, 4 * H, bprime, 4 * H, w->dec_bias, 0))) return r;
+        if (side_small) {
+            hipEvent_t e_wk = asr::next_event();
+            if (hipEventRecord(e_wk, ss) != hipSuccess || hipStreamWaitEvent(ms, e_wk, 0) != hipSuccess) return ASR_ELAUNCH;
+        }
+        return ASR_OK;
+    };
+    hipEvent_t e_x = nullptr;          // the saved InputProjection output of the training graph (side stream, joined at the end)
     auto feedback = [&](int i) {       // is tok[i+1] produced on the device from step i's logits?
         if (i < 0 || i + 1 >= T) return false;
         if (mode == 1) return true;
@@ -90,8 +106,7 @@ extern "C" int asr_attn_decoder_fwd(void* stream, const asr_dec_weights* w, cons
         asr_decoder_greedy_supported(B, Te, D, A, H, lmH, E, V)) {
         float* wk = ws->w2k;                       // [(lmH+D), 4H] followed by b' [4H] (InputProjection folded, as below)
         float* bprime = wk + (size_t)(lmH + D) * 4 * H;
-        if ((rc = asr_gemm_f32(stream, 0, 0, lmH + D, 4 * H, E, w->inp_w, E, w->dec_kernel, 4 * H, wk, 4 * H, nullptr, 0))) return rc;
-        if ((rc = asr_gemm_f32(stream, 0, 0, 1, 4 * H, E, w->inp_b, E, w->dec_kernel, 4 * H, bprime, 4 * H, w->dec_bias, 0))) return rc;
+        if ((rc = fold_input_projection(wk, bprime))) return rc;
         if ((rc = asr_decoder_greedy_fwd(stream, w->embedding, w->lm_kernel, w->lm_bias, wk, bprime, w->dec_kernel + (size_t)E * 4 * H,
                                          w->attn_w, w->attn_b, w->attn_v, w->ap_w, w->ap_b, w->out_w, w->out_b, ws->hf, enc, enc_len,
                                          seq_len, ws->tok, logits, ws->greedy_ws, ws->err, B, Te, D, A, H, lmH, E, V, T))) return rc;
@@ -108,8 +123,7 @@ extern "C" int asr_attn_decoder_fwd(void* stream, const asr_dec_weights* w, cons
         ws->lm_act && ws->lm_hprev && (keep_lm >= 1.0f || ws->lm_hd) && asr_decoder_greedy_supported(B, Te, D, A, H, lmH, E, V)) {
         float* wk = ws->w2k;                       // [(lmH+D), 4H] followed by b' [4H] (InputProjection folded, as below)
         float* bprime = wk + (size_t)(lmH + D) * 4 * H;
-        if ((rc = asr_gemm_f32(stream, 0, 0, lmH + D, 4 * H, E, w->inp_w, E, w->dec_kernel, 4 * H, wk, 4 * H, nullptr, 0))) return rc;
-        if ((rc = asr_gemm_f32(stream, 0, 0, 1, 4 * H, E, w->inp_b, E, w->dec_kernel, 4 * H, bprime, 4 * H, w->dec_bias, 0))) return rc;
+        if ((rc = fold_input_projection(wk, bprime))) return rc;
         unsigned fbmask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (int i = 0; i < T; ++i)
             if (feedback(i)) fbmask[i >> 5] |= 1u << (i & 31);
@@ -119,10 +133,19 @@ extern "C" int asr_attn_decoder_fwd(void* stream, const asr_dec_weights* w, cons
                                         seq_len, ws->tok, fbmask, keep_lm, seed, lm_out_buf, ws->lm_hprev, ws->lm_act, ws->dec_gates,
                                         ws->dec_c, ws->dec_h, ws->y, ws->alpha, ws->ctx, ws->greedy_ws, ws->err,
                                         B, Te, D, A, H, lmH, E, V, T))) return rc;
-        // x (saved for the backward) = lm_out . W_inp[:P] + b_inp + ctx_prev . W_inp[P:]  -- two GEMMs over all steps
-        if ((rc = asr_gemm_f32(stream, 0, 0, T * B, E, lmH, lm_out_buf, lmH, w->inp_w, E, ws->x, E, w->inp_b, 0))) return rc;
-        if (T > 1 && (rc = asr_gemm_f32(stream, 0, 0, (T - 1) * B, E, D, ws->ctx, D, w->inp_w + (size_t)lmH * E, E,
+        // x (saved for the backward: only the outer cell's weight gradient reads it, on the side stream) = lm_out . W_inp[:P] +
+        // b_inp + ctx_prev . W_inp[P:]  -- two GEMMs over all steps, on the side stream next to the projections of p and the logits
+        if (side_small) {
+            hipEvent_t e_k = asr::next_event();
+            if (hipEventRecord(e_k, ms) != hipSuccess || hipStreamWaitEvent(ss, e_k, 0) != hipSuccess) return ASR_ELAUNCH;
+        }
+        if ((rc = asr_gemm_f32(small_s, 0, 0, T * B, E, lmH, lm_out_buf, lmH, w->inp_w, E, ws->x, E, w->inp_b, 0))) return rc;
+        if (T > 1 && (rc = asr_gemm_f32(small_s, 0, 0, (T - 1) * B, E, D, ws->ctx, D, w->inp_w + (size_t)lmH * E, E,
                                         ws->x + (size_t)B * E, E, nullptr, 1))) return rc;
+        if (side_small) {
+            e_x = asr::next_event();
+            if (hipEventRecord(e_x, ss) != hipSuccess) return ASR_ELAUNCH;
+        }
         done_train_kernel = true;
     }
     // ---- persistent chain path: the per-step attention chain of a whole SEGMENT (steps up to and
@@ -294,6 +317,7 @@ extern "C" int asr_attn_decoder_fwd(void* stream, const asr_dec_weights* w, cons
         if ((rc = asr_gemm_f32(stream, 0, 0, TB, V, H, ws->p, H, w->out_w, V, logits, V, w->out_b, 0))) return rc;
         if ((rc = asr_zero_finished_rows(stream, logits, seq_len, T, B, V))) return rc;
     }
+    if (e_x && hipStreamWaitEvent(ms, e_x, 0) != hipSuccess) return ASR_ELAUNCH;      // whatever follows the call is ordered after x
     asr::prof_end(ASR_PROF_DECODER_FWD, ms);
     return ASR_OK;
 }
