@@ -353,6 +353,26 @@ extern "C" int asr_attn_decoder_bwd(void* stream, const asr_dec_weights* w, cons
     hipEvent_t e_lm_bptt = nullptr;
     hipEvent_t e_fork = next_event();
     if (hipEventRecord(e_fork, s) != hipSuccess || hipStreamWaitEvent(ss, e_fork, 0) != hipSuccess) return ASR_ELAUNCH;
+    // ---- what the chain needs besides dQC -- the composed context weight wc = W_inp[P:] . K_x (weights only) and three zeroed
+    // accumulators -- goes to the side stream, next to the two data-gradient products below instead of in a row behind them
+    // (ASR_DEC_SIDE_SMALL=0: on the caller's stream)
+    static const bool side_small = [] { const char* e = getenv("ASR_DEC_SIDE_SMALL"); return !(e && e[0] == '0'); }();
+    const bool chain_ok = bw->chain_ws && bw->wc && ws->y && ws->err &&
+                          asr_decoder_chain_supported(B, Te, D, A, H) && asr_decoder_chain_bwd_fits(Te, D, A, H);
+    hipEvent_t e_small = nullptr;
+    {
+        hipStream_t zs = side_small ? ss : s;
+        if (hipMemsetAsync(bw->dc_dec, 0, sizeof(float) * B * H, zs) != hipSuccess) return ASR_ELAUNCH;
+        if (hipMemsetAsync(bw->dhf, 0, sizeof(float) * (size_t)B * Te * A, zs) != hipSuccess) return ASR_ELAUNCH;
+        if (hipMemsetAsync(bw->dv_part, 0, sizeof(float) * B * A, zs) != hipSuccess) return ASR_ELAUNCH;
+        if (chain_ok && side_small &&
+            (rc = asr_gemm_f32(side, 0, 0, D, 4 * H, E, w->inp_w + (size_t)P * E, E, w->dec_kernel, 4 * H, bw->wc, 4 * H, nullptr, 0)))
+            return rc;
+        if (side_small) {
+            e_small = next_event();
+            if (hipEventRecord(e_small, ss) != hipSuccess) return ASR_ELAUNCH;
+        }
+    }
     // ---- hoisted data gradients: dP = dLogits.W_out^T ; dQC = dP.W_ap^T
     if ((rc = asr_gemm_f32(stream, 0, 1, TB, H, V, dlogits, V, w->out_w, V, bw->dP, H, nullptr, 0))) return rc;
     if ((rc = asr_gemm_f32(stream, 0, 1, TB, H + D, H, bw->dP, H, w->ap_w, H, bw->dQC, H + D, nullptr, 0))) return rc;
@@ -365,17 +385,15 @@ extern "C" int asr_attn_decoder_bwd(void* stream, const asr_dec_weights* w, cons
         float* gw0 = const_cast<float*>(g->out_w);                       // OutputProjection
         if ((rc = wg0(H, V, TB, ws->p, H, dlogits, V, gw0))) return rc;
     }
-    if (hipMemsetAsync(bw->dc_dec, 0, sizeof(float) * B * H, s) != hipSuccess) return ASR_ELAUNCH;
-    if (hipMemsetAsync(bw->dhf, 0, sizeof(float) * (size_t)B * Te * A, s) != hipSuccess) return ASR_ELAUNCH;
-    if (hipMemsetAsync(bw->dv_part, 0, sizeof(float) * B * A, s) != hipSuccess) return ASR_ELAUNCH;
+    if (e_small && hipStreamWaitEvent(s, e_small, 0) != hipSuccess) return ASR_ELAUNCH;
     const int ldXH = E + H, ldLC = P + D, ldEH = E + lmH;
     // ---- persistent chain (csrc/decoder_chain_bwd.hip): the whole reverse-time recursion in one launch
-    const bool use_chain = bw->chain_ws && bw->wc && ws->y && ws->err &&
-                           asr_decoder_chain_supported(B, Te, D, A, H) && asr_decoder_chain_bwd_fits(Te, D, A, H);
+    const bool use_chain = chain_ok;
     int dv_rows = B;
     if (use_chain) {
         // wc = W_inp[P:] . K_x : the context rows of the composed input weight (decoder.hip, forward chain)
-        if ((rc = asr_gemm_f32(stream, 0, 0, D, 4 * H, E, w->inp_w + (size_t)P * E, E, w->dec_kernel, 4 * H, bw->wc, 4 * H, nullptr, 0)))
+        if (!side_small &&
+            (rc = asr_gemm_f32(stream, 0, 0, D, 4 * H, E, w->inp_w + (size_t)P * E, E, w->dec_kernel, 4 * H, bw->wc, 4 * H, nullptr, 0)))
             return rc;
         if ((rc = asr_decoder_chain_bwd(stream, ws->dec_gates, ws->dec_c, ws->alpha, ws->y, ws->ctx, bw->dQC,
                                         w->dec_kernel + (size_t)E * 4 * H, bw->wc, w->attn_w, w->attn_v, ws->hf, enc, enc_len,
