@@ -13,6 +13,14 @@ from .devcache import dev_i32
 from .weights import dec_name
 
 
+def sampling_coins(seed, stream, step, n):
+    """The scheduled-sampling coins of ONE decoder call: n uniforms, one per output step for the whole batch
+    (attn_decoder.py:131-133 draws a single tf.random_uniform([]) per step).  A pure function of (seed, stream, step) and
+    prefix-stable in n, so data-parallel ranks whose shards end at different longest targets still see the SAME coin at
+    every step they share -- a per-process generator consumed t_out draws per call and drifted apart."""
+    return np.random.default_rng([int(seed) & 0xFFFFFFFF, int(stream) & 0xFFFFFFFF, int(step) & 0xFFFFFFFF]).random(int(n))
+
+
 class AttnDecoder(Decoder):
     @classmethod
     def class_params(cls):
@@ -30,7 +38,19 @@ class AttnDecoder(Decoder):
         if self.params.num_layers_dec > 1:          # MultiRNNCell stacks: host-composed per-step path
             from .multi_decoder import MultiLayerPath
             self.multi = MultiLayerPath(self)
-        self.coin_rng = np.random.default_rng(0)
+        # scheduled-sampling coin = f(coin_seed, task, coin_step): common to all data-parallel ranks by construction.
+        # Seq2SeqModel sets coin_step to its global step before every call; stand-alone use counts calls.
+        self.coin_seed = 0
+        self.coin_stream = sum(map(ord, self.scope or "")) % 9973
+        self.coin_step = 0
+        self.last_coin = None
+
+    def draw_coins(self, t_out):
+        """One uniform scalar per output step for the whole batch (attn_decoder.py:132), for THIS call."""
+        coin = sampling_coins(self.coin_seed, self.coin_stream, self.coin_step, t_out)
+        self.coin_step += 1
+        self.last_coin = coin
+        return coin
 
     def weight_tensors(self):
         """struct field -> tensor, by TF variable name (beam_search.py:56-98)."""
@@ -57,9 +77,7 @@ class AttnDecoder(Decoder):
         if p.lm_hidden_size != p.hidden_size_dec and dec_name(self.scope, "rnn/SimpleProjection/kernel") not in self.variables:
             raise ValueError("Could not find SimpleProjection weights for lm_hidden_size != hidden_size_dec")
         mode = self.feedback_mode()          # prepare_decoder_input's choice (decoder.py:100-113); the lookup itself is fused
-        coin = None
-        if mode == 2:   # one uniform scalar per step for the whole batch (attn_decoder.py:132)
-            coin = self.coin_rng.random(t_out)
+        coin = self.draw_coins(t_out) if mode == 2 else None
         keep_lm = p.out_prob_dec if self.isTraining else 1.0
         tok = decoder_inp if decoder_inp.dtype == torch.int32 else decoder_inp.to(torch.int32)
         enc = encoder_hidden_states.contiguous()

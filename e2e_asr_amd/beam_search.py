@@ -187,10 +187,13 @@ class BeamSearch(BaseParams):
         weight set: the weights are constants of this object (ASR_BEAM_TILED=0: the TF column order, as before round 3)."""
         if os.environ.get("ASR_BEAM_TILED", "1") == "0":
             return (None, None, None)
-        if getattr(self, "_tiled", None) is None:
+        src = (self.dec_params.lm_lstm_w, self.lm_params.lstm_w, self.dec_params.dec_lstm_w)
+        key = tuple((w.data_ptr(), w._version, tuple(w.shape)) for w in src)      # replaced or updated in place -> re-tile
+        if getattr(self, "_tiled", None) is None or getattr(self, "_tiled_key", None) != key:
+            self._tiled_key = key
             L = _lib.lib()
             out = []
-            for w in (self.dec_params.lm_lstm_w, self.lm_params.lstm_w, self.dec_params.dec_lstm_w):
+            for w in src:
                 w = w.contiguous()
                 t = torch.empty_like(w)
                 ops._check(L.asr_lstm_kernel_tile_order(ops._stream(), ops._p(w), w.shape[0], w.shape[1] // 4, ops._p(t)),

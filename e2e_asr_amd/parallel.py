@@ -85,7 +85,9 @@ class DataParallel(object):
             self.overlap = False
         model.dist = self
         # dropout masks and the sampler's noise are per replica (a TF replica draws its own); the scheduled-sampling COIN
-        # stays common to all ranks (attn_decoder.py:132 draws one scalar for the whole batch)
+        # stays common to all ranks (attn_decoder.py:132 draws one scalar for the whole batch): it is a pure
+        # function of (coin_seed, task, global step, output step) -- attn_decoder.sampling_coins -- so shards that end at
+        # different longest targets cannot drift apart (tests/test_parallel_gloo.py::test_sampling_coin_is_common_across_ranks)
         model.rank_seed = (self.rank * 0x9E3779B1) & 0x7FFFFFFF
 
     @staticmethod
@@ -120,6 +122,15 @@ class DataParallel(object):
             half = flat_grad[lo:hi].to(torch.bfloat16)
             return (self.comm.all_reduce(half, async_op=async_op), half, flat_grad[lo:hi])
         return (self.comm.all_reduce(flat_grad[lo:hi], async_op=async_op), None, None)
+
+    def begin_step(self):
+        """Called at the top of every backward pass: a backward that raised mid-step, or two backward passes before one
+        exchange, must not leave last step's bucket reports behind.  Collectives still pending are finished first (their
+        sums land in a gradient buffer the new backward pass zeroes anyway), never abandoned in flight."""
+        for w, _, _ in self._pending:
+            if w is not None:
+                w.wait()
+        self._pending, self._done, self._ready, self._reported = [], set(), [], set()
 
     def grad_ready(self, key, flat_grad):
         """Called by the model's backward when bucket `key` is final on the caller's + side streams: encoder layers

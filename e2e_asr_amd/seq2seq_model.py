@@ -151,6 +151,7 @@ class Seq2SeqModel(BaseParams):
             d = params.num_layers[task]
             dec = self.decoder[task]
             dec.rng_seed = ((self.global_step * 2654435761 + sum(map(ord, task)) % 9973) ^ self.rank_seed) & 0x7FFFFFFF
+            dec.coin_step = self.global_step      # NOT mixed with rank_seed: the coin is common to all replicas (attn_decoder.py:132)
             if not self.isTraining and self.decoder_inputs[task].shape[0] < params.max_output[task]:
                 pad = params.max_output[task] - self.decoder_inputs[task].shape[0]
                 self.decoder_inputs[task] = torch.cat(
@@ -178,6 +179,8 @@ class Seq2SeqModel(BaseParams):
         params = self.params
         v = self.variables
         v.ensure_grad()
+        if self.dist is not None:
+            self.dist.begin_step()
         v.grad.zero_()
         if getattr(self, "_gscale", None) is None:          # d total_loss / d task loss: constant for the model's life
             self._gscale = torch.full((1,), 1.0 / len(params.tasks) if params.avg else 1.0, device=self.device)

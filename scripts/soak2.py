@@ -63,7 +63,7 @@ for it in range(n):
     lo = []
     for c in ("1", "0"):
         os.environ["ASR_DEC_CHAIN"] = c
-        tr.decoder["char"].coin_rng = np.random.default_rng(it)
+        tr.decoder["char"].coin_seed = it
         tr.forward(b); tr.backward()
         ops.check_device_flag(dev)
         lo.append((float(tr.total_loss.item()), tr.variables.grad.clone()))

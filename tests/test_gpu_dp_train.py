@@ -94,6 +94,51 @@ def test_two_rank_step_equals_one_global_batch_step(overlap):
     assert ranks[0].rank_seed != ranks[1].rank_seed              # replicas draw their own dropout masks / sampler noise
 
 
+def test_two_rank_sampling_coin_is_common_with_ragged_shards():
+    """attn_decoder.py:131-133: ONE uniform per output step for the whole batch; SURVEY 8e: the same coin on all ranks.
+    Two ranks (loop-back comm, HIP path) with samp_prob = 0.3 on shards whose longest targets differ, three optimizer
+    steps: the coin vectors agree on every output step both ranks run, change from step to step, and tokens really are fed
+    back.  (A per-process generator consumed t_out draws per step and drifted apart from step 2 on.)"""
+    from e2e_asr_amd import ops
+    from e2e_asr_amd.parallel import DataParallel, shard_batch
+    from e2e_asr_amd.seq2seq_model import Seq2SeqModel
+    from e2e_asr_amd.weights import synthetic_batch
+    p = _params(samp=0.3)
+    store = []
+    ranks = [Seq2SeqModel(None, True, p, device=DEV, feat_length=20, seed=4) for _ in range(2)]
+    dps = [DataParallel(m, overlap=False, comm=LoopbackComm(r, store)) for r, m in enumerate(ranks)]
+    seen, fed_any = [], 0
+    for step in range(3):
+        gb = synthetic_batch(B=8, T=40, F=20, t_dec=12, vocab=40, variable_len=True, seed=50 + step)
+        ln = np.asarray(gb["char_len"])
+        ln[:4] = np.minimum(ln[:4], 5 + step)          # rank 0's shard ends earlier than rank 1's (whose last row has 11)
+        for b in range(4):
+            gb["char"][b, ln[b]:] = 0; gb["char"][b, ln[b]] = 2
+        del store[:]
+        dps[1].comm.mode, dps[1].comm.calls = "record", 0
+        dps[0].comm.mode, dps[0].comm.calls = "replay", 0
+        coins, t_outs = [None, None], [0, 0]
+        for r in (1, 0):
+            sb = shard_batch(gb, r, 2)
+            ranks[r].forward(sb)
+            dec = ranks[r].decoder["char"]
+            coins[r], t_outs[r] = dec.last_coin.copy(), dec.saved["t_out"]
+            tok = dec.saved["ws"]["tok"].cpu().numpy()
+            teacher = np.asarray(sb["char"]).T[:tok.shape[0]]
+            fed_any += int((tok[1:t_outs[r]] != teacher[1:t_outs[r]]).sum())
+            ranks[r].backward()
+            ranks[r].apply_gradients()
+        ops.check_device_flag(torch.device(DEV))
+        assert t_outs[0] != t_outs[1] and len(coins[0]) == t_outs[0] and len(coins[1]) == t_outs[1]
+        n = min(t_outs)
+        np.testing.assert_array_equal(coins[0][:n], coins[1][:n])
+        np.testing.assert_array_equal(coins[0][:n] < 0.7, coins[1][:n] < 0.7)
+        seen.append(coins[1][:5].copy())
+    assert not np.array_equal(seen[0], seen[1]) and not np.array_equal(seen[1], seen[2])
+    assert fed_any > 0                                  # scheduled sampling really fed drawn tokens
+    assert ranks[0].global_step == ranks[1].global_step == 3
+
+
 def test_rccl_world1_steps_with_and_without_overlap():
     """RCCL itself next to the persistent kernels, as far as one GPU allows: a child process initialises the "nccl" backend at
     world size 1 and runs config-2-width train steps plain, with the blocking exchange, with the tail overlap and with the

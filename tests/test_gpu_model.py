@@ -517,7 +517,7 @@ def test_decoder_chain_long_encoder_one_row_groups(monkeypatch, nb, T, fwd_r2):
     for chain in ("1", "0"):
         monkeypatch.setenv("ASR_DEC_CHAIN", chain)
         m = _chain_model(samp=0.3, seed=11)
-        m.decoder["char"].coin_rng = np.random.default_rng(5)
+        m.decoder["char"].coin_seed = 5
         m.forward(b)
         ws = m.decoder["char"].saved["ws"]
         assert (ws.get("chain_ws") is not None) == (chain == "1")
@@ -551,7 +551,7 @@ def test_decoder_chain_equals_launch_path_under_scheduled_sampling(monkeypatch, 
     for chain in ("1", "0"):
         monkeypatch.setenv("ASR_DEC_CHAIN", chain)
         m = _chain_model(samp=0.4, seed=7)
-        m.decoder["char"].coin_rng = np.random.default_rng(5)
+        m.decoder["char"].coin_seed = 5
         m.forward(b)
         ws = m.decoder["char"].saved["ws"]
         assert (ws.get("chain_ws") is not None) == (chain == "1")
@@ -570,7 +570,7 @@ def test_decoder_chain_equals_launch_path_under_scheduled_sampling(monkeypatch, 
         monkeypatch.setenv("ASR_DEC_CHAIN", "1")
         for rep in range(4):
             m = _chain_model(samp=0.4, seed=7)
-            m.decoder["char"].coin_rng = np.random.default_rng(5)
+            m.decoder["char"].coin_seed = 5
             m.forward(b)
             m.backward()
             for n, g0 in outs[1][3].items():
@@ -598,7 +598,7 @@ def test_persistent_lm_chain_equals_per_step_lm_cells(monkeypatch, variant):
     for lm in ("1", "0"):
         monkeypatch.setenv("ASR_LM_CHAIN", lm)
         m = _model(enc_update=dict(hidden_size=64), num_layers={"char": 2}, seed=11, dec_update=dict(dec))
-        m.decoder["char"].coin_rng = np.random.default_rng(6)
+        m.decoder["char"].coin_seed = 6
         m.global_step = 2
         m.forward(b)
         ws = m.decoder["char"].saved["ws"]
@@ -636,7 +636,7 @@ def test_config2_full_batch_persistent_paths_equal_launch_paths(monkeypatch):
         monkeypatch.setenv("ASR_DEC_CHAIN", chain)
         monkeypatch.setenv("ASR_LM_CHAIN", chain)
         m = _model(**kw)
-        m.decoder["char"].coin_rng = np.random.default_rng(8)
+        m.decoder["char"].coin_seed = 8
         m.global_step = 1
         m.forward(b)
         ws = m.decoder["char"].saved["ws"]
