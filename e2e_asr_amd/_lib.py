@@ -51,6 +51,12 @@ class BeamBook(C.Structure):
     _fields_ = [(n, vp) for n in ("ints", "cum", "state", "bp", "fin", "fin_score", "cand", "cand_idx")]
 
 
+class LstmP3(C.Structure):
+    """asr_lstm_p3 (include/e2e_asr_hip.h): plane operands of one (Bi)LSTM layer."""
+    _fields_ = [("np", C.c_int), ("x_p3", vp), ("x_cols", C.c_int), ("kxT_p3", vp), ("out_p3", vp), ("hprev_p3", vp),
+                ("dg_p3", vp), ("kxu_p3", vp), ("colmap", vp)]
+
+
 class DecGrads(C.Structure):
     _fields_ = [(n, vp) for n in (
         "embedding", "attn_enc_w", "attn_v", "attn_w", "attn_b", "lm_kernel", "lm_bias",
@@ -60,6 +66,19 @@ class DecGrads(C.Structure):
 
 # name -> (restype, argtypes); every symbol include/e2e_asr_hip.h declares
 SIGNATURES = {
+    "asr_p3_bytes": (C.c_size_t, [C.c_int] * 3),
+    "asr_p3_split_ex": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "asr_lstm_p3_supported": (C.c_int, [C.c_int] * 5),
+    "asr_lstm_layer_fwd_p3": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, vp, vp, vp,
+                                        vp, C.c_int, vp, vp, vp, vp, C.c_size_t, vp, C.c_float, C.c_uint, vp, vp, C.POINTER(LstmP3)]),
+    "asr_lstm_layer_bwd_p3": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, vp,
+                                        vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp, C.c_float, C.c_uint, vp,
+                                        C.POINTER(LstmP3)]),
+    "asr_p3_split_f32": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int]),
+    "asr_gemm_p3_rr": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int,
+                                 vp, C.c_int, C.c_int, C.c_int, vp]),
+    "asr_gemm_p3_kk": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int,
+                                 vp, C.c_int, vp, C.c_int, C.c_int]),
     "asr_gemm_f32": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp,
                                C.c_int, vp, C.c_int, vp, C.c_int]),
     "asr_gemm_f32_batched": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_longlong, vp,

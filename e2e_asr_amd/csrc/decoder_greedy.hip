@@ -224,6 +224,7 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
     if (STAMP) tlast = __builtin_amdgcn_s_memtime();
     bool lm_ready = false;      // uniform: this step's LM output is already in LDS (gathered during the previous step)
     const int tid_outer = tid;
+    int nfb = 0;                // feedback steps so far (uniform): numbers the exchange of p, which only those steps make
     for (int i = 0; i < a.T; ++i) {
         sph = 0;
         // Everything derived from the thread index is derived AGAIN in every step, from a copy the compiler cannot see through.
@@ -253,7 +254,15 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
         // slots and use the first half of each
         uint32_t* tLM = reinterpret_cast<uint32_t*>(gLM); uint32_t* tQH = reinterpret_cast<uint32_t*>(gQH);
         uint32_t* tY = reinterpret_cast<uint32_t*>(gY); uint32_t* tE = reinterpret_cast<uint32_t*>(gE);
-        uint32_t* tC = reinterpret_cast<uint32_t*>(gC); uint32_t* tP = reinterpret_cast<uint32_t*>(gP);
+        uint32_t* tC = reinterpret_cast<uint32_t*>(gC);
+        // The 1-bit tag of a tagged float tells a slot's write of this step from the one two steps before ONLY if the slot is
+        // written every second step.  p is exchanged at the feedback steps alone (training graph: ~10 % of the steps), so its
+        // parity buffer and tag bit follow the COUNT of feedback steps, not the step index: with the step index a first feedback
+        // step i with ((i >> 1) & 1) == 1 expected the bit the host's memset left (0), and a poller that came before the
+        // publisher took zeros for p -- a wrong draw now and then (found in round 4 by a coin pattern with feedback at steps 2, 3).
+        (void)gP;
+        uint32_t* tP = reinterpret_cast<uint32_t*>(gbase + (size_t)(nfb & 1) * NPAR + (NLM + NQH + NY + NE + NC));
+        const uint32_t tbp = tag_bit(nfb);
         // ---- (1) LM cell of my units: gates = EK[tok] + h_lm_{step-1} . K_h (the matvec ran one step earlier), published into the
         // LM region of `step`'s parity with `step`'s tag bit.  The training graph calls it for step i+1 already DURING step i when
         // the next token is the teacher's (below): the LM recurrence depends on tokens only, not on the attention chain.
@@ -655,14 +664,14 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
         if (wave0 && cell) {
             const float pv = pbias + (psum[(0 * PS + cu) * R + cr] + psum[(1 * PS + cu) * R + cr]) +
                              (psum[(2 * PS + cu) * R + cr] + psum[(3 * PS + cu) * R + cr]);
-            if (cb_ok) tagged_publish(tP + (size_t)cr * H + mem * PS + cu, tb, pv, fast);
+            if (cb_ok) tagged_publish(tP + (size_t)cr * H + mem * PS + cu, tbp, pv, fast);
         }
         // ---- (7) gather p; logits of my vocabulary slice (+ the h-part of the NEXT step's LM gates)
         if (poller) {
             for (int p = tid - 64; p < NP / 4; p += NPOLL) {
                 const int idx = 4 * p, r = idx / H;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (rok(r)) tagged_poll4(tP + idx, tb, v, a.err);
+                if (rok(r)) tagged_poll4(tP + idx, tbp, v, a.err);
                 *reinterpret_cast<float4*>(v_p + idx) = v;
             }
         }
@@ -763,6 +772,7 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
             tokr = min(max(tokr, 0), V - 1);
         }
         GREEDY_STAMP()
+        ++nfb;
         // (LDS written by this step's last phases is rewritten only after later barriers of the next step)
     }
     if (STAMP && a.dbg && blockIdx.x == 0 && threadIdx.x == 0) { for (int j = 0; j < 24; ++j) a.dbg[48 + j] = stamp[j]; }

@@ -27,6 +27,7 @@
 // lanes of a DPP row hold the 16 K-chunks of one unit, so the K reduction is 4 DPP
 // butterflies with no LDS, and lanes kq < R of each row run the cell for batch row kq.
 #include "common.h"
+#include "p3.h"
 
 namespace asr {
 
@@ -54,6 +55,10 @@ struct LstmRecArgs {
     // kx[dir] = the input rows [in_dim][4H] of the TF kernel, bias[dir] [4H]
     const float* __restrict__ x; int ldx;
     const float* kx[2]; const float* bias[2];
+    // lstm_rec_fwd4_kernel: outputs ALSO as bf16 planes (csrc/p3.h) for the GEMMs of csrc/gemm_p3.hip, or nullptr:
+    // out_p3 = P3 image of out [B*Tout][ND*H] (the next layer's input), hprev_p3 = P3 image of hprev [B*T][ND*H] (then the
+    // fp32 hprev is not written)
+    char* out_p3; char* hprev_p3; int p3_np;
 };
 
 __device__ __forceinline__ bool poll_granule(const u64* g, uint32_t epoch, float& val, int* err) {
@@ -779,6 +784,9 @@ __global__ __launch_bounds__(512) void lstm_rec_fwd4_kernel(LstmRecArgs a) {
                     __builtin_nontemporal_store(f32x4{gi, gj, gf, go}, rp);
                     __builtin_nontemporal_store(f32x4{c, c_old, 0.f, 0.f}, rp + 1);
                 }
+                // the same values as bf16 planes for the GEMMs that consume them (no split inside their k-loops)
+                if (a.out_p3) p3_store1(a.out_p3, p3_elem_off((size_t)cb * a.osb + (size_t)t * a.ost, dir * H + cj, a.ldo >> 3, a.p3_np), o, a.p3_np, false);
+                if (a.hprev_p3) p3_store1(a.hprev_p3, p3_elem_off((size_t)cb * a.sb + (size_t)t * a.st, dir * H + cj, (a.ND * H) >> 3, a.p3_np), h_old, a.p3_np, true);
             }
             if (more) {
                 prefetch(s + 1);
@@ -798,6 +806,20 @@ __global__ __launch_bounds__(512) void lstm_rec_fwd4_kernel(LstmRecArgs a) {
             if (a.hprev && tt < a.T)
                 a.hprev[(((size_t)cb * a.sb + (size_t)tt * a.st) * a.ND + dir) * H + mem * HS + uu] = 0.f;
         }
+        // ... and in the plane images: the workgroup's 64 columns of a row are HS / 8 chunks = HS / 8 * np contiguous pieces
+        const int ppr = HS / 8 * a.p3_np;
+        if (a.out_p3)
+            for (int idx = tid; idx < nz * ppr; idx += NT) {
+                const int tt = S + idx / ppr;
+                char* rowp = a.out_p3 + p3_elem_off((size_t)cb * a.osb + (size_t)tt * a.ost, dir * H + mem * HS, a.ldo >> 3, a.p3_np);
+                reinterpret_cast<uint4*>(rowp)[idx % ppr] = make_uint4(0u, 0u, 0u, 0u);
+            }
+        if (a.hprev_p3)
+            for (int idx = tid; idx < (a.T - S) * ppr; idx += NT) {
+                const int tt = S + idx / ppr;
+                char* rowp = a.hprev_p3 + p3_elem_off((size_t)cb * a.sb + (size_t)tt * a.st, dir * H + mem * HS, (a.ND * H) >> 3, a.p3_np);
+                reinterpret_cast<uint4*>(rowp)[idx % ppr] = make_uint4(0u, 0u, 0u, 0u);
+            }
     }
 }
 
@@ -877,6 +899,26 @@ extern "C" size_t asr_lstm_ws_bytes(int B, int H, int ndir) {
     return lstm_hx_bytes(B, H, ndir) + (size_t)ndir * (size_t)((B + 7) / 8 * 8) * 16 * sizeof(u64);   // + XCC slots
 }
 
+// bf16-plane operands of one layer (include/e2e_asr_hip.h: asr_lstm_p3)
+struct asr_lstm_p3 {
+    int np; const void* x_p3; int x_cols; const void* kxT_p3; void* out_p3; void* hprev_p3;
+    void* dg_p3; const void* kxu_p3; const int* colmap;
+};
+extern "C" int asr_gemm_p3_kk(void* stream, int M, int N, int K, const void* A, int lda8, const void* B, int ldb8, int np,
+                              float* C, int ldc, const float* bias, int accumulate, int splits);
+bool asr_lstm_g4_selected(int B, int H, int ndir);
+// 1 when asr_lstm_layer_fwd_p3 / _bwd_p3 take plane operands for this shape (the groups-of-four recurrent kernels write planes)
+extern "C" int asr_lstm_p3_supported(int B, int T, int in_dim, int H, int ndir) {
+    return H == 256 && ndir == 2 && (B * T) % 128 == 0 && asr_lstm_g4_selected(B, H, ndir) ? 1 : 0;
+}
+extern "C" int asr_lstm_layer_fwd_p3(void* stream, const float* x, int B, int T, int in_dim, int ldx,
+                                  const int* len, int H, int ndir,
+                                  const float* kernel_fw, const float* bias_fw,
+                                  const float* kernel_bw, const float* bias_bw,
+                                  float* out, int Tout, float* gates, float* act, float* hprev,
+                                  void* hx_ws, size_t hx_bytes, int* err_flag,
+                                  float keep_prob, unsigned seed, const float* kx_cat, const float* bias_cat,
+                                  const asr_lstm_p3* p3);
 extern "C" int asr_lstm_layer_fwd(void* stream, const float* x, int B, int T, int in_dim, int ldx,
                                   const int* len, int H, int ndir,
                                   const float* kernel_fw, const float* bias_fw,
@@ -884,6 +926,25 @@ extern "C" int asr_lstm_layer_fwd(void* stream, const float* x, int B, int T, in
                                   float* out, int Tout, float* gates, float* act, float* hprev,
                                   void* hx_ws, size_t hx_bytes, int* err_flag,
                                   float keep_prob, unsigned seed, const float* kx_cat, const float* bias_cat) {
+    return asr_lstm_layer_fwd_p3(stream, x, B, T, in_dim, ldx, len, H, ndir, kernel_fw, bias_fw, kernel_bw, bias_bw, out, Tout, gates,
+                                 act, hprev, hx_ws, hx_bytes, err_flag, keep_prob, seed, kx_cat, bias_cat, nullptr);
+}
+bool asr_lstm_g4_selected(int B, int H, int ndir) {
+    const char* e = getenv("ASR_LSTM_G4");
+    const char* v2e = getenv("ASR_LSTM_V2");
+    const char* ce = getenv("ASR_LSTM_G4_CHUNKS");
+    const int rpl = asr_lstm_max_wgs() / (4 * ndir);
+    return !(e && e[0] == '0') && !(v2e && v2e[0] == '0') && !(asr::g_lstm_dbg && getenv("ASR_LSTM_STAMP")) &&
+           !(asr::asr_get_lstm_mfma() != 0 && asr::asr_get_gemm_precision() == 1) && H == 256 && rpl >= 1 && (B + rpl - 1) / rpl <= (ce ? atoi(ce) : 4);
+}
+extern "C" int asr_lstm_layer_fwd_p3(void* stream, const float* x, int B, int T, int in_dim, int ldx,
+                                  const int* len, int H, int ndir,
+                                  const float* kernel_fw, const float* bias_fw,
+                                  const float* kernel_bw, const float* bias_bw,
+                                  float* out, int Tout, float* gates, float* act, float* hprev,
+                                  void* hx_ws, size_t hx_bytes, int* err_flag,
+                                  float keep_prob, unsigned seed, const float* kx_cat, const float* bias_cat,
+                                  const asr_lstm_p3* p3) {
     using namespace asr;
     if (!x || !len || !kernel_fw || !bias_fw || !out || !gates || !hx_ws || !err_flag) return ASR_EINVAL;
     if (ndir != 1 && ndir != 2) return ASR_EINVAL;
@@ -897,17 +958,20 @@ extern "C" int asr_lstm_layer_fwd(void* stream, const float* x, int B, int T, in
     // inside that kernel: no projection GEMM, no gates written or read (ASR_LSTM_XIN=0: the GEMM, as for every other width)
     bool g4 = false, xin = false;
     {
-        const char* e = getenv("ASR_LSTM_G4");
-        const char* v2e = getenv("ASR_LSTM_V2");
-        const char* ce = getenv("ASR_LSTM_G4_CHUNKS");
         const char* xe = getenv("ASR_LSTM_XIN");
-        const int rpl = asr_lstm_max_wgs() / (4 * ndir);
-        g4 = !(e && e[0] == '0') && !(v2e && v2e[0] == '0') && !(g_lstm_dbg && getenv("ASR_LSTM_STAMP")) &&
-             !(asr_get_lstm_mfma() != 0 && asr_get_gemm_precision() == 1) && H == 256 && rpl >= 1 && (B + rpl - 1) / rpl <= (ce ? atoi(ce) : 4);
+        g4 = asr_lstm_g4_selected(B, H, ndir);
         xin = g4 && in_dim == 80 && !(xe && xe[0] == '0');
     }
+    if (p3 && (p3->out_p3 || p3->hprev_p3) && !g4) return ASR_EUNSUPPORTED;       // only the groups-of-four kernel writes planes
+    if (p3 && (p3->np < 1 || p3->np > 3)) return ASR_EINVAL;
     // input projection for all timesteps: gates[b,t,dir,:] = x[b,t,:] . K_x + bias
     if (xin) {
+    } else if (p3 && p3->x_p3 && p3->kxT_p3 && bias_cat && (B * T) % 128 == 0 && (ndir * H4) % 256 == 0 && in_dim % 16 == 0 &&
+               p3->x_cols >= in_dim && p3->x_cols % 8 == 0) {
+        // both operands arrive as bf16 planes (x: written by the layer below; K_x^T: split once per step): csrc/gemm_p3.hip
+        int rc = asr_gemm_p3_kk(stream, B * T, ndir * H4, in_dim, p3->x_p3, p3->x_cols / 8, p3->kxT_p3, in_dim / 8, p3->np,
+                                gates, ndir * H4, bias_cat, 0, 1);
+        if (rc) return rc;
     } else if (ndir == 2 && kx_cat && bias_cat) {
         // both directions as ONE product with N = 8H: gates rows are [fw 4H | bw 4H] and the caller supplies the input rows of
         // the two kernels side by side ([in, 8H]) -- twice the tiles per launch (less tile quantisation: 1 600 instead of
@@ -931,6 +995,10 @@ extern "C" int asr_lstm_layer_fwd(void* stream, const float* x, int B, int T, in
     a.sb = T; a.st = 1; a.osb = Tout; a.ost = 1; a.ldo = ndir * H; a.dsb = Tout; a.dst = 1; a.toff = 0;
     a.h0 = a.c0 = nullptr; a.h_last = a.c_last = nullptr; a.ep0 = 0;
     a.x = nullptr; a.ldx = 0; a.kx[0] = a.kx[1] = nullptr; a.bias[0] = a.bias[1] = nullptr;
+    a.out_p3 = p3 ? static_cast<char*>(p3->out_p3) : nullptr;
+    a.hprev_p3 = p3 ? static_cast<char*>(p3->hprev_p3) : nullptr;
+    a.p3_np = p3 ? p3->np : 0;
+    if (a.hprev_p3) a.hprev = nullptr;          // (the fp32 copy has no reader then)
     if (g4) {   // one row per group; larger batches as consecutive launches over ranges of 32 rows (measured against the first-version
                 // kernels with four / eight rows per group: B = 64 2.25 vs 2.69 us per step of a layer, B = 128 4.85 vs 4.97)
         const int rpl = asr_lstm_max_wgs() / (4 * ndir);
@@ -944,7 +1012,9 @@ extern "C" int asr_lstm_layer_fwd(void* stream, const float* x, int B, int T, in
             c.len = len + b0;
             c.out = out + (size_t)b0 * Tout * ndir * H;
             c.act = act ? act + (size_t)b0 * T * ndir * H * 8 : nullptr;
-            c.hprev = hprev ? hprev + (size_t)b0 * T * ndir * H : nullptr;
+            c.hprev = a.hprev ? a.hprev + (size_t)b0 * T * ndir * H : nullptr;
+            if (a.out_p3) c.out_p3 = a.out_p3 + (size_t)b0 * Tout * (ndir * H / 8) * 16 * a.p3_np;
+            if (a.hprev_p3) c.hprev_p3 = a.hprev_p3 + (size_t)b0 * T * (ndir * H / 8) * 16 * a.p3_np;
             c.boff = b0;
             const int groups = ndir * c.B;
             const int padded = ((groups + 7) & ~7) * 4;
@@ -1015,6 +1085,7 @@ int asr_lstm_rec_fwd_tm(hipStream_t s, const float* gates, const float* kh, cons
     a.sb = 1; a.st = B; a.osb = 1; a.ost = B; a.ldo = ldo; a.dsb = 1; a.dst = B; a.toff = toff;
     a.h0 = h0; a.c0 = c0; a.h_last = h_last; a.c_last = c_last; a.ep0 = toff;
     a.x = nullptr; a.ldx = 0; a.kx[0] = a.kx[1] = nullptr; a.bias[0] = a.bias[1] = nullptr;
+    a.out_p3 = a.hprev_p3 = nullptr; a.p3_np = 0;
     const int R = asr_lstm_pick_rows(B, 1, H / 32);
     switch (H) {
         case 64: return launch_rec_h<64>(s, a, R);

@@ -21,6 +21,7 @@
 // columns = 2 units x 4 gates) and each lane KG = H/32 output rows k, so the reduction over
 // columns is again 4 DPP butterflies.
 #include "common.h"
+#include "p3.h"
 #include "granule.h"
 #include <cstdlib>
 namespace asr { extern unsigned long long* g_lstm_dbg; }
@@ -43,6 +44,10 @@ struct LstmBwdArgs {
     int sb, st, osb, ost, ldo, dsb, dst;
     unsigned long long* dbg;   // STAMP build only
     float* db_part;            // [B][ND][4H] per-utterance sums of dG over time (bias gradient partials) or nullptr
+    // lstm_rec_bwd4_kernel: dG ALSO (dg_f32 = 0: ONLY) as bf16 planes for the GEMMs of csrc/gemm_p3.hip, or nullptr: the P3 image
+    // of dG [B*T][ND*4H] with the columns of a direction UNIT-major (column dir*4H + 4*unit + gate: a lane's four gates are 8
+    // contiguous bytes of a plane; the consumers permute their weights / output columns instead)
+    char* dg_p3; int p3_np; int dg_f32;
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -972,8 +977,13 @@ __global__ __launch_bounds__(512) void lstm_rec_bwd4_kernel(LstmBwdArgs a) {
                 }
             }
             {       // bookkeeping, off the critical path
-                float* gp = a.gates + (((size_t)cb * a.sb + (size_t)t * a.st) * a.ND + dir) * H4 + cj;
-                gp[0] = dg.x; gp[H] = dg.y; gp[2 * H] = dg.z; gp[3 * H] = dg.w;
+                if (a.dg_f32) {
+                    float* gp = a.gates + (((size_t)cb * a.sb + (size_t)t * a.st) * a.ND + dir) * H4 + cj;
+                    gp[0] = dg.x; gp[H] = dg.y; gp[2 * H] = dg.z; gp[3 * H] = dg.w;
+                }
+                if (a.dg_p3)
+                    p3_store4(a.dg_p3, p3_elem_off((size_t)cb * a.sb + (size_t)t * a.st, dir * H4 + 4 * cj, (a.ND * H4) >> 3, a.p3_np),
+                              dg.x, dg.y, dg.z, dg.w, a.p3_np, true);
             }
             if (more) {
                 // first half of the own slice for the next step: the truncated values the peers will read
@@ -994,9 +1004,18 @@ __global__ __launch_bounds__(512) void lstm_rec_bwd4_kernel(LstmBwdArgs a) {
     }
     {   // dG = 0 past the row's length (the weight/input GEMMs read every row)
         const int nz = a.T - S;
+        if (a.dg_f32)
         for (int idx = tid; idx < nz * 4 * HS; idx += NT) {
             const int tt = S + idx / (4 * HS), q = idx % (4 * HS);
             a.gates[(((size_t)cb * a.sb + (size_t)tt * a.st) * a.ND + dir) * H4 + (q / HS) * H + j0 + (q % HS)] = 0.f;
+        }
+        if (a.dg_p3) {       // the workgroup's 4 * 64 unit-major columns of a row: HS / 2 chunks = HS / 2 * np contiguous pieces
+            const int ppr = HS / 2 * a.p3_np;
+            for (int idx = tid; idx < nz * ppr; idx += NT) {
+                const int tt = S + idx / ppr;
+                char* rowp = a.dg_p3 + p3_elem_off((size_t)cb * a.sb + (size_t)tt * a.st, dir * H4 + 4 * j0, (a.ND * H4) >> 3, a.p3_np);
+                reinterpret_cast<uint4*>(rowp)[idx % ppr] = make_uint4(0u, 0u, 0u, 0u);
+            }
         }
     }
 }
@@ -1064,6 +1083,21 @@ extern "C" size_t asr_lstm_bwd_ws_bytes(int B, int H, int ndir) {
 // forward's input-projection buffer) is overwritten with dG.  dx [B,T,in] (may be NULL for the first layer) receives the input
 // gradient; dkernel_*/dbias_* are ACCUMULATED into (TF layout [in+H,4H] / [4H]).
 int asr_colsum_pair_f32(hipStream_t s, const float* x, int ldx, int M, int N, float* out0, float* out1);
+struct asr_lstm_p3 {            // include/e2e_asr_hip.h
+    int np; const void* x_p3; int x_cols; const void* kxT_p3; void* out_p3; void* hprev_p3;
+    void* dg_p3; const void* kxu_p3; const int* colmap;
+};
+extern "C" int asr_gemm_p3_kk(void* stream, int M, int N, int K, const void* A, int lda8, const void* B, int ldb8, int np,
+                              float* C, int ldc, const float* bias, int accumulate, int splits);
+bool asr_lstm_g4_selected(int B, int H, int ndir);
+extern "C" int asr_lstm_layer_bwd_p3(void* stream, const float* x, int B, int T, int in_dim, int ldx,
+                                  const int* len, int H, int ndir,
+                                  const float* kernel_fw, const float* kernel_bw,
+                                  const float* dout, int Tout, float* gates, const float* act,
+                                  const float* hprev, float* dx,
+                                  float* dkernel_fw, float* dbias_fw, float* dkernel_bw, float* dbias_bw,
+                                  void* hx_ws, size_t hx_bytes, int* err_flag, float keep_prob, unsigned seed,
+                                  const float* kx_cat, const asr_lstm_p3* p3);
 extern "C" int asr_lstm_layer_bwd(void* stream, const float* x, int B, int T, int in_dim, int ldx,
                                   const int* len, int H, int ndir,
                                   const float* kernel_fw, const float* kernel_bw,
@@ -1072,8 +1106,27 @@ extern "C" int asr_lstm_layer_bwd(void* stream, const float* x, int B, int T, in
                                   float* dkernel_fw, float* dbias_fw, float* dkernel_bw, float* dbias_bw,
                                   void* hx_ws, size_t hx_bytes, int* err_flag, float keep_prob, unsigned seed,
                                   const float* kx_cat) {
+    return asr_lstm_layer_bwd_p3(stream, x, B, T, in_dim, ldx, len, H, ndir, kernel_fw, kernel_bw, dout, Tout, gates, act, hprev, dx,
+                                 dkernel_fw, dbias_fw, dkernel_bw, dbias_bw, hx_ws, hx_bytes, err_flag, keep_prob, seed, kx_cat, nullptr);
+}
+// With p3 (asr_lstm_p3_supported shapes): the BPTT writes dG as bf16 planes (p3->dg_p3, unit-major columns) and the products
+// that consume it run on plane operands (csrc/gemm_p3.hip): dX = dG . K_x^T with p3->kxu_p3, and every weight gradient of the
+// layer in ONE launch from p3->x_p3 / p3->hprev_p3 (the forward wrote them).  `gates` / `hprev` (fp32) are then not touched.
+extern "C" int asr_lstm_layer_bwd_p3(void* stream, const float* x, int B, int T, int in_dim, int ldx,
+                                  const int* len, int H, int ndir,
+                                  const float* kernel_fw, const float* kernel_bw,
+                                  const float* dout, int Tout, float* gates, const float* act,
+                                  const float* hprev, float* dx,
+                                  float* dkernel_fw, float* dbias_fw, float* dkernel_bw, float* dbias_bw,
+                                  void* hx_ws, size_t hx_bytes, int* err_flag, float keep_prob, unsigned seed,
+                                  const float* kx_cat, const asr_lstm_p3* p3) {
     using namespace asr;
-    if (!x || !len || !kernel_fw || !dout || !gates || !act || !hprev || !dkernel_fw || !dbias_fw || !hx_ws || !err_flag)
+    const bool p3_dg = p3 && p3->dg_p3;
+    const bool p3_dx = p3_dg && (!dx || (p3->kxu_p3 && in_dim % 256 == 0 && (B * T) % 128 == 0));
+    const bool p3_wg = p3_dg && p3->x_p3 && p3->hprev_p3 && p3->colmap && p3->x_cols % 128 == 0 && p3->x_cols >= in_dim && ndir == 2 &&
+                       dkernel_bw && (B * T) % 16 == 0;
+    if (p3_dg && !(p3_dx && p3_wg)) return ASR_EUNSUPPORTED;        // (all consumers of dG or none: the fp32 dG is not written)
+    if (!x || !len || !kernel_fw || !dout || !gates || !act || (!hprev && !p3_wg) || !dkernel_fw || !dbias_fw || !hx_ws || !err_flag)
         return ASR_EINVAL;
     if (ndir != 1 && ndir != 2) return ASR_EINVAL;
     if (ndir == 2 && (!kernel_bw || !dkernel_bw || !dbias_bw)) return ASR_EINVAL;
@@ -1090,6 +1143,7 @@ extern "C" int asr_lstm_layer_bwd(void* stream, const float* x, int B, int T, in
     a.B = B; a.T = T; a.Tout = Tout; a.ND = ndir; a.boff = 0; a.keep = keep_prob; a.seed = seed;
     a.sb = T; a.st = 1; a.osb = Tout; a.ost = 1; a.ldo = ndir * H; a.dsb = Tout; a.dst = 1;
     a.dbg = getenv("ASR_LSTM_STAMP") ? asr::g_lstm_dbg : nullptr;
+    a.dg_p3 = p3_dg ? static_cast<char*>(p3->dg_p3) : nullptr; a.p3_np = p3_dg ? p3->np : 0; a.dg_f32 = p3_dg ? 0 : 1;
     int R = asr_lstm_pick_rows(B, ndir, G);
     // H = 512: the reduce-scatter kernel for four or eight rows per group spills (256 registers + 200-768 bytes of scratch: 9.6 us
     // per step at B = 32); two rows per group through the all-gather kernel in twice the launches are 4.0 us per step of a layer
@@ -1114,6 +1168,7 @@ extern "C" int asr_lstm_layer_bwd(void* stream, const float* x, int B, int T, in
         g4 = !(e && e[0] == '0') && !(v2e && v2e[0] == '0') && ag_env && !a.dbg && !(asr_get_lstm_mfma() != 0 && asr_get_gemm_precision() == 1) &&
              H == 256 && rpl4 >= 1 && (B + rpl4 - 1) / rpl4 <= max_chunks;
     }
+    if (p3_dg && !g4) return ASR_EUNSUPPORTED;            // only the groups-of-four BPTT writes planes
     if (g4) {
         const int rpl4 = asr_lstm_max_wgs() / (4 * ndir);
         if (!a.db_part) a.db_part = reinterpret_cast<float*>(static_cast<char*>(hx_ws) + lstm_bwd_sync_bytes(B, H, ndir));
@@ -1124,6 +1179,7 @@ extern "C" int asr_lstm_layer_bwd(void* stream, const float* x, int B, int T, in
             c.B = (B - b0 < rpl4) ? (B - b0) : rpl4;
             c.boff = b0;
             c.gates = gates + (size_t)b0 * T * ndir * H4;
+            if (a.dg_p3) c.dg_p3 = a.dg_p3 + (size_t)b0 * T * (ndir * H4 / 8) * 16 * a.p3_np;
             c.act = act + (size_t)b0 * T * ndir * H * 8;
             c.dout = dout + (size_t)b0 * Tout * ndir * H;
             c.len = len + b0;
@@ -1172,6 +1228,21 @@ extern "C" int asr_lstm_layer_bwd(void* stream, const float* x, int B, int T, in
     // whose workgroups mostly wait on the exchange and leave the matrix pipes idle.
     // asr_side_join() orders them before the gradients are consumed.
     const int M = B * T;
+    if (p3_dg) {
+        int rc;
+        if (dx && (rc = asr_gemm_p3_kk(stream, M, in_dim, ndir * H4, p3->dg_p3, ndir * H4 / 8, p3->kxu_p3, ndir * H4 / 8, p3->np,
+                                       dx, in_dim, nullptr, 0, 1))) return rc;
+        static const bool wg_inline_p = [] { const char* e = getenv("ASR_WGRAD_INLINE"); return e && e[0] == '1'; }();
+        hipStream_t ssp = wg_inline_p ? s : side_stream();
+        hipEvent_t e_dgp = next_event();
+        if (!wg_inline_p && (hipEventRecord(e_dgp, s) != hipSuccess || hipStreamWaitEvent(ssp, e_dgp, 0) != hipSuccess)) return ASR_ELAUNCH;
+        if ((rc = p3_lstm_wgrad(ssp, M, p3->x_cols, in_dim, H, ndir, p3->x_p3, p3->x_cols / 8, p3->hprev_p3, p3->dg_p3, p3->np,
+                                dkernel_fw, (long long)(dkernel_bw - dkernel_fw), p3->colmap))) return rc;
+        hipEvent_t e_donep = next_event();
+        if (hipEventRecord(e_donep, ssp) != hipSuccess) return ASR_ELAUNCH;
+        set_pending_join(e_donep);
+        return ASR_OK;
+    }
     if (dx && ndir == 2 && kx_cat) {
         // dX = [dG_fw | dG_bw] . [K_x,fw | K_x,bw]^T as ONE product with K = 8H (dG rows are contiguous over the two
         // directions; kx_cat is the [in, 8H] array the forward used): no second accumulating pass over dX
@@ -1236,6 +1307,7 @@ int asr_lstm_rec_bwd_tm(hipStream_t s, float* gates, const float* act, const flo
     a.B = B; a.T = T; a.Tout = T; a.ND = 1; a.boff = 0; a.keep = keep; a.seed = seed;
     a.sb = 1; a.st = B; a.osb = 1; a.ost = B; a.ldo = ldo; a.dsb = 1; a.dst = B;
     a.dbg = nullptr; a.db_part = nullptr;
+    a.dg_p3 = nullptr; a.p3_np = 0; a.dg_f32 = 1;
     const int R = asr_lstm_pick_rows(B, 1, H / 32);
     switch (H) {
         case 64: return launch_bwd_h<64>(s, a, R);

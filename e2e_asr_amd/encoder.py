@@ -87,21 +87,46 @@ class Encoder(BaseParams):
                 chunk = todo[c0:c0 + 4]
                 for t, kc in zip(chunk, ops.concat_kx_layers([t[1:] for t in chunk])):
                     ahead[t[0]] = kc
+        # Operands as bf16 planes (csrc/gemm_p3.hip): the recurrent kernels write their outputs (h for the layer
+        # above, h_prev, and in the backward dG) as planes, the weights are split once per step, and no GEMM of the encoder splits
+        # fp32 operands inside its k-loop.  np_ = 0: off (ASR_P3=0, exact-fp32 mode, CPU tensors).
+        np_ = ops.p3_planes() if x.is_cuda and params.bi_dir else 0
+        x_p3 = None                                                 # P3 image of the current layer's input, if any
         for i in range(max_depth):
             d = i + 1
-            B, T, _ = x.shape
+            B, T, IN = x.shape
             reduce_after = params.skip_step > 1 and i != max_depth - 1 and res < params.max_scaling_down
             t_out = self._pyramid_plan(T, lens) if reduce_after else T
             lens_dev = dev_i32(lens, x.device)
             kf, bf, kb, bb = self._layer_weights(d)
             seed = (self.dropout_seed * 1000003 + d * 7919) & 0x7FFFFFFF
             kx, bc = ahead.get(d, (None, None))
+            p3 = None
+            H = kf.shape[1] // 4
+            if np_ and kx is not None and ops.lstm_p3_supported(B, T, IN, H, 2):
+                p3 = dict(np=np_)
+                if x_p3 is not None and x_p3.np == np_ and IN % 16 == 0:
+                    p3["x"] = x_p3
+                    p3["kxT"] = ops.p3_split(kx, np_, transpose=True)          # K_x^T [8H][in], once per step
+                elif save and d == 1 and IN <= 128:
+                    # first layer: the frames as a 128-column image for its weight gradient (the projection itself runs
+                    # inside the recurrent kernel)
+                    p3["x"] = ops.p3_split(x.reshape(B * T, IN), np_, cols=128)
+                if i != max_depth - 1:
+                    p3["out"] = ops.p3_alloc(B * t_out, 2 * H, np_, x.device)
+                if save and p3.get("x") is not None and p3["x"].cols % 128 == 0 and (d == 1 or IN % 256 == 0):
+                    p3["hprev"] = ops.p3_alloc(B * T, 2 * H, np_, x.device)
             r = ops.lstm_layer_fwd(x, lens_dev, kf, bf, kb, bb, t_out=t_out, save=save,
-                                   keep_prob=keep, seed=seed, kx_cat=kx, bias_cat=bc)
+                                   keep_prob=keep, seed=seed, kx_cat=kx, bias_cat=bc, p3=p3)
             out = r[0] if save else r
             if save:
                 self.saved.append(dict(x=x, lens=lens, lens_dev=lens_dev, gates=r[1], c=r[2], hprev=r[3], kx=getattr(r[1], "kx_cat", None), out=out,
-                                       T=T, t_out=t_out, keep=keep, seed=seed, depth=d))
+                                       T=T, t_out=t_out, keep=keep, seed=seed, depth=d, p3=p3))
+            x_p3 = None
+            if p3 is not None and p3.get("out") is not None:
+                o = p3["out"]
+                skip = params.skip_step if reduce_after else 1
+                x_p3 = ops.P3(o.buf, o.rows // skip, o.cols * skip, o.np)      # the pyramid reshape is a view here too
             view = out[:, :T] if t_out != T else out
             if d in time_major_states:
                 time_major_states[d] = view.transpose(0, 1)
@@ -145,9 +170,20 @@ class Encoder(BaseParams):
                 names = [enc_name(d, "", "kernel", False), enc_name(d, "", "bias", False)]
                 kf, kb = v[names[0]], None
                 g = [v.grad_of(n) for n in names] + [None, None]
+            p3 = sv.get("p3")
+            if p3 is not None and p3.get("hprev") is not None and sv["kx"] is not None and (d == 1 or sv["x"].shape[2] % 256 == 0):
+                B_, T_, IN_ = sv["x"].shape
+                H = kf.shape[1] // 4
+                p3 = dict(p3)
+                p3["dg"] = ops.p3_alloc(B_ * T_, 8 * H, p3["np"], sv["x"].device)
+                p3["colmap"] = ops.p3_colmap(H, sv["x"].device)
+                if d > 1:
+                    p3["kxu"] = ops.p3_split(sv["kx"], p3["np"], unit_major_h=H)    # K_x with unit-major columns, for dX
+            else:
+                p3 = None
             dx = ops.lstm_layer_bwd(sv["x"], sv["lens_dev"], kf, kb, dout.contiguous(), sv["gates"], sv["c"], sv["hprev"],
                                     g[0], g[1], g[2], g[3], need_dx=d > 1, keep_prob=sv["keep"], seed=sv["seed"],
-                                    join=False, kx_cat=sv["kx"])
+                                    join=False, kx_cat=sv["kx"], p3=p3)
             if on_layer_done is not None:
                 on_layer_done(d)
         self.saved = None

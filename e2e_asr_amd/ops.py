@@ -68,6 +68,97 @@ def gemm(a, b, bias=None, trans_a=False, trans_b=False, out=None, accumulate=Fal
     return out
 
 
+# ---- operands pre-split into bf16 planes ("P3", csrc/gemm_p3.hip) ------------------------------------------------------------
+class P3(object):
+    """P3 image of a logical [rows, cols] matrix: uint8 CUDA buffer + shape + plane count (include/e2e_asr_hip.h)."""
+
+    def __init__(self, buf, rows, cols, np_):
+        self.buf, self.rows, self.cols, self.np = buf, rows, cols, np_
+
+    @property
+    def ld8(self):
+        return self.cols // 8
+
+
+def p3_split(x, np_=3, transpose=False, out=None, cols=0, unit_major_h=0):
+    """fp32 [R, C] -> P3 image of x (or of x^T).  cols > the logical column count: a zero-padded, tile-aligned image;
+    unit_major_h = h: image column d*4h + 4u + g holds source column d*4h + g*h + u (asr_p3_split_ex)."""
+    _f32(x, "x")
+    R, Cc = x.shape
+    rows, lc = (Cc, R) if transpose else (R, Cc)
+    cols = cols if cols else (lc + 7) // 8 * 8
+    if out is None:
+        out = P3(torch.empty(int(_lib.lib().asr_p3_bytes(rows, cols, np_)), device=x.device, dtype=torch.uint8), rows, cols, np_)
+    _check(_lib.lib().asr_p3_split_ex(_stream(), _p(x), R, Cc, x.shape[1], _p(out.buf), np_, int(transpose), cols, int(unit_major_h)),
+           "asr_p3_split_ex")
+    return out
+
+
+def p3_alloc(rows, cols, np_, dev):
+    return P3(torch.empty(int(_lib.lib().asr_p3_bytes(rows, cols, np_)), device=dev, dtype=torch.uint8), rows, cols, np_)
+
+
+def p3_planes():
+    """Planes per value the P3 GEMMs run with in the current precision mode: 3 = fp32-accurate (the default), 2 = bf16x2,
+    1 = bf16 (BASELINE config 3); 0 = plane operands off (ASR_P3=0, or the exact-fp32 MFMA kernels were asked for)."""
+    if os.environ.get("ASR_P3", "1") == "0":
+        return 0
+    mode = get_gemm_precision()
+    if mode == "f32":
+        return 3 if get_gemm_split() else 0
+    return 1 if mode == "bf16" else 2
+
+
+_colmap_cache = {}
+
+
+def p3_colmap(H, dev):
+    """unit-major column 4u + g -> gate-major column g*H + u (one direction of a TF LSTM kernel)."""
+    key = (H, dev)
+    if key not in _colmap_cache:
+        c = torch.arange(4 * H, dtype=torch.int32)
+        _colmap_cache[key] = ((c % 4) * H + c // 4).to(torch.int32).to(dev)
+    return _colmap_cache[key]
+
+
+def lstm_p3_supported(B, T, IN, H, ndir):
+    return bool(_lib.lib().asr_lstm_p3_supported(B, T, IN, H, ndir))
+
+
+def _lstm_p3_struct(p3):
+    """dict(np, x (P3), kxT (P3), out (P3), hprev (P3), dg (P3), kxu (P3), colmap) -> ctypes struct (kept alive by the caller)."""
+    if p3 is None:
+        return None
+    g = lambda k: _p(p3[k].buf) if p3.get(k) is not None else None
+    return _lib.LstmP3(int(p3["np"]), g("x"), int(p3["x"].cols) if p3.get("x") is not None else 0, g("kxT"), g("out"), g("hprev"),
+                       g("dg"), g("kxu"), _p(p3.get("colmap")))
+
+
+def gemm_p3_kk(a, b, bias=None, out=None, accumulate=False, splits=1):
+    """out[M, N] (+)= A . B^T + bias with A = P3 [M, K], B = P3 [N, K]."""
+    if a.cols != b.cols or a.np != b.np:
+        raise ValueError("gemm_p3_kk: operands disagree (K %d vs %d, planes %d vs %d)" % (a.cols, b.cols, a.np, b.np))
+    if out is None:
+        out = torch.empty((a.rows, b.rows), device=a.buf.device, dtype=torch.float32)
+    _f32(out, "out"); _f32(bias, "bias")
+    _check(_lib.lib().asr_gemm_p3_kk(_stream(), a.rows, b.rows, a.cols, _p(a.buf), a.ld8, _p(b.buf), b.ld8, a.np,
+                                     _p(out), out.shape[1], _p(bias), int(accumulate), int(splits)), "asr_gemm_p3_kk")
+    return out
+
+
+def gemm_p3_rr(a, b, out=None, accumulate=False, splits=0, colmap=None):
+    """out[M, N] (+)= A^T . B with A = P3 [K, M], B = P3 [K, N] (contraction over the rows of both)."""
+    if a.rows != b.rows or a.np != b.np:
+        raise ValueError("gemm_p3_rr: operands disagree (K %d vs %d, planes %d vs %d)" % (a.rows, b.rows, a.np, b.np))
+    if out is None:
+        out = torch.zeros((a.cols, b.cols), device=a.buf.device, dtype=torch.float32)
+        accumulate = True
+    _f32(out, "out")
+    _check(_lib.lib().asr_gemm_p3_rr(_stream(), a.cols, b.cols, a.rows, _p(a.buf), a.ld8, _p(b.buf), b.ld8, a.np,
+                                     _p(out), out.shape[1], int(accumulate), int(splits), _p(colmap)), "asr_gemm_p3_rr")
+    return out
+
+
 class _Flag:
     """Device int that kernels set when an inter-workgroup wait times out."""
     _t = {}
@@ -151,7 +242,7 @@ def concat_kx_layers(layers):
 
 
 def lstm_layer_fwd(x, seq_len, kernel_fw, bias_fw, kernel_bw=None, bias_bw=None, t_out=None,
-                   save=False, keep_prob=1.0, seed=0, kx_cat=None, bias_cat=None):
+                   save=False, keep_prob=1.0, seed=0, kx_cat=None, bias_cat=None, p3=None):
     """One (Bi)LSTM layer (encoder.py:55-91).  x [B,T,in] batch-major, seq_len int32 [B].
 
     Returns out [B,t_out,ndir*H] (zeros past each length) and, when save=True, the
@@ -183,7 +274,7 @@ def lstm_layer_fwd(x, seq_len, kernel_fw, bias_fw, kernel_bw=None, bias_bw=None,
     out = torch.empty((B, t_out, ndir * H), device=dev, dtype=torch.float32)
     gates = torch.empty((B, T, ndir, 4 * H), device=dev, dtype=torch.float32)
     act = torch.empty((B, T, ndir, H, 8), device=dev, dtype=torch.float32) if save else None
-    hprev = torch.empty((B, T, ndir, H), device=dev, dtype=torch.float32) if save else None
+    hprev = torch.empty((B, T, ndir, H), device=dev, dtype=torch.float32) if save and not (p3 and p3.get("hprev") is not None) else None
     L = _lib.lib()
     nbytes = L.asr_lstm_ws_bytes(B, H, ndir)
     hx = _hx(dev, nbytes)
@@ -193,11 +284,13 @@ def lstm_layer_fwd(x, seq_len, kernel_fw, bias_fw, kernel_bw=None, bias_bw=None,
             bias_cat = torch.cat([bias_fw, bias_bw])
     else:
         kx_cat = bias_cat = None
-    rc = L.asr_lstm_layer_fwd(_stream(), _p(x), B, T, IN, IN, _p(seq_len), H, ndir,
-                              _p(_f32(kernel_fw, "kernel_fw")), _p(_f32(bias_fw, "bias_fw")),
-                              _p(_f32(kernel_bw, "kernel_bw")), _p(_f32(bias_bw, "bias_bw")),
-                              _p(out), t_out, _p(gates), _p(act), _p(hprev), _p(hx), nbytes,
-                              _p(_Flag.get(dev)), float(keep_prob), int(seed) & 0xFFFFFFFF, _p(kx_cat), _p(bias_cat))
+    st = _lstm_p3_struct(p3)
+    rc = L.asr_lstm_layer_fwd_p3(_stream(), _p(x), B, T, IN, IN, _p(seq_len), H, ndir,
+                                 _p(_f32(kernel_fw, "kernel_fw")), _p(_f32(bias_fw, "bias_fw")),
+                                 _p(_f32(kernel_bw, "kernel_bw")), _p(_f32(bias_bw, "bias_bw")),
+                                 _p(out), t_out, _p(gates), _p(act), _p(hprev), _p(hx), nbytes,
+                                 _p(_Flag.get(dev)), float(keep_prob), int(seed) & 0xFFFFFFFF, _p(kx_cat), _p(bias_cat),
+                                 C.byref(st) if st is not None else None)
     _check(rc, "asr_lstm_layer_fwd")
     gates.kx_cat = kx_cat        # rides along for lstm_layer_bwd(kx_cat=...): dX as one product over both directions
     return (out, gates, act, hprev) if save else out
@@ -211,7 +304,7 @@ def _hx(dev, nbytes):
 
 
 def lstm_layer_bwd(x, seq_len, kernel_fw, kernel_bw, dout, gates, act, hprev, dk_fw, db_fw, dk_bw=None,
-                   db_bw=None, need_dx=True, keep_prob=1.0, seed=0, join=True, kx_cat=None):
+                   db_bw=None, need_dx=True, keep_prob=1.0, seed=0, join=True, kx_cat=None, p3=None):
     """Backward of lstm_layer_fwd.  `gates` is overwritten with dG; weight/bias gradients are
     ACCUMULATED into dk_*/db_* (views of the flat gradient buffer) on the library's side stream:
     join=False leaves them in flight (overlapping the next layer's BPTT) until ops.side_join().
@@ -241,13 +334,15 @@ def lstm_layer_bwd(x, seq_len, kernel_fw, kernel_bw, dout, gates, act, hprev, dk
     dx = torch.empty_like(x) if need_dx else None
     L = _lib.lib()
     nbytes = L.asr_lstm_bwd_ws_bytes(B, H, ndir)
-    rc = L.asr_lstm_layer_bwd(_stream(), _p(x), B, T, IN, IN, _p(seq_len), H, ndir, _p(kernel_fw), _p(kernel_bw),
-                              _p(_f32(dout, "dout")), dout.shape[1], _p(gates), _p(act), _p(hprev), _p(dx),
-                              _p(dk_fw), _p(db_fw), _p(dk_bw), _p(db_bw), _p(_hx(dev, nbytes)), nbytes,
-                              _p(_Flag.get(dev)), float(keep_prob), int(seed) & 0xFFFFFFFF,
-                              _p(kx_cat if (ndir == 2 and need_dx and _KXCAT >= 2) else None))
+    st = _lstm_p3_struct(p3)
+    rc = L.asr_lstm_layer_bwd_p3(_stream(), _p(x), B, T, IN, IN, _p(seq_len), H, ndir, _p(kernel_fw), _p(kernel_bw),
+                                 _p(_f32(dout, "dout")), dout.shape[1], _p(gates), _p(act), _p(hprev), _p(dx),
+                                 _p(dk_fw), _p(db_fw), _p(dk_bw), _p(db_bw), _p(_hx(dev, nbytes)), nbytes,
+                                 _p(_Flag.get(dev)), float(keep_prob), int(seed) & 0xFFFFFFFF,
+                                 _p(kx_cat if (ndir == 2 and need_dx and _KXCAT >= 2) else None),
+                                 C.byref(st) if st is not None else None)
     _check(rc, "asr_lstm_layer_bwd")
-    keep_until_join(x, dout, gates, act, hprev, seq_len, kx_cat)
+    keep_until_join(x, dout, gates, act, hprev, seq_len, kx_cat, p3)
     if join:          # weight/bias gradients are produced on the library's side stream
         side_join()
     return dx

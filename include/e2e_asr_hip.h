@@ -48,6 +48,34 @@ int asr_get_gemm_precision(void);
 int asr_set_gemm_split(int on);
 int asr_get_gemm_split(void);
 
+/* ---- GEMMs on operands pre-split into bf16 planes ("P3" operands; csrc/gemm_p3.hip) -------------------------------------
+ * Same products as asr_gemm_f32 (encoder.py:78-81 input projections, seq2seq_model.py:148 tf.gradients products), with the
+ * fp32 -> bf16-plane split taken OUT of the GEMM's k-loop: the producer of an operand writes it as planes.
+ * P3 image of a logical matrix X[rows][cols] (cols % 8 == 0) with np planes (3: x = h1 + h2 + h3 exactly = fp32-accurate
+ * products; 2: 16 significand bits; 1: plain bf16): 16-byte pieces, piece(r, c8, p) = the 8 bf16 values of plane p for
+ * X[r][8 c8 .. 8 c8 + 7] at byte  r * ld8 * 16 np + (c8 * np + p) * 16  (ld8 >= cols / 8: row pitch in 8-element chunks). */
+size_t asr_p3_bytes(int rows, int cols, int np);
+/* fp32 src[rows][cols] (leading dimension ld) -> P3 image of src (transpose = 0) or of src^T (transpose = 1), tightly packed. */
+int asr_p3_split_f32(void* stream, const float* src, int rows, int cols, int ld, void* dst, int np, int transpose);
+/* KK form: C[M,N] (+)= A . B^T + bias[N], A = P3[M][K], B = P3[N][K] (both contiguous along the contraction).
+ * M % 128 == 0, N % 256 == 0, K % 16 == 0 (ASR_EUNSUPPORTED otherwise).  splits > 1: K split over that many workgroups
+ * per tile, float-atomic epilogue. */
+int asr_gemm_p3_kk(void* stream, int M, int N, int K, const void* A, int lda8, const void* B, int ldb8, int np,
+                   float* C, int ldc, const float* bias, int accumulate, int splits);
+
+/* General form of asr_p3_split_f32: dst_cols (0 = the logical column count rounded up to 8): columns of the image, zero past the
+ * logical ones (a tile-aligned image of a narrower matrix); unit_major_h > 0 (transpose = 0): image column d*4h + 4u + g holds
+ * source column d*4h + g*h + u -- the gate-major columns of a TF LSTM kernel (beam_search.py:56-59 layout) in the unit-major order
+ * the BPTT writes dG in. */
+int asr_p3_split_ex(void* stream, const float* src, int rows, int cols, int ld, void* dst, int np, int transpose,
+                    int dst_cols, int unit_major_h);
+/* RR form: C[M,N] (+)= A^T . B, A = P3[K][M], B = P3[K][N] (the contraction runs over the ROWS of both: the B*T frames of a weight
+ * gradient X^T . dG, seq2seq_model.py:148).  M % 128 == 0, N % 256 == 0, K % 16 == 0.  splits: K slices per output tile (0: fill
+ * the chip); slices meet in C through float atomics (C zeroed first unless accumulate).  colmap (device int[N] or NULL): product
+ * column n goes to column colmap[n] of C. */
+int asr_gemm_p3_rr(void* stream, int M, int N, int K, const void* A, int lda8, const void* B, int ldb8, int np,
+                   float* C, int ldc, int accumulate, int splits, const int* colmap);
+
 /* One (Bi)LSTM encoder layer over a whole padded batch -- encoder.py:55-91
  * (bidirectional_dynamic_rnn / dynamic_rnn over BasicLSTMCell with sequence_length).
  * x [B,T,in] batch-major (row stride ldx); out [B,Tout,ndir*H] with fw in [:H], bw in
@@ -69,6 +97,36 @@ int asr_lstm_layer_fwd(void* stream, const float* x, int B, int T, int in_dim, i
                        float* out, int Tout, float* gates, float* act, float* hprev,
                        void* hx_ws, size_t hx_bytes, int* err_flag,
                        float keep_prob, unsigned seed, const float* kx_cat, const float* bias_cat);
+
+/* Plane operands of one (Bi)LSTM layer (asr_lstm_layer_fwd_p3 / asr_lstm_layer_bwd_p3; shapes: asr_lstm_p3_supported).  Every
+ * pointer may be NULL = that product keeps its fp32 operands.  The groups-of-four recurrent kernels (H = 256) write the planes. */
+typedef struct {
+    int np;                 /* planes per value: 3 (fp32-accurate products), 2, 1 (bf16) */
+    const void* x_p3;       /* P3 image of the layer input x [B*T][x_cols]: forward projection, weight gradient dK_x */
+    int x_cols;             /* >= in_dim, zero columns past it; a multiple of 128 for the weight gradient */
+    const void* kxT_p3;     /* forward: P3 image of kx_cat^T [ndir*4H][in_dim] (asr_p3_split_f32, transpose = 1) */
+    void* out_p3;           /* forward, WRITTEN: P3 image of out [B*Tout][ndir*H] (= the next layer's x_p3) */
+    void* hprev_p3;         /* forward, WRITTEN: P3 image of hprev [B*T][ndir*H] (then `hprev` is not written); read by the backward */
+    void* dg_p3;            /* backward, WRITTEN: P3 image of dG [B*T][ndir*4H], unit-major columns inside a direction */
+    const void* kxu_p3;     /* backward: P3 image of kx_cat [in_dim][ndir*4H] with unit-major columns (asr_p3_split_ex) */
+    const int* colmap;      /* backward: device int[4H], unit-major column 4u+g -> gate-major column g*H+u */
+} asr_lstm_p3;
+int asr_lstm_p3_supported(int B, int T, int in_dim, int H, int ndir);
+int asr_lstm_layer_fwd_p3(void* stream, const float* x, int B, int T, int in_dim, int ldx,
+                          const int* len, int H, int ndir,
+                          const float* kernel_fw, const float* bias_fw,
+                          const float* kernel_bw, const float* bias_bw,
+                          float* out, int Tout, float* gates, float* act, float* hprev,
+                          void* hx_ws, size_t hx_bytes, int* err_flag,
+                          float keep_prob, unsigned seed, const float* kx_cat, const float* bias_cat, const asr_lstm_p3* p3);
+int asr_lstm_layer_bwd_p3(void* stream, const float* x, int B, int T, int in_dim, int ldx,
+                          const int* len, int H, int ndir,
+                          const float* kernel_fw, const float* kernel_bw,
+                          const float* dout, int Tout, float* gates, const float* act,
+                          const float* hprev, float* dx,
+                          float* dkernel_fw, float* dbias_fw, float* dkernel_bw, float* dbias_bw,
+                          void* hx_ws, size_t hx_bytes, int* err_flag, float keep_prob, unsigned seed,
+                          const float* kx_cat, const asr_lstm_p3* p3);
 
 /* Backward of asr_lstm_layer_fwd (tf.gradients through encoder.py:55-91): persistent BPTT
  * kernel (dG overwrites `gates`), then dX = dG.K_x^T, dK_x = X^T.dG, dK_h = Hprev^T.dG and

@@ -25,12 +25,22 @@ for T, IN in ((800, 80), (400, 1024), (100, 1024)):
     for it in range(n + 2):
         if it == 2:
             torch.cuda.synchronize(); ops.prof_enable(False); ops.prof_enable(True)
-        out, gates, act, hp = ops.lstm_layer_fwd(x, ln, k[0], bz[0], k[1], bz[1], save=True)
+        p3f = p3b = None
+        kxc = bc = None
+        if os.environ.get("P3") == "1":       # outputs / dG as bf16 planes, the GEMMs on plane operands (csrc/gemm_p3.hip)
+            kxc = torch.cat([k[0][:IN], k[1][:IN]], 1); bc = torch.cat(bz)
+            xp = ops.p3_split(x.reshape(B * T, IN), 3, cols=128 if IN < 128 else 0)
+            p3f = dict(np=3, x=xp, out=ops.p3_alloc(B * T, 2 * H, 3, dev), hprev=ops.p3_alloc(B * T, 2 * H, 3, dev))
+            if IN >= 128:
+                p3f["kxT"] = ops.p3_split(kxc, 3, transpose=True)
+            p3b = dict(p3f, dg=ops.p3_alloc(B * T, 8 * H, 3, dev), colmap=ops.p3_colmap(H, dev), kxu=ops.p3_split(kxc, 3, unit_major_h=H))
+        out, gates, act, hp = ops.lstm_layer_fwd(x, ln, k[0], bz[0], k[1], bz[1], save=True, kx_cat=kxc, bias_cat=bc, p3=p3f)
         dout = torch.ones_like(out)
         if os.environ.get("FLUSH") == "1":      # evict the Infinity Cache: in the train step the saved activations are ~8 ms old
             flush.add_(1.0)
         torch.cuda.synchronize()
-        ops.lstm_layer_bwd(x, ln, k[0], k[1], dout, gates, act, hp, dk[0], db[0], dk[1], db[1], need_dx=True, join=True)
+        ops.lstm_layer_bwd(x, ln, k[0], k[1], dout, gates, act, hp, dk[0], db[0], dk[1], db[1], need_dx=IN % 256 == 0, join=True,
+                           kx_cat=kxc, p3=p3b)
         torch.cuda.synchronize()
     f_ms, f_n = ops.prof_read("lstm_rec_fwd")
     b_ms, b_n = ops.prof_read("lstm_rec_bwd")
