@@ -100,8 +100,9 @@ def p3_alloc(rows, cols, np_, dev):
 
 def p3_planes():
     """Planes per value the P3 GEMMs run with in the current precision mode: 3 = fp32-accurate (the default), 2 = bf16x2,
-    1 = bf16 (BASELINE config 3); 0 = plane operands off (ASR_P3=0, or the exact-fp32 MFMA kernels were asked for)."""
-    if os.environ.get("ASR_P3", "1") == "0":
+    1 = bf16 (BASELINE config 3); 0 = plane operands off (the default: ASR_P3=1 turns them on; or the exact-fp32 MFMA kernels were
+    asked for)."""
+    if os.environ.get("ASR_P3", "0") != "1":          # OPT-IN (round 4: measured, not adopted -- DESIGN section 4b)
         return 0
     mode = get_gemm_precision()
     if mode == "f32":

@@ -1,0 +1,150 @@
+"""GPU: the GEMMs on operands pre-split into bf16 planes (csrc/gemm_p3.hip, "P3" operands) -- the products of encoder.py:78-81
+(input projections) and of tf.gradients through them (seq2seq_model.py:148) with the fp32 -> bf16-plane split taken out of the
+k-loop.  Held to the error of the exact-fp32 MFMA kernel against float64 on the same operands (three planes), and to the product
+of the rounded planes (one / two planes); the encoder layer run on plane operands end to end (ASR_P3=1: the recurrent kernels
+write h, h_prev and dG as planes) must reproduce the default path's outputs and gradients."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _err(c, ref, den):
+    return ((c.double() - ref).abs() / den).max().item()
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 256, 16), (256, 512, 48), (1280, 256, 1024), (384, 768, 2048)])
+@pytest.mark.parametrize("scale", ["normal", "wide"])
+def test_kk_three_planes_is_fp32_accurate(M, N, K, scale):
+    from e2e_asr_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    a = torch.randn(M, K, device=DEV, generator=g)
+    b = torch.randn(N, K, device=DEV, generator=g)
+    if scale == "wide":          # eight decades of magnitudes: every plane carries bits
+        a = a * torch.pow(10.0, torch.rand(M, K, device=DEV, generator=g) * 8 - 4)
+        b = b * torch.pow(10.0, torch.rand(N, K, device=DEV, generator=g) * 8 - 4)
+    bias = torch.randn(N, device=DEV, generator=g)
+    ref = a.double() @ b.double().t()
+    den = a.double().abs() @ b.double().abs().t()
+    c = ops.gemm_p3_kk(ops.p3_split(a, 3), ops.p3_split(b, 3), bias)
+    e_p3 = _err(c - bias, ref, den)
+    ops.set_gemm_split(False)
+    try:
+        c32 = ops.gemm(a, b, None, trans_b=True)
+    finally:
+        ops.set_gemm_split(True)
+    e_32 = _err(c32, ref, den)
+    assert e_p3 <= max(1.5 * e_32, 2e-7), (e_p3, e_32)
+    # transposed split (the weights of the forward projection arrive as [K, N])
+    c2 = ops.gemm_p3_kk(ops.p3_split(a, 3), ops.p3_split(b.t().contiguous(), 3, transpose=True), bias)
+    assert torch.equal(c, c2)
+    # accumulate, and K split over two workgroups per tile (float atomics into a live C)
+    c3 = c.clone()
+    ops.gemm_p3_kk(ops.p3_split(a, 3), ops.p3_split(b, 3), None, out=c3, accumulate=True)
+    assert _err(c3 - c - bias * 0, ref, den) <= max(2.5 * e_32, 4e-7)
+    if K >= 32:
+        c4 = torch.empty_like(c)
+        ops.gemm_p3_kk(ops.p3_split(a, 3), ops.p3_split(b, 3), bias, out=c4, splits=2)
+        assert _err(c4 - bias, ref, den) <= max(1.5 * e_32, 2e-7)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 256, 16), (256, 256, 400), (1280, 1024, 1600)])
+def test_rr_three_planes_is_fp32_accurate(M, N, K):
+    from e2e_asr_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(7 * M + N + K)
+    a = torch.randn(K, M, device=DEV, generator=g)
+    b = torch.randn(K, N, device=DEV, generator=g)
+    ref = a.double().t() @ b.double()
+    den = a.double().abs().t() @ b.double().abs()
+    ops.set_gemm_split(False)
+    try:
+        c32 = ops.gemm(a, b, None, trans_a=True)
+    finally:
+        ops.set_gemm_split(True)
+    e_32 = _err(c32, ref, den)
+    for splits in (1, 0):
+        c = torch.zeros(M, N, device=DEV)
+        ops.gemm_p3_rr(ops.p3_split(a, 3), ops.p3_split(b, 3), out=c, splits=splits)
+        # (fp32 accumulation over up to K terms in one chain when splits = 1: the exact-fp32 MFMA chain itself is at
+        # 0.75-3.5e-7 of sum |a||b| for K = 1024 .. 4096, MI355X_MICROARCH.md)
+        assert _err(c, ref, den) <= max(3.0 * e_32, 4e-7), splits
+    # output column map (a producer that writes its columns unit-major for a gate-major C)
+    perm = torch.randperm(N, device=DEV, generator=g).to(torch.int32)
+    c = torch.zeros(M, N, device=DEV)
+    ops.gemm_p3_rr(ops.p3_split(a, 3), ops.p3_split(b, 3), out=c, splits=1, colmap=perm)
+    full = torch.zeros(M, N, device=DEV)
+    ops.gemm_p3_rr(ops.p3_split(a, 3), ops.p3_split(b, 3), out=full, splits=1)
+    assert torch.equal(c[:, perm.long()], full)
+
+
+@pytest.mark.parametrize("np_", [1, 2])
+def test_reduced_plane_counts_equal_the_product_of_the_rounded_planes(np_):
+    from e2e_asr_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(11)
+    M, N, K = 256, 512, 512
+    a = torch.randn(M, K, device=DEV, generator=g)
+    b = torch.randn(N, K, device=DEV, generator=g)
+
+    def planes(x):
+        out, r = [], x.clone()
+        for _ in range(np_):
+            h = r.to(torch.bfloat16).float()
+            out.append(h.double())
+            r = r - h
+        return out
+    pa, pb = planes(a), planes(b)
+    ref = sum(pa[i] @ pb[j].t() for i in range(np_) for j in range(np_) if i + j <= np_ - 1)
+    c = ops.gemm_p3_kk(ops.p3_split(a, np_), ops.p3_split(b, np_))
+    den = a.double().abs() @ b.double().abs().t()
+    assert _err(c, ref, den) < 3e-7
+    a2, b2 = a.t().contiguous(), b.t().contiguous()           # RR: [K, M], [K, N]
+    c = torch.zeros(M, N, device=DEV)
+    ops.gemm_p3_rr(ops.p3_split(a2, np_), ops.p3_split(b2, np_), out=c, splits=1)
+    assert _err(c, ref, den) < 3e-7
+
+
+def test_split_layouts():
+    """asr_p3_split_ex: padded image, transposed image, unit-major column permutation -- against the layout formula."""
+    from e2e_asr_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.randn(24, 80, device=DEV, generator=g)
+
+    def decode(p3):       # P3 image -> float64 [rows, cols] (sum of the planes)
+        raw = p3.buf.view(torch.int16).view(p3.rows, p3.cols // 8, p3.np, 8)
+        f = (raw.to(torch.int32) << 16).view(torch.float32)
+        return f.double().sum(2).reshape(p3.rows, p3.cols)
+    d = decode(ops.p3_split(x, 3, cols=128))
+    assert torch.equal(d[:, :80].float(), x) and (d[:, 80:] == 0).all()
+    assert torch.equal(decode(ops.p3_split(x, 3, transpose=True)).float(), x.t())
+    H = 8
+    w = torch.randn(16, 2 * 4 * H, device=DEV, generator=g)
+    du = decode(ops.p3_split(w, 3, unit_major_h=H)).float()
+    for dd in range(2):
+        for u in range(H):
+            for gg in range(4):
+                assert torch.equal(du[:, dd * 4 * H + 4 * u + gg], w[:, dd * 4 * H + gg * H + u])
+    cm = ops.p3_colmap(H, torch.device(DEV)).cpu().numpy()
+    assert [int(cm[4 * u + gg]) for u in range(H) for gg in range(4)] == [gg * H + u for u in range(H) for gg in range(4)]
+
+
+def test_encoder_on_plane_operands_equals_default_path(monkeypatch):
+    """ASR_P3=1: the groups-of-four recurrent kernels write h / h_prev / dG as planes and every encoder GEMM of layers >= 2 (and
+    the first layer's weight gradients) runs on plane operands.  Same arithmetic as the default path's split3 products, other
+    summation order: logits to 2e-5, every gradient to 2e-4 of its largest entry, with dropout and ragged lengths."""
+    from tests.test_gpu_parity3 import _model
+    from e2e_asr_amd import ops
+    from e2e_asr_amd.weights import synthetic_batch
+    b = synthetic_batch(B=32, T=160, F=80, t_dec=21, vocab=1000, variable_len=True, seed=100)
+    res = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("ASR_P3", flag)
+        m = _model(feat=80, vocab={"char": 1000}, max_output={"char": 30}, seed=6, enc_update=dict(out_prob=0.9))
+        m.forward(b); m.backward()
+        torch.cuda.synchronize()
+        ops.check_device_flag(torch.device(DEV))
+        res[flag] = (m.outputs["char"].cpu().numpy().copy(), {n: m.variables.grad_of(n).cpu().numpy().copy() for n in m.variables.names()})
+    assert np.abs(res["1"][0] - res["0"][0]).max() < 2e-5
+    for n, g0 in res["0"][1].items():
+        assert np.abs(res["1"][1][n] - g0).max() <= 2e-4 * max(1e-30, np.abs(g0).max()), n
