@@ -59,6 +59,11 @@ struct LstmRecArgs {
     // out_p3 = P3 image of out [B*Tout][ND*H] (the next layer's input), hprev_p3 = P3 image of hprev [B*T][ND*H] (then the
     // fp32 hprev is not written)
     char* out_p3; char* hprev_p3; int p3_np;
+    // lstm_rec_fwd4_kernel / lstm_rec_bwd4_kernel: 20-byte records in two planes instead of the 32-byte record -- `act` holds the
+    // activated gates {i,j,f,o} (16 bytes per unit-step), act_c the cell state c (4 bytes); c_prev(t) is the c of the record
+    // the BPTT fetches next, and the record's 8 bytes of padding are gone (round-3 review: the record stream is what slows the
+    // exchange of the BPTT most).  Same buffer: act_c = act + 4 * records.
+    float* act_c;
 };
 
 __device__ __forceinline__ bool poll_granule(const u64* g, uint32_t epoch, float& val, int* err) {
@@ -780,9 +785,8 @@ __global__ __launch_bounds__(512) void lstm_rec_fwd4_kernel(LstmRecArgs a) {
                 a.out[((size_t)cb * a.osb + (size_t)t * a.ost) * a.ldo + dir * H + cj] = o;
                 if (a.hprev) __builtin_nontemporal_store(h_old, a.hprev + ridx);
                 if (a.act) {
-                    f32x4* rp = reinterpret_cast<f32x4*>(a.act + ridx * 8);
-                    __builtin_nontemporal_store(f32x4{gi, gj, gf, go}, rp);
-                    __builtin_nontemporal_store(f32x4{c, c_old, 0.f, 0.f}, rp + 1);
+                    __builtin_nontemporal_store(f32x4{gi, gj, gf, go}, reinterpret_cast<f32x4*>(a.act + ridx * 4));
+                    __builtin_nontemporal_store(c, a.act_c + ridx);
                 }
                 // the same values as bf16 planes for the GEMMs that consume them (no split inside their k-loops)
                 if (a.out_p3) p3_store1(a.out_p3, p3_elem_off((size_t)cb * a.osb + (size_t)t * a.ost, dir * H + cj, a.ldo >> 3, a.p3_np), o, a.p3_np, false);
@@ -934,7 +938,8 @@ bool asr_lstm_g4_selected(int B, int H, int ndir) {
     const char* v2e = getenv("ASR_LSTM_V2");
     const char* ce = getenv("ASR_LSTM_G4_CHUNKS");
     const int rpl = asr_lstm_max_wgs() / (4 * ndir);
-    return !(e && e[0] == '0') && !(v2e && v2e[0] == '0') && !(asr::g_lstm_dbg && getenv("ASR_LSTM_STAMP")) &&
+    const char* ag = getenv("ASR_BPTT_AG");       // (the forward and the BPTT of a layer must agree: they share a record format)
+    return !(e && e[0] == '0') && !(v2e && v2e[0] == '0') && !(ag && ag[0] == '0') && !(asr::g_lstm_dbg && getenv("ASR_LSTM_STAMP")) &&
            !(asr::asr_get_lstm_mfma() != 0 && asr::asr_get_gemm_precision() == 1) && H == 256 && rpl >= 1 && (B + rpl - 1) / rpl <= (ce ? atoi(ce) : 4);
 }
 extern "C" int asr_lstm_layer_fwd_p3(void* stream, const float* x, int B, int T, int in_dim, int ldx,
@@ -997,7 +1002,7 @@ extern "C" int asr_lstm_layer_fwd_p3(void* stream, const float* x, int B, int T,
     a.x = nullptr; a.ldx = 0; a.kx[0] = a.kx[1] = nullptr; a.bias[0] = a.bias[1] = nullptr;
     a.out_p3 = p3 ? static_cast<char*>(p3->out_p3) : nullptr;
     a.hprev_p3 = p3 ? static_cast<char*>(p3->hprev_p3) : nullptr;
-    a.p3_np = p3 ? p3->np : 0;
+    a.p3_np = p3 ? p3->np : 0; a.act_c = nullptr;
     if (a.hprev_p3) a.hprev = nullptr;          // (the fp32 copy has no reader then)
     if (g4) {   // one row per group; larger batches as consecutive launches over ranges of 32 rows (measured against the first-version
                 // kernels with four / eight rows per group: B = 64 2.25 vs 2.69 us per step of a layer, B = 128 4.85 vs 4.97)
@@ -1011,7 +1016,8 @@ extern "C" int asr_lstm_layer_fwd_p3(void* stream, const float* x, int B, int T,
             c.x = x + (size_t)b0 * T * ldx;
             c.len = len + b0;
             c.out = out + (size_t)b0 * Tout * ndir * H;
-            c.act = act ? act + (size_t)b0 * T * ndir * H * 8 : nullptr;
+            c.act = act ? act + (size_t)b0 * T * ndir * H * 4 : nullptr;                       // gates plane, then the c plane
+            c.act_c = act ? act + (size_t)B * T * ndir * H * 4 + (size_t)b0 * T * ndir * H : nullptr;
             c.hprev = a.hprev ? a.hprev + (size_t)b0 * T * ndir * H : nullptr;
             if (a.out_p3) c.out_p3 = a.out_p3 + (size_t)b0 * Tout * (ndir * H / 8) * 16 * a.p3_np;
             if (a.hprev_p3) c.hprev_p3 = a.hprev_p3 + (size_t)b0 * T * (ndir * H / 8) * 16 * a.p3_np;
@@ -1085,7 +1091,7 @@ int asr_lstm_rec_fwd_tm(hipStream_t s, const float* gates, const float* kh, cons
     a.sb = 1; a.st = B; a.osb = 1; a.ost = B; a.ldo = ldo; a.dsb = 1; a.dst = B; a.toff = toff;
     a.h0 = h0; a.c0 = c0; a.h_last = h_last; a.c_last = c_last; a.ep0 = toff;
     a.x = nullptr; a.ldx = 0; a.kx[0] = a.kx[1] = nullptr; a.bias[0] = a.bias[1] = nullptr;
-    a.out_p3 = a.hprev_p3 = nullptr; a.p3_np = 0;
+    a.out_p3 = a.hprev_p3 = nullptr; a.p3_np = 0; a.act_c = nullptr;
     const int R = asr_lstm_pick_rows(B, 1, H / 32);
     switch (H) {
         case 64: return launch_rec_h<64>(s, a, R);

@@ -48,6 +48,7 @@ struct LstmBwdArgs {
     // of dG [B*T][ND*4H] with the columns of a direction UNIT-major (column dir*4H + 4*unit + gate: a lane's four gates are 8
     // contiguous bytes of a plane; the consumers permute their weights / output columns instead)
     char* dg_p3; int p3_np; int dg_f32;
+    const float* act_c;        // lstm_rec_bwd4_kernel: c plane of the 20-byte split records (csrc/lstm.hip LstmRecArgs::act_c)
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -887,20 +888,31 @@ __global__ __launch_bounds__(512) void lstm_rec_bwd4_kernel(LstmBwdArgs a) {
     const bool fast = group_shares_xcd(a.xcc_slots + (size_t)grp * 16, G, mem, tid, a.err, nullptr, 0, 17);
 
     // cell wave: the record of step s (time t) -> registers; then -> the operands of the pointwise backward in LDS
+    // 20-byte split records (LstmRecArgs::act_c): gates {i,j,f,o} in one plane, c in another; c_prev of a step IS the c of the
+    // step the BPTT takes next (the forward's previous step), 0 behind the first forward step.
+    // (32-bit element offsets from per-thread base pointers: 64-bit index arithmetic for every address of every step sat on
+    // the cell wave, the wave all others wait for.)
     float4 ra = make_float4(0.f, 0.f, 0.f, 0.f);
-    float rc_ = 0.f, rcp = 0.f, dout_v = 0.f;
+    float rc_ = 0.f, rcn = 0.f, dout_v = 0.f;
+    const float* const act_g = a.act + ((((size_t)cb * a.sb) * a.ND + dir) * H + cj) * 4;
+    const float* const act_cc = a.act_c + (((size_t)cb * a.sb) * a.ND + dir) * H + cj;
+    const float* const dout_b = a.dout + ((size_t)cb * a.osb) * a.ldo + dir * H + cj;
+    const unsigned tstr = (unsigned)(a.st * a.ND * H), ostr = (unsigned)(a.ost * a.ldo);
+    auto time_of = [&](int s) { const int t = dir ? s : (S - 1 - s); return (unsigned)min(max(t, 0), a.T - 1); };
     auto prefetch = [&](int s) {
-        const int t = dir ? s : (S - 1 - s);
-        const int ts = min(max(t, 0), a.T - 1);
-        const float4* rp = reinterpret_cast<const float4*>(a.act + ((((size_t)cb * a.sb + (size_t)ts * a.st) * a.ND + dir) * H + cj) * 8);
-        ra = rp[0];
-        const float2 cc2 = *reinterpret_cast<const float2*>(rp + 1);
-        rc_ = cc2.x; rcp = cc2.y;
-        dout_v = a.dout[((size_t)cb * a.osb + (size_t)ts * a.ost) * a.ldo + dir * H + cj];
+        const unsigned ts = time_of(s), tn = time_of(min(s + 1, S - 1));
+        ra = *reinterpret_cast<const float4*>(act_g + ts * tstr * 4u);
+        // c of this step AND of the next one (= this step's c_prev), both loaded here: carrying the second over to the next step
+        // in a register made the compiler copy it at the loop's back edge, i.e. wait for the load it had just issued.  The two
+        // are neighbours in time: the second load is the next step's first and hits the same lines.
+        rc_ = act_cc[ts * tstr];
+        rcn = act_cc[tn * tstr];
+        dout_v = dout_b[ts * ostr];
     };
     auto hand_over = [&](int s) {
         const int t = dir ? s : (S - 1 - s);
         const float gi = ra.x, gj = ra.y, gf = ra.z, go = ra.w;
+        const float rcp = s + 1 < S ? rcn : 0.f;
         const float tc = fast_tanh(rc_);
         float dm = dout_v;
         if (a.keep < 1.0f)
@@ -1144,6 +1156,7 @@ extern "C" int asr_lstm_layer_bwd_p3(void* stream, const float* x, int B, int T,
     a.sb = T; a.st = 1; a.osb = Tout; a.ost = 1; a.ldo = ndir * H; a.dsb = Tout; a.dst = 1;
     a.dbg = getenv("ASR_LSTM_STAMP") ? asr::g_lstm_dbg : nullptr;
     a.dg_p3 = p3_dg ? static_cast<char*>(p3->dg_p3) : nullptr; a.p3_np = p3_dg ? p3->np : 0; a.dg_f32 = p3_dg ? 0 : 1;
+    a.act_c = nullptr;
     int R = asr_lstm_pick_rows(B, ndir, G);
     // H = 512: the reduce-scatter kernel for four or eight rows per group spills (256 registers + 200-768 bytes of scratch: 9.6 us
     // per step at B = 32); two rows per group through the all-gather kernel in twice the launches are 4.0 us per step of a layer
@@ -1158,16 +1171,9 @@ extern "C" int asr_lstm_layer_bwd_p3(void* stream, const float* x, int B, int T,
     const int rows_per_launch = max_groups * R;
     // groups of four workgroups, one row per group (lstm_rec_bwd4_kernel), when the whole batch is resident at once
     // (ASR_LSTM_G4=0: the eight-workgroup groups of version 2)
-    bool g4 = false;
-    {
-        const char* e = getenv("ASR_LSTM_G4");
-        const char* v2e = getenv("ASR_LSTM_V2");
-        const int rpl4 = asr_lstm_max_wgs() / (4 * ndir);
-        const char* ce = getenv("ASR_LSTM_G4_CHUNKS");
-        const int max_chunks = ce ? atoi(ce) : 4;          // larger batches as consecutive launches of 32 rows (B = 64: 2.4 vs 3.3 us per step of a layer, B = 128: 4.9 vs 6.1)
-        g4 = !(e && e[0] == '0') && !(v2e && v2e[0] == '0') && ag_env && !a.dbg && !(asr_get_lstm_mfma() != 0 && asr_get_gemm_precision() == 1) &&
-             H == 256 && rpl4 >= 1 && (B + rpl4 - 1) / rpl4 <= max_chunks;
-    }
+    // groups of four workgroups, one row per group (lstm_rec_bwd4_kernel): the same predicate as the forward's (csrc/lstm.hip) --
+    // the pair shares the 20-byte split record format
+    const bool g4 = asr_lstm_g4_selected(B, H, ndir);
     if (p3_dg && !g4) return ASR_EUNSUPPORTED;            // only the groups-of-four BPTT writes planes
     if (g4) {
         const int rpl4 = asr_lstm_max_wgs() / (4 * ndir);
@@ -1180,7 +1186,8 @@ extern "C" int asr_lstm_layer_bwd_p3(void* stream, const float* x, int B, int T,
             c.boff = b0;
             c.gates = gates + (size_t)b0 * T * ndir * H4;
             if (a.dg_p3) c.dg_p3 = a.dg_p3 + (size_t)b0 * T * (ndir * H4 / 8) * 16 * a.p3_np;
-            c.act = act + (size_t)b0 * T * ndir * H * 8;
+            c.act = act + (size_t)b0 * T * ndir * H * 4;                       // gates plane, then the c plane (csrc/lstm.hip)
+            c.act_c = act + (size_t)B * T * ndir * H * 4 + (size_t)b0 * T * ndir * H;
             c.dout = dout + (size_t)b0 * Tout * ndir * H;
             c.len = len + b0;
             const int groups = ndir * c.B;
@@ -1307,7 +1314,7 @@ int asr_lstm_rec_bwd_tm(hipStream_t s, float* gates, const float* act, const flo
     a.B = B; a.T = T; a.Tout = T; a.ND = 1; a.boff = 0; a.keep = keep; a.seed = seed;
     a.sb = 1; a.st = B; a.osb = 1; a.ost = B; a.ldo = ldo; a.dsb = 1; a.dst = B;
     a.dbg = nullptr; a.db_part = nullptr;
-    a.dg_p3 = nullptr; a.p3_np = 0; a.dg_f32 = 1;
+    a.dg_p3 = nullptr; a.p3_np = 0; a.dg_f32 = 1; a.act_c = nullptr;
     const int R = asr_lstm_pick_rows(B, 1, H / 32);
     switch (H) {
         case 64: return launch_bwd_h<64>(s, a, R);
