@@ -690,11 +690,22 @@ __global__ __launch_bounds__(512) void lstm_rec_fwd4_kernel(LstmRecArgs a) {
     u64* hxg = a.hx + (size_t)grp * 2 * H;             // [2 parities][H] granules
     const bool fast = group_shares_xcd(a.xcc_slots + (size_t)grp * 16, G, mem, tid, a.err, nullptr, (uint32_t)a.ep0, 4);
     float gx0 = 0.f, gx1 = 0.f, gx2 = 0.f, gx3 = 0.f;
+    // per-thread base pointers + 32-bit element offsets per step (the cell wave is the wave the others wait for: 64-bit index
+    // arithmetic for each of its five or six addresses per step was measurable on the BPTT's cell wave, csrc/lstm_bwd.hip)
+    const unsigned rstr = (unsigned)(a.st * a.ND * H);                 // elements of a [.., ND, H] array per time step
+    const size_t rb0 = (((size_t)cb * a.sb) * a.ND + dir) * H + cj;     // (b, t = 0, dir, unit)
+    const float* const gates_b = XIN ? nullptr : a.gates + rb0 * 4 - (size_t)cj * 3;     // ((b,0,dir) * 4H + cj)
+    // (not in the instantiation with the input projection inside: its 248 registers leave no room for four more pointers)
+    float* const out_b = XIN ? nullptr : a.out + ((size_t)cb * a.osb) * a.ldo + dir * H + cj;
+    const unsigned ostr = (unsigned)(a.ost * a.ldo);
+    float* const hprev_b = !XIN && a.hprev ? a.hprev + rb0 : nullptr;
+    float* const actg_b = !XIN && a.act ? a.act + rb0 * 4 : nullptr;
+    float* const actc_b = !XIN && a.act_c ? a.act_c + rb0 : nullptr;
     auto prefetch = [&](int s) {
         if constexpr (XIN) return;            // (gx = the bias, loaded once below)
         const int t = dir ? (S - 1 - s) : s;
-        const int ts = min(max(t, 0), a.T - 1);
-        const float* gp_ = a.gates + (((size_t)cb * a.sb + (size_t)ts * a.st) * a.ND + dir) * H4 + cj;
+        const unsigned ts = (unsigned)min(max(t, 0), a.T - 1);
+        const float* gp_ = gates_b + ts * rstr * 4u;
         gx0 = gp_[0]; gx1 = gp_[H]; gx2 = gp_[2 * H]; gx3 = gp_[3 * H];
     };
     if (cell_wave) {
@@ -778,15 +789,25 @@ __global__ __launch_bounds__(512) void lstm_rec_fwd4_kernel(LstmRecArgs a) {
                 else __hip_atomic_store(dst, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             {
-                const size_t ridx = (((size_t)cb * a.sb + (size_t)t * a.st) * a.ND + dir) * H + cj;
+                const unsigned roff = (unsigned)t * rstr;
                 float o = h;
                 if (a.keep < 1.0f)
                     o *= keep_scale(a.seed, (uint32_t)((a.boff + cb) * a.dsb + (a.toff + t) * a.dst), (uint32_t)(dir * H + cj), a.keep);
-                a.out[((size_t)cb * a.osb + (size_t)t * a.ost) * a.ldo + dir * H + cj] = o;
-                if (a.hprev) __builtin_nontemporal_store(h_old, a.hprev + ridx);
-                if (a.act) {
-                    __builtin_nontemporal_store(f32x4{gi, gj, gf, go}, reinterpret_cast<f32x4*>(a.act + ridx * 4));
-                    __builtin_nontemporal_store(c, a.act_c + ridx);
+                if constexpr (XIN) {
+                    const size_t ridx = (((size_t)cb * a.sb + (size_t)t * a.st) * a.ND + dir) * H + cj;
+                    a.out[((size_t)cb * a.osb + (size_t)t * a.ost) * a.ldo + dir * H + cj] = o;
+                    if (a.hprev) __builtin_nontemporal_store(h_old, a.hprev + ridx);
+                    if (a.act) {
+                        __builtin_nontemporal_store(f32x4{gi, gj, gf, go}, reinterpret_cast<f32x4*>(a.act + ridx * 4));
+                        __builtin_nontemporal_store(c, a.act_c + ridx);
+                    }
+                } else {
+                    out_b[(unsigned)t * ostr] = o;
+                    if (a.hprev) __builtin_nontemporal_store(h_old, hprev_b + roff);
+                    if (a.act) {
+                        __builtin_nontemporal_store(f32x4{gi, gj, gf, go}, reinterpret_cast<f32x4*>(actg_b + roff * 4u));
+                        __builtin_nontemporal_store(c, actc_b + roff);
+                    }
                 }
                 // the same values as bf16 planes for the GEMMs that consume them (no split inside their k-loops)
                 if (a.out_p3) p3_store1(a.out_p3, p3_elem_off((size_t)cb * a.osb + (size_t)t * a.ost, dir * H + cj, a.ldo >> 3, a.p3_np), o, a.p3_np, false);
