@@ -66,6 +66,7 @@ class DecGrads(C.Structure):
 
 # name -> (restype, argtypes); every symbol include/e2e_asr_hip.h declares
 SIGNATURES = {
+    "asr_masked_ce_fwd_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int]),
     "asr_p3_bytes": (C.c_size_t, [C.c_int] * 3),
     "asr_p3_split_ex": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int]),
     "asr_lstm_p3_supported": (C.c_int, [C.c_int] * 5),

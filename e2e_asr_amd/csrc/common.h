@@ -7,6 +7,9 @@
 #define ASR_EINVAL (-1)
 #define ASR_ELAUNCH (-2)
 #define ASR_EUNSUPPORTED (-3)
+// OR-ed into a workspace size argument (hx_bytes): the caller hands over memory it has ALREADY zeroed (one fill per train step
+// over an arena of all the step's exchange workspaces instead of one memset launch in front of every persistent kernel)
+#define ASR_WS_PREZEROED ((size_t)1 << 62)
 
 #define ASR_CHECK_LAUNCH()                                  \
     do {                                                    \

@@ -66,6 +66,35 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* logits, const 
     for (int v = lane; v < V; v += 64) dp[v] = sc * (expf(lp[v] - l) - (v == tg ? 1.f : 0.f));
 }
 
+// Forward rows and backward in ONE pass over the logits (training: the gradient scale is known when the loss is formed): the
+// row's log-sum-exp, its nll, and d loss / d logits while the row is still in cache -- one launch instead of two dependent
+// ones with the row read from memory again in between.
+__global__ __launch_bounds__(256) void ce_rows_bwd_kernel(const float* logits, const int* targets, const int* len,
+                                                          const float* gscale, float* nll, float* lse_out, float* dlogits,
+                                                          int T, int B, int V) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= T * B) return;
+    const int t = row / B, b = row % B;
+    const float* lp = logits + (size_t)row * V;
+    float* dp = dlogits + (size_t)row * V;
+    float m = -INFINITY;
+    for (int v = lane; v < V; v += 64) m = fmaxf(m, lp[v]);
+    m = wave_allreduce_max(m);
+    float s = 0.f;
+    for (int v = lane; v < V; v += 64) s += expf(lp[v] - m);
+    s = wave_allreduce_sum(s);
+    const float lse = m + logf(s);
+    const int tg = targets[row];
+    if (lane == 0) {
+        nll[row] = lse - ((tg >= 0 && tg < V) ? lp[tg] : 0.f);
+        if (lse_out) lse_out[row] = lse;
+    }
+    if (t >= len[b]) { for (int v = lane; v < V; v += 64) dp[v] = 0.f; return; }
+    const float sc = gscale[0] / ((float)len[b] * (float)B);
+    for (int v = lane; v < V; v += 64) dp[v] = sc * (expf(lp[v] - lse) - (v == tg ? 1.f : 0.f));
+}
+
 // argmax with first-max tie-breaking (tf.argmax / np.argmax); optional Gumbel-max sampling
 // (tf.multinomial draws from softmax(logits); decoder.py:176-177).
 __global__ __launch_bounds__(256) void next_token_kernel(const float* logits, int V, int ldl, int* tok_out,
@@ -120,6 +149,19 @@ extern "C" int asr_masked_ce_fwd(void* stream, const float* logits, const int* t
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int rows = T * B;
     hipLaunchKernelGGL(asr::ce_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, logits, targets, nll_ws, lse_ws, rows, V);
+    hipLaunchKernelGGL(asr::ce_reduce_kernel, dim3(1), dim3(256), 0, s, nll_ws, len, loss, T, B);
+    ASR_CHECK_LAUNCH();
+    return ASR_OK;
+}
+
+// asr_masked_ce_fwd + asr_masked_ce_bwd in one pass over the logits (losses.py:20-35 and its gradient): the same values, bit for bit
+extern "C" int asr_masked_ce_fwd_bwd(void* stream, const float* logits, const int* targets, const int* len, const float* grad_scale,
+                                     float* nll_ws, float* lse_ws, float* loss, float* dlogits, int T, int B, int V) {
+    if (!logits || !targets || !len || !grad_scale || !nll_ws || !loss || !dlogits || T <= 0 || B <= 0 || V <= 0) return ASR_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int rows = T * B;
+    hipLaunchKernelGGL(asr::ce_rows_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, logits, targets, len, grad_scale, nll_ws, lse_ws,
+                       dlogits, T, B, V);
     hipLaunchKernelGGL(asr::ce_reduce_kernel, dim3(1), dim3(256), 0, s, nll_ws, len, loss, T, B);
     ASR_CHECK_LAUNCH();
     return ASR_OK;

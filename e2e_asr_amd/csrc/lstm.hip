@@ -977,6 +977,8 @@ extern "C" int asr_lstm_layer_fwd_p3(void* stream, const float* x, int B, int T,
     if (ndir == 2 && (!kernel_bw || !bias_bw)) return ASR_EINVAL;
     if (B <= 0 || T <= 0 || in_dim <= 0 || Tout < T || ldx < in_dim) return ASR_EINVAL;
     if (H != 64 && H != 128 && H != 256 && H != 512) return ASR_EUNSUPPORTED;
+    const bool prezeroed = (hx_bytes & ASR_WS_PREZEROED) != 0;
+    hx_bytes &= ~ASR_WS_PREZEROED;
     if (hx_bytes < asr_lstm_ws_bytes(B, H, ndir)) return ASR_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int H4 = 4 * H;
@@ -1010,7 +1012,7 @@ extern "C" int asr_lstm_layer_fwd_p3(void* stream, const float* x, int B, int T,
                               gates + (size_t)d * H4, ndir * H4, d ? bias_bw : bias_fw, 0);
         if (rc) return rc;
     }
-    if (hipMemsetAsync(hx_ws, 0, asr_lstm_ws_bytes(B, H, ndir), s) != hipSuccess) return ASR_ELAUNCH;
+    if (!prezeroed && hipMemsetAsync(hx_ws, 0, asr_lstm_ws_bytes(B, H, ndir), s) != hipSuccess) return ASR_ELAUNCH;
     LstmRecArgs a;
     a.gates = gates;
     a.kh[0] = kernel_fw + (size_t)in_dim * H4;

@@ -1143,6 +1143,8 @@ extern "C" int asr_lstm_layer_bwd_p3(void* stream, const float* x, int B, int T,
     if (ndir != 1 && ndir != 2) return ASR_EINVAL;
     if (ndir == 2 && (!kernel_bw || !dkernel_bw || !dbias_bw)) return ASR_EINVAL;
     if (H != 64 && H != 128 && H != 256 && H != 512) return ASR_EUNSUPPORTED;
+    const bool prezeroed = (hx_bytes & ASR_WS_PREZEROED) != 0;
+    hx_bytes &= ~ASR_WS_PREZEROED;
     if (hx_bytes < asr_lstm_bwd_ws_bytes(B, H, ndir)) return ASR_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int H4 = 4 * H, G = H / 32;
@@ -1180,7 +1182,7 @@ extern "C" int asr_lstm_layer_bwd_p3(void* stream, const float* x, int B, int T,
         if (!a.db_part) a.db_part = reinterpret_cast<float*>(static_cast<char*>(hx_ws) + lstm_bwd_sync_bytes(B, H, ndir));
         db_part = a.db_part;
         for (int b0 = 0; b0 < B; b0 += rpl4) {
-            if (hipMemsetAsync(hx_ws, 0, lstm_bwd_sync_bytes(B, H, ndir), s) != hipSuccess) return ASR_ELAUNCH;
+            if (!(prezeroed && b0 == 0) && hipMemsetAsync(hx_ws, 0, lstm_bwd_sync_bytes(B, H, ndir), s) != hipSuccess) return ASR_ELAUNCH;
             LstmBwdArgs c = a;
             c.B = (B - b0 < rpl4) ? (B - b0) : rpl4;
             c.boff = b0;
@@ -1200,7 +1202,7 @@ extern "C" int asr_lstm_layer_bwd_p3(void* stream, const float* x, int B, int T,
         }
     } else
     for (int b0 = 0; b0 < B; b0 += rows_per_launch) {
-        if (hipMemsetAsync(hx_ws, 0, lstm_bwd_sync_bytes(B, H, ndir), s) != hipSuccess) return ASR_ELAUNCH;
+        if (!(prezeroed && b0 == 0) && hipMemsetAsync(hx_ws, 0, lstm_bwd_sync_bytes(B, H, ndir), s) != hipSuccess) return ASR_ELAUNCH;
         LstmBwdArgs c = a;
         c.B = (B - b0 < rows_per_launch) ? (B - b0) : rows_per_launch;
         c.boff = b0;

@@ -278,7 +278,7 @@ def lstm_layer_fwd(x, seq_len, kernel_fw, bias_fw, kernel_bw=None, bias_bw=None,
     hprev = torch.empty((B, T, ndir, H), device=dev, dtype=torch.float32) if save and not (p3 and p3.get("hprev") is not None) else None
     L = _lib.lib()
     nbytes = L.asr_lstm_ws_bytes(B, H, ndir)
-    hx = _hx(dev, nbytes)
+    hx, nbytes = _hx_zeroed(dev, nbytes)
     if ndir == 2 and _KXCAT >= 1:       # input rows of the two kernels side by side: both directions' projection as ONE product (N = 8H)
         if kx_cat is None or bias_cat is None:      # (the encoder passes all its layers' concatenations, built by one launch)
             kx_cat = torch.cat([kernel_fw[:IN], kernel_bw[:IN]], 1)
@@ -302,6 +302,35 @@ def _hx(dev, nbytes):
     if key not in _hx_cache:
         _hx_cache[key] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     return _hx_cache[key]
+
+
+WS_PREZEROED = 1 << 62          # include/e2e_asr_hip.h ASR_WS_PREZEROED
+_arena = {}
+
+
+def ws_arena_begin(dev, nbytes=24 << 20):
+    """One zero fill for all the exchange workspaces of a train step (Seq2SeqModel.step): the persistent launches then take
+    slices of it (`_hx_zeroed`) instead of each running a memset launch in front of its kernel -- ~10 dependent launches of
+    4-5 us per step.  ASR_WS_ARENA=0 turns it off."""
+    if os.environ.get("ASR_WS_ARENA", "1") == "0" or dev.type != "cuda":
+        _arena.pop(dev, None)
+        return
+    _arena[dev] = [torch.zeros(nbytes, dtype=torch.uint8, device=dev), 0]
+
+
+def ws_arena_end(dev):
+    _arena.pop(dev, None)
+
+
+def _hx_zeroed(dev, nbytes):
+    """(buffer, size argument): a slice of the step's zeroed arena + the PREZEROED flag, or the cached buffer the library zeroes."""
+    a = _arena.get(dev)
+    if a is not None:
+        off = (a[1] + 255) // 256 * 256
+        if off + nbytes <= a[0].numel():
+            a[1] = off + nbytes
+            return a[0][off:off + nbytes], nbytes | WS_PREZEROED
+    return _hx(dev, nbytes), nbytes
 
 
 def lstm_layer_bwd(x, seq_len, kernel_fw, kernel_bw, dout, gates, act, hprev, dk_fw, db_fw, dk_bw=None,
@@ -334,16 +363,16 @@ def lstm_layer_bwd(x, seq_len, kernel_fw, kernel_bw, dout, gates, act, hprev, dk
         return dx
     dx = torch.empty_like(x) if need_dx else None
     L = _lib.lib()
-    nbytes = L.asr_lstm_bwd_ws_bytes(B, H, ndir)
+    hxb, nbytes = _hx_zeroed(dev, L.asr_lstm_bwd_ws_bytes(B, H, ndir))
     st = _lstm_p3_struct(p3)
     rc = L.asr_lstm_layer_bwd_p3(_stream(), _p(x), B, T, IN, IN, _p(seq_len), H, ndir, _p(kernel_fw), _p(kernel_bw),
                                  _p(_f32(dout, "dout")), dout.shape[1], _p(gates), _p(act), _p(hprev), _p(dx),
-                                 _p(dk_fw), _p(db_fw), _p(dk_bw), _p(db_bw), _p(_hx(dev, nbytes)), nbytes,
+                                 _p(dk_fw), _p(db_fw), _p(dk_bw), _p(db_bw), _p(hxb), nbytes,
                                  _p(_Flag.get(dev)), float(keep_prob), int(seed) & 0xFFFFFFFF,
                                  _p(kx_cat if (ndir == 2 and need_dx and _KXCAT >= 2) else None),
                                  C.byref(st) if st is not None else None)
     _check(rc, "asr_lstm_layer_bwd")
-    keep_until_join(x, dout, gates, act, hprev, seq_len, kx_cat, p3)
+    keep_until_join(x, dout, gates, act, hprev, seq_len, kx_cat, p3, hxb)
     if join:          # weight/bias gradients are produced on the library's side stream
         side_join()
     return dx
@@ -519,6 +548,21 @@ def masked_ce(logits, targets, seq_len):
                                       _p(loss), T, B, V)
     _check(rc, "asr_masked_ce_fwd")
     return loss, lse
+
+
+def masked_ce_fwd_bwd(logits, targets, seq_len, grad_scale):
+    """losses.py:7-35 forward AND its gradient in one pass over the logits -> (loss, lse, dlogits)."""
+    _f32(logits, "logits"); _i32(targets, "targets"); _i32(seq_len, "seq_len"); _f32(grad_scale, "grad_scale")
+    T, B = targets.shape
+    V = logits.shape[1]
+    dev = logits.device
+    nll = torch.empty(T * B, device=dev, dtype=torch.float32)
+    lse = torch.empty(T * B, device=dev, dtype=torch.float32)
+    loss = torch.empty(1, device=dev, dtype=torch.float32)
+    d = torch.empty_like(logits)
+    _check(_lib.lib().asr_masked_ce_fwd_bwd(_stream(), _p(logits), _p(targets), _p(seq_len), _p(grad_scale), _p(nll), _p(lse),
+                                            _p(loss), _p(d), T, B, V), "asr_masked_ce_fwd_bwd")
+    return loss, lse, d
 
 
 def masked_ce_bwd(logits, targets, lse, seq_len, grad_scale):

@@ -161,10 +161,13 @@ class Seq2SeqModel(BaseParams):
                                      self.encoder_hidden_states[d], self.seq_len_encs[d])
         if self.isTraining:
             self.losses = {}
+            if getattr(self, "_gscale", None) is None:          # d total_loss / d task loss: constant for the model's life
+                self._gscale = torch.full((1,), 1.0 / len(params.tasks) if params.avg else 1.0, device=self.device)
             for task in params.tasks:
                 T_out = self.decoder[task].saved["t_out"]
                 self.losses[task], self._loss_ws[task] = LossUtils.cross_entropy_loss(
-                    self.outputs[task], self.targets[task][:T_out], self.seq_len_target[task], return_ws=True)
+                    self.outputs[task], self.targets[task][:T_out], self.seq_len_target[task], return_ws=True,
+                    grad_scale=self._gscale)          # (the logit gradient in the same pass over the logits)
             total = None
             for task in params.tasks:                               # :140-144
                 total = self.losses[task] if total is None else total + self.losses[task]
@@ -188,7 +191,9 @@ class Seq2SeqModel(BaseParams):
         d_states = {}
         for task in params.tasks:
             lw = self._loss_ws[task]
-            dlogits = ops.masked_ce_bwd(self.outputs[task], lw["targets"], lw["lse"], lw["len"], gscale)
+            dlogits = lw.pop("dlogits", None)
+            if dlogits is None:
+                dlogits = ops.masked_ce_bwd(self.outputs[task], lw["targets"], lw["lse"], lw["len"], gscale)
             d = params.num_layers[task]
             if d not in d_states:
                 d_states[d] = torch.zeros_like(self.decoder[task].saved["enc"])
@@ -222,8 +227,12 @@ class Seq2SeqModel(BaseParams):
         dict (device scalars; no host synchronisation inside the step)."""
         if not self.isTraining:
             raise ValueError("step() needs a model built with isTraining=True")
-        self.forward(batch)
-        self.backward()
+        ops.ws_arena_begin(self.device)           # one zero fill for the step's exchange workspaces
+        try:
+            self.forward(batch)
+            self.backward()
+        finally:
+            ops.ws_arena_end(self.device)
         self.apply_gradients()
         return self.losses
 

@@ -76,6 +76,11 @@ int asr_p3_split_ex(void* stream, const float* src, int rows, int cols, int ld, 
 int asr_gemm_p3_rr(void* stream, int M, int N, int K, const void* A, int lda8, const void* B, int ldb8, int np,
                    float* C, int ldc, int accumulate, int splits, const int* colmap);
 
+/* Workspace sizes (hx_bytes arguments) may carry this flag: the caller has ALREADY zeroed the workspace (e.g. one fill per train
+ * step over an arena of all the step's exchange workspaces) and the library skips its memset launch in front of the persistent
+ * kernel.  Each call needs its own zeroed region: a persistent launch leaves its workspace dirty. */
+#define ASR_WS_PREZEROED ((size_t)1 << 62)
+
 /* One (Bi)LSTM encoder layer over a whole padded batch -- encoder.py:55-91
  * (bidirectional_dynamic_rnn / dynamic_rnn over BasicLSTMCell with sequence_length).
  * x [B,T,in] batch-major (row stride ldx); out [B,Tout,ndir*H] with fw in [:H], bw in
@@ -204,6 +209,10 @@ int asr_attention_shared_fwd(void* stream, const float* q, int ldq, const float*
                              const float* enc, const int* enc_len, float* alpha, float* ctx,
                              int B, int Te, int H, int A, int D, int shared);
 
+/* asr_masked_ce_fwd and asr_masked_ce_bwd in ONE pass over the logits (the training step knows the gradient scale when it forms
+ * the loss): same loss, lse and dlogits bit for bit, one launch less and the logits read once (losses.py:20-35). */
+int asr_masked_ce_fwd_bwd(void* stream, const float* logits, const int* targets, const int* len, const float* grad_scale,
+                          float* nll_ws, float* lse_ws, float* loss, float* dlogits, int T, int B, int V);
 /* losses.py:7-35.  logits [T*B,V] time-major; targets [T,B]; nll_ws,lse_ws [T*B]. */
 int asr_masked_ce_fwd(void* stream, const float* logits, const int* targets, const int* len,
                       float* nll_ws, float* lse_ws, float* loss, int T, int B, int V);
