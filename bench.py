@@ -69,21 +69,29 @@ def decoder_flop_fwd(te, steps, vocab, D=512, A=128, E=256, Hd=256):
     return B * (steps * per_step + 2 * te * D * A)
 
 
-def gemm_roofline(dev):
+def gemm_roofline(dev, form="nn"):
     """Second roofline line, for the throughput-bound kernel family (all GEMMs together are ~30 % of the GPU time):
     the layer-2 input projection [B*T/2, 1024] x [1024, 4H] of config 2, alone on the chip, HIP events on the
-    current stream (the stream the kernel is launched on)."""
+    current stream (the stream the kernel is launched on).  form "tn": the weight gradient of the same layer, dK_x = X^T . dG
+    ([1024, B*T/2]^T x [B*T/2, 4H], split-K with float atomics -- the largest row of the kernel statistics); "nt": its data
+    gradient dX = dG . K_x^T over both directions ([B*T/2, 8H] x [1024, 8H]^T)."""
     import torch
     from e2e_asr_amd import ops
     M, N, K = B * ENC_LAYER_T[1], 4 * H, ENC_LAYER_IN[1]
-    a = torch.randn(M, K, device=dev); b = torch.randn(K, N, device=dev); c = torch.empty(M, N, device=dev)
+    ta = tb = False
+    if form == "tn":
+        M, N, K, ta = ENC_LAYER_IN[1], 4 * H, B * ENC_LAYER_T[1], True
+    elif form == "nt":
+        M, N, K, tb = B * ENC_LAYER_T[1], ENC_LAYER_IN[1], 8 * H, True
+    a = torch.randn((K, M) if ta else (M, K), device=dev); b = torch.randn((N, K) if tb else (K, N), device=dev)
+    c = torch.zeros(M, N, device=dev)
     for _ in range(3):
-        ops.gemm(a, b, None, False, False, out=c)
+        ops.gemm(a, b, None, ta, tb, out=c, accumulate=ta)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     n = 10
     e0.record()
     for _ in range(n):
-        ops.gemm(a, b, None, False, False, out=c)
+        ops.gemm(a, b, None, ta, tb, out=c, accumulate=ta)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / n
     tf = 2.0 * M * N * K / (ms * 1e-3) / 1e12
@@ -93,12 +101,15 @@ def gemm_roofline(dev):
     # peaks (MI355X_MICROARCH.md): dense bf16 MFMA ~2.5 PFLOP/s; fp32-input MFMA 157.3 TFLOP/s (1/16 of it).  The split3
     # kernel issues 6 bf16 MFMA products per fp32-equivalent product: its ceiling is 2500 / 6 = 416.7 TFLOP/s fp32-equivalent.
     peak = (2500.0 if prec == "bf16" else 2500.0 / 3.0) if bf16 else (2500.0 / 6.0 if split else PEAK_F32_MFMA_TFLOPS)
-    name = ("gemm_planes_kernel<NN, 1 plane> (fp32 operands rounded to bf16 on the way into LDS)" if prec == "bf16" else
-            "gemm_planes_kernel<NN, 2 planes> (bf16x2: three bf16 MFMA products per product; peak = bf16 dense peak / 3)" if bf16 else
-            "gemm_planes_kernel<NN, 3 planes> = split3 (fp32-accurate: operands split exactly into 3 bf16 planes, 6 bf16 MFMA products, fp32 "
-            "accumulate; achieved/peak in fp32-equivalent TFLOP/s, peak = bf16 dense peak / 6)" if split else
-            "gemm_f32_kernel<NN,128,full> (v_mfma_f32_32x32x2_f32)")
-    return {"bound": "mfma", "kernel": "%s layer-2 input projection %dx%dx%d" % (name, M, N, K),
+    F = form.upper()
+    name = ("gemm_planes_kernel<%s, 1 plane> (fp32 operands rounded to bf16 on the way into LDS)" % F if prec == "bf16" else
+            "gemm_planes_kernel<%s, 2 planes> (bf16x2: three bf16 MFMA products per product; peak = bf16 dense peak / 3)" % F if bf16 else
+            "gemm_planes_kernel<%s, 3 planes> = split3 (fp32-accurate: operands split exactly into 3 bf16 planes, 6 bf16 MFMA products, fp32 "
+            "accumulate; achieved/peak in fp32-equivalent TFLOP/s, peak = bf16 dense peak / 6)" % F if split else
+            "gemm_f32_kernel<%s,128,full> (v_mfma_f32_32x32x2_f32)" % F)
+    what = {"nn": "layer-2 input projection", "tn": "layer-2 weight gradient dK_x (split-K, float atomics)",
+            "nt": "layer-2 data gradient dX (both directions, K = 8H)"}[form]
+    return {"bound": "mfma", "kernel": "%s %s %dx%dx%d" % (name, what, M, N, K),
             "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak, "avg_launch_ms": ms,
             "vs_fp32_mfma_peak": tf / PEAK_F32_MFMA_TFLOPS}
 
@@ -539,6 +550,8 @@ def main():
     if comm is not None:
         out["comm"] = comm
     out["roofline_gemm"] = gemm_roofline(dev)
+    out["roofline_gemm_tn"] = gemm_roofline(dev, "tn")
+    out["roofline_gemm_nt"] = gemm_roofline(dev, "nt")
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(multitask_depth=mt)
     sys.stdout.flush()

@@ -22,6 +22,10 @@ class Decoder(BaseParams):
         self.scope = scope              # task name: variables live under model/rnn_decoder_<scope>/
         self.variables = variables
         self.rng_seed = 0
+        if not self.params.use_lstm:
+            # decoder.py:56-59: the GRU branch is not built (the reference's main.py never clears use_lstm; the decoder's own
+            # default is LSTM, decoder.py:34).  Refused here, not inside the first call.
+            raise ValueError("Decoder: GRU cells (use_lstm=False) are not built; leave params.use_lstm = True (decoder.py:34)")
 
     def get_cell(self, hidden_size=None):
         """decoder.py:49-72.  The cell itself is csrc/skinny.hip's fused LSTM epilogue."""

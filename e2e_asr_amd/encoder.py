@@ -34,10 +34,20 @@ class Encoder(BaseParams):
         self.variables = variables
         self.saved = None          # per-layer activations for the backward pass
         self.dropout_seed = 0
+        self._require_lstm()
+
+    def _require_lstm(self):
+        """The GRU branch of encoder.py:45-48 is not built: the reference CLI cannot reach it (`--use_lstm` is
+        `default=True, action="store_true"`, encoder.py:187), although `class_params()` itself says GRU (encoder.py:27).  Refused at
+        construction, with what to set, instead of somewhere inside the first call."""
+        if not self.params.use_lstm:
+            raise ValueError("Encoder: GRU cells (use_lstm=False, the class_params() default) are not built; set "
+                             "params.use_lstm = True as the reference's main.py always does (encoder.py:187)")
 
     def get_cell(self):
         """encoder.py:42-53.  The cell is realised inside csrc/lstm.hip; only LSTM exists
         (the GRU branch is unreachable from the reference CLI, encoder.py:187)."""
+        self._require_lstm()
         if not self.params.use_lstm:
             raise NotImplementedError("GRUCell encoder: not on the hot path (reference CLI always sets use_lstm)")
         return "BasicLSTMCell(%d)" % self.params.hidden_size

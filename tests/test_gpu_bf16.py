@@ -135,8 +135,10 @@ def test_model_bf16_logits_and_gradients_close_to_fp64_oracle():
         assert cos > 0.995, (n, cos)
 
 
-@pytest.mark.parametrize("prec,tol", [("bf16", 1e-3), ("bf16-one-plane-everywhere", 5e-3), ("bf16x2", 1e-3)])
-def test_config3_full_size_logits_vs_oracle(prec, tol):
+@pytest.mark.parametrize("prec,tol,seed,wscale", [("bf16", 1e-3, 17, 1.0), ("bf16", 1e-3, 23, 1.0), ("bf16", 1e-3, 31, 1.0),
+                                                   ("bf16", 5e-3, 17, 1.5),
+                                                   ("bf16-one-plane-everywhere", 5e-3, 17, 1.0), ("bf16x2", 1e-3, 17, 1.0)])
+def test_config3_full_size_logits_vs_oracle(prec, tol, seed, wscale):
     """BASELINE config 3's per-GPU workload at FULL size (B = 32, T = 800): logits against the float64 oracle.
     "bf16" = the mode `bench.py --config 3` runs: one bf16 operand plane in the encoder's products (91 % of the GEMM FLOPs), two
     in the decoder's (ops._decoder_precision), fp32 recurrences: WITHIN THE NORTH STAR'S 1e-3 (measured 0.82e-3), loss within
@@ -149,8 +151,19 @@ def test_config3_full_size_logits_vs_oracle(prec, tol):
     ops.set_decoder_bf16_planes(1 if prec == "bf16-one-plane-everywhere" else 2)
     prec = prec.split("-")[0]
     ops.set_gemm_precision(prec)
-    m = _model(feat=80, vocab={"char": 1000}, params_update=dict(max_output={"char": 120}), seed=17)
-    b = synthetic_batch(B=32, T=800, F=80, t_dec=121, vocab=1000, variable_len=True, seed=4321)
+    m = _model(feat=80, vocab={"char": 1000}, params_update=dict(max_output={"char": 120}), seed=seed)
+    if wscale != 1.0:
+        # "trained-like" weights: every LSTM kernel 1.5 x the init scale (larger pre-activations, logits 3 x larger) -- how the
+        # bf16 margin behaves away from a random init (round-3 review).  Measured (scripts/exp_bf16_scale.py, round 4): the
+        # error of bf16 mode AND of the fp32 path grow together with the scale -- x1 0.68e-3 / 2.8e-7, x1.5 3.2e-3 / 8.1e-7,
+        # x2 1.1e-2 / 1.7e-6, x3 0.12 / 2.7e-5 (max |logit| 0.27 -> 2.3): the recurrence amplifies any rounding, the ratio
+        # bf16 : fp32 stays 2 400 - 6 800.  So the 1e-3 of the north star is met by bf16 mode at init scale only; stated bound
+        # here 5e-3 at x 1.5 (two planes everywhere, `bf16x2`, stay at 1e-5).
+        with torch.no_grad():
+            for n in m.variables.names():
+                if n.endswith("/kernel") and ("basic_lstm_cell" in n):
+                    m.variables[n].mul_(wscale)
+    b = synthetic_batch(B=32, T=800, F=80, t_dec=121, vocab=1000, variable_len=True, seed=4321 + seed - 17)
     m.forward(b)
     ops.check_device_flag(torch.device(DEV))
     out = m.outputs["char"].cpu().numpy()
@@ -161,7 +174,8 @@ def test_config3_full_size_logits_vs_oracle(prec, tol):
     ops.set_decoder_bf16_planes(2)
     assert (1e-5 if prec == "bf16" else 0.0) < err < tol, err
     assert abs(m.total_loss.item() - r["total_loss"]) < 1e-2 * abs(r["total_loss"])
-    print("config-3 (%s operands) full size: max |logit diff| = %.3g" % (prec, err))
+    print("config-3 (%s operands, weight seed %d, LSTM kernels x %g) full size: max |logit diff| = %.3g (bound %.0e, margin x%.2f)" % (
+        prec, seed, wscale, err, tol, tol / max(err, 1e-30)))
 
 
 def _lstm_ref_bf16(x, lens, k, b, reverse, rb):

@@ -342,6 +342,51 @@ def test_lm_model_shares_decoder_variables_and_trains():
     assert lm.lm_global_step == 1 and m.global_step == 0
 
 
+def test_stacked_lm_shares_the_decoder_lm_stack_and_trains():
+    """lm_encoder.py:61-63: num_layers > 1 = MultiRNNCell of DropoutWrapper(BasicLSTMCell) layers under dynamic_rnn -- here L stacked
+    persistent layers on the variables of the multi-layer decoder's LM stack (weights.multi_cell_leaf): loss and every gradient
+    against float64 autograd."""
+    from e2e_asr_amd.lm_encoder import LMEncoder
+    from e2e_asr_amd.lm_model import LMModel
+    from e2e_asr_amd.weights import multi_cell_leaf
+    from oracle import torch_ref as R
+    rng = np.random.default_rng(13)
+    m = _model(enc_update=dict(hidden_size=64), num_layers={"char": 2},
+               dec_update=dict(hidden_size_dec=64, lm_hidden_size=64, emb_size=24, attention_vec_size=16, num_layers_dec=2),
+               vocab={"char": 31})
+    ep = LMEncoder.class_params()
+    ep.out_prob = 1.0; ep.lm_hidden_size = 64; ep.proj_size = 64; ep.emb_size = 24; ep.vocab_size = 31; ep.num_layers = 2
+    lm = LMModel(LMEncoder(isTraining=True, params=ep, variables=m.variables))
+    B, T = 5, 9
+    lens = np.array([9, 3, 6, 1, 9])
+    ids = np.zeros((B, T + 1), np.int64)
+    for b in range(B):
+        ids[b, :lens[b] + 1] = rng.integers(1, 31, lens[b] + 1)
+    before = m.variables.to_arrays()
+    loss = lm.step({"char": ids, "char_len": lens})
+    W = R.weights_to_torch({k: v.astype(np.float64) for k, v in before.items()})
+    pre = "model/rnn_decoder_char/"
+    h = W[pre + "decoder/embedding"][torch.tensor(ids[:, :-1].T)]            # [T,B,E]
+    for k in range(2):
+        h = R.lstm_layer(h, lens, W[pre + multi_cell_leaf("lm", k, "kernel")], W[pre + multi_cell_leaf("lm", k, "bias")])
+    logits = h.reshape(T * B, -1) @ W[pre + "rnn/OutputProjection/kernel"] + W[pre + "rnn/OutputProjection/bias"]
+    ref = R.cross_entropy_loss(logits, ids[:, 1:].T, lens)
+    np.testing.assert_allclose(loss.item(), ref.item(), rtol=2e-5)
+    ref.backward()
+    touched = []
+    for name in m.variables.names():
+        got = m.variables.grad_of(name).cpu().numpy()
+        want = W[name].grad
+        if want is None:
+            assert not got.any(), name
+        else:
+            touched.append(name)
+            assert np.abs(got - want.numpy()).max() <= 2e-3 * max(1e-3, np.abs(want.numpy()).max()), name
+    assert sorted(touched) == sorted(pre + l for l in (
+        "decoder/embedding", multi_cell_leaf("lm", 0, "kernel"), multi_cell_leaf("lm", 0, "bias"),
+        multi_cell_leaf("lm", 1, "kernel"), multi_cell_leaf("lm", 1, "bias"), "rnn/OutputProjection/kernel", "rnn/OutputProjection/bias"))
+
+
 def test_train_loop_checkpoint_resume_and_eval(tmp_path):
     """train.py:160-394 policy on a tiny synthetic task: loss falls, checkpoints carry TF names,
     best.txt/asr_err.txt are written, resume restores step/lr/weights, eval graph decodes."""
