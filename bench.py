@@ -85,13 +85,23 @@ def gemm_roofline(dev, form="nn"):
         M, N, K, tb = B * ENC_LAYER_T[1], ENC_LAYER_IN[1], 8 * H, True
     a = torch.randn((K, M) if ta else (M, K), device=dev); b = torch.randn((N, K) if tb else (K, N), device=dev)
     c = torch.zeros(M, N, device=dev)
+    npl = ops.p3_planes()            # > 0: the encoder's GEMMs run on operands their producers wrote as bf16 planes (csrc/gemm_p3.hip)
+    if npl:
+        if ta:
+            ap, bp = ops.p3_split(a, npl), ops.p3_split(b, npl)
+            run = lambda: ops.gemm_p3_rr(ap, bp, out=c, accumulate=True)
+        else:
+            ap, bp = ops.p3_split(a, npl), ops.p3_split(b, npl, transpose=not tb)
+            run = lambda: ops.gemm_p3_kk(ap, bp, None, out=c)
+    else:
+        run = lambda: ops.gemm(a, b, None, ta, tb, out=c, accumulate=ta)
     for _ in range(3):
-        ops.gemm(a, b, None, ta, tb, out=c, accumulate=ta)
+        run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     n = 10
     e0.record()
     for _ in range(n):
-        ops.gemm(a, b, None, ta, tb, out=c, accumulate=ta)
+        run()
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / n
     tf = 2.0 * M * N * K / (ms * 1e-3) / 1e12
@@ -107,6 +117,9 @@ def gemm_roofline(dev, form="nn"):
             "gemm_planes_kernel<%s, 3 planes> = split3 (fp32-accurate: operands split exactly into 3 bf16 planes, 6 bf16 MFMA products, fp32 "
             "accumulate; achieved/peak in fp32-equivalent TFLOP/s, peak = bf16 dense peak / 6)" % F if split else
             "gemm_f32_kernel<%s,128,full> (v_mfma_f32_32x32x2_f32)" % F)
+    if npl:
+        name = ("gemm_p3_kernel<%s, %d plane%s> (operands pre-split into bf16 planes by their producers: LDS-DMA staging, no conversion "
+                "in the k-loop; csrc/gemm_p3.hip)" % ("RR" if ta else "KK", npl, "" if npl == 1 else "s"))
     what = {"nn": "layer-2 input projection", "tn": "layer-2 weight gradient dK_x (split-K, float atomics)",
             "nt": "layer-2 data gradient dX (both directions, K = 8H)"}[form]
     return {"bound": "mfma", "kernel": "%s %s %dx%dx%d" % (name, what, M, N, K),

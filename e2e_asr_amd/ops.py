@@ -99,15 +99,22 @@ def p3_alloc(rows, cols, np_, dev):
 
 
 def p3_planes():
-    """Planes per value the P3 GEMMs run with in the current precision mode: 3 = fp32-accurate (the default), 2 = bf16x2,
-    1 = bf16 (BASELINE config 3); 0 = plane operands off (the default: ASR_P3=1 turns them on; or the exact-fp32 MFMA kernels were
-    asked for)."""
-    if os.environ.get("ASR_P3", "0") != "1":          # OPT-IN (round 4: measured, not adopted -- DESIGN section 4b)
-        return 0
+    """Planes per value the encoder's P3 GEMMs run with, 0 = plane operands off (the fp32 operands are split inside the GEMM).
+    Default (round 4, measured in the train step -- DESIGN section 4b): ON in bf16 mode (one plane = plain bf16 activations
+    written by the recurrent kernels: BASELINE config 3, 6.97 -> 6.70 ms per step), OFF in fp32 mode (three planes: the
+    producers' 6 bytes per value and the split passes cost what the faster k-loop gains; 8.14 against 7.85 ms) and in bf16x2.
+    ASR_P3=1 / ASR_P3=0 force it on (3 / 2 / 1 planes by mode; not with the exact-fp32 MFMA kernels) / off."""
+    e = os.environ.get("ASR_P3")
     mode = get_gemm_precision()
+    if e == "0":
+        return 0
+    if mode == "bf16":
+        return 1
+    if e != "1":
+        return 0
     if mode == "f32":
         return 3 if get_gemm_split() else 0
-    return 1 if mode == "bf16" else 2
+    return 2
 
 
 _colmap_cache = {}
