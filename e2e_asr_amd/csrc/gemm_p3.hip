@@ -421,6 +421,15 @@ extern "C" int asr_gemm_p3_kk(void* stream, int M, int N, int K, const void* A, 
     if ((long long)M * g.rbA >= (1ll << 32) || (long long)N * g.rbB >= (1ll << 32)) return ASR_EUNSUPPORTED;   // 32-bit tile offsets
     if (g.splits > 1 && !accumulate &&
         hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, s) != hipSuccess) return ASR_ELAUNCH;
+    // One plane (bf16): a 128 x 256 tile asks the LDS-DMA for 48 bytes per CU and cycle at full MFMA rate -- more than it delivers;
+    // the 256 x 256 tile of eight waves (two per SIMD, 249 registers) needs 32: 4096^3 870 -> 1 124 TF/s, the layer-2 projection
+    // 543 -> 748 (ASR_P3_TILE256=0: the four-wave tile everywhere)
+    static const int big = [] { const char* e = getenv("ASR_P3_TILE256"); return e ? atoi(e) : 1; }();
+    if (big && np == 1 && M % 256 == 0 && K % 32 == 0 && (M / 256) * (N / 256) >= 128) {
+        hipLaunchKernelGGL((gemm_p3_kernel<false, 1, 2, 4, 2>), dim3((M / 256) * (N / 256), g.splits, 1), dim3(512), 0, s, g);
+        ASR_CHECK_LAUNCH();
+        return ASR_OK;
+    }
     const dim3 grid((M / 128) * (N / 256), g.splits, 1);
     static const int dbg = [] { const char* e = getenv("ASR_P3_DBG"); return e ? atoi(e) : 0; }();
     if (np == 3 && dbg == 1) hipLaunchKernelGGL((gemm_p3_kernel<false, 3, 1, 2, 2, 1>), grid, dim3(256), 0, s, g);
@@ -485,9 +494,18 @@ int p3_lstm_wgrad(hipStream_t s, int rows, int in_pad, int in_valid, int H, int 
     g.C = dk; g.zC = dk_stride; g.bias = nullptr; g.ldc = H4; g.accumulate = 1; g.colmap = colmap;
     g.mA = in_pad; g.mA_valid = in_valid;
     g.M = in_pad + H; g.N = H4; g.K = rows;
-    const int tiles = (g.M / 128) * (g.N / 256) * ndir, nk = rows / 16;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+    // (256 x 256 tiles double the bytes every K slice adds into dK with float atomics -- 61 instead of 30 MB per launch at ~1.3 TB/s:
+    // measured in the bf16 train step, the larger tile LOSES here what it wins in the k-loop; opt-in ASR_P3_WGRAD256=1)
+    static const int big = [] { const char* e = getenv("ASR_P3_WGRAD256"); return e ? atoi(e) : 0; }();
+    if (big && np == 1 && in_pad % 256 == 0 && H % 256 == 0 && rows % 32 == 0) {       // one plane: 256 x 256 tiles (see asr_gemm_p3_kk)
+        const int tiles2 = (g.M / 256) * (g.N / 256) * ndir, nk2 = rows / 32;
+        g.splits = std::max(1, std::min(cus / tiles2, nk2 / 8));
+        hipLaunchKernelGGL((gemm_p3_kernel<true, 1, 2, 4, 2>), dim3(tiles2 / ndir, g.splits, ndir), dim3(512), 0, s, g);
+        return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
+    }
+    const int tiles = (g.M / 128) * (g.N / 256) * ndir, nk = rows / 16;
     g.splits = std::max(1, std::min(cus / tiles, nk / 8));                 // one workgroup per CU and no second round
     const dim3 grid(tiles / ndir, g.splits, ndir);
     if (np == 3)      hipLaunchKernelGGL((gemm_p3_kernel<true, 3, 1, 2, 2>), grid, dim3(256), 0, s, g);
