@@ -3,7 +3,7 @@
 # and WRITE_SIZE do not fit one pass; GRBM independent), --kernel-trace only, the program directly after `--`.
 # usage (on the GPU box, from the repo root):  bash scripts/pmc_collect.sh <outdir under gpurun_out>
 set -e
-OUT=${1:-gpurun_out/pmc_r03}
+OUT=${1:-gpurun_out/pmc_r04}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 RP="rocprofv3 --kernel-trace --output-format csv"

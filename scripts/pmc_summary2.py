@@ -104,7 +104,9 @@ traffic = {
             "over the 4 launches per step (T = 800/400/200/100).",
     "lstm_rec_bwd_bytes_per_launch": per_launch("lstm_rec_bwd4_kernel") or per_launch("lstm_rec_bwd2_kernel<256, 2") or per_launch("lstm_rec_bwd_ag_kernel<256, 2") or per_launch("lstm_rec_bwd_ag_kernel<256, 1"),
     "lstm_rec_fwd_bytes_per_launch": per_launch("lstm_rec_fwd4_kernel") or per_launch("lstm_rec_fwd2_kernel<256, 2") or per_launch("lstm_rec_fwd_kernel<256, 32, 2") or per_launch("lstm_rec_fwd_kernel<256, 32, 1"),
-    "algorithmic_bytes_per_launch": {"lstm_rec_bwd": steps * B * 2 * 13 * H * 4 // 4, "lstm_rec_fwd": steps * B * 2 * 14 * H * 4 // 4},
+    # floats per unit-step since round 4 (20-byte split records): BPTT reads {i,j,f,o} + c + dout and writes dG = 10; the forward
+    # reads x.K_x + b (4) and writes out, h_prev, {i,j,f,o}, c = 11 (rounds 1-3: 13 / 14 with the 32-byte record)
+    "algorithmic_bytes_per_launch": {"lstm_rec_bwd": steps * B * 2 * 10 * H * 4 // 4, "lstm_rec_fwd": steps * B * 2 * 11 * H * 4 // 4},
 }
 json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic_%s.json" % tag), "w"), indent=1)
 for f in glob.glob(os.path.join(src, "step_stats", "**", "*kernel_stats.csv"), recursive=True):
