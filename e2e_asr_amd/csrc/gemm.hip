@@ -882,8 +882,12 @@ extern "C" int asr_gemm_f32_batched(void* stream, int transA, int transB, int M,
         // tiles and 14 % behind at 400 (a lone workgroup on a CU multiplies a k-tile in 0.77 us, two sharing it in 0.73 us
         // each: the "rounds" a partial last round wastes are mostly not there to win back), and inside the train step the runs
         // that wait for a slot of a workgroup still queued behind the other stream's GEMM cost +0.19 ms (7.99 vs 7.80 ms).
-        const char* sk_e = getenv("ASR_GEMM_SK");
-        const int sk_on = sk_e ? atoi(sk_e) : 0;
+        static const int sk_env = [] { const char* e = getenv("ASR_GEMM_SK"); return e ? atoi(e) : 0; }();      // (read once, not per launch)
+        // stream-K numbers its launches on the HOST (a flag is raised by writing the launch's number): a captured graph would replay
+        // a stale number, so it is refused while the stream is capturing (advisor, round 3)
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        const bool capturing = sk_env && hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+        const int sk_on = capturing ? 0 : sk_env;
         static const int sk_slots = [] {
             int dev = 0, cus = 256;
             if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
