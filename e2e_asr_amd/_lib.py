@@ -57,6 +57,11 @@ class LstmP3(C.Structure):
                 ("dg_p3", vp), ("kxu_p3", vp), ("colmap", vp)]
 
 
+class P3SplitJob(C.Structure):
+    _fields_ = [("src", vp), ("rows", C.c_int), ("cols", C.c_int), ("ld", C.c_int), ("dst", vp), ("np", C.c_int),
+                ("transpose", C.c_int), ("dst_cols", C.c_int), ("unit_major_h", C.c_int)]
+
+
 class DecGrads(C.Structure):
     _fields_ = [(n, vp) for n in (
         "embedding", "attn_enc_w", "attn_v", "attn_w", "attn_b", "lm_kernel", "lm_bias",
@@ -68,6 +73,7 @@ class DecGrads(C.Structure):
 SIGNATURES = {
     "asr_masked_ce_fwd_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int]),
     "asr_p3_bytes": (C.c_size_t, [C.c_int] * 3),
+    "asr_p3_split_multi": (C.c_int, [vp, C.c_int, C.POINTER(P3SplitJob)]),
     "asr_p3_split_ex": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int]),
     "asr_lstm_p3_supported": (C.c_int, [C.c_int] * 5),
     "asr_lstm_layer_fwd_p3": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, vp, vp, vp,

@@ -398,6 +398,67 @@ extern "C" int asr_p3_split_ex(void* stream, const float* src, int rows, int col
     return ASR_OK;
 }
 
+// Up to 8 splits in ONE launch (blockIdx.y = job): the per-step weight images of all encoder layers (K_x^T for the forward
+// projections, unit-major K_x for the data gradients) -- six launches of ~9 us each otherwise, back to back on the critical path.
+struct asr_p3_split_job { const float* src; int rows, cols, ld; void* dst; int np, transpose, dst_cols, unit_major_h; };
+namespace asr {
+struct P3SplitJobs { asr_p3_split_job j[8]; };
+template <int NP>
+__device__ __forceinline__ void p3_split_job_body(const asr_p3_split_job& q, long long idx) {
+    const bool TR = q.transpose != 0;
+    const int R = q.rows, Cc = q.cols, ld = q.ld, umh = q.unit_major_h;
+    const int DR = TR ? Cc : R, DC = TR ? R : Cc, DC8 = q.dst_cols / 8;
+    if (idx >= (long long)DR * DC8) return;
+    const long long rb = (long long)DC8 * 16 * NP;
+    float x[8];
+    int dr, c8;
+    if (TR) {
+        dr = (int)(idx % DR); c8 = (int)(idx / DR);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = (c8 * 8 + j < DC) ? q.src[(size_t)(c8 * 8 + j) * ld + dr] : 0.f;
+    } else {
+        dr = (int)(idx / DC8); c8 = (int)(idx % DC8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = c8 * 8 + j;
+            int sc = c;
+            if (umh > 0) { const int d = c / (4 * umh), w = c % (4 * umh); sc = d * 4 * umh + (w & 3) * umh + (w >> 2); }
+            x[j] = c < DC ? q.src[(size_t)dr * ld + sc] : 0.f;
+        }
+    }
+    uint4 out[NP];
+    p3_split8<NP>(x, out);
+    uint4* d = reinterpret_cast<uint4*>(static_cast<char*>(q.dst) + (long long)dr * rb + (long long)c8 * (NP * 16));
+#pragma unroll
+    for (int p = 0; p < NP; ++p) d[p] = out[p];
+}
+__global__ __launch_bounds__(256) void p3_split_multi_kernel(P3SplitJobs jobs) {
+    const asr_p3_split_job& q = jobs.j[blockIdx.y];
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (q.np == 3) p3_split_job_body<3>(q, idx); else if (q.np == 2) p3_split_job_body<2>(q, idx); else p3_split_job_body<1>(q, idx);
+}
+}  // namespace asr
+extern "C" int asr_p3_split_multi(void* stream, int njobs, const asr_p3_split_job* jobs) {
+    using namespace asr;
+    if (njobs <= 0 || njobs > 8 || !jobs) return ASR_EINVAL;
+    P3SplitJobs J;
+    long long maxn = 0;
+    for (int i = 0; i < njobs; ++i) {
+        asr_p3_split_job q = jobs[i];
+        if (!q.src || !q.dst || q.rows <= 0 || q.cols <= 0 || q.ld < q.cols || q.np < 1 || q.np > 3) return ASR_EINVAL;
+        const int DR = q.transpose ? q.cols : q.rows, DC = q.transpose ? q.rows : q.cols;
+        if (q.dst_cols <= 0) q.dst_cols = (DC + 7) / 8 * 8;
+        if (q.dst_cols % 8 || q.dst_cols < DC) return ASR_EINVAL;
+        if (q.unit_major_h > 0 && (q.transpose || DC % (4 * q.unit_major_h))) return ASR_EINVAL;
+        J.j[i] = q;
+        maxn = std::max(maxn, (long long)DR * (q.dst_cols / 8));
+    }
+    for (int i = njobs; i < 8; ++i) J.j[i] = J.j[0];
+    hipLaunchKernelGGL(p3_split_multi_kernel, dim3((unsigned)((maxn + 255) / 256), njobs), dim3(256), 0, static_cast<hipStream_t>(stream), J);
+    ASR_CHECK_LAUNCH();
+    return ASR_OK;
+}
+
 extern "C" int asr_p3_split_f32(void* stream, const float* src, int rows, int cols, int ld, void* dst, int np, int transpose) {
     if ((transpose ? rows : cols) % 8) return ASR_EINVAL;
     return asr_p3_split_ex(stream, src, rows, cols, ld, dst, np, transpose, 0, 0);

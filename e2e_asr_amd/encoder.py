@@ -102,6 +102,16 @@ class Encoder(BaseParams):
         # fp32 operands inside its k-loop.  np_ = 0: off (ASR_P3=0, exact-fp32 mode, CPU tensors).
         np_ = ops.p3_planes() if x.is_cuda and params.bi_dir else 0
         x_p3 = None                                                 # P3 image of the current layer's input, if any
+        wsplit = {}                                                 # {depth: (K_x^T image, unit-major K_x image or None)}: ONE launch
+        if np_ and ahead:
+            ds = [d for d in sorted(ahead) if d > 1 and ahead[d][0] is not None]
+            jobs = [(ahead[d][0], np_, True, 0) for d in ds]
+            if save:
+                jobs += [(ahead[d][0], np_, False, ahead[d][0].shape[1] // 8) for d in ds]
+            if jobs and len(jobs) <= 8:
+                outs = ops.p3_split_many(jobs)
+                for i, d in enumerate(ds):
+                    wsplit[d] = (outs[i], outs[len(ds) + i] if save else None)
         for i in range(max_depth):
             d = i + 1
             B, T, IN = x.shape
@@ -117,7 +127,9 @@ class Encoder(BaseParams):
                 p3 = dict(np=np_)
                 if x_p3 is not None and x_p3.np == np_ and IN % 16 == 0:
                     p3["x"] = x_p3
-                    p3["kxT"] = ops.p3_split(kx, np_, transpose=True)          # K_x^T [8H][in], once per step
+                    p3["kxT"] = wsplit[d][0] if d in wsplit else ops.p3_split(kx, np_, transpose=True)     # K_x^T [8H][in], once per step
+                    if d in wsplit and wsplit[d][1] is not None:
+                        p3["kxu_ahead"] = wsplit[d][1]
                 elif save and d == 1 and IN <= 128:
                     # first layer: the frames as a 128-column image for its weight gradient (the projection itself runs
                     # inside the recurrent kernel)
@@ -187,8 +199,8 @@ class Encoder(BaseParams):
                 p3 = dict(p3)
                 p3["dg"] = ops.p3_alloc(B_ * T_, 8 * H, p3["np"], sv["x"].device)
                 p3["colmap"] = ops.p3_colmap(H, sv["x"].device)
-                if d > 1:
-                    p3["kxu"] = ops.p3_split(sv["kx"], p3["np"], unit_major_h=H)    # K_x with unit-major columns, for dX
+                if d > 1:       # K_x with unit-major columns, for dX (formed with the forward's weight images, one launch per step)
+                    p3["kxu"] = p3.get("kxu_ahead") or ops.p3_split(sv["kx"], p3["np"], unit_major_h=H)
             else:
                 p3 = None
             dx = ops.lstm_layer_bwd(sv["x"], sv["lens_dev"], kf, kb, dout.contiguous(), sv["gates"], sv["c"], sv["hprev"],

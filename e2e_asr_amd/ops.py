@@ -94,6 +94,23 @@ def p3_split(x, np_=3, transpose=False, out=None, cols=0, unit_major_h=0):
     return out
 
 
+def p3_split_many(jobs):
+    """[(x, np, transpose, unit_major_h)] -> [P3]: up to 8 splits per launch (asr_p3_split_multi)."""
+    outs = []
+    for c0 in range(0, len(jobs), 8):
+        chunk = jobs[c0:c0 + 8]
+        arr = (_lib.P3SplitJob * len(chunk))()
+        for i, (x, np_, tr, umh) in enumerate(chunk):
+            _f32(x, "x")
+            R, Cc = x.shape
+            rows, cols = (Cc, R) if tr else (R, Cc)
+            o = p3_alloc(rows, (cols + 7) // 8 * 8, np_, x.device)
+            outs.append(o)
+            arr[i] = _lib.P3SplitJob(_p(x), R, Cc, x.shape[1], _p(o.buf), np_, int(tr), o.cols, int(umh))
+        _check(_lib.lib().asr_p3_split_multi(_stream(), len(chunk), arr), "asr_p3_split_multi")
+    return outs
+
+
 def p3_alloc(rows, cols, np_, dev):
     return P3(torch.empty(int(_lib.lib().asr_p3_bytes(rows, cols, np_)), device=dev, dtype=torch.uint8), rows, cols, np_)
 

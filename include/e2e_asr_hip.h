@@ -69,6 +69,9 @@ int asr_gemm_p3_kk(void* stream, int M, int N, int K, const void* A, int lda8, c
  * the BPTT writes dG in. */
 int asr_p3_split_ex(void* stream, const float* src, int rows, int cols, int ld, void* dst, int np, int transpose,
                     int dst_cols, int unit_major_h);
+/* Up to 8 asr_p3_split_ex jobs in ONE launch (the per-step weight images of all encoder layers). */
+typedef struct { const float* src; int rows, cols, ld; void* dst; int np, transpose, dst_cols, unit_major_h; } asr_p3_split_job;
+int asr_p3_split_multi(void* stream, int njobs, const asr_p3_split_job* jobs);
 /* RR form: C[M,N] (+)= A^T . B, A = P3[K][M], B = P3[K][N] (the contraction runs over the ROWS of both: the B*T frames of a weight
  * gradient X^T . dG, seq2seq_model.py:148).  M % 128 == 0, N % 256 == 0, K % 16 == 0.  splits: K slices per output tile (0: fill
  * the chip); slices meet in C through float atomics (C zeroed first unless accumulate).  colmap (device int[N] or NULL): product
