@@ -148,3 +148,34 @@ def test_encoder_on_plane_operands_equals_default_path(monkeypatch):
     assert np.abs(res["1"][0] - res["0"][0]).max() < 2e-5
     for n, g0 in res["0"][1].items():
         assert np.abs(res["1"][1][n] - g0).max() <= 2e-4 * max(1e-30, np.abs(g0).max()), n
+
+
+@pytest.mark.parametrize("B,T", [(64, 64), (40, 64), (32, 96)])
+def test_bf16_mode_plane_path_equals_fp32_operand_path(monkeypatch, B, T):
+    """bf16 mode (BASELINE config 3) runs the encoder's GEMMs on bf16 activations written by the recurrent kernels by default
+    (one plane).  Same roundings as the path that rounds fp32 operands inside the GEMM (ASR_P3=0) -- other summation order: logits
+    to 1e-4, gradients to 1e-3 of their largest entry.  B = 64 / 40: two launches of the recurrent kernels per layer (row ranges,
+    plane pointers offset per range; 40 rows: a partial second range); ragged lengths, dropout on."""
+    from tests.test_gpu_parity3 import _model
+    from e2e_asr_amd import ops
+    from e2e_asr_amd.weights import synthetic_batch
+    b = synthetic_batch(B=B, T=T, F=80, t_dec=13, vocab=1000, variable_len=True, seed=7)
+    ops.set_gemm_precision("bf16")
+    try:
+        res = {}
+        for flag in ("0", None):
+            if flag is None:
+                monkeypatch.delenv("ASR_P3", raising=False)
+            else:
+                monkeypatch.setenv("ASR_P3", flag)
+            assert ops.p3_planes() == (0 if flag == "0" else 1)
+            m = _model(feat=80, vocab={"char": 1000}, max_output={"char": 20}, seed=9, enc_update=dict(out_prob=0.9))
+            m.forward(b); m.backward()
+            torch.cuda.synchronize()
+            ops.check_device_flag(torch.device(DEV))
+            res[flag] = (m.outputs["char"].cpu().numpy().copy(), {n: m.variables.grad_of(n).cpu().numpy().copy() for n in m.variables.names()})
+    finally:
+        ops.set_gemm_precision("f32")
+    assert np.abs(res[None][0] - res["0"][0]).max() < 1e-4
+    for n, g0 in res["0"][1].items():
+        assert np.abs(res[None][1][n] - g0).max() <= 1e-3 * max(1e-30, np.abs(g0).max()), n
