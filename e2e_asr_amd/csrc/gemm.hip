@@ -17,6 +17,7 @@
 // filled without split-K and the result stays bit-reproducible.
 #include "common.h"
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <map>
 #include <mutex>
@@ -859,6 +860,8 @@ extern "C" int asr_gemm_f32_batched(void* stream, int transA, int transB, int M,
     }
     g.splits = splits;
     g.xcd_split = 0;
+    static const bool shape_log = getenv("ASR_GEMM_LOG") != nullptr;          // diagnostic: one line per product on stderr
+    if (shape_log) fprintf(stderr, "gemm tA=%d tB=%d M=%d N=%d K=%d batch=%d splits=%d acc=%d stream=%p\n", transA, transB, M, N, K, batch, splits, accumulate, stream);
     if (splits > 1 && !accumulate) {
         if (hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, s) != hipSuccess) return ASR_ELAUNCH;
     }
