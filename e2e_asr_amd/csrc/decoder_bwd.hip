@@ -18,6 +18,7 @@
 #include "common.h"
 #include <cstdlib>
 #include <algorithm>
+#include <type_traits>
 #include "../../include/e2e_asr_hip.h"
 
 namespace asr {
@@ -169,49 +170,52 @@ __global__ __launch_bounds__(DBW_NT) void dec_attn_cell_bwd_kernel(DecBwdStepArg
         float4 dyl[CA], dvl[CA];
 #pragma unroll
         for (int c = 0; c < CA; ++c) { dyl[c] = make_float4(0.f, 0.f, 0.f, 0.f); dvl[c] = dyl[c]; }
-        const bool two = (A >> 2) <= 32;              // A <= 128: 2 chunks per lane, keep 4 passes in flight
-        for (int t0 = 0; t0 < L; t0 += RW * PP) {
-            float4 hv[PP][2], gv[PP][2];
-            if (two) {
+        // A <= 128: 2 chunks per lane, 4 passes in flight from registers (one instantiation per case: an array that only one
+        // branch fills stays a stack object -- 272 bytes of scratch stores per lane and pass that nothing read back)
+        auto passes = [&](auto two_c) {
+            constexpr bool two = decltype(two_c)::value;
+            for (int t0 = 0; t0 < L; t0 += RW * PP) {
+                float4 hv[PP][2], gv[PP][2];
 #pragma unroll
                 for (int p = 0; p < PP; ++p) {
                     const int tau = t0 + p * RW + rr;
 #pragma unroll
                     for (int c = 0; c < 2; ++c) {
                         const int a4 = kq + 16 * c;
-                        const bool ok = tau < L && a4 < (A >> 2);
+                        const bool ok = two && tau < L && a4 < (A >> 2);
                         const size_t off = ((size_t)b * Te + (ok ? tau : 0)) * A + 4 * (ok ? a4 : 0);
                         hv[p][c] = ok ? *reinterpret_cast<const float4*>(a.hf + off) : make_float4(0.f, 0.f, 0.f, 0.f);
                         gv[p][c] = ok ? *reinterpret_cast<const float4*>(a.dhf + off) : make_float4(0.f, 0.f, 0.f, 0.f);
                     }
                 }
-            }
 #pragma unroll
-            for (int p = 0; p < PP; ++p) {
-                const int tau = t0 + p * RW + rr;
-                if (tau < L) {
-                    const float de = al[tau];
+                for (int p = 0; p < PP; ++p) {
+                    const int tau = t0 + p * RW + rr;
+                    if (tau < L) {
+                        const float de = al[tau];
 #pragma unroll
-                    for (int c = 0; c < CA; ++c) {
-                        const int a4 = kq + 16 * c;
-                        if (a4 < (A >> 2) && (!two || c < 2)) {
-                            float* gp = a.dhf + ((size_t)b * Te + tau) * A + 4 * a4;
-                            float4 h4, g4;
-                            if (two) { h4 = hv[p][c & 1]; g4 = gv[p][c & 1]; }
-                            else { h4 = *reinterpret_cast<const float4*>(a.hf + ((size_t)b * Te + tau) * A + 4 * a4);
-                                   g4 = *reinterpret_cast<float4*>(gp); }
-                            const float4 yv = *reinterpret_cast<const float4*>(ys + 4 * a4);
-                            const float4 vv = *reinterpret_cast<const float4*>(a.v + 4 * a4);
-                            float th, ds;
+                        for (int c = 0; c < (two ? 2 : CA); ++c) {
+                            const int a4 = kq + 16 * c;
+                            if (a4 < (A >> 2)) {
+                                float* gp = a.dhf + ((size_t)b * Te + tau) * A + 4 * a4;
+                                float4 h4, g4;
+                                if constexpr (two) { h4 = hv[p][c & 1]; g4 = gv[p][c & 1]; }
+                                else { h4 = *reinterpret_cast<const float4*>(a.hf + ((size_t)b * Te + tau) * A + 4 * a4);
+                                       g4 = *reinterpret_cast<float4*>(gp); }
+                                const float4 yv = *reinterpret_cast<const float4*>(ys + 4 * a4);
+                                const float4 vv = *reinterpret_cast<const float4*>(a.v + 4 * a4);
+                                float th, ds;
 #define ASR_TB(f) th = fast_tanh(h4.f + yv.f); ds = de * vv.f * (1.f - th * th); g4.f += ds; dyl[c].f += ds; dvl[c].f = fmaf(de, th, dvl[c].f);
-                            ASR_TB(x) ASR_TB(y) ASR_TB(z) ASR_TB(w)
+                                ASR_TB(x) ASR_TB(y) ASR_TB(z) ASR_TB(w)
 #undef ASR_TB
-                            *reinterpret_cast<float4*>(gp) = g4;
+                                *reinterpret_cast<float4*>(gp) = g4;
+                            }
                         }
                     }
                 }
             }
-        }
+        };
+        if ((A >> 2) <= 32) passes(std::true_type{}); else passes(std::false_type{});
         // reduce the RW DPP rows of the block through LDS, fixed order
         __syncthreads();
         float* pdy = part;                 // [RW rows][A]

@@ -896,7 +896,9 @@ static int launch_rec_h(hipStream_t s, const LstmRecArgs& a, int R) {
         case 1: return launch_rec<H, 1>(s, a);
         case 2: return launch_rec<H, 2>(s, a);
         case 4: return launch_rec<H, 4>(s, a);
-        case 8: return launch_rec<H, 8>(s, a);
+        case 8:
+            if constexpr (H == 512) return ASR_EUNSUPPORTED;     // (would spill: the caller runs four rows per group in twice the launches)
+            else return launch_rec<H, 8>(s, a);
     }
     return ASR_EINVAL;
 }
@@ -1057,7 +1059,10 @@ extern "C" int asr_lstm_layer_fwd_p3(void* stream, const float* x, int B, int T,
         }
         return ASR_OK;
     }
-    const int R = asr_lstm_pick_rows(B, ndir, H / 32);
+    int R = asr_lstm_pick_rows(B, ndir, H / 32);
+    // H = 512: eight rows per group need 256 registers + scratch; four rows in twice the launches take the same time (B = 64:
+    // 5.80 against 5.85 ms for an 800-step layer) without it
+    if (H == 512 && R > 4) R = 4;
     // batches too large for one resident grid run as consecutive launches over row ranges
     const int max_groups = asr_lstm_max_wgs() / (H / 32) / ndir;
     if (max_groups < 1) return ASR_EUNSUPPORTED;      // one group (both directions) cannot be co-resident on this device
@@ -1096,7 +1101,8 @@ extern "C" int asr_lstm_layer_fwd_p3(void* stream, const float* x, int B, int T,
 bool asr_lstm_tm_supported(int B, int H) {
     if (H != 64 && H != 128 && H != 256 && H != 512) return false;
     const int G = H / 32;
-    const int R = asr_lstm_pick_rows(B, 1, G);
+    int R = asr_lstm_pick_rows(B, 1, G);
+    if (H == 512 && R > 2) R = 2;          // the BPTT's cap (csrc/lstm_bwd.hip): forward and backward take the same batches
     return ((B + R - 1) / R) * G <= asr_lstm_max_wgs();
 }
 int asr_lstm_rec_fwd_tm(hipStream_t s, const float* gates, const float* kh, const int* full_len, float* out, int ldo,
@@ -1115,7 +1121,8 @@ int asr_lstm_rec_fwd_tm(hipStream_t s, const float* gates, const float* kh, cons
     a.h0 = h0; a.c0 = c0; a.h_last = h_last; a.c_last = c_last; a.ep0 = toff;
     a.x = nullptr; a.ldx = 0; a.kx[0] = a.kx[1] = nullptr; a.bias[0] = a.bias[1] = nullptr;
     a.out_p3 = a.hprev_p3 = nullptr; a.p3_np = 0; a.act_c = nullptr;
-    const int R = asr_lstm_pick_rows(B, 1, H / 32);
+    int R = asr_lstm_pick_rows(B, 1, H / 32);
+    if (H == 512 && R > 4) R = 4;          // (asr_lstm_tm_supported has checked that the batch fits)
     switch (H) {
         case 64: return launch_rec_h<64>(s, a, R);
         case 128: return launch_rec_h<128>(s, a, R);

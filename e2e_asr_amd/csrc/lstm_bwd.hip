@@ -1062,8 +1062,14 @@ static int launch_bwd_h(hipStream_t s, const LstmBwdArgs& a, int R) {
     switch (R) {
         case 1: hipLaunchKernelGGL((lstm_rec_bwd_kernel<H, 1>), dim3(grid), dim3(512), 0, s, a); break;
         case 2: hipLaunchKernelGGL((lstm_rec_bwd_kernel<H, 2>), dim3(grid), dim3(512), 0, s, a); break;
-        case 4: hipLaunchKernelGGL((lstm_rec_bwd_kernel<H, 4>), dim3(grid), dim3(512), 0, s, a); break;
-        case 8: hipLaunchKernelGGL((lstm_rec_bwd_kernel<H, 8>), dim3(grid), dim3(512), 0, s, a); break;
+        case 4:
+            if constexpr (H == 512) return ASR_EUNSUPPORTED;       // (spilling instantiations: never selected, see asr_lstm_layer_bwd_p3)
+            else hipLaunchKernelGGL((lstm_rec_bwd_kernel<H, 4>), dim3(grid), dim3(512), 0, s, a);
+            break;
+        case 8:
+            if constexpr (H == 512) return ASR_EUNSUPPORTED;
+            else hipLaunchKernelGGL((lstm_rec_bwd_kernel<H, 8>), dim3(grid), dim3(512), 0, s, a);
+            break;
         default: return ASR_EINVAL;
     }
     return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
@@ -1162,7 +1168,7 @@ extern "C" int asr_lstm_layer_bwd_p3(void* stream, const float* x, int B, int T,
     int R = asr_lstm_pick_rows(B, ndir, G);
     // H = 512: the reduce-scatter kernel for four or eight rows per group spills (256 registers + 200-768 bytes of scratch: 9.6 us
     // per step at B = 32); two rows per group through the all-gather kernel in twice the launches are 4.0 us per step of a layer
-    if (H == 512 && R > 2 && !getenv("ASR_LSTM_R")) R = 2;
+    if (H == 512 && R > 2) R = 2;
     // the all-gather kernel (R <= 2) sums dG over time per utterance itself: the bias gradient is then a colsum over B rows
     // instead of over B*T rows of dG (0.4 GB of side-stream reads per step at config 2)
     static const bool ag_env = [] { const char* e = getenv("ASR_BPTT_AG"); return !(e && e[0] == '0'); }();
@@ -1317,7 +1323,8 @@ int asr_lstm_rec_bwd_tm(hipStream_t s, float* gates, const float* act, const flo
     a.sb = 1; a.st = B; a.osb = 1; a.ost = B; a.ldo = ldo; a.dsb = 1; a.dst = B;
     a.dbg = nullptr; a.db_part = nullptr;
     a.dg_p3 = nullptr; a.p3_np = 0; a.dg_f32 = 1; a.act_c = nullptr;
-    const int R = asr_lstm_pick_rows(B, 1, H / 32);
+    int R = asr_lstm_pick_rows(B, 1, H / 32);
+    if (H == 512 && R > 2) R = 2;          // (asr_lstm_tm_supported has checked that the batch fits)
     switch (H) {
         case 64: return launch_bwd_h<64>(s, a, R);
         case 128: return launch_bwd_h<128>(s, a, R);

@@ -44,5 +44,5 @@ for T, IN in ((800, 80), (400, 1024), (100, 1024)):
         torch.cuda.synchronize()
     f_ms, f_n = ops.prof_read("lstm_rec_fwd")
     b_ms, b_n = ops.prof_read("lstm_rec_bwd")
-    print("T=%4d in=%4d  fwd %.3f us/step (%d launches)   bwd %.3f us/step (%d launches)" % (
-        T, IN, f_ms / f_n / T * 1e3, f_n, b_ms / b_n / T * 1e3, b_n))
+    print("T=%4d in=%4d  fwd %.3f us/step (%d launches)   bwd %.3f us/step (%d launches)   per layer call: fwd %.1f us  bwd %.1f us" % (
+        T, IN, f_ms / f_n / T * 1e3, f_n, b_ms / b_n / T * 1e3, b_n, f_ms / n * 1e3, b_ms / n * 1e3))

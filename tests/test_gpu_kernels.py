@@ -56,6 +56,7 @@ def _lstm_case(rng, B, Tn, IN, H, bi, lens):
     (32, 48, 80, 256, True, None, None),                         # C2 layer-1 shape (short T)
     (3, 20, 1024, 256, True, [20, 11, 7], None),                 # C2 layer-2 input width
     (9, 16, 32, 512, True, [16] * 9, None),                      # H=512, B not a multiple of R
+    (40, 6, 16, 512, True, None, None),                          # H=512, 40 rows: four rows per group in two launches (never eight: spills)
     (70, 12, 16, 256, True, None, None),                         # batch larger than one resident grid
     (45, 9, 16, 256, True, None, None),                          # two launches of the groups-of-four kernel (32 + 13 rows)
     (45, 11, 80, 256, True, None, 12),                           # ... with the projection inside (x rows offset by the launch's first row), pad frame
@@ -250,6 +251,7 @@ def test_next_token_argmax_first_max(dev):
     (6, 12, 16, 64, True, [12, 5, 12, 3, 8, 1], 0.9),        # with output dropout
     (70, 6, 16, 256, True, None, 1.0),                        # multi-launch batch split (R = 8: reduce-scatter kernel)
     (9, 10, 32, 512, True, None, 1.0),                        # H = 512, R = 2 (all-gather kernel, 32 positions per lane)
+    (40, 5, 16, 512, True, None, 1.0),                        # H = 512, 40 rows: R = 2 in three launches (the R >= 4 kernels would spill)
     (40, 9, 16, 128, True, None, 0.9),                        # H = 128, R = 2, dropout
     (20, 7, 16, 256, False, None, 1.0),                       # uni-directional, R = 1
     (8, 15, 16, 256, True, [15, 9, 1, 15, 7, 3, 11, 2], 0.9),  # H = 256, ragged, dropout: groups of four workgroups
