@@ -80,13 +80,18 @@ __device__ __forceinline__ void row16_argmax(float& bv, int& bi) {
     amax_dpp<0xB1>(bv, bi); amax_dpp<0x4E>(bv, bi); amax_dpp<0x141>(bv, bi); amax_dpp<0x140>(bv, bi);
 }
 
-template <int H, int D, int A, int LMH, bool STAMP = false, bool TRAIN = false>
+// MAXTS = encoder positions per workgroup: 8 (Te <= 256: the hf rows of the slice live in LDS) or 16 (Te <= 512, the phone decoder
+// of BASELINE config 4 on encoder depth 2: scores in two passes of 8 positions with the hf rows read from L2 every step -- 26 KB
+// per workgroup -- because LDS holds the 102 KB of context columns; everything else is the same step).
+template <int H, int D, int A, int LMH, bool STAMP = false, bool TRAIN = false, int MAXTS = 8>
 __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
+    static_assert(MAXTS == 8 || MAXTS == 16, "positions per workgroup");
     unsigned int stamp[24] = {0};
     unsigned long long tlast = 0;
     int sph = 0;
 #define GREEDY_STAMP() if (STAMP) { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); stamp[sph < 23 ? sph : 23] += (unsigned int)(t__ - tlast); tlast = t__; ++sph; }
-    constexpr int R = 4, G = 32, NT = 512, MAXTS = 8, VS = 32;
+    constexpr int R = 4, G = 32, NT = 512, VS = 32;
+    constexpr bool HFL = MAXTS == 8;             // hf rows of my positions in LDS
     constexpr int HS = H / G, LS = LMH / G, AS = A / G, DS = D / G, PS = H / G;
     constexpr int KD = LMH + H + D;              // outer cell input [lm_out | h | ctx]
     constexpr int KA = H + D;                    // AttnProjection input [q | ctx]
@@ -108,15 +113,15 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
     float* ysum = lmsum + 4 * 8 * R * 4;         // [4][AS][R]
     float* psum = ysum + 4 * AS * R;             // [4][PS][R]
     float* cpart = psum + 4 * PS * R;            // [8][R][DS]
-    float* eout = cpart + 8 * R * DS;            // [32]
-    float* lg = eout + 32;                       // [R][VS] logits of my vocabulary slice
+    float* eout = cpart + 8 * R * DS;            // [R * MAXTS]
+    float* lg = eout + R * MAXTS;                // [R][VS] logits of my vocabulary slice
     float* mv = lg + R * VS;                     // [R][G] partial maxima, then [R][G] their indices (int)
     int* mi = reinterpret_cast<int*>(mv + R * G);
     float* vl = mv + 2 * R * G;                  // [A]
-    float* hfl = vl + A;                         // [R][MAXTS][A]
+    float* hfl = vl + A;                         // [R][MAXTS][A]  (HFL)
     const int Te = a.Te, V = a.V;
     const int TS = (Te + G - 1) / G;
-    float* v_lmh = hfl + R * MAXTS * A;          // [R][LMH]  TRAIN: undropped h_lm_i (the LM's own recurrence input)
+    float* v_lmh = hfl + (HFL ? R * MAXTS * A : 0);   // [R][LMH]  TRAIN: undropped h_lm_i (the LM's own recurrence input)
     float* encl = v_lmh + (TRAIN ? R * LMH : 0); // [R][Te][DS]
 
     const int grp_l = blockIdx.x & 7, mem = blockIdx.x >> 3;       // round-robin dispatch: a group = the 32 workgroups of one XCD
@@ -191,6 +196,7 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
 
     // ---- resident activations (LDS)
     const int tau0 = mem * TS;
+    if (HFL)
     for (int idx = tid; idx < R * MAXTS * A; idx += NT) {
         const int r = idx / (MAXTS * A), rem = idx % (MAXTS * A), tl = rem / A, aa = rem % A, tau = tau0 + tl;
         hfl[idx] = (tl < TS && tau < Te) ? a.hf[((size_t)browf(r) * Te + tau) * A + aa] : 0.f;
@@ -483,7 +489,7 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
         }
         __syncthreads();
         GREEDY_STAMP()
-        {
+        if constexpr (HFL) {
             const int tl = row % MAXTS, r = row / MAXTS;     // DPP row -> (utterance, position); lane kq -> A/16 columns
             float sc = 0.f;
             if (tl < TS) {
@@ -501,6 +507,36 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
             }
             sc = row16_allreduce_sum(sc);
             if (kq == 0) eout[row] = sc;
+        } else {
+            // two passes of 8 positions per utterance (DPP row -> (utterance, position % 8)); the hf rows come from L2, all loads
+            // of both passes first
+            static_assert(MAXTS == 8 || AL / 4 == 2, "two 64-column chunks per row");
+            const int r = row / 8;
+            const float* yrow = yl + r * A;
+            float4 h4[2][2];
+#pragma unroll
+            for (int ps = 0; ps < 2; ++ps) {
+                const int tl = (row % 8) + 8 * ps, tau = min(tau0 + min(tl, TS - 1), Te - 1);
+                const float* hrow = a.hf + ((size_t)browf(r) * Te + tau) * A;
+#pragma unroll
+                for (int c = 0; c < 2; ++c) h4[ps][c] = *reinterpret_cast<const float4*>(hrow + c * 64 + kq * 4);
+            }
+#pragma unroll
+            for (int ps = 0; ps < 2; ++ps) {
+                const int tl = (row % 8) + 8 * ps;
+                float sc = 0.f;
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const int a0 = c * 64 + kq * 4;
+                    const float4 y4 = *reinterpret_cast<const float4*>(yrow + a0);
+                    const float4 v4 = *reinterpret_cast<const float4*>(vl + a0);
+                    const float4 x4 = h4[ps][c];
+                    sc = fmaf(v4.x, fast_tanh(x4.x + y4.x), sc); sc = fmaf(v4.y, fast_tanh(x4.y + y4.y), sc);
+                    sc = fmaf(v4.z, fast_tanh(x4.z + y4.z), sc); sc = fmaf(v4.w, fast_tanh(x4.w + y4.w), sc);
+                }
+                sc = row16_allreduce_sum(sc);
+                if (kq == 0) eout[r * MAXTS + tl] = (tl < TS && tau0 + tl < Te) ? sc : 0.f;
+            }
         }
         __syncthreads();
         GREEDY_STAMP()
@@ -510,11 +546,12 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
         }
         // ---- (5) gather all scores, softmax over tau < len (replicated), context slice
         if (poller) {
-            const int nq = (TS + 3) / 4;                        // quads per (utterance, source workgroup): 1 or 2 (MAXTS = 8)
-            const int lq = nq - 1;                              // ... so the index arithmetic is shifts, not four runtime divisions
-            static_assert(MAXTS == 8 && G == 32, "nq in {1, 2}; r = p >> (5 + lq)");
-            for (int p = tid - 64; p < R * G * nq; p += NPOLL) {
-                const int r = p >> (5 + lq), rem = p & ((G << lq) - 1), m = rem >> lq, q = rem & lq;
+            const int nq = (TS + 3) / 4;                        // quads per (utterance, source workgroup): 1 or 2 (MAXTS = 8), up to 4 (16)
+            const int lq = nq > 2 ? 2 : nq - 1;                 // log2 of the quads polled (3 -> 4: every slot is published) ...
+            const int mq = (1 << lq) - 1;                       // ... so the index arithmetic is shifts, not four runtime divisions
+            static_assert(G == 32, "r = p >> (5 + lq)");
+            for (int p = tid - 64; p < ((R * G) << lq); p += NPOLL) {
+                const int r = p >> (5 + lq), rem = p & ((G << lq) - 1), m = rem >> lq, q = rem & mq;
                 const int off = r * G * MAXTS + m * MAXTS + 4 * q;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (rok(r)) tagged_poll4(tE + off, tb, v, a.err);
@@ -551,7 +588,6 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
             // (positions past Te are clamped onto the last row: alpha = 0 there)
             const int dd = tid & 15, r = (tid >> 4) & 3, tp = tid >> 6;
             float cs = 0.f, cs2 = 0.f;
-            static_assert(MAXTS == 8, "two float4 of alpha per source workgroup");
 #pragma unroll
             for (int mm = 0; mm < G / 8; ++mm) {
                 const int m = tp + 8 * mm;
@@ -559,12 +595,15 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
                 const float* xr = encl + (size_t)r * Te * DS + dd;
                 // all MAXTS slots, loads first (slots >= TS hold alpha = 0; their position is clamped onto a valid row): the serial
                 // "load, load, fma" chain over TS positions was 11 % of the step; the unrolled form spilled until round 3 freed registers
-                const float4 a0 = *reinterpret_cast<const float4*>(ap), a1 = *reinterpret_cast<const float4*>(ap + 4);
-                float xv[MAXTS];
 #pragma unroll
-                for (int tl = 0; tl < MAXTS; ++tl) xv[tl] = xr[min(m * TS + min(tl, TS - 1), Te - 1) * DS];
-                cs = fmaf(a0.x, xv[0], cs); cs2 = fmaf(a0.y, xv[1], cs2); cs = fmaf(a0.z, xv[2], cs); cs2 = fmaf(a0.w, xv[3], cs2);
-                cs = fmaf(a1.x, xv[4], cs); cs2 = fmaf(a1.y, xv[5], cs2); cs = fmaf(a1.z, xv[6], cs); cs2 = fmaf(a1.w, xv[7], cs2);
+                for (int h8 = 0; h8 < MAXTS / 8; ++h8) {
+                    const float4 a0 = *reinterpret_cast<const float4*>(ap + 8 * h8), a1 = *reinterpret_cast<const float4*>(ap + 8 * h8 + 4);
+                    float xv[8];
+#pragma unroll
+                    for (int tl = 0; tl < 8; ++tl) xv[tl] = xr[min(m * TS + min(8 * h8 + tl, TS - 1), Te - 1) * DS];
+                    cs = fmaf(a0.x, xv[0], cs); cs2 = fmaf(a0.y, xv[1], cs2); cs = fmaf(a0.z, xv[2], cs); cs2 = fmaf(a0.w, xv[3], cs2);
+                    cs = fmaf(a1.x, xv[4], cs); cs2 = fmaf(a1.y, xv[5], cs2); cs = fmaf(a1.z, xv[6], cs); cs2 = fmaf(a1.w, xv[7], cs2);
+                }
             }
             cpart[(tp * R + r) * DS + dd] = cs + cs2;
         }
@@ -781,19 +820,31 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
 
 }  // namespace asr
 
+// positions per workgroup of the instantiation that takes Te (see the kernel), and the dynamic LDS it asks for
+static int greedy_maxts(int Te) { return Te <= 256 ? 8 : 16; }
+static size_t greedy_lds_bytes(int Te, bool train) {
+    constexpr int R = 4, KD = 1024, KA = 768, Hc = 256, Ac = 128, G = 32, lmH = 256;
+    const int mts = greedy_maxts(Te);
+    return sizeof(float) * (4 + (size_t)R * KD + R * KA + R * Hc + R * Ac + R * G * mts + 2 * (4 * 8 * R * 4) +
+                            4 * 4 * R + 4 * 8 * R + 8 * R * 16 + R * mts + R * 32 + 2 * R * G + Ac + (mts == 8 ? R * mts * Ac : 0) +
+                            (train ? (size_t)R * lmH : 0) + (size_t)R * Te * 16);
+}
 extern "C" int asr_decoder_greedy_supported(int B, int Te, int D, int A, int H, int lmH, int E, int V) {
     if (getenv("ASR_DEC_GREEDY") && atoi(getenv("ASR_DEC_GREEDY")) == 0) return 0;
     (void)E;
     if (asr::resident_wg_budget() < 256) return 0;         // 8 one-XCD groups of 32 workgroups per launch must be co-resident
-    return B > 0 && Te > 0 && Te <= 256 && V > 0 && V <= 1024 && H == 256 && D == 512 && A == 128 && lmH == 256;
+    const char* te_env = getenv("ASR_DEC_GREEDY_TEMAX");      // (256: round 3's limit -- longer memories on the segment chains; read per call: tests switch it)
+    const int te_max = te_env ? atoi(te_env) : 512;
+    if (!(B > 0 && Te > 0 && Te <= 512 && Te <= te_max && V > 0 && V <= 1024 && H == 256 && D == 512 && A == 128 && lmH == 256)) return 0;
+    return greedy_lds_bytes(Te, true) <= 160 * 1024 - 64;  // (Te <= 256 always fits; 16 positions per workgroup: up to Te = 408)
 }
 
-static size_t greedy_npar(int D, int A, int H, int lmH, bool train) {      // = NPAR of the kernel instantiation
-    return 4 * ((train ? 2 : 1) * (size_t)lmH + 2 * (size_t)H + A + 32 * 8 + D + H + 2 * 32);
+static size_t greedy_npar(int D, int A, int H, int lmH, bool train, int maxts = 16) {      // = NPAR of the kernel instantiation
+    return 4 * ((train ? 2 : 1) * (size_t)lmH + 2 * (size_t)H + A + 32 * (size_t)maxts + D + H + 2 * 32);
 }
-static size_t greedy_gran_bytes(int B, int D, int A, int H, int lmH) {     // sized for the larger (training) layout
+static size_t greedy_gran_bytes(int B, int D, int A, int H, int lmH) {     // sized for the largest layout (training, 16 positions)
     const size_t groups = ((size_t)B + 3) / 4;
-    return (groups * 2 * greedy_npar(D, A, H, lmH, true) * sizeof(u64) + groups * 32 * sizeof(u64) + 255) / 256 * 256;
+    return (groups * 2 * greedy_npar(D, A, H, lmH, true, 16) * sizeof(u64) + groups * 32 * sizeof(u64) + 255) / 256 * 256;
 }
 // granules + XCC slots | EK [V][4 lmH]
 extern "C" size_t asr_decoder_greedy_ws_bytes(int B, int D, int A, int H, int lmH, int V) {
@@ -817,25 +868,26 @@ static int greedy_launch(void* stream, asr::GreedyArgs a, bool train, const floa
     a.ek = ek; a.lm_kh = lm_kernel + (size_t)E * 4 * lmH;
     a.gx = static_cast<u64*>(ws);
     const int groups = (B + 3) / 4;
-    a.xcc_slots = a.gx + (size_t)groups * 2 * greedy_npar(D, A, H, lmH, train);
+    const int mts = greedy_maxts(Te);
+    a.xcc_slots = a.gx + (size_t)groups * 2 * greedy_npar(D, A, H, lmH, train, mts);
     a.B = B; a.Te = Te; a.V = V;
-    constexpr int R = 4, KD = 1024, KA = 768, Hc = 256, Ac = 128, G = 32, MAXTS = 8;
-    const size_t lds = sizeof(float) * (4 + (size_t)R * KD + R * KA + R * Hc + R * Ac + R * G * MAXTS + 2 * (4 * 8 * R * 4) +
-                                        4 * 4 * R + 4 * 8 * R + 8 * R * 16 + 32 + R * 32 + 2 * R * G + Ac + R * MAXTS * Ac +
-                                        (train ? (size_t)R * lmH : 0) + (size_t)R * Te * 16);
+    constexpr int G = 32;
+    const size_t lds = greedy_lds_bytes(Te, train);
     if (lds > 160 * 1024 - 64) return ASR_EUNSUPPORTED;
     a.dbg = getenv("ASR_CHAIN_STAMP") ? asr::g_lstm_dbg : nullptr;
-    if (train) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asr::decoder_greedy_kernel<256, 512, 128, 256, false, true>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    else (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asr::decoder_greedy_kernel<256, 512, 128, 256>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (a.dbg && !train) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asr::decoder_greedy_kernel<256, 512, 128, 256, true>),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (a.dbg && train) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asr::decoder_greedy_kernel<256, 512, 128, 256, true, true>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const void* kfn;
+    if (mts == 16) kfn = train ? reinterpret_cast<const void*>(&asr::decoder_greedy_kernel<256, 512, 128, 256, false, true, 16>)
+                               : reinterpret_cast<const void*>(&asr::decoder_greedy_kernel<256, 512, 128, 256, false, false, 16>);
+    else if (a.dbg) kfn = train ? reinterpret_cast<const void*>(&asr::decoder_greedy_kernel<256, 512, 128, 256, true, true>)
+                                : reinterpret_cast<const void*>(&asr::decoder_greedy_kernel<256, 512, 128, 256, true>);
+    else kfn = train ? reinterpret_cast<const void*>(&asr::decoder_greedy_kernel<256, 512, 128, 256, false, true>)
+                     : reinterpret_cast<const void*>(&asr::decoder_greedy_kernel<256, 512, 128, 256>);
+    (void)hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     for (int g0 = 0; g0 < groups; g0 += 8) {            // 8 groups (one per XCD) = 256 workgroups per launch
         a.g0 = g0; a.ng = std::min(8, groups - g0);
-        if (train && a.dbg) hipLaunchKernelGGL((asr::decoder_greedy_kernel<256, 512, 128, 256, true, true>), dim3(8 * G), dim3(512), lds, s, a);
+        if (mts == 16 && train) hipLaunchKernelGGL((asr::decoder_greedy_kernel<256, 512, 128, 256, false, true, 16>), dim3(8 * G), dim3(512), lds, s, a);
+        else if (mts == 16) hipLaunchKernelGGL((asr::decoder_greedy_kernel<256, 512, 128, 256, false, false, 16>), dim3(8 * G), dim3(512), lds, s, a);
+        else if (train && a.dbg) hipLaunchKernelGGL((asr::decoder_greedy_kernel<256, 512, 128, 256, true, true>), dim3(8 * G), dim3(512), lds, s, a);
         else if (train) hipLaunchKernelGGL((asr::decoder_greedy_kernel<256, 512, 128, 256, false, true>), dim3(8 * G), dim3(512), lds, s, a);
         else if (a.dbg) hipLaunchKernelGGL((asr::decoder_greedy_kernel<256, 512, 128, 256, true>), dim3(8 * G), dim3(512), lds, s, a);
         else hipLaunchKernelGGL((asr::decoder_greedy_kernel<256, 512, 128, 256>), dim3(8 * G), dim3(512), lds, s, a);

@@ -81,16 +81,21 @@ def _grad_check(m, b, tol=2e-3, outs=None, **kw):
 
 # ------------------------------------------------------------------ config 4 at its stated shape
 @pytest.mark.parametrize("Te", [260, 400])
-def test_config4_phone_decoder_on_layer2_states_real_widths(Te):
+@pytest.mark.parametrize("fwd_path", ["one_launch", "segment_chains"])
+def test_config4_phone_decoder_on_layer2_states_real_widths(monkeypatch, Te, fwd_path):
     """BASELINE config 4: char decoder on depth 4 + phone decoder (V=50) on LAYER-2 states, real widths (BiLSTM(256),
-    decoder 256, A=128).  Te = T/2 > 256 encoder positions puts the phone decoder on
-    decoder_chain_{fwd,bwd}_kernel<256,512,128,R=1> (one utterance per group, 32 positions per workgroup); Te = 400 is
-    the 800-frame batch of the config.  Logits and losses vs the float64 oracle (seq2seq_model.py:88-144, losses
-    averaged), every gradient vs float64 autograd."""
+    decoder 256, A=128).  Te = T/2 > 256 encoder positions: the phone decoder's forward is the one-launch training kernel
+    with 16 positions per workgroup (decoder_greedy_kernel<..., TRAIN, 16>, round 4), or -- ASR_DEC_GREEDY_TEMAX=256, the
+    path of rounds 1-3 -- decoder_chain_fwd_kernel<256,512,128,R=1> per scheduled-sampling segment; the backward is
+    decoder_chain_bwd_kernel<256,512,128,R=1> either way.  Te = 400 is the 800-frame batch of the config.  Logits and
+    losses vs the float64 oracle (seq2seq_model.py:88-144, losses averaged), every gradient vs float64 autograd."""
     from e2e_asr_amd import _lib, ops
     L = _lib.lib()
     T = 2 * Te
+    if fwd_path == "segment_chains":
+        monkeypatch.setenv("ASR_DEC_GREEDY_TEMAX", "256")
     assert L.asr_decoder_chain_rows(Te) == 1 and L.asr_decoder_chain_supported(3, Te, 512, 128, 256) == 1
+    assert L.asr_decoder_greedy_supported(3, Te, 512, 128, 256, 256, 256, 50) == (1 if fwd_path == "one_launch" else 0)
     tasks = ("char", "phone")
     nl = {"char": 4, "phone": 2}
     m = _model(tasks=tasks, num_layers=nl, feat=80, vocab={"char": 1000, "phone": 50}, seed=23)
@@ -99,6 +104,7 @@ def test_config4_phone_decoder_on_layer2_states_real_widths(Te):
     m.forward(b)
     for t in tasks:
         assert m.decoder[t].saved["ws"].get("chain_ws") is not None                    # the persistent chains really ran
+    assert (m.decoder["phone"].saved["ws"].get("greedy_ws") is not None) == (fwd_path == "one_launch")
     ops.check_device_flag(torch.device(DEV))
     assert m.encoder_hidden_states[2].shape[1] == Te
     got = {t: m.outputs[t].cpu().numpy() for t in tasks}
@@ -427,13 +433,15 @@ def test_persistent_grid_that_cannot_be_coresident_is_refused(monkeypatch):
 
 
 # ------------------------------------------------------------------ training graph in one persistent launch
-@pytest.mark.parametrize("nb,T", [(32, 48), (37, 96), (3, 512)])
+@pytest.mark.parametrize("nb,T", [(32, 48), (37, 96), (3, 512), (3, 800), (6, 640), (32, 800)])
 def test_training_decoder_one_launch_equals_segment_chain_path(monkeypatch, nb, T):
     """csrc/decoder_greedy.hip, TRAIN instantiation: the whole training-graph decoder (teacher forcing, scheduled-sampling
     feedback with Gumbel draws at the coin-selected steps, LM dropout, saved activations) in ONE persistent launch must give
     the segment-wise chain path's sampled tokens, logits, loss and every gradient (the backward consumes the activations
     the kernel saved).  32 utterances = 8 one-XCD groups = 256 workgroups; 37 = two launches; T=512 at depth 2 = 256 encoder
-    positions (8 per workgroup, the kernel's limit).  Repeated runs: race detector at full occupancy."""
+    positions (8 per workgroup); T=800 / 640 at depth 2 = 400 / 320 positions: the instantiation with 16 positions per
+    workgroup (13 / 10 used: four / three quads of scores per source workgroup), config 4's phone memory, incl. its full batch
+    of 32.  Repeated runs: race detector at full occupancy."""
     from e2e_asr_amd import ops
     kw = dict(feat=80, vocab={"char": 1000}, num_layers={"char": 3 if T < 512 else 2}, seed=13, max_output={"char": 14},
               enc_update=dict(hidden_size=256, out_prob=0.9),
