@@ -836,7 +836,7 @@ extern "C" int asr_decoder_greedy_supported(int B, int Te, int D, int A, int H, 
     const char* te_env = getenv("ASR_DEC_GREEDY_TEMAX");      // (256: round 3's limit -- longer memories on the segment chains; read per call: tests switch it)
     const int te_max = te_env ? atoi(te_env) : 512;
     if (!(B > 0 && Te > 0 && Te <= 512 && Te <= te_max && V > 0 && V <= 1024 && H == 256 && D == 512 && A == 128 && lmH == 256)) return 0;
-    return greedy_lds_bytes(Te, true) <= 160 * 1024 - 64;  // (Te <= 256 always fits; 16 positions per workgroup: up to Te = 408)
+    return greedy_lds_bytes(Te, true) <= 160 * 1024 - 64;  // (Te <= 256 always fits; 16 positions per workgroup: up to Te = 419)
 }
 
 static size_t greedy_npar(int D, int A, int H, int lmH, bool train, int maxts = 16) {      // = NPAR of the kernel instantiation

@@ -439,17 +439,19 @@ def test_train_loop_checkpoint_resume_and_eval(tmp_path):
 
 
 # ------------------------------------------------------------------ inference graph: persistent greedy decoder
-@pytest.mark.parametrize("nb,T,nl", [(7, 64, 4), (37, 96, 4), (6, 512, 2)])
+@pytest.mark.parametrize("nb,T,nl", [(7, 64, 4), (37, 96, 4), (6, 512, 2), (6, 800, 2), (5, 514, 2)])
 def test_greedy_decoder_one_launch_equals_per_step_path_and_oracle(monkeypatch, nb, T, nl):
     """csrc/decoder_greedy.hip: the inference graph (argmax feedback at every step, max_output steps) of the config-2
     decoder in ONE persistent launch.  Same token ids and logits as the per-step launch path; logits and ids vs the float64
     oracle (eval_model.py:56-118 semantics).  7 utterances = a half-empty group; 37 = two launches (8 + 2 groups);
-    T=512 at depth 2 = 256 encoder positions (the kernel's limit: 8 positions per workgroup)."""
+    T=512 at depth 2 = 256 encoder positions (8 positions per workgroup); T=800 / 514 = 400 / 257 positions: the instantiation
+    with 16 positions per workgroup (13 / 9 used; its LDS holds up to 419 positions)."""
     from e2e_asr_amd import _lib, ops
     L = _lib.lib()
     Te = T >> (nl - 1)
     assert L.asr_decoder_greedy_supported(nb, Te, 512, 128, 256, 256, 256, 1000) == 1
-    assert L.asr_decoder_greedy_supported(nb, 257, 512, 128, 256, 256, 256, 1000) == 0
+    assert L.asr_decoder_greedy_supported(nb, 419, 512, 128, 256, 256, 256, 1000) == 1
+    assert L.asr_decoder_greedy_supported(nb, 420, 512, 128, 256, 256, 256, 1000) == 0
     rng = np.random.default_rng(41)
     b = _batch(rng, nb, T, 80, 21, 1000)
     outs = []
