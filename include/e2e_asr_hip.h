@@ -415,7 +415,9 @@ int asr_decoder_chain_supported(int B, int Te, int D, int A, int H);
 int asr_decoder_chain_rows(int Te);
 /* Inference graph (mode 1) as one persistent launch (csrc/decoder_greedy.hip): argmax feedback, LM cell, attention,
  * projections of all steps on chip.  Used inside asr_attn_decoder_fwd when supported and ws->greedy_ws is set; only the
- * logits and tok are produced (no saved activations). */
+ * logits and tok are produced (no saved activations).  The same kernel's training instantiation runs the training graph
+ * (modes 0 / 2) in one launch.  Supported: config-2 widths (H 256, D 512, A 128, lmH 256, V <= 1024) and Te <= 419 encoder
+ * positions (8 per workgroup up to 256, 16 beyond; ASR_DEC_GREEDY_TEMAX lowers the limit). */
 int asr_decoder_greedy_supported(int B, int Te, int D, int A, int H, int lmH, int E, int V);
 size_t asr_decoder_greedy_ws_bytes(int B, int D, int A, int H, int lmH, int V);
 int asr_decoder_greedy_fwd(void* stream, const float* embedding, const float* lm_kernel, const float* lm_bias,
