@@ -1,6 +1,7 @@
 """Soak: many train steps over randomly shaped ragged batches (batch 1..40, frames 40..300, targets 3..40, scheduled
 sampling + dropout on) through the config-2-width model -- every step must finish (no exchange time-out), with a finite
-loss and finite parameters.  Exercises the persistent kernels across group counts, segment patterns and lengths."""
+loss and finite parameters.  Exercises the persistent kernels across group counts, segment patterns and lengths.
+soak.py seed steps [f32|bf16]   (bf16: BASELINE config 3's precision mode, the plane kernels in the encoder)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -10,6 +11,8 @@ from e2e_asr_amd import ops
 from e2e_asr_amd.weights import synthetic_batch
 
 dev = torch.device("cuda:0")
+if len(sys.argv) > 3:
+    ops.set_gemm_precision(sys.argv[3])
 model = bench.build_model(dev, training=True)
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 60
