@@ -432,13 +432,52 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    # self-diagnosis of the timed region (no synchronisation inside it): an event at every step's end on the launch stream,
+    # read after the loop, and the host's clock when each step's enqueue returned.  An outlier step, a host-bound loop
+    # (host_enqueue_ms ~ the whole region) and lost side-stream overlap (side_stream_tail_ms) are three different pictures.
+    step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    host_marks = []
+    # BENCH_r04's 10.34 ms (20 x 7.78 + 51 ms): ONE generation-2 pass of CPython's cyclic garbage collector (26-40 ms over the
+    # ~172 000 container objects that torch + the model keep alive; scripts/host_stall.py, profiles/r05_host_stall.txt) landed in
+    # the 0.16-s timed window: the enqueue of one step took 40 ms and the GPU ran dry.  Whether a run meets one depends on the
+    # allocation count since the interpreter started (generation-2 threshold 10 x 10 x 700), so it came and went with unrelated
+    # edits.  The step itself makes no cyclic garbage: collect once and move the survivors to the permanent generation --
+    # exactly what Train.train does before its loop (e2e_asr_amd/train.py) -- and count what still runs in the window.
+    import gc
+    gc.collect()
+    gc.freeze()
+    gc_log, gc_t = [], [0.0]
+
+    def gc_cb(phase, info):
+        if phase == "start":
+            gc_t[0] = time.perf_counter()
+        else:
+            gc_log.append((info["generation"], (time.perf_counter() - gc_t[0]) * 1e3))
+    gc.callbacks.append(gc_cb)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    step_ev[0].record()
+    for i in range(args.steps):
         one_step()
+        step_ev[i + 1].record()
+        host_marks.append(time.perf_counter())
+    t_enqueued = time.perf_counter()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
+    gc.callbacks.remove(gc_cb)
+    step_ms = [step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(args.steps)]
+    host_step_ms = [(b - a) * 1e3 for a, b in zip([t0] + host_marks[:-1], host_marks)]
+    diag = {"step_ms": [round(x, 4) for x in step_ms],
+            "step_ms_median": float(np.median(step_ms)) if step_ms else None, "step_ms_max": max(step_ms) if step_ms else None,
+            "step_ms_min": min(step_ms) if step_ms else None,
+            "gpu_span_ms": step_ev[0].elapsed_time(step_ev[-1]) if step_ms else None,
+            "host_enqueue_ms": (t_enqueued - t0) * 1e3,
+            "host_enqueue_ms_per_step": [round(x, 4) for x in host_step_ms],
+            "host_enqueue_ms_per_step_median": float(np.median(host_step_ms)) if host_step_ms else None,
+            "wall_ms": dt * 1e3,
+            "gc_passes_in_timed_region": [{"generation": g, "ms": round(ms, 3)} for g, ms in gc_log],
+            "gc_ms_in_timed_region": sum(ms for _, ms in gc_log)}
     if dist is not None:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -472,7 +511,15 @@ def main():
     recb_ms, recb_n = ops.prof_read("lstm_rec_bwd")
     decf_ms, decf_n = ops.prof_read("decoder_fwd")
     decb_ms, decb_n = ops.prof_read("decoder_bwd")
+    opt_ms, opt_n = ops.prof_read("optim")
+    tails = ops.prof_read_each("side_tail")
     ops.prof_enable(False)
+    if tails:
+        # per step: from the launch stream reaching asr_side_join (everything of the backward pass enqueued in front of it done)
+        # to the end of the side stream's work.  ~0.6-0.8 ms = the layer-1 weight gradients that follow the last BPTT; a
+        # value near the side stream's whole load (~2.5 ms) means the two streams did not overlap.
+        diag["side_stream_tail_ms"] = [round(x, 4) for x in tails]
+        diag["side_stream_tail_ms_median"] = float(np.median(tails))
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -551,6 +598,8 @@ def main():
         "phases_ms_per_step": {"lstm_rec_fwd": rec_per_step_ms, "lstm_rec_bwd": recb_ms / args.steps,
                                "decoder_fwd": decf_ms / args.steps, "decoder_bwd": decb_ms / args.steps},
     }
+    out["phases_ms_per_step"]["optimizer"] = opt_ms / args.steps
+    out.update(diag)
     sum_len = int(np.sum(batch["logmel_len"])) * world
     out["frames_true_sum_len_per_s"] = sum_len / (dt / args.steps)      # rate on the true sum of lengths next to padded B*T
     out["frames_padded_per_step"], out["frames_true_per_step"] = frames, sum_len

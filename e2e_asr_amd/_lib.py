@@ -154,6 +154,7 @@ SIGNATURES = {
     "asr_prof_enable": (C.c_int, [C.c_int]),
     "asr_debug_set_buffer": (C.c_int, [vp]),
     "asr_prof_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "asr_prof_read_each": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int)]),
     "asr_attn_decoder_fwd": (C.c_int, [vp, C.POINTER(DecWeights), C.POINTER(DecDims), C.POINTER(DecWs),
                                        vp, vp, vp, C.c_int, c_fp, C.c_float, C.c_float, C.c_uint, vp]),
 }

@@ -28,6 +28,7 @@ typedef unsigned long long u64;
 #define ASR_PROF_DECODER_FWD 3
 #define ASR_PROF_DECODER_BWD 4
 #define ASR_PROF_OPTIM 5
+#define ASR_PROF_SIDE_TAIL 6      // asr_side_join: caller's stream at the join -> end of the side stream's work
 
 // Optional back-off between two polls of a granule that has not arrived (s_sleep units of 64 cycles; 0 = none, the
 // default: measured, a back-off of 1 makes the forward recurrence 6 % slower and changes nothing else): a spinning wave's

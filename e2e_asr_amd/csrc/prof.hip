@@ -49,6 +49,23 @@ extern "C" int asr_prof_read(int tag, double* total_ms, int* launches) {
     return ASR_OK;
 }
 
+// As asr_prof_read, one value per occurrence (in recording order): out[i] = elapsed ms of occurrence i, *n = how many were
+// written (at most cap).  ASR_PROF_SIDE_TAIL values may be negative: the side stream was done before the caller's stream
+// reached the join.
+extern "C" int asr_prof_read_each(int tag, double* out, int cap, int* n) {
+    if (tag < 0 || tag >= ASR_PROF_TAGS || !out || !n || cap < 0) return ASR_EINVAL;
+    asr::ProfPool& p = asr::g_pool[tag];
+    int k = 0;
+    for (size_t i = 0; i < p.used && k < cap; ++i, ++k) {
+        float ms = 0;
+        if (hipEventSynchronize(p.a[i]) != hipSuccess || hipEventSynchronize(p.b[i]) != hipSuccess) return ASR_ELAUNCH;
+        if (hipEventElapsedTime(&ms, p.a[i], p.b[i]) != hipSuccess) return ASR_ELAUNCH;
+        out[k] = ms;
+    }
+    *n = k;
+    return ASR_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Co-residency budget of the persistent kernels.  They exchange data between workgroups of one launch without a grid
 // barrier, which is only safe when all those workgroups are resident at once: one 512-thread workgroup per compute unit
@@ -128,6 +145,10 @@ void set_pending_join(hipEvent_t e) { g_join = e; }
 // asr_attn_decoder_bwd).  Must be called before the gradients are consumed.
 extern "C" int asr_side_join(void* stream) {
     if (asr::g_join) {
+        if (asr::g_prof_on && asr::g_side) {      // bench.py's side_stream_tail_ms: how long the caller's stream waits here
+            asr::prof_begin(ASR_PROF_SIDE_TAIL, static_cast<hipStream_t>(stream));
+            asr::prof_end(ASR_PROF_SIDE_TAIL, asr::g_side);
+        }
         if (hipStreamWaitEvent(static_cast<hipStream_t>(stream), asr::g_join, 0) != hipSuccess) return ASR_ELAUNCH;
         asr::g_join = nullptr;
     }

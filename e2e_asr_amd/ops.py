@@ -795,7 +795,7 @@ def get_gemm_precision():
     return ("f32", "bf16", "bf16x2")[_lib.lib().asr_get_gemm_precision()]
 
 
-PROF_TAGS = {"lstm_rec_fwd": 0, "lstm_rec_bwd": 1, "gemm": 2, "decoder_fwd": 3, "decoder_bwd": 4, "optim": 5}
+PROF_TAGS = {"lstm_rec_fwd": 0, "lstm_rec_bwd": 1, "gemm": 2, "decoder_fwd": 3, "decoder_bwd": 4, "optim": 5, "side_tail": 6}
 
 
 def prof_enable(on=True):
@@ -807,6 +807,13 @@ def prof_read(tag):
     ms, n = C.c_double(0), C.c_int(0)
     _check(_lib.lib().asr_prof_read(PROF_TAGS[tag], C.byref(ms), C.byref(n)), "asr_prof_read")
     return ms.value, n.value
+
+
+def prof_read_each(tag, cap=4096):
+    """[elapsed ms] per recorded occurrence of a profiled family, in order (synchronises)."""
+    buf, n = (C.c_double * cap)(), C.c_int(0)
+    _check(_lib.lib().asr_prof_read_each(PROF_TAGS[tag], buf, cap, C.byref(n)), "asr_prof_read_each")
+    return [buf[i] for i in range(n.value)]
 
 
 _keepalive = []      # tensors still read by side-stream kernels: PyTorch's allocator only tracks the

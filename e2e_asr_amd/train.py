@@ -10,6 +10,7 @@ decode (322), LR halving when the dev error is no better than the worst of the l
 builds them from the TFRecord buckets `train_1k.<bucket>.*` / `dev*` of `data_dir` (94-131); `train()` also takes
 injected ones (tests, synthetic corpora)."""
 import copy
+import gc
 import glob
 import math
 import os
@@ -183,6 +184,11 @@ class Train(BaseParams):
             lm_global_step=lm_model.lm_global_step, lm_learning_rate=lm_model.learning_rate, lm_epoch=lm_model.epoch)
             if lm_model is not None else {}))
         carry = None                          # the next epoch's first bucket, its reader already running
+        # A train step makes no cyclic garbage, but a generation-2 pass of CPython's collector walks every container object
+        # torch and the model keep alive (~170 000: 26-40 ms, five steps' worth of GPU time, and the GPU runs dry meanwhile --
+        # measured, scripts/host_stall.py).  Collect once, then park the survivors in the permanent generation.
+        gc.collect()
+        gc.freeze()
         while epoch <= params.max_epochs:
             print("\nEpochs done: %d" % epoch)
             # (each bucket's batches are staged into HBM one batch ahead of the step: the iterator's prefetch of the reference)

@@ -452,6 +452,9 @@ int asr_prof_enable(int on);
 /* Diagnostic: device buffer (>= 8 u64) for in-kernel phase stamps of the stamped LSTM build (ASR_LSTM_STAMP=1). */
 int asr_debug_set_buffer(void* dev_buf);
 int asr_prof_read(int tag, double* total_ms, int* launches);
+/* One elapsed time per recorded occurrence of `tag`, in recording order (at most cap; *n = how many).  Tag 6
+ * (side tail) = from the caller's stream reaching asr_side_join to the end of the side stream's work: may be negative. */
+int asr_prof_read_each(int tag, double* out, int cap, int* n);
 
 #ifdef __cplusplus
 }
