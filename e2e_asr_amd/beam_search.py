@@ -188,7 +188,11 @@ class BeamSearch(BaseParams):
         if os.environ.get("ASR_BEAM_TILED", "1") == "0":
             return (None, None, None)
         src = (self.dec_params.lm_lstm_w, self.lm_params.lstm_w, self.dec_params.dec_lstm_w)
-        key = tuple((w.data_ptr(), w._version, tuple(w.shape)) for w in src)      # replaced or updated in place -> re-tile
+        # Re-tiled when a weight tensor is REPLACED or updated through torch (its _version moves).  The library's own optimizer
+        # writes weights through raw pointers and moves no version counter: a BeamSearch that shares tensors with a model
+        # being trained must call invalidate() after the weights change (the reference reads them once from a checkpoint,
+        # beam_search.py:42-47, so they are constants there).
+        key = tuple((w.data_ptr(), w._version, tuple(w.shape)) for w in src)
         if getattr(self, "_tiled", None) is None or getattr(self, "_tiled_key", None) != key:
             self._tiled_key = key
             L = _lib.lib()
@@ -201,6 +205,12 @@ class BeamSearch(BaseParams):
                 out.append(t)
             self._tiled = tuple(out)
         return self._tiled
+
+    def invalidate(self):
+        """Drop the cached tile-ordered weight copies: call after the weight tensors were changed behind torch's back (the
+        fused clip+Adam kernel of a model that shares them)."""
+        self._tiled = None
+        self._tiled_key = None
 
     def _decode_on_device(self, get_top_k, max_steps=120):
         """The loop of beam_search.py:255-337 with scoring, selection and bookkeeping on the device."""

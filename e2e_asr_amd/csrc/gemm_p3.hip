@@ -334,7 +334,7 @@ __device__ __forceinline__ void p3_split8(const float* x, uint4* out) {     // o
 // gate-major columns of a TF LSTM kernel in the unit-major order the BPTT writes dG in.
 template <int NP, bool TR>
 __global__ __launch_bounds__(256) void p3_split_kernel(const float* __restrict__ src, int R, int C, int ld, char* __restrict__ dst,
-                                                       long long rb, int dcols, int umh) {
+                                                       long long rb, int dcols, int umh, bool vec) {
     // logical destination [DR][dcols]: one thread per 8-element chunk
     const int DR = TR ? C : R, DC = TR ? R : C, DC8 = dcols / 8;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -354,7 +354,8 @@ __global__ __launch_bounds__(256) void p3_split_kernel(const float* __restrict__
         }
     } else {
         dr = (int)(idx / DC8); c8 = (int)(idx % DC8);
-        if (c8 * 8 + 8 <= DC) {
+        // vec: rows start 16-byte aligned (base aligned, ld % 4 == 0); otherwise (feat_length 39 / 43 / 83 ...) scalar loads
+        if (vec && c8 * 8 + 8 <= DC) {
             const float4* p = reinterpret_cast<const float4*>(src + (size_t)dr * ld + c8 * 8);
             const float4 u = p[0], v = p[1];
             x[0] = u.x; x[1] = u.y; x[2] = u.z; x[3] = u.w; x[4] = v.x; x[5] = v.y; x[6] = v.z; x[7] = v.w;
@@ -384,14 +385,14 @@ extern "C" int asr_p3_split_ex(void* stream, const float* src, int rows, int col
     if (dst_cols <= 0) dst_cols = (DC + 7) / 8 * 8;
     if (dst_cols % 8 || dst_cols < DC) return ASR_EINVAL;
     if (unit_major_h > 0 && (transpose || DC % (4 * unit_major_h))) return ASR_EINVAL;
-    if (!transpose && !unit_major_h && ((reinterpret_cast<uintptr_t>(src) & 15) || ld % 4)) return ASR_EINVAL;
+    const bool vec = !(reinterpret_cast<uintptr_t>(src) & 15) && ld % 4 == 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const long long rb = (long long)(dst_cols / 8) * 16 * np;
     const long long n = (long long)DR * (dst_cols / 8);
     const unsigned grid = (unsigned)((n + 255) / 256);
     char* d = static_cast<char*>(dst);
-#define P3_SPLIT(NP_) do { if (transpose) hipLaunchKernelGGL((p3_split_kernel<NP_, true>), dim3(grid), dim3(256), 0, s, src, rows, cols, ld, d, rb, dst_cols, 0); \
-                           else hipLaunchKernelGGL((p3_split_kernel<NP_, false>), dim3(grid), dim3(256), 0, s, src, rows, cols, ld, d, rb, dst_cols, unit_major_h); } while (0)
+#define P3_SPLIT(NP_) do { if (transpose) hipLaunchKernelGGL((p3_split_kernel<NP_, true>), dim3(grid), dim3(256), 0, s, src, rows, cols, ld, d, rb, dst_cols, 0, vec); \
+                           else hipLaunchKernelGGL((p3_split_kernel<NP_, false>), dim3(grid), dim3(256), 0, s, src, rows, cols, ld, d, rb, dst_cols, unit_major_h, vec); } while (0)
     if (np == 3) P3_SPLIT(3); else if (np == 2) P3_SPLIT(2); else P3_SPLIT(1);
 #undef P3_SPLIT
     ASR_CHECK_LAUNCH();
@@ -520,7 +521,10 @@ extern "C" int asr_gemm_p3_rr(void* stream, int M, int N, int K, const void* A, 
     g.M = M; g.N = N; g.K = K; g.rbA = (long long)lda8 * 16 * np; g.rbB = (long long)ldb8 * 16 * np;
     g.ldc = ldc; g.accumulate = accumulate; g.colmap = colmap;
     g.A2 = nullptr; g.rbA2 = 0; g.mA = M; g.mA_valid = M; g.zA2 = g.zB = g.zC = 0;
-    const int tiles = (M / 128) * (N / 256), nk = K / 16;
+    // one plane runs two MFMA k-steps per stage (KS = 2: 32 contraction rows) when K allows it; K % 32 == 16 takes the KS = 1
+    // instantiation -- the KS = 2 kernel would drop the last 16 rows (nk_all = K / 32)
+    const int ks = (np == 1 && K % 32 == 0) ? 2 : 1;
+    const int tiles = (M / 128) * (N / 256), nk = K / (16 * ks);
     if (splits < 1) {
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
@@ -528,13 +532,14 @@ extern "C" int asr_gemm_p3_rr(void* stream, int M, int N, int K, const void* A, 
     }
     g.splits = splits;
     const int per = (nk + splits - 1) / splits;
-    if (16ll * per * std::max(g.rbA, g.rbB) >= (1ll << 31)) return ASR_EUNSUPPORTED;       // 32-bit offsets inside a stage only: always true
+    if (16ll * ks * per * std::max(g.rbA, g.rbB) >= (1ll << 31)) return ASR_EUNSUPPORTED;       // 32-bit offsets inside a stage only: always true
     if (splits > 1 && !accumulate &&
         hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, s) != hipSuccess) return ASR_ELAUNCH;
     const dim3 grid(tiles, splits, 1);
     if (np == 3)      hipLaunchKernelGGL((gemm_p3_kernel<true, 3, 1, 2, 2>), grid, dim3(256), 0, s, g);
     else if (np == 2) hipLaunchKernelGGL((gemm_p3_kernel<true, 2, 1, 2, 2>), grid, dim3(256), 0, s, g);
-    else              hipLaunchKernelGGL((gemm_p3_kernel<true, 1, 2, 2, 2>), grid, dim3(256), 0, s, g);
+    else if (ks == 2) hipLaunchKernelGGL((gemm_p3_kernel<true, 1, 2, 2, 2>), grid, dim3(256), 0, s, g);
+    else              hipLaunchKernelGGL((gemm_p3_kernel<true, 1, 1, 2, 2>), grid, dim3(256), 0, s, g);
     ASR_CHECK_LAUNCH();
     return ASR_OK;
 }
@@ -566,12 +571,14 @@ int p3_lstm_wgrad(hipStream_t s, int rows, int in_pad, int in_valid, int H, int 
         hipLaunchKernelGGL((gemm_p3_kernel<true, 1, 2, 4, 2>), dim3(tiles2 / ndir, g.splits, ndir), dim3(512), 0, s, g);
         return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
     }
-    const int tiles = (g.M / 128) * (g.N / 256) * ndir, nk = rows / 16;
-    g.splits = std::max(1, std::min(cus / tiles, nk / 8));                 // one workgroup per CU and no second round
+    const int ks = (np == 1 && rows % 32 == 0) ? 2 : 1;                    // (rows % 32 == 16: the KS = 1 kernel, see asr_gemm_p3_rr)
+    const int tiles = (g.M / 128) * (g.N / 256) * ndir, nk = rows / (16 * ks);
+    g.splits = std::max(1, std::min(cus / tiles, std::max(1, nk / 8)));    // one workgroup per CU and no second round
     const dim3 grid(tiles / ndir, g.splits, ndir);
     if (np == 3)      hipLaunchKernelGGL((gemm_p3_kernel<true, 3, 1, 2, 2>), grid, dim3(256), 0, s, g);
     else if (np == 2) hipLaunchKernelGGL((gemm_p3_kernel<true, 2, 1, 2, 2>), grid, dim3(256), 0, s, g);
-    else              hipLaunchKernelGGL((gemm_p3_kernel<true, 1, 2, 2, 2>), grid, dim3(256), 0, s, g);
+    else if (ks == 2) hipLaunchKernelGGL((gemm_p3_kernel<true, 1, 2, 2, 2>), grid, dim3(256), 0, s, g);
+    else              hipLaunchKernelGGL((gemm_p3_kernel<true, 1, 1, 2, 2>), grid, dim3(256), 0, s, g);
     return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
 }
 }  // namespace asr

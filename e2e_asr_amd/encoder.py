@@ -137,7 +137,10 @@ class Encoder(BaseParams):
                 if i != max_depth - 1:
                     p3["out"] = ops.p3_alloc(B * t_out, 2 * H, np_, x.device)
                 if save and p3.get("x") is not None and p3["x"].cols % 128 == 0 and (d == 1 or IN % 256 == 0):
+                    # decided HERE, once, for the backward pass too (p3["bwd"]): with h_prev as planes there is no fp32 h_prev, so the
+                    # BPTT of this layer must run on plane operands -- backward() follows the record, it does not re-derive it
                     p3["hprev"] = ops.p3_alloc(B * T, 2 * H, np_, x.device)
+                    p3["bwd"] = True
             r = ops.lstm_layer_fwd(x, lens_dev, kf, bf, kb, bb, t_out=t_out, save=save,
                                    keep_prob=keep, seed=seed, kx_cat=kx, bias_cat=bc, p3=p3)
             out = r[0] if save else r
@@ -193,7 +196,7 @@ class Encoder(BaseParams):
                 kf, kb = v[names[0]], None
                 g = [v.grad_of(n) for n in names] + [None, None]
             p3 = sv.get("p3")
-            if p3 is not None and p3.get("hprev") is not None and sv["kx"] is not None and (d == 1 or sv["x"].shape[2] % 256 == 0):
+            if p3 is not None and p3.get("bwd"):
                 B_, T_, IN_ = sv["x"].shape
                 H = kf.shape[1] // 4
                 p3 = dict(p3)

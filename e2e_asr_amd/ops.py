@@ -332,24 +332,35 @@ WS_PREZEROED = 1 << 62          # include/e2e_asr_hip.h ASR_WS_PREZEROED
 _arena = {}
 
 
-def ws_arena_begin(dev, nbytes=24 << 20):
+_arena_need = {}                # {device: bytes the last step's workspaces asked for}: the next arena is sized from it
+
+
+def ws_arena_begin(dev, nbytes=None):
     """One zero fill for all the exchange workspaces of a train step (Seq2SeqModel.step): the persistent launches then take
     slices of it (`_hx_zeroed`) instead of each running a memset launch in front of its kernel -- ~10 dependent launches of
-    4-5 us per step.  ASR_WS_ARENA=0 turns it off."""
+    4-5 us per step.  Sized from what the previous step asked for (a few hundred KB at config 2; 24 MB the first time, and a
+    step that outgrows its arena falls back to per-launch memsets and the next arena is larger).  ASR_WS_ARENA=0 turns it off."""
     if os.environ.get("ASR_WS_ARENA", "1") == "0" or dev.type != "cuda":
         _arena.pop(dev, None)
         return
-    _arena[dev] = [torch.zeros(nbytes, dtype=torch.uint8, device=dev), 0]
+    if nbytes is None:
+        need = _arena_need.get(dev)
+        nbytes = (24 << 20) if need is None else max(1 << 16, (need * 5 // 4 + 4095) // 4096 * 4096)
+    _arena[dev] = [torch.zeros(nbytes, dtype=torch.uint8, device=dev), 0, 0]
 
 
 def ws_arena_end(dev):
-    _arena.pop(dev, None)
+    a = _arena.pop(dev, None)
+    if a is not None:
+        _arena_need[dev] = a[2]
 
 
 def _hx_zeroed(dev, nbytes):
-    """(buffer, size argument): a slice of the step's zeroed arena + the PREZEROED flag, or the cached buffer the library zeroes."""
+    """(buffer, size argument): a slice of the step's zeroed arena + the PREZEROED flag, or the cached buffer the library zeroes.
+    A slice is zero ONCE: it is handed out for one launch and never again within the step."""
     a = _arena.get(dev)
     if a is not None:
+        a[2] += (nbytes + 255) // 256 * 256
         off = (a[1] + 255) // 256 * 256
         if off + nbytes <= a[0].numel():
             a[1] = off + nbytes

@@ -105,6 +105,25 @@ def test_reduced_plane_counts_equal_the_product_of_the_rounded_planes(np_):
     assert _err(c, ref, den) < 3e-7
 
 
+@pytest.mark.parametrize("K", [16, 48, 400, 512])
+def test_rr_one_plane_keeps_every_contraction_row(K):
+    """One plane runs two MFMA k-steps per stage (32 contraction rows); K % 32 == 16 must not drop the last 16 rows (advisor,
+    round 4: asr_gemm_p3_rr accepted K % 16 == 0 and launched the 32-row kernel).  The last 16 rows carry the largest values."""
+    from e2e_asr_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(K)
+    M, N = 128, 256
+    a = torch.randn(K, M, device=DEV, generator=g)
+    b = torch.randn(K, N, device=DEV, generator=g)
+    a[-16:] *= 8.0
+    ar, br = a.to(torch.bfloat16).double(), b.to(torch.bfloat16).double()
+    ref = ar.t() @ br
+    den = ar.abs().t() @ br.abs()
+    for splits in (1, 0):
+        c = torch.zeros(M, N, device=DEV)
+        ops.gemm_p3_rr(ops.p3_split(a, 1), ops.p3_split(b, 1), out=c, splits=splits)
+        assert _err(c, ref, den) < 3e-7, (K, splits)
+
+
 def test_split_layouts():
     """asr_p3_split_ex: padded image, transposed image, unit-major column permutation -- against the layout formula."""
     from e2e_asr_amd import ops
@@ -117,6 +136,10 @@ def test_split_layouts():
         return f.double().sum(2).reshape(p3.rows, p3.cols)
     d = decode(ops.p3_split(x, 3, cols=128))
     assert torch.equal(d[:, :80].float(), x) and (d[:, 80:] == 0).all()
+    for cols in (83, 39, 43):          # rows that do not start 16-byte aligned (fbank + pitch, MFCC): the scalar-load branch
+        xo = torch.randn(24, cols, device=DEV, generator=g)
+        d = decode(ops.p3_split(xo, 3, cols=128))
+        assert torch.equal(d[:, :cols].float(), xo) and (d[:, cols:] == 0).all()
     assert torch.equal(decode(ops.p3_split(x, 3, transpose=True)).float(), x.t())
     H = 8
     w = torch.randn(16, 2 * 4 * H, device=DEV, generator=g)
@@ -174,6 +197,39 @@ def test_bf16_mode_plane_path_equals_fp32_operand_path(monkeypatch, B, T):
             torch.cuda.synchronize()
             ops.check_device_flag(torch.device(DEV))
             res[flag] = (m.outputs["char"].cpu().numpy().copy(), {n: m.variables.grad_of(n).cpu().numpy().copy() for n in m.variables.names()})
+    finally:
+        ops.set_gemm_precision("f32")
+    assert np.abs(res[None][0] - res["0"][0]).max() < 1e-4
+    for n, g0 in res["0"][1].items():
+        assert np.abs(res[None][1][n] - g0).max() <= 1e-3 * max(1e-30, np.abs(g0).max()), n
+
+
+@pytest.mark.parametrize("feat", [83, 39])
+def test_bf16_mode_takes_any_feat_length(monkeypatch, feat):
+    """bf16 mode builds a 128-column plane image of the frames for the first layer's weight gradient; feat_length 83 (fbank +
+    pitch) or 39 (MFCC) gives rows that are not 16-byte aligned (advisor, round 4: the split refused them and the train step
+    raised).  The reference takes any --feat_length.  Held to the fp32-operand bf16 path as above."""
+    from tests.test_gpu_parity3 import _model
+    from e2e_asr_amd import ops
+    from e2e_asr_amd.weights import synthetic_batch
+    b = synthetic_batch(B=32, T=64, F=feat, t_dec=13, vocab=1000, variable_len=True, seed=17)
+    ops.set_gemm_precision("bf16")
+    try:
+        res = {}
+        for flag in ("0", None):
+            if flag is None:
+                monkeypatch.delenv("ASR_P3", raising=False)
+            else:
+                monkeypatch.setenv("ASR_P3", flag)
+            m = _model(feat=feat, vocab={"char": 1000}, max_output={"char": 20}, seed=9, enc_update=dict(out_prob=0.9))
+            m.forward(b); m.backward()
+            torch.cuda.synchronize()
+            ops.check_device_flag(torch.device(DEV))
+            res[flag] = (m.outputs["char"].cpu().numpy().copy(), {n: m.variables.grad_of(n).cpu().numpy().copy() for n in m.variables.names()})
+            m.apply_gradients()
+            m.step(b)                      # and a whole step through the arena path
+            torch.cuda.synchronize()
+            ops.check_device_flag(torch.device(DEV))
     finally:
         ops.set_gemm_precision("f32")
     assert np.abs(res[None][0] - res["0"][0]).max() < 1e-4
