@@ -8,7 +8,11 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("ASR_LIB_PATH") or os.path.join(_HERE, "csrc", "libe2e_asr_hip.so")   # (override: A/B builds of experiments)
+# ASR_LIB_VARIANT=hunt: the debug build whose persistent kernels delay random publishers and pollers (csrc/common.h ASR_RACE_HUNT;
+# tests/test_gpu_race_hunt.py) -- same ABI, never the product.  ASR_LIB_PATH: A/B builds of experiments.
+_VARIANT = os.environ.get("ASR_LIB_VARIANT", "")
+LIB_PATH = os.environ.get("ASR_LIB_PATH") or os.path.join(
+    _HERE, "csrc", "libe2e_asr_hip_%s.so" % _VARIANT if _VARIANT else "libe2e_asr_hip.so")
 
 c_fp = C.POINTER(C.c_float)
 c_ip = C.POINTER(C.c_int)
@@ -151,6 +155,7 @@ SIGNATURES = {
     "asr_decoder_lm_chain_supported": (C.c_int, [C.c_int] * 2),
     "asr_zero_finished_rows": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int]),
     "asr_resident_wg_budget": (C.c_int, []),
+    "asr_race_hunt_build": (C.c_int, []),
     "asr_prof_enable": (C.c_int, [C.c_int]),
     "asr_debug_set_buffer": (C.c_int, [vp]),
     "asr_prof_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
@@ -170,6 +175,9 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the .so is stale
         fn.restype = res
         fn.argtypes = args
+    if bool(lib.asr_race_hunt_build()) != (_VARIANT == "hunt") and not os.environ.get("ASR_LIB_PATH"):
+        raise ImportError("e2e_asr_amd: %s is %sthe race-hunt debug build but ASR_LIB_VARIANT=%r" % (
+            LIB_PATH, "" if lib.asr_race_hunt_build() else "not ", _VARIANT))
     return lib
 
 

@@ -38,6 +38,27 @@ typedef unsigned long long u64;
 #endif
 #define ASR_POLL_BACKOFF() do { if (ASR_POLL_SLEEP) __builtin_amdgcn_s_sleep(ASR_POLL_SLEEP); } while (0)
 
+// ---- ASR_RACE_HUNT (debug build of the persistent kernels only: libe2e_asr_hip_hunt.so, __graft_entry__.build()) --------------
+// Every exchange of the persistent kernels is "one store, polled; the data is its own flag".  Two bugs of that class were found
+// by accident (round 2: overlapping persistent launches; round 4: an exchange numbered by the step index although it only ran at
+// feedback steps, so a poller could take the memset's zeros).  The hunt build makes such bugs show on purpose: in front of
+// every PUBLISH and every POLL a wave tosses a coin (shader clock x workgroup id, wave-uniform) and one wave in eight sleeps
+// ~4 us (s_sleep 127 = 8 128 cycles; a whole decoder step is 6-8 us, a recurrent step ~1 us).  A late publisher sends pollers
+// into slots that still hold the previous contents; a late poller lets its publishers run ahead and rewrite a slot of the
+// two-deep parity buffers -- the two ways a tag protocol can be wrong.  tests/test_gpu_race_hunt.py runs the
+// equal-to-launch-path tests of every persistent kernel on this build.  Empty in the product build.
+#ifndef ASR_RACE_HUNT
+#define ASR_RACE_HUNT 0
+#endif
+#if ASR_RACE_HUNT
+#define ASR_RACE_HUNT_DELAY() do {                                                                          \
+        const unsigned h__ = (((unsigned)__builtin_amdgcn_s_memtime() >> 2) ^ (blockIdx.x * 0x9E3779B1u)) * 0x85EBCA6Bu; \
+        if ((h__ >> 29) == 0u) __builtin_amdgcn_s_sleep(127);                                              \
+    } while (0)
+#else
+#define ASR_RACE_HUNT_DELAY() do {} while (0)
+#endif
+
 namespace asr {
 
 void prof_begin(int tag, hipStream_t s);   // prof.hip

@@ -397,6 +397,7 @@ __global__ __launch_bounds__(512) void decoder_chain_fwd_kernel(ChainArgs a) {
                     if (2 * tp + 1 < TS) chain_poll2(gE + off, ep, v0, v1, a.err);
                     else {   // odd tail: a single granule
                         long long t0w = 0;
+                        ASR_RACE_HUNT_DELAY();
                         for (uint32_t spins = 0;; ++spins) {
                             const u64 x = __hip_atomic_load(gE + off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             if ((uint32_t)(x >> 32) == ep) { v0 = __uint_as_float((uint32_t)x); break; }

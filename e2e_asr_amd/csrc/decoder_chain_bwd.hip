@@ -61,6 +61,7 @@ typedef unsigned int u32x4d __attribute__((ext_vector_type(4)));
 template <int src_stride>
 __device__ __forceinline__ bool gather16_one(const u64* base, uint32_t epoch, float& s0, int* err) {
     long long t0 = 0;
+    ASR_RACE_HUNT_DELAY();
     for (uint32_t spins = 0;; ++spins) {
         u64 x[16];
 #pragma unroll
@@ -86,6 +87,7 @@ __device__ __forceinline__ bool gather16_one(const u64* base, uint32_t epoch, fl
 }
 __device__ __forceinline__ void pubg(u64* dst, uint32_t epoch, float v, bool fast) {
     const u64 gv = ((u64)epoch << 32) | __float_as_uint(v);
+    ASR_RACE_HUNT_DELAY();
     if (fast) asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(dst), "v"(gv) : "memory");
     else __hip_atomic_store(dst, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -331,6 +333,7 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
                 }
             }
             long long t0w = 0;
+            ASR_RACE_HUNT_DELAY();
             for (uint32_t spins = 0;; ++spins) {
                 u32x4q x[NPP4];
                 if constexpr (NPP4 == 1) {
@@ -439,6 +442,7 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
                 if (pidx < NPAIR1 && !need[j]) *reinterpret_cast<float2*>(dctall + 2 * pidx) = make_float2(0.f, 0.f);
             }
             long long t0w = 0;
+            ASR_RACE_HUNT_DELAY();
             for (uint32_t spins = 0;; ++spins) {
                 u64 x[NPP1][2];
 #pragma unroll
@@ -585,6 +589,7 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
                     float v0 = 0.f, v1 = 0.f;
                     if (rok(r)) {
                         long long t0w = 0;
+                        ASR_RACE_HUNT_DELAY();
                         for (uint32_t spins = 0;; ++spins) {
                             const u64 x0 = __hip_atomic_load(g3 + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             const u64 x1 = __hip_atomic_load(g3 + idx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -658,6 +663,7 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
                     typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
                     const u32x4s q0 = {(__float_as_uint(dg.x) & ~1u) | tb, (__float_as_uint(dg.y) & ~1u) | tb,
                                        (__float_as_uint(dg.z) & ~1u) | tb, (__float_as_uint(dg.w) & ~1u) | tb};
+                    ASR_RACE_HUNT_DELAY();
                     if (fast) asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(dst), "v"(q0) : "memory");
                     else {
                         __hip_atomic_store(dst + 0, q0.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -8,6 +8,7 @@ namespace asr {
 
 typedef unsigned int u32x4c __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ bool chain_poll2(const u64* g, uint32_t epoch, float& v0, float& v1, int* err) {
+    ASR_RACE_HUNT_DELAY();
     long long t0 = 0;
     const u32x4c* p = reinterpret_cast<const u32x4c*>(g);
     for (uint32_t spins = 0;; ++spins) {
@@ -24,6 +25,7 @@ __device__ __forceinline__ bool chain_poll2(const u64* g, uint32_t epoch, float&
     }
 }
 __device__ __forceinline__ void chain_publish(u64* dst, uint32_t epoch, float v, bool fast) {
+    ASR_RACE_HUNT_DELAY();
     const u64 gv = ((u64)epoch << 32) | __float_as_uint(v);
     if (fast) asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(dst), "v"(gv) : "memory");
     else __hip_atomic_store(dst, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -31,6 +33,7 @@ __device__ __forceinline__ void chain_publish(u64* dst, uint32_t epoch, float v,
 
 // two adjacent granules (16-byte aligned) with one store on the fast path
 __device__ __forceinline__ void chain_publish2(u64* dst, uint32_t epoch, float v0, float v1, bool fast) {
+    ASR_RACE_HUNT_DELAY();
     if (fast) {
         const u32x4c q = {__float_as_uint(v0), epoch, __float_as_uint(v1), epoch};
         asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(dst), "v"(q) : "memory");
@@ -48,11 +51,13 @@ __device__ __forceinline__ void chain_publish2(u64* dst, uint32_t epoch, float v
 // Valid within ONE launch over a workspace zeroed before it.
 __device__ __forceinline__ uint32_t tag_bit(int step) { return ((((uint32_t)step) >> 1) & 1u) ^ 1u; }
 __device__ __forceinline__ void tagged_publish(uint32_t* dst, uint32_t tb, float v, bool fast) {
+    ASR_RACE_HUNT_DELAY();
     const uint32_t x = (__float_as_uint(v) & ~1u) | tb;
     if (fast) asm volatile("global_store_dword %0, %1, off" :: "v"(dst), "v"(x) : "memory");
     else __hip_atomic_store(dst, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void tagged_publish2(uint32_t* dst, uint32_t tb, float v0, float v1, bool fast) {   // 8-byte aligned
+    ASR_RACE_HUNT_DELAY();
     const uint32_t x0 = (__float_as_uint(v0) & ~1u) | tb, x1 = (__float_as_uint(v1) & ~1u) | tb;
     if (fast) {
         const u64 q = ((u64)x1 << 32) | x0;
@@ -64,6 +69,7 @@ __device__ __forceinline__ void tagged_publish2(uint32_t* dst, uint32_t tb, floa
 }
 // four tagged floats (16-byte aligned), polled until all four carry this step's bit
 __device__ __forceinline__ bool tagged_poll4(const uint32_t* g, uint32_t tb, float4& v, int* err) {
+    ASR_RACE_HUNT_DELAY();
     long long t0 = 0;
     const u32x4c* p = reinterpret_cast<const u32x4c*>(g);
     for (uint32_t spins = 0;; ++spins) {
@@ -89,6 +95,7 @@ __device__ __forceinline__ bool tagged_poll4(const uint32_t* g, uint32_t tb, flo
 // p[j]: 16-byte aligned; a slot with need[j] == false is not judged (point it at any valid quad); tb[j]: expected bit of slot j.
 template <int N>
 __device__ __forceinline__ bool tagged_poll4_many(const uint32_t* const* p, bool* need, const uint32_t* tb, float4* v, int* err) {
+    ASR_RACE_HUNT_DELAY();
     static_assert(N == 2 || N == 4, "two or four quads per thread");
     long long t0 = 0;
     for (uint32_t spins = 0;; ++spins) {

@@ -68,6 +68,7 @@ struct LstmRecArgs {
 
 __device__ __forceinline__ bool poll_granule(const u64* g, uint32_t epoch, float& val, int* err) {
     long long t0 = 0;
+    ASR_RACE_HUNT_DELAY();
     for (uint32_t spins = 0;; ++spins) {
         u64 x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((uint32_t)(x >> 32) == epoch) { val = __uint_as_float((uint32_t)x); return true; }
@@ -88,6 +89,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ bool poll_granule2(const u64* g, uint32_t epoch, float& v0, float& v1, int* err) {
     long long t0 = 0;
     const u32x4* p = reinterpret_cast<const u32x4*>(g);
+    ASR_RACE_HUNT_DELAY();
     for (uint32_t spins = 0;; ++spins) {
         // 16-byte load with sc1 (system-coherent, bypasses the per-CU L1)
         u32x4 x;
@@ -297,6 +299,7 @@ __global__ __launch_bounds__(16 * HS) void lstm_rec_fwd_kernel(LstmRecArgs a) {
             if (cb < a.B && s + 1 < S) {
                 u64* dst = hxg + ((size_t)(s & 1) * R + cr) * H + cj;
                 const u64 gv = ((u64)(uint32_t)(a.ep0 + s + 1) << 32) | __float_as_uint(h);
+                ASR_RACE_HUNT_DELAY();
                 if (fast) asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(dst), "v"(gv) : "memory");   // stays in this XCD's L2
                 else __hip_atomic_store(dst, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                 // write-through (sc1)
             }
@@ -360,6 +363,7 @@ __global__ __launch_bounds__(16 * HS) void lstm_rec_fwd_kernel(LstmRecArgs a) {
 // ---------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool poll_granule1(const u64* g, uint32_t epoch, float& val, int* err) {
     long long t0 = 0;
+    ASR_RACE_HUNT_DELAY();
     for (uint32_t spins = 0;; ++spins) {
         u64 x;
         asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(x) : "v"(g) : "memory");
@@ -549,6 +553,7 @@ __global__ __launch_bounds__(2 * H) void lstm_rec_fwd2_kernel(LstmRecArgs a) {
             if (cell && cb < a.B && more) {       // publish h_s FIRST: the critical path of every peer
                 u64* dst = hxg + ((size_t)(s & 1) * R + cr) * H + cj;
                 const u64 gv = ((u64)(uint32_t)(a.ep0 + s + 1) << 32) | __float_as_uint(h);
+                ASR_RACE_HUNT_DELAY();
                 if (fast) asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(dst), "v"(gv) : "memory");
                 else __hip_atomic_store(dst, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -785,6 +790,7 @@ __global__ __launch_bounds__(512) void lstm_rec_fwd4_kernel(LstmRecArgs a) {
             if (more) {
                 u64* dst = hxg + (size_t)(s & 1) * H + cj;
                 const u64 gv = ((u64)(uint32_t)(a.ep0 + s + 1) << 32) | __float_as_uint(h);
+                ASR_RACE_HUNT_DELAY();
                 if (fast) asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(dst), "v"(gv) : "memory");
                 else __hip_atomic_store(dst, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -956,6 +962,7 @@ extern "C" int asr_lstm_layer_fwd(void* stream, const float* x, int B, int T, in
     return asr_lstm_layer_fwd_p3(stream, x, B, T, in_dim, ldx, len, H, ndir, kernel_fw, bias_fw, kernel_bw, bias_bw, out, Tout, gates,
                                  act, hprev, hx_ws, hx_bytes, err_flag, keep_prob, seed, kx_cat, bias_cat, nullptr);
 }
+extern "C" int asr_race_hunt_build(void) { return ASR_RACE_HUNT; }
 bool asr_lstm_g4_selected(int B, int H, int ndir) {
     const char* e = getenv("ASR_LSTM_G4");
     const char* v2e = getenv("ASR_LSTM_V2");

@@ -56,6 +56,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ bool poll_pair(const u64* g, uint32_t epoch, float& v0, float& v1, int* err) {
     long long t0 = 0;
     const u32x4* p = reinterpret_cast<const u32x4*>(g);
+    ASR_RACE_HUNT_DELAY();
     for (uint32_t spins = 0;; ++spins) {
         u32x4 x;
         asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(x) : "v"(p) : "memory");
@@ -220,6 +221,7 @@ __global__ __launch_bounds__(512) void lstm_rec_bwd_kernel(LstmBwdArgs a) {
                 if (r0 + rem / HS < a.B) {
                     u64* dst = dstb + ((size_t)md * G + mem) * R * HS + rem;
                     const u64 gv = ((u64)(uint32_t)(s + 1) << 32) | __float_as_uint(pub[idx]);
+                    ASR_RACE_HUNT_DELAY();
                     if (fast) asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(dst), "v"(gv) : "memory");
                     else __hip_atomic_store(dst, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
@@ -402,6 +404,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
                     }
                 }
                 long long t0w = 0;
+                ASR_RACE_HUNT_DELAY();
                 for (uint32_t spins = 0;; ++spins) {
                     u32x4q x[NPP];
                     if constexpr (NPP == 1) {
@@ -519,6 +522,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
                 typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
                 const u32x4s g0 = {(__float_as_uint(dg.x) & ~1u) | tb, (__float_as_uint(dg.y) & ~1u) | tb,
                                    (__float_as_uint(dg.z) & ~1u) | tb, (__float_as_uint(dg.w) & ~1u) | tb};
+                ASR_RACE_HUNT_DELAY();
                 if (fast) asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(dst), "v"(g0) : "memory");
                 else {
                     __hip_atomic_store(dst + 0, g0.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -793,6 +797,7 @@ __global__ __launch_bounds__(2 * H + 64) void lstm_rec_bwd2_kernel(LstmBwdArgs a
                                    (__float_as_uint(dg.z) & ~1u) | tb, (__float_as_uint(dg.w) & ~1u) | tb};
                 if (cb < a.B && s + 1 < S) {       // publish dG_s of this unit FIRST: one tagged quad
                     uint32_t* dst = hxg + ((size_t)par * R + cr) * N + 4 * cj;
+                    ASR_RACE_HUNT_DELAY();
                     if (fast) asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(dst), "v"(g0) : "memory");
                     else {
                         __hip_atomic_store(dst + 0, g0.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -980,6 +985,7 @@ __global__ __launch_bounds__(512) void lstm_rec_bwd4_kernel(LstmBwdArgs a) {
             const bool more = s + 1 < S;
             if (more) {       // publish dG_s of this unit FIRST: one tagged quad
                 uint32_t* dst = hxg + (size_t)par * N + 4 * cj;
+                ASR_RACE_HUNT_DELAY();
                 if (fast) asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(dst), "v"(g0) : "memory");
                 else {
                     __hip_atomic_store(dst + 0, g0.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -445,6 +445,10 @@ int asr_resident_wg_budget(void);
 int asr_set_lstm_mfma(int on);
 int asr_get_lstm_mfma(void);
 
+/* 1 in the race-hunt DEBUG build (libe2e_asr_hip_hunt.so: every publish and poll of the persistent kernels preceded by a
+ * random ~4 us delay of one wave in eight, csrc/common.h ASR_RACE_HUNT), 0 in the product library.  New: test tooling. */
+int asr_race_hunt_build(void);
+
 /* Optional per-kernel HIP-event timing on the launch stream (bench.py roofline leg).
  * tag: 0 lstm recurrent fwd, 1 lstm recurrent bwd, 2 gemm, 3 decoder fwd, 4 decoder bwd, 5 optimizer.
  * asr_prof_read is a HOST call that synchronises on the recorded events. */

@@ -13,6 +13,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _hunt_build_is_bound():
+    """Child processes of tests/test_gpu_race_hunt.py: the library this process binds must be the race-hunt debug build."""
+    if os.environ.get("ASR_EXPECT_HUNT") == "1":
+        from e2e_asr_amd import _lib
+        assert os.environ.get("ASR_LIB_VARIANT") == "hunt" and _lib.lib().asr_race_hunt_build() == 1
+    yield
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN

@@ -233,5 +233,7 @@ def test_bf16_mode_takes_any_feat_length(monkeypatch, feat):
     finally:
         ops.set_gemm_precision("f32")
     assert np.abs(res[None][0] - res["0"][0]).max() < 1e-4
+    # (a ragged input width sends the fp32-operand path's first-layer products through the edge kernels, which do not round
+    # their operands to bf16: the two paths then differ by the bf16 rounding itself, 2^-8 of the largest entry -- measured 2e-3)
     for n, g0 in res["0"][1].items():
-        assert np.abs(res[None][1][n] - g0).max() <= 1e-3 * max(1e-30, np.abs(g0).max()), n
+        assert np.abs(res[None][1][n] - g0).max() <= 4e-3 * max(1e-30, np.abs(g0).max()), n
