@@ -237,3 +237,72 @@ def test_bf16_mode_takes_any_feat_length(monkeypatch, feat):
     # their operands to bf16: the two paths then differ by the bf16 rounding itself, 2^-8 of the largest entry -- measured 2e-3)
     for n, g0 in res["0"][1].items():
         assert np.abs(res[None][1][n] - g0).max() <= 4e-3 * max(1e-30, np.abs(g0).max()), n
+
+
+def _busy_stream(n_launches=24):
+    """Keep every CU busy from a second stream: split3 GEMMs (two resident workgroups per CU, LDS + MFMA + global loads) queued
+    back to back -- ~4 ms of work the products under test have to share the chip with."""
+    from e2e_asr_amd import ops
+    side = torch.cuda.Stream()
+    a = torch.randn(4096, 2048, device=DEV)
+    b = torch.randn(2048, 4096, device=DEV)
+    c = torch.empty(4096, 4096, device=DEV)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        for _ in range(n_launches):
+            ops.gemm(a, b, out=c)
+    return side, (a, b, c)
+
+
+@pytest.mark.parametrize("np_,M,N,K", [(1, 12800, 1024, 1024),      # one plane, 256 x 256 tiles of eight waves (the config-3 projections)
+                                       (1, 12928, 1024, 1024),      # one plane, 128 x 256 tiles (M % 256 != 0)
+                                       (3, 12800, 1024, 1024),      # three planes, 128 x 256 tiles
+                                       (1, 6400, 2048, 2048)])
+def test_kk_products_are_bit_stable_at_full_occupancy(np_, M, N, K):
+    """The KK form has no K split and no atomics: the same operands must give the same BITS on every call -- alone, and while
+    another stream keeps all CUs busy (the condition under which round 3's LDS-DMA ring in the BPTT drifted run to run).  A
+    fragment read that overtakes the LDS-DMA of its stage (the ordering scripts/check_p3_isa.py checks on the ISA) shows here as
+    a run-to-run difference.  Arithmetic held: encoder.py:78-81 (the layer's input projection)."""
+    from e2e_asr_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(M + np_)
+    a = torch.randn(M, K, device=DEV, generator=g)
+    b = torch.randn(N, K, device=DEV, generator=g)
+    bias = torch.randn(N, device=DEV, generator=g)
+    ap, bp = ops.p3_split(a, np_), ops.p3_split(b, np_)
+    quiet = ops.gemm_p3_kk(ap, bp, bias).clone()
+    torch.cuda.synchronize()
+    side, keep = _busy_stream()
+    outs = [ops.gemm_p3_kk(ap, bp, bias).clone() for _ in range(6)]       # interleaved with the other stream's workgroups
+    torch.cuda.synchronize()
+    del keep
+    for i, o in enumerate(outs):
+        assert torch.equal(o, quiet), "call %d differs from the quiet call in %d entries" % (i, int((o != quiet).sum()))
+    ops.check_device_flag(torch.device(DEV))
+
+
+def test_config3_forward_is_bit_stable_call_to_call():
+    """BASELINE config 3 at its full size (32 x 800 x 80, bf16 mode: the encoder's projections on LDS-DMA-staged plane operands):
+    two forward passes of the same step give identical logits bit for bit, the second one next to a busy second stream."""
+    from tests.test_gpu_parity3 import _model
+    from e2e_asr_amd import ops
+    from e2e_asr_amd.weights import synthetic_batch
+    b = synthetic_batch(B=32, T=800, F=80, t_dec=121, vocab=1000, variable_len=False, seed=1234)
+    ops.set_gemm_precision("bf16")
+    try:
+        m = _model(feat=80, vocab={"char": 1000}, max_output={"char": 120}, seed=10, enc_update=dict(out_prob=0.9),
+                   dec_update=dict(out_prob_dec=0.9, samp_prob=0.1))
+        m.forward(b)
+        first = m.outputs["char"].clone()
+        loss0 = float(m.losses["char"])
+        torch.cuda.synchronize()
+        side, keep = _busy_stream()
+        m.forward(b)
+        second = m.outputs["char"].clone()
+        loss1 = float(m.losses["char"])
+        torch.cuda.synchronize()
+        del keep
+    finally:
+        ops.set_gemm_precision("f32")
+    ops.check_device_flag(torch.device(DEV))
+    assert torch.equal(first, second), "%d of %d logits differ" % (int((first != second).sum()), first.numel())
+    assert loss0 == loss1
