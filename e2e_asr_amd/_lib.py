@@ -156,6 +156,9 @@ SIGNATURES = {
     "asr_zero_finished_rows": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int]),
     "asr_resident_wg_budget": (C.c_int, []),
     "asr_race_hunt_build": (C.c_int, []),
+    "asr_set_wgrad_mode": (C.c_int, [C.c_int]),
+    "asr_get_wgrad_mode": (C.c_int, []),
+    "asr_scatter_add_rows_ordered": (C.c_int, [vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int]),
     "asr_prof_enable": (C.c_int, [C.c_int]),
     "asr_debug_set_buffer": (C.c_int, [vp]),
     "asr_prof_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]),

@@ -68,6 +68,18 @@ void prof_end(int tag, hipStream_t s);
 // launch sizes its grid by this; a group that does not fit returns ASR_EUNSUPPORTED instead of spinning into the
 // exchange timeout (prof.hip).
 int resident_wg_budget();
+// splitk.hip: split-K partial tiles through per-stream slabs + a fixed-order reduce instead of float atomics (opt-in deterministic mode)
+int wgrad_slabs();
+float* slab_arena(hipStream_t s, size_t bytes);
+struct SlabMap {
+    int M, N, nsl, nsl_alloc, batch;       // slab s of batch z at ((z * nsl_alloc + s) * M) * N floats (N % 4 == 0); nsl of them hold data
+    int Nvalid;                            // columns n >= Nvalid of a slab row are padding (never read)
+    int mA, mA_valid;                      // product row m -> C row (plain products: mA = mA_valid = M)
+    const int* colmap;                     // product column n -> C column (NULL: identity)
+    int ldc; long long zC;                 // C row pitch, batch stride (elements)
+    int accumulate;                        // C += sum (else C = sum)
+};
+int slab_reduce(hipStream_t s, float* C, const float* slab, const SlabMap& q);
 hipStream_t side_stream();                 // prof.hip: library-owned side stream + pooled events
 hipEvent_t next_event();
 void set_pending_join(hipEvent_t e);

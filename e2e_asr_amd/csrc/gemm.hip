@@ -34,6 +34,7 @@ struct GemmArgs {
     int vecA, vecB;   // 16-B vector loads legal for this operand
     int xcd_split;    // split-K with one 1-D grid: K slice s runs entirely on XCD s % 8 (splits is a multiple of 8)
     long long sA, sB, sC;   // batch strides (elements); batch index = blockIdx.z
+    float* slab; int slab_ld;   // splits > 1: partial tiles go to slab[(blockIdx.z * splits + slice) * M * slab_ld + m * slab_ld + n] (csrc/splitk.hip); NULL: float atomics into C
     float* sk_ws; int* sk_flag; int sk_epoch;   // gemm_planes_kernel<..., SK = true>: one partial tile ([256 threads][64 accumulators]) and one flag per workgroup
 };
 
@@ -207,7 +208,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                 if (FULL || m < a.M) {
                     float* cp = a.C + (size_t)m * a.ldc + n;
                     float v = acc[mi][ni][r] + bv;
-                    if (a.splits > 1) { atomicAdd(cp, v); }      // 32 lanes x 4 B = one 128-B segment per row
+                    if (a.splits > 1) {                          // 32 lanes x 4 B = one 128-B segment per row
+                        if (a.slab) a.slab[((size_t)(blockIdx.z * a.splits + ksl) * a.M + m) * a.slab_ld + n] = v;
+                        else atomicAdd(cp, v);
+                    }
                     else { if (a.accumulate) v += *cp; *cp = v; }
                 }
             }
@@ -629,7 +633,10 @@ __global__ __launch_bounds__(256, 2) void gemm_planes_kernel(GemmArgs a) {
                 if (PARTM && m >= a.M) continue;
                 float* cp = a.C + (size_t)m * a.ldc + n;
                 float v = acc[mi][ni][r] + bv;
-                if (a.splits > 1) { atomicAdd(cp, v); }
+                if (a.splits > 1) {
+                    if (a.slab) a.slab[((size_t)(blockIdx.z * a.splits + ksl) * a.M + m) * a.slab_ld + n] = v;
+                    else atomicAdd(cp, v);
+                }
                 else { if (a.accumulate) v += *cp; *cp = v; }
             }
         }
@@ -832,6 +839,19 @@ extern "C" int asr_gemm_f32_batched(void* stream, int transA, int transB, int M,
     if (M < 0 || N < 0 || K < 0 || !C || (K > 0 && (!A || !B))) return ASR_EINVAL;
     if (M == 0 || N == 0) return ASR_OK;
     if (lda < (transA ? M : K) || ldb < (transB ? K : N) || ldc < N) return ASR_EINVAL;
+    // Weight-gradient form with a long K and a ragged N (the decoder's OutputProjection gradient h^T . dlogits, 256 x 1000 x 3840):
+    // the whole-tile split3 kernel takes N % 128 == 0 only and the product fell to the exact-fp32 MFMA kernel with bounds
+    // checks (40 TF/s, 59 us per step; rocBLAS: 76 TF/s).  Columns [0, N - N % 128) go to the split3 kernel, the ragged rest
+    // to the bounds-checked one: two launches, same arithmetic per column as before for the rest, split3 (fp32-accurate) for
+    // the whole tiles.
+    if (transA && !transB && !bias && (g_gemm_split || g_gemm_bf16 != 0) && N % 128 != 0 && N > 256 && M >= 64 && K >= 1024 && K % BKS == 0 &&
+        (batch == 1 || accumulate) && (ldb % 4 == 0) && (strideB % 4 == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0)) {
+        const int n1 = N - N % 128;
+        const int rc = asr_gemm_f32_batched(stream, transA, transB, M, n1, K, A, lda, strideA, B, ldb, strideB, C, ldc, strideC, nullptr, accumulate, batch);
+        if (rc != ASR_OK) return rc;
+        return asr_gemm_f32_batched(stream, transA, transB, M, N - n1, K, A, lda, strideA, B + n1, ldb, strideB, C + n1, ldc, strideC, nullptr,
+                                    accumulate, batch);
+    }
     GemmArgs g;
     g.A = A; g.B = B; g.C = C; g.bias = bias;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
@@ -862,7 +882,23 @@ extern "C" int asr_gemm_f32_batched(void* stream, int transA, int transB, int M,
     g.xcd_split = 0;
     static const bool shape_log = getenv("ASR_GEMM_LOG") != nullptr;          // diagnostic: one line per product on stderr
     if (shape_log) fprintf(stderr, "gemm tA=%d tB=%d M=%d N=%d K=%d batch=%d splits=%d acc=%d stream=%p\n", transA, transB, M, N, K, batch, splits, accumulate, stream);
-    if (splits > 1 && !accumulate) {
+    // K slices meet either through float atomics in a pre-zeroed / live C (rounds 1-4; ASR_WGRAD_SLABS=0) or -- default -- as
+    // partial tiles in this stream's slab arena, added into C in slice order by slab_reduce (csrc/splitk.hip): bit-reproducible
+    g.slab = nullptr; g.slab_ld = 0;
+    if (splits > 1 && wgrad_slabs()) {
+        const int ldp = (N + 3) & ~3, smax = std::max(splits, (splits + 4) / 8 * 8);      // (the XCD-pinned form rounds the slices up to 8 n)
+        g.slab = slab_arena(s, (size_t)batch * smax * M * ldp * sizeof(float));
+        if (g.slab) g.slab_ld = ldp;
+    }
+    auto slab_end = [&](int bkt) -> int {       // behind the launch: C (+)= the slices in ascending order; bkt = the kernel's k-tile
+        if (!g.slab) return ASR_OK;
+        const int nk_all = (K + bkt - 1) / bkt, per = (nk_all + g.splits - 1) / g.splits, nsl = (nk_all + per - 1) / per;
+        SlabMap q;
+        q.M = M; q.N = g.slab_ld; q.Nvalid = N; q.nsl = nsl; q.nsl_alloc = g.splits; q.batch = batch; q.mA = M; q.mA_valid = M;
+        q.colmap = nullptr; q.ldc = ldc; q.zC = strideC; q.accumulate = accumulate;
+        return slab_reduce(s, C, g.slab, q);
+    };
+    if (splits > 1 && !accumulate && !g.slab) {
         if (hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, s) != hipSuccess) return ASR_ELAUNCH;
     }
     // bf16 matrix pipe (gemm_planes_kernel): fp32 mode with the exact 3-way split (NP = 3, fp32-accurate; default), or the
@@ -921,7 +957,7 @@ extern "C" int asr_gemm_f32_batched(void* stream, int transA, int transB, int M,
         else if (K % 32 == 0)             launch_planes<1, 32>(grid, s, g, transA, transB, partm);
         else                              launch_planes<1, 16>(grid, s, g, transA, transB, partm);
         ASR_CHECK_LAUNCH();
-        return ASR_OK;
+        return slab_end((np == 1 && K % 32 == 0) ? 32 : 16);
     }
     // few output tiles and no split-K: 64x64 block tiles fill the chip 4x better (still reproducible)
     static const int small_thr = [] { const char* e = getenv("ASR_GEMM_SMALL"); return e ? atoi(e) : 160; }();
@@ -959,18 +995,18 @@ extern "C" int asr_gemm_f32_batched(void* stream, int transA, int transB, int M,
             g.xcd_split = 1;
             hipLaunchKernelGGL((gemm_f32_kernel<true, false, 128, true>), dim3(nwg * g.splits, 1, batch), dim3(256), ta_pad, s, g);
             ASR_CHECK_LAUNCH();
-            return ASR_OK;
+            return slab_end(BK);
         }
         if (transA)       hipLaunchKernelGGL((gemm_f32_kernel<true, false, 128, true>), dim3(nwg, splits, batch), dim3(256), ta_pad, s, g);
         else if (transB)  hipLaunchKernelGGL((gemm_f32_kernel<false, true, 128, true>), dim3(nwg, splits, batch), dim3(256), 0, s, g);
         else              hipLaunchKernelGGL((gemm_f32_kernel<false, false, 128, true>), dim3(nwg, splits, batch), dim3(256), 0, s, g);
         ASR_CHECK_LAUNCH();
-        return ASR_OK;
+        return slab_end(BK);
     }
     if (transA && transB)       hipLaunchKernelGGL((gemm_f32_kernel<true, true>), dim3(nwg, splits, batch), dim3(256), 0, s, g);
     else if (transA)            hipLaunchKernelGGL((gemm_f32_kernel<true, false>), dim3(nwg, splits, batch), dim3(256), 0, s, g);
     else if (transB)            hipLaunchKernelGGL((gemm_f32_kernel<false, true>), dim3(nwg, splits, batch), dim3(256), 0, s, g);
     else                        hipLaunchKernelGGL((gemm_f32_kernel<false, false>), dim3(nwg, splits, batch), dim3(256), 0, s, g);
     ASR_CHECK_LAUNCH();
-    return ASR_OK;
+    return slab_end(BK);
 }

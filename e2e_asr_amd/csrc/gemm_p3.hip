@@ -48,6 +48,9 @@ struct P3Args {
     // columns of A (mA of them staged: a multiple of 128, zero columns past mA_valid), rows mA_valid ... from the columns of A2;
     // blockIdx.z = direction: A2 += z * zA2, B += z * zB (bytes), C += z * zC (elements)
     const char* A2; long long rbA2; int mA, mA_valid; long long zA2, zB, zC;
+    // splits > 1: slice y of batch z stores its partial tile at slab[((z * splits + y) * M + m) * N + n] in PRODUCT coordinates (row
+    // m of [A | A2]^T, column n before colmap) and slab_reduce (csrc/splitk.hip) adds the slices into C in order; NULL: float atomics
+    float* slab;
 };
 
 __device__ __forceinline__ constexpr int p3_ctz(int v) { int n = 0; while (!(v & 1)) { v >>= 1; ++n; } return n; }
@@ -299,7 +302,10 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void gemm_p3_kernel(P3Args a) {
                 const int m = crow0 + ml;
                 float* cp = a.C + (size_t)m * a.ldc + n;
                 float v = acc[i][j][e] + bv;
-                if (a.splits > 1) atomicAdd(cp, v);
+                if (a.splits > 1) {
+                    if (a.slab) a.slab[((size_t)(blockIdx.z * a.splits + blockIdx.y) * a.M + (m0 + ml)) * a.N + (n0 + wn * 128 + j * 32 + fr)] = v;
+                    else atomicAdd(cp, v);
+                }
                 else { if (a.accumulate) v += *cp; *cp = v; }
             }
         }
@@ -481,7 +487,16 @@ extern "C" int asr_gemm_p3_kk(void* stream, int M, int N, int K, const void* A, 
     g.ldc = ldc; g.accumulate = accumulate; g.splits = splits < 1 ? 1 : splits; g.colmap = nullptr;
     g.A2 = nullptr; g.rbA2 = 0; g.mA = M; g.mA_valid = M; g.zA2 = g.zB = g.zC = 0;
     if ((long long)M * g.rbA >= (1ll << 32) || (long long)N * g.rbB >= (1ll << 32)) return ASR_EUNSUPPORTED;   // 32-bit tile offsets
-    if (g.splits > 1 && !accumulate &&
+    g.slab = (g.splits > 1 && wgrad_slabs()) ? slab_arena(s, (size_t)g.splits * M * N * sizeof(float)) : nullptr;
+    auto slab_end = [&](int ks) -> int {
+        if (!g.slab) return ASR_OK;
+        const int nk_all = K / (16 * ks), per = (nk_all + g.splits - 1) / g.splits;
+        SlabMap q;
+        q.M = M; q.N = N; q.Nvalid = N; q.nsl = (nk_all + per - 1) / per; q.nsl_alloc = g.splits; q.batch = 1; q.mA = M; q.mA_valid = M;
+        q.colmap = nullptr; q.ldc = ldc; q.zC = 0; q.accumulate = accumulate;
+        return slab_reduce(s, C, g.slab, q);
+    };
+    if (g.splits > 1 && !accumulate && !g.slab &&
         hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, s) != hipSuccess) return ASR_ELAUNCH;
     // One plane (bf16): a 128 x 256 tile asks the LDS-DMA for 48 bytes per CU and cycle at full MFMA rate -- more than it delivers;
     // the 256 x 256 tile of eight waves (two per SIMD, 249 registers) needs 32: 4096^3 870 -> 1 124 TF/s, the layer-2 projection
@@ -490,7 +505,7 @@ extern "C" int asr_gemm_p3_kk(void* stream, int M, int N, int K, const void* A, 
     if (big && np == 1 && M % 256 == 0 && K % 32 == 0 && (M / 256) * (N / 256) >= 128) {
         hipLaunchKernelGGL((gemm_p3_kernel<false, 1, 2, 4, 2>), dim3((M / 256) * (N / 256), g.splits, 1), dim3(512), 0, s, g);
         ASR_CHECK_LAUNCH();
-        return ASR_OK;
+        return slab_end(2);
     }
     const dim3 grid((M / 128) * (N / 256), g.splits, 1);
     static const int dbg = [] { const char* e = getenv("ASR_P3_DBG"); return e ? atoi(e) : 0; }();
@@ -502,7 +517,7 @@ extern "C" int asr_gemm_p3_kk(void* stream, int M, int N, int K, const void* A, 
     else if (K % 32 == 0) hipLaunchKernelGGL((gemm_p3_kernel<false, 1, 2, 2, 2>), grid, dim3(256), 0, s, g);
     else              hipLaunchKernelGGL((gemm_p3_kernel<false, 1, 1, 2, 2>), grid, dim3(256), 0, s, g);
     ASR_CHECK_LAUNCH();
-    return ASR_OK;
+    return slab_end((np == 1 && K % 32 == 0) ? 2 : 1);
 }
 
 // RR form: C[M,N] (+)= A^T . B on P3 operands A [K][M], B [K][N] (K = rows of both: the B*T frames of a weight gradient X^T . dG).
@@ -533,7 +548,8 @@ extern "C" int asr_gemm_p3_rr(void* stream, int M, int N, int K, const void* A, 
     g.splits = splits;
     const int per = (nk + splits - 1) / splits;
     if (16ll * ks * per * std::max(g.rbA, g.rbB) >= (1ll << 31)) return ASR_EUNSUPPORTED;       // 32-bit offsets inside a stage only: always true
-    if (splits > 1 && !accumulate &&
+    g.slab = (splits > 1 && wgrad_slabs()) ? slab_arena(s, (size_t)splits * M * N * sizeof(float)) : nullptr;
+    if (splits > 1 && !accumulate && !g.slab &&
         hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, s) != hipSuccess) return ASR_ELAUNCH;
     const dim3 grid(tiles, splits, 1);
     if (np == 3)      hipLaunchKernelGGL((gemm_p3_kernel<true, 3, 1, 2, 2>), grid, dim3(256), 0, s, g);
@@ -541,6 +557,12 @@ extern "C" int asr_gemm_p3_rr(void* stream, int M, int N, int K, const void* A, 
     else if (ks == 2) hipLaunchKernelGGL((gemm_p3_kernel<true, 1, 2, 2, 2>), grid, dim3(256), 0, s, g);
     else              hipLaunchKernelGGL((gemm_p3_kernel<true, 1, 1, 2, 2>), grid, dim3(256), 0, s, g);
     ASR_CHECK_LAUNCH();
+    if (g.slab) {
+        SlabMap q;
+        q.M = M; q.N = N; q.Nvalid = N; q.nsl = (nk + per - 1) / per; q.nsl_alloc = splits; q.batch = 1; q.mA = M; q.mA_valid = M;
+        q.colmap = colmap; q.ldc = ldc; q.zC = 0; q.accumulate = accumulate;
+        return slab_reduce(s, C, g.slab, q);
+    }
     return ASR_OK;
 }
 
@@ -565,20 +587,35 @@ int p3_lstm_wgrad(hipStream_t s, int rows, int in_pad, int in_valid, int H, int 
     // (256 x 256 tiles double the bytes every K slice adds into dK with float atomics -- 61 instead of 30 MB per launch at ~1.3 TB/s:
     // measured in the bf16 train step, the larger tile LOSES here what it wins in the k-loop; opt-in ASR_P3_WGRAD256=1)
     static const int big = [] { const char* e = getenv("ASR_P3_WGRAD256"); return e ? atoi(e) : 0; }();
+    auto with_slabs = [&](int nk_all) {          // g.splits is final: partial tiles through this stream's slab arena (csrc/splitk.hip)
+        g.slab = (g.splits > 1 && wgrad_slabs()) ? slab_arena(s, (size_t)ndir * g.splits * g.M * g.N * sizeof(float)) : nullptr;
+        (void)nk_all;
+    };
+    auto slab_end = [&](int nk_all) -> int {
+        if (hipGetLastError() != hipSuccess) return ASR_ELAUNCH;
+        if (!g.slab) return ASR_OK;
+        const int per = (nk_all + g.splits - 1) / g.splits;
+        SlabMap q;
+        q.M = g.M; q.N = g.N; q.Nvalid = g.N; q.nsl = (nk_all + per - 1) / per; q.nsl_alloc = g.splits; q.batch = ndir;
+        q.mA = g.mA; q.mA_valid = g.mA_valid; q.colmap = colmap; q.ldc = g.ldc; q.zC = dk_stride; q.accumulate = 1;
+        return slab_reduce(s, dk, g.slab, q);
+    };
     if (big && np == 1 && in_pad % 256 == 0 && H % 256 == 0 && rows % 32 == 0) {       // one plane: 256 x 256 tiles (see asr_gemm_p3_kk)
         const int tiles2 = (g.M / 256) * (g.N / 256) * ndir, nk2 = rows / 32;
         g.splits = std::max(1, std::min(cus / tiles2, nk2 / 8));
+        with_slabs(nk2);
         hipLaunchKernelGGL((gemm_p3_kernel<true, 1, 2, 4, 2>), dim3(tiles2 / ndir, g.splits, ndir), dim3(512), 0, s, g);
-        return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
+        return slab_end(nk2);
     }
     const int ks = (np == 1 && rows % 32 == 0) ? 2 : 1;                    // (rows % 32 == 16: the KS = 1 kernel, see asr_gemm_p3_rr)
     const int tiles = (g.M / 128) * (g.N / 256) * ndir, nk = rows / (16 * ks);
     g.splits = std::max(1, std::min(cus / tiles, std::max(1, nk / 8)));    // one workgroup per CU and no second round
     const dim3 grid(tiles / ndir, g.splits, ndir);
+    with_slabs(nk);
     if (np == 3)      hipLaunchKernelGGL((gemm_p3_kernel<true, 3, 1, 2, 2>), grid, dim3(256), 0, s, g);
     else if (np == 2) hipLaunchKernelGGL((gemm_p3_kernel<true, 2, 1, 2, 2>), grid, dim3(256), 0, s, g);
     else if (ks == 2) hipLaunchKernelGGL((gemm_p3_kernel<true, 1, 2, 2, 2>), grid, dim3(256), 0, s, g);
     else              hipLaunchKernelGGL((gemm_p3_kernel<true, 1, 1, 2, 2>), grid, dim3(256), 0, s, g);
-    return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
+    return slab_end(nk);
 }
 }  // namespace asr

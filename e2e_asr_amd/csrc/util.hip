@@ -35,6 +35,47 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* x, int ldx, in
     }
 }
 
+// deterministic form (ASR_WGRAD_SLABS, default): the row slabs' partial sums go to a workspace [slabs][N] instead of meeting in
+// `out` through atomics, and colsum_finish_kernel adds them in ascending slab order
+__global__ __launch_bounds__(256) void colsum_part_kernel(const float* x, int ldx, int M, int N, float* ws, int rows_per_slab) {
+    __shared__ float part[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), strip = threadIdx.x >> 6;
+    const int s0 = blockIdx.y * rows_per_slab, s1 = min(M, s0 + rows_per_slab);
+    float s = 0.f;
+    if (c < N) {
+        const int rows = (s1 - s0 + 3) / 4;
+        const int m0 = s0 + strip * rows, m1 = min(s1, m0 + rows);
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int m = m0;
+        for (; m + 3 < m1; m += 4) {
+            a0 += x[(size_t)m * ldx + c]; a1 += x[(size_t)(m + 1) * ldx + c];
+            a2 += x[(size_t)(m + 2) * ldx + c]; a3 += x[(size_t)(m + 3) * ldx + c];
+        }
+        for (; m < m1; ++m) a0 += x[(size_t)m * ldx + c];
+        s = (a0 + a1) + (a2 + a3);
+    }
+    part[strip][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (strip == 0 && c < N)
+        ws[(size_t)blockIdx.y * N + c] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* ws, int slabs, int N, float* out, int split, float* out2) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= N) return;
+    float t = 0.f;
+    int s = 0;
+    for (; s + 8 <= slabs; s += 8) {            // eight independent loads, then added in ascending order
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = ws[(size_t)(s + j) * N + c];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t += v[j];
+    }
+    for (; s < slabs; ++s) t += ws[(size_t)s * N + c];
+    float* o = c >= split ? out2 + (c - split) : out + c;
+    *o += t;
+}
+
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float* table, const int* idx, float* out, int rows, int width) {
     const int w4 = width >> 2;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)rows * w4; i += (size_t)gridDim.x * 256) {
@@ -177,6 +218,18 @@ extern "C" int asr_colsum_f32(void* stream, const float* x, int ldx, int M, int 
     const int rows_per_slab = (M + slabs - 1) / slabs;
     slabs = (M + rows_per_slab - 1) / rows_per_slab;
     if (M == 0) return ASR_OK;
+    if (slabs > 1 && asr::wgrad_slabs()) {
+        // (at most 64 row slabs: colsum_finish_kernel walks them in order, eight loads in flight)
+        const int rps = std::max(rows_per_slab, (M + 63) / 64);
+        slabs = (M + rps - 1) / rps;
+        float* ws = asr::slab_arena(s, (size_t)slabs * N * sizeof(float));
+        if (ws) {
+            hipLaunchKernelGGL(asr::colsum_part_kernel, dim3(nx, slabs), dim3(256), 0, s, x, ldx, M, N, ws, rps);
+            hipLaunchKernelGGL(asr::colsum_finish_kernel, dim3((N + 63) / 64), dim3(64), 0, s, ws, slabs, N, out, 0x7fffffff, (float*)nullptr);
+            ASR_CHECK_LAUNCH();
+            return ASR_OK;
+        }
+    }
     hipLaunchKernelGGL(asr::colsum_kernel, dim3(nx, slabs), dim3(256), 0, s, x, ldx, M, N, out, rows_per_slab);
     ASR_CHECK_LAUNCH();
     return ASR_OK;
@@ -189,6 +242,17 @@ int asr_colsum_pair_f32(hipStream_t s, const float* x, int ldx, int M, int N, fl
     int slabs = std::max(1, std::min(M / 32, (2048 + nx - 1) / nx));
     const int rows_per_slab = (M + slabs - 1) / slabs;
     slabs = (M + rows_per_slab - 1) / rows_per_slab;
+    if (slabs > 1 && asr::wgrad_slabs()) {
+        const int rps = std::max(rows_per_slab, (M + 63) / 64);
+        slabs = (M + rps - 1) / rps;
+        float* ws = asr::slab_arena(s, (size_t)slabs * 2 * N * sizeof(float));
+        if (ws) {
+            hipLaunchKernelGGL(asr::colsum_part_kernel, dim3(nx, slabs), dim3(256), 0, s, x, ldx, M, 2 * N, ws, rps);
+            hipLaunchKernelGGL(asr::colsum_finish_kernel, dim3((2 * N + 63) / 64), dim3(64), 0, s, ws, slabs, 2 * N, out0, N, out1);
+            ASR_CHECK_LAUNCH();
+            return ASR_OK;
+        }
+    }
     hipLaunchKernelGGL(asr::colsum_kernel, dim3(nx, slabs), dim3(256), 0, s, x, ldx, M, 2 * N, out0, rows_per_slab, N, out1);
     ASR_CHECK_LAUNCH();
     return ASR_OK;
@@ -220,8 +284,10 @@ extern "C" int asr_scatter_add_rows_ld(void* stream, float* tg, const int* idx, 
 extern "C" int asr_scatter_add_rows(void* stream, float* tg, const int* idx, const float* g, int rows, int width) {
     return asr_scatter_add_rows_ld(stream, tg, idx, g, rows, width, width);
 }
+extern "C" int asr_scatter_add_rows_ordered(void* stream, float* tg, int vocab, const int* idx, const float* g, int rows, int width, int ldg);
 extern "C" int asr_scatter_add_rows_ld(void* stream, float* tg, const int* idx, const float* g, int rows, int width, int ldg) {
     if (!tg || !idx || !g || rows <= 0 || width <= 0 || ldg < width) return ASR_EINVAL;
+    if (asr::wgrad_slabs() && width <= 1024) return asr_scatter_add_rows_ordered(stream, tg, 0, idx, g, rows, width, ldg);   // no atomics: fixed order
     const int grid = (int)std::min<size_t>(2048, ((size_t)rows * width + 255) / 256);
     hipLaunchKernelGGL(asr::scatter_add_rows_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), tg, idx, g, rows, width, ldg);
     ASR_CHECK_LAUNCH();

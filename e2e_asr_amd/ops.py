@@ -479,7 +479,13 @@ def gather_rows(table, idx):
 
 
 def scatter_add_rows(table_grad, idx, g):
-    _check(_lib.lib().asr_scatter_add_rows(_stream(), _p(table_grad), _p(idx), _p(g), idx.numel(), table_grad.shape[1]),
+    """table_grad[idx[r]] += g[r] (embedding gradient).  Deterministic wgrad mode: a row's occurrences in ascending order, no atomics."""
+    L = _lib.lib()
+    if L.asr_get_wgrad_mode() and table_grad.shape[1] <= 1024:
+        _check(L.asr_scatter_add_rows_ordered(_stream(), _p(table_grad), table_grad.shape[0], _p(idx), _p(g), idx.numel(),
+                                              table_grad.shape[1], g.shape[1]), "asr_scatter_add_rows_ordered")
+        return
+    _check(L.asr_scatter_add_rows(_stream(), _p(table_grad), _p(idx), _p(g), idx.numel(), table_grad.shape[1]),
            "asr_scatter_add_rows")
 
 
@@ -804,6 +810,16 @@ def get_gemm_split():
 
 def get_gemm_precision():
     return ("f32", "bf16", "bf16x2")[_lib.lib().asr_get_gemm_precision()]
+
+
+def set_wgrad_mode(slabs=True):
+    """True: the deterministic mode -- split-K weight gradients through slabs + a fixed-order reduce, two-stage bias sums, ordered
+    embedding scatter: every gradient bit-reproducible run to run (+0.1 ... 0.3 ms per config-2 step); False (default): float atomics."""
+    _check(_lib.lib().asr_set_wgrad_mode(int(bool(slabs))), "asr_set_wgrad_mode")
+
+
+def get_wgrad_mode():
+    return bool(_lib.lib().asr_get_wgrad_mode())
 
 
 PROF_TAGS = {"lstm_rec_fwd": 0, "lstm_rec_bwd": 1, "gemm": 2, "decoder_fwd": 3, "decoder_bwd": 4, "optim": 5, "side_tail": 6}

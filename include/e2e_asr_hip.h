@@ -445,6 +445,18 @@ int asr_resident_wg_budget(void);
 int asr_set_lstm_mfma(int on);
 int asr_get_lstm_mfma(void);
 
+/* How the K slices of a split-K weight-gradient product (tf.gradients, seq2seq_model.py:148: X^T . dY with K = B*T) meet in C.
+ * 0 (default): float atomics into C (order, hence the last bits, vary from run to run).  1 = DETERMINISTIC mode (environment
+ * ASR_WGRAD_SLABS=1): each slice stores its partial tile into a per-stream slab arena owned by the library and a streaming
+ * kernel adds the slabs into C in slice order; bias column sums run in two stages and the embedding gradient adds a row's
+ * occurrences in token order -- every gradient is bit-reproducible run to run, at +0.1 ... +0.3 ms per config-2 train step.
+ * New: the reference computes on one CPU thread and is deterministic by construction. */
+int asr_set_wgrad_mode(int slabs);
+int asr_get_wgrad_mode(void);
+/* table[idx[r]] += g[r] (g rows of pitch ldg), the occurrences of a table row added in ascending r, no atomics; width <= 1024.
+ * vocab = rows of `table` (0 if unknown: a slower form with the same sums).  The form asr_scatter_add_rows takes in wgrad mode 1. */
+int asr_scatter_add_rows_ordered(void* stream, float* table, int vocab, const int* idx, const float* g, int rows, int width, int ldg);
+
 /* 1 in the race-hunt DEBUG build (libe2e_asr_hip_hunt.so: every publish and poll of the persistent kernels preceded by a
  * random ~4 us delay of one wave in eight, csrc/common.h ASR_RACE_HUNT), 0 in the product library.  New: test tooling. */
 int asr_race_hunt_build(void);

@@ -42,6 +42,110 @@ def test_gemm(dev, ta, tb, M, N, K):
     np.testing.assert_allclose(out2.cpu().numpy(), 2 * ref - bias, rtol=0, atol=4e-5 * np.sqrt(K) + 2e-5)
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 1000, 3840), (512, 300, 1024), (80, 1000, 2048)])
+def test_gemm_weight_gradient_form_with_ragged_n(dev, M, N, K):
+    """X^T . dY with a long K and N % 128 != 0 (the decoder's OutputProjection gradient, attn_decoder.py:119-125 under
+    tf.gradients): whole 128-column tiles on the split3 kernel, the ragged columns on the bounds-checked one, both accumulating
+    into the same live C.  Held to the float64 product like every other fp32 GEMM."""
+    from e2e_asr_amd import ops
+    rng = np.random.default_rng(M + N + K)
+    a = rng.standard_normal((K, M)).astype(np.float32)
+    b = rng.standard_normal((K, N)).astype(np.float32)
+    c0 = rng.standard_normal((M, N)).astype(np.float32)
+    ref = a.T.astype(np.float64) @ b.astype(np.float64)
+    out = ops.gemm(T(a, dev), T(b, dev), None, True, False)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=0, atol=2e-5 * np.sqrt(K) + 1e-5)
+    acc = ops.gemm(T(a, dev), T(b, dev), None, True, False, out=T(c0, dev), accumulate=True)
+    np.testing.assert_allclose(acc.cpu().numpy(), ref + c0, rtol=0, atol=2e-5 * np.sqrt(K) + 1e-5)
+    # a view with a row pitch (the gradient lives inside the flat buffer next to other variables)
+    big = torch.zeros(M, N + 24, device=dev)
+    rc_view = big[:, :N]
+    from e2e_asr_amd import _lib
+    import ctypes as C
+    ta, tb = T(a, dev), T(b, dev)          # (kept alive across the launch)
+    rc = _lib.lib().asr_gemm_f32(ops._stream(), 1, 0, M, N, K, ops._p(ta), M, ops._p(tb), N, ops._p(big), N + 24, None, 0)
+    assert rc == 0
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(rc_view.cpu().numpy(), ref, rtol=0, atol=2e-5 * np.sqrt(K) + 1e-5)
+    assert float(big[:, N:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("form", ["planes", "exact", "p3_rr"])
+def test_split_k_through_slabs_is_bit_stable_and_equals_the_atomic_form(dev, form):
+    """Weight-gradient products with K split over workgroups (seq2seq_model.py:148): in slab mode (the opt-in deterministic mode) the same
+    bits on every call, next to a busy second stream too; equal to the float-atomic form to summation-order rounding."""
+    from e2e_asr_amd import ops
+    from tests.test_gpu_gemm_p3 import _busy_stream
+    g = torch.Generator(device=dev).manual_seed(5)
+    M, N, K = (1024, 1024, 6400) if form != "exact" else (256, 104, 3840)
+    a = torch.randn(K, M, device=dev, generator=g)
+    b = torch.randn(K, N, device=dev, generator=g)
+    c0 = torch.randn(M, N, device=dev, generator=g)
+    if form == "p3_rr":
+        ap, bp = ops.p3_split(a, 3), ops.p3_split(b, 3)
+        run = lambda: ops.gemm_p3_rr(ap, bp, out=c0.clone(), accumulate=True, splits=0)
+    else:
+        run = lambda: ops.gemm(a, b, None, True, False, out=c0.clone(), accumulate=True)
+    assert not ops.get_wgrad_mode()              # default: float atomics
+    atom = run()
+    ops.set_wgrad_mode(True)
+    try:
+        first = run()
+        torch.cuda.synchronize()
+        side, keep = _busy_stream(12)
+        outs = [run() for _ in range(4)]
+        torch.cuda.synchronize()
+        del keep
+        for o in outs:
+            assert torch.equal(o, first)
+        if form != "p3_rr":                      # not accumulating: C is overwritten (no pre-zero needed in slab mode)
+            fresh = torch.full((M, N), 7.0, device=dev)
+            ops.gemm(a, b, None, True, False, out=fresh)
+    finally:
+        ops.set_wgrad_mode(False)
+    ref = a.double().t() @ b.double() + c0.double()
+    den = (a.double().abs().t() @ b.double().abs()).max().item()
+    assert (first.double() - ref).abs().max().item() <= 4e-7 * den
+    assert (atom.double() - ref).abs().max().item() <= 4e-7 * den
+    if form != "p3_rr":
+        assert (fresh.double() - (ref - c0.double())).abs().max().item() <= 4e-7 * den
+
+
+def test_ordered_embedding_scatter_equals_index_add_in_token_order(dev):
+    """decoder/embedding gradient (decoder.py:97-99 under tf.gradients): rows of one token added in ascending position, no
+    atomics -- bit-identical to a sequential float32 loop, run to run, and equal to index_add to rounding."""
+    from e2e_asr_amd import ops, _lib
+    g = torch.Generator(device=dev).manual_seed(2)
+    rows, width, vocab = 3840, 256, 1000
+    idx = torch.randint(0, 60, (rows,), device=dev, generator=g, dtype=torch.int32)      # many repeats per row
+    idx[:50] = torch.randint(0, vocab, (50,), device=dev, generator=g, dtype=torch.int32)
+    grad = torch.randn(rows, width + 8, device=dev, generator=g)
+    t0 = torch.randn(vocab, width, device=dev, generator=g)
+    outs = []
+    for voc in (vocab, vocab, 0):                 # by vocabulary row (twice), and the form that does not know the table height
+        t = t0.clone()
+        rc = _lib.lib().asr_scatter_add_rows_ordered(ops._stream(), ops._p(t), voc, ops._p(idx), ops._p(grad), rows, width, width + 8)
+        assert rc == 0
+        outs.append(t)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    ref = t0.cpu().numpy().copy()
+    gi, gg = idx.cpu().numpy(), grad.cpu().numpy()[:, :width]
+    # the kernel's order: four quarters of the token list, each summed in ascending token order from zero, then
+    # ((q0 + q1) + q2) + q3 added to the table row once
+    Q = ((rows + 3) // 4 + 63) // 64 * 64
+    part = {}
+    for r in range(rows):
+        k = (gi[r], r // Q)
+        part[k] = (part.get(k, np.zeros(width, np.float32)) + gg[r]).astype(np.float32)
+    for v in set(int(x) for x in gi):
+        q = [part.get((v, w), np.zeros(width, np.float32)) for w in range(4)]
+        ref[v] = (ref[v] + (((q[0] + q[1]).astype(np.float32) + q[2]).astype(np.float32) + q[3]).astype(np.float32)).astype(np.float32)
+    np.testing.assert_array_equal(outs[0].cpu().numpy(), ref)
+    ia = t0.clone().index_add_(0, idx.long(), grad[:, :width].contiguous())
+    assert (outs[0] - ia).abs().max().item() < 1e-4
+
+
 # ------------------------------------------------------------------ LSTM layer
 def _lstm_case(rng, B, Tn, IN, H, bi, lens):
     x = rng.standard_normal((B, Tn, IN)).astype(np.float32)
