@@ -488,7 +488,7 @@ extern "C" int asr_attn_decoder_bwd(void* stream, const asr_dec_weights* w, cons
         } else if (T > 1 && (rc = asr_gemm_f32(side, 1, 0, lmH, 4 * lmH, TB - B, ws->lm_h, lmH, ws->lm_gates + (size_t)B * 4 * lmH, 4 * lmH,
                                         gwl + (size_t)E * 4 * lmH, 4 * lmH, nullptr, 1))) return rc;
         if ((rc = asr_colsum_f32(side, ws->lm_gates, 4 * lmH, TB, 4 * lmH, const_cast<float*>(g->lm_bias), 1))) return rc;
-        if (asr::wgrad_slabs() && E <= 1024) {      // occurrences of a token added in ascending order, no atomics (csrc/splitk.hip)
+        if (asr::wgrad_slabs() == 1 && E <= 1024) {      // occurrences of a token added in ascending order, no atomics (csrc/splitk.hip)
             if ((rc = asr_scatter_add_rows_ordered(side, const_cast<float*>(g->embedding), V, ws->tok, bw->dEH, TB, E, ldEH))) return rc;
         } else if ((rc = asr_scatter_add_rows_ld(side, const_cast<float*>(g->embedding), ws->tok, bw->dEH, TB, E, ldEH))) return rc;
     }

@@ -876,14 +876,32 @@ __global__ __launch_bounds__(512) void lstm_rec_bwd4_kernel(LstmBwdArgs a) {
     const bool cell_wave = wave == 0;
     const int sbase = ((mem + (wave >> 1)) % G) * HS + (wave & 1) * 32;      // first source unit of this wave's half slice
 
-    // K_h row of the own unit cj over the wave's 128 positions q = 4*su + gate (column gate*H + sbase + su), as pairs
+    // K_h row of the own unit cj over the wave's 128 positions q = 4*su + gate (column gate*H + sbase + su), as pairs.
+    // lane = own unit means every lane reads ANOTHER ROW of K_h (4 KB apart): read straight from memory that is 128 scattered
+    // 4-byte loads per lane, 64 lines per wave instruction -- ~15 us of prologue per launch, four launches per step (round 5:
+    // the BPTT of 100 steps took 126 us, the forward 95).  Coalesced instead: a wave instruction covers 32 consecutive floats
+    // of two rows, the 64 x 32 tile of one gate goes through a wave-private LDS tile (pitch 33: conflict-free both ways) and
+    // each lane picks up its own row.
     f32x2 wq[64];
     {
-        const float* kr = a.kh[dir] + (size_t)cj * H4 + sbase;
+        __shared__ float wt[NW][64 * 33];
+        float* tile = &wt[wave][0];
+        const float* kr = a.kh[dir] + (size_t)j0 * H4 + sbase + (lane & 31);
+        const int rh = lane >> 5;
 #pragma unroll
-        for (int su = 0; su < 32; ++su) {
-            wq[2 * su] = f32x2{kr[su], kr[H + su]};
-            wq[2 * su + 1] = f32x2{kr[2 * H + su], kr[3 * H + su]};
+        for (int g = 0; g < 4; ++g) {
+            float v[32];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) v[i] = kr[(size_t)(2 * i + rh) * H4 + g * H];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) tile[(2 * i + rh) * 33 + (lane & 31)] = v[i];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int su = 0; su < 32; ++su) {
+                const float x = tile[lane * 33 + su];
+                if (g == 0) wq[2 * su].x = x; else if (g == 1) wq[2 * su].y = x; else if (g == 2) wq[2 * su + 1].x = x; else wq[2 * su + 1].y = x;
+            }
+            __builtin_amdgcn_wave_barrier();
         }
     }
     const int S = min(a.len[cb], a.T);

@@ -23,7 +23,7 @@ namespace asr {
 
 static int g_wgrad_slabs = -1;
 int wgrad_slabs() {
-    if (g_wgrad_slabs < 0) { const char* e = getenv("ASR_WGRAD_SLABS"); g_wgrad_slabs = e ? (atoi(e) != 0) : 0; }
+    if (g_wgrad_slabs < 0) { const char* e = getenv("ASR_WGRAD_SLABS"); g_wgrad_slabs = e ? atoi(e) : 0; }
     return g_wgrad_slabs;
 }
 
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void scatter_rows_ordered_kernel(float* __rest
 
 // 1: split-K partial tiles through slabs + fixed-order reduce, ordered embedding scatter, two-stage column sums -- every gradient
 // bit-reproducible run to run; 0 (default): float atomics.  Environment: ASR_WGRAD_SLABS.
-extern "C" int asr_set_wgrad_mode(int slabs) { asr::g_wgrad_slabs = slabs != 0; return ASR_OK; }
+extern "C" int asr_set_wgrad_mode(int slabs) { asr::g_wgrad_slabs = slabs; return ASR_OK; }       // (2: EXPERIMENT -- the GEMMs only)
 extern "C" int asr_get_wgrad_mode(void) { return asr::wgrad_slabs(); }
 
 // tg[idx[r]] += g[r], the occurrences of a row added in ascending r (deterministic form of asr_scatter_add_rows); width <= 1024.

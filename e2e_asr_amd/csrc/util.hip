@@ -218,7 +218,7 @@ extern "C" int asr_colsum_f32(void* stream, const float* x, int ldx, int M, int 
     const int rows_per_slab = (M + slabs - 1) / slabs;
     slabs = (M + rows_per_slab - 1) / rows_per_slab;
     if (M == 0) return ASR_OK;
-    if (slabs > 1 && asr::wgrad_slabs()) {
+    if (slabs > 1 && asr::wgrad_slabs() == 1) {
         // (at most 64 row slabs: colsum_finish_kernel walks them in order, eight loads in flight)
         const int rps = std::max(rows_per_slab, (M + 63) / 64);
         slabs = (M + rps - 1) / rps;
@@ -242,7 +242,7 @@ int asr_colsum_pair_f32(hipStream_t s, const float* x, int ldx, int M, int N, fl
     int slabs = std::max(1, std::min(M / 32, (2048 + nx - 1) / nx));
     const int rows_per_slab = (M + slabs - 1) / slabs;
     slabs = (M + rows_per_slab - 1) / rows_per_slab;
-    if (slabs > 1 && asr::wgrad_slabs()) {
+    if (slabs > 1 && asr::wgrad_slabs() == 1) {
         const int rps = std::max(rows_per_slab, (M + 63) / 64);
         slabs = (M + rps - 1) / rps;
         float* ws = asr::slab_arena(s, (size_t)slabs * 2 * N * sizeof(float));
@@ -287,7 +287,7 @@ extern "C" int asr_scatter_add_rows(void* stream, float* tg, const int* idx, con
 extern "C" int asr_scatter_add_rows_ordered(void* stream, float* tg, int vocab, const int* idx, const float* g, int rows, int width, int ldg);
 extern "C" int asr_scatter_add_rows_ld(void* stream, float* tg, const int* idx, const float* g, int rows, int width, int ldg) {
     if (!tg || !idx || !g || rows <= 0 || width <= 0 || ldg < width) return ASR_EINVAL;
-    if (asr::wgrad_slabs() && width <= 1024) return asr_scatter_add_rows_ordered(stream, tg, 0, idx, g, rows, width, ldg);   // no atomics: fixed order
+    if (asr::wgrad_slabs() == 1 && width <= 1024) return asr_scatter_add_rows_ordered(stream, tg, 0, idx, g, rows, width, ldg);   // no atomics: fixed order
     const int grid = (int)std::min<size_t>(2048, ((size_t)rows * width + 255) / 256);
     hipLaunchKernelGGL(asr::scatter_add_rows_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), tg, idx, g, rows, width, ldg);
     ASR_CHECK_LAUNCH();
