@@ -558,7 +558,7 @@ def main():
     # HBM traffic per launch cannot be read by the process that is being timed (the PMC passes are separate rocprofv3
     # runs, MI355X_MICROARCH.md): the committed summary of those passes is quoted, and its provenance is stated.
     traffic, traffic_source = None, None
-    for name in (() if mt is not None else ("traffic_r04.json", "traffic_r03.json", "traffic_r02.json", "traffic_r01.json")):
+    for name in (() if mt is not None else ("traffic_r05.json", "traffic_r04.json", "traffic_r03.json", "traffic_r02.json", "traffic_r01.json")):
         tp = os.path.join(ROOT, "profiles", name)
         if os.path.exists(tp):
             try:

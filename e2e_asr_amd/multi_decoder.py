@@ -8,8 +8,9 @@ the single-layer names only), so this configuration is off the hot path: it runs
 library's step kernels -- `asr_lstm_cell_fwd` (fused gemv + cell + dropout), `asr_linear_fwd`, `asr_attention_fwd`,
 `asr_next_token` forward; `asr_attn_cell_bwd` (attention + top-cell backward), `asr_lstm_cell_bwd` (lower layers, LM stack),
 `asr_linear_wt_fwd` backward; every product over all steps (projections, logits, weight gradients) as MFMA GEMMs after the
-loops.  Everything stays on the caller's stream.  Variable names: weights.multi_cell_leaf.  A SimpleProjection
-(lm_hidden_size != hidden_size_dec) is not combined with stacks here (NotImplementedError).
+loops.  Everything stays on the caller's stream.  Variable names: weights.multi_cell_leaf.  With lm_hidden_size !=
+hidden_size_dec the LM stack's (dropped) top output passes through `rnn/SimpleProjection` before the InputProjection
+(attn_decoder.py:149-151), here one `asr_linear_fwd` per step and its gradients as GEMMs over all steps (round 5).
 """
 import numpy as np
 import torch
@@ -30,8 +31,7 @@ class MultiLayerPath(object):
         self.dec = decoder
         p = decoder.params
         self.L = int(p.num_layers_dec)
-        if p.lm_hidden_size != p.hidden_size_dec:
-            raise NotImplementedError("MultiRNNCell decoder with a SimpleProjection (lm_hidden_size != hidden_size_dec)")
+        self.simple = p.lm_hidden_size != p.hidden_size_dec          # attn_decoder.py:149-151
 
     # ---- variables ---------------------------------------------------------------------------------------------
     def _name(self, leaf):
@@ -56,6 +56,8 @@ class MultiLayerPath(object):
                  inp_w=get("rnn/InputProjection/kernel"), inp_b=get("rnn/InputProjection/bias"),
                  ap_w=get("rnn/AttnProjection/kernel"), ap_b=get("rnn/AttnProjection/bias"),
                  out_w=get(self._out_leaf("rnn/OutputProjection/kernel")), out_b=get(self._out_leaf("rnn/OutputProjection/bias")))
+        if self.simple:
+            d["sp_w"], d["sp_b"] = get("rnn/SimpleProjection/kernel"), get("rnn/SimpleProjection/bias")
         for stack in ("lm", "dec"):
             d[stack + "_k"] = [get(multi_cell_leaf(stack, k, "kernel")) for k in range(self.L)]
             d[stack + "_b"] = [get(multi_cell_leaf(stack, k, "bias")) for k in range(self.L)]
@@ -103,7 +105,8 @@ class MultiLayerPath(object):
         steps = []
         logits_fb = {}
         for i in range(T):
-            lm_out, lm_st = self._stack_step("lm", w, w["emb"], tok[i], lm_prev, keep, seed, i, top_plain=False)
+            lm_top, lm_st = self._stack_step("lm", w, w["emb"], tok[i], lm_prev, keep, seed, i, top_plain=False)
+            lm_out = ops.linear(lm_top, w["sp_w"], w["sp_b"]) if self.simple else lm_top      # attn_decoder.py:149-151
             x = ops.linear(lm_out, w["inp_w"], w["inp_b"], x2=ctx_prev)                       # attn_decoder.py:157-158
             _, dec_st = self._stack_step("dec", w, x, None, dec_prev, keep, seed, i, top_plain=True)
             q = dec_st[-1][0]                                                                 # decoder.py:77-80
@@ -113,7 +116,7 @@ class MultiLayerPath(object):
                 lg = ops.linear(pr, w["out_w"], w["out_b"], zero_from=len_dev, zero_t=i)
                 tok[i + 1] = ops.next_token(lg, sample=(mode == 2), seed=seed, step=i)
                 logits_fb[i] = lg
-            steps.append(dict(lm=lm_st, lm_out=lm_out, x=x, dec=dec_st, alpha=alpha, ctx=ctx))
+            steps.append(dict(lm=lm_st, lm_out=lm_out, lm_top=lm_top, x=x, dec=dec_st, alpha=alpha, ctx=ctx))
             lm_prev = [(s[0], s[1]) for s in lm_st]
             dec_prev = [(s[0], s[1]) for s in dec_st]
             ctx_prev = ctx
@@ -139,7 +142,7 @@ class MultiLayerPath(object):
         H, A = w["attn_w"].shape
         E = w["emb"].shape[1]
         lmH = w["lm_k"][0].shape[1] // 4
-        P = lmH
+        P = H if self.simple else lmH                               # width of the InputProjection's first input
         dev = enc.device
         f = lambda *s: torch.zeros(s, device=dev)
         TB = T * B
@@ -157,6 +160,7 @@ class MultiLayerPath(object):
         dXH = [f(T, B, in_dec[k] + H) for k in range(L)]            # [d input | dh_prev] of outer layer k
         dEH = [f(T, B, in_lm[k] + lmH) for k in range(L)]           # same, LM stack
         dLC = f(T, B, P + D)                                        # [dlm_out | dctx_prev]
+        dSP = f(T, B, lmH) if self.simple else None                 # gradient of the LM stack's top output (behind SimpleProjection)
         dctx, dY = f(T, B, D), f(T, B, A)
         dhf, dv_part = f(B, Te, A), f(B, A)
         dc_dec = [f(B, H) for _ in range(L)]
@@ -180,8 +184,10 @@ class MultiLayerPath(object):
                 ops.linear_wt(dg("dec", k, i), w["dec_k"][k], out=dXH[k][i])
             # [dlm_out | dctx_prev] = dx . W_inp^T
             ops.linear_wt(dXH[0][i], w["inp_w"], out=dLC[i], k=E)
+            if self.simple:                      # d lm_top = d lm_out . W_sp^T
+                ops.linear_wt(dLC[i], w["sp_w"], out=dSP[i], k=P)
             for k in range(L - 1, -1, -1):       # LM stack, top first
-                dout = dLC[i][:, :P] if k == L - 1 else dEH[k + 1][i][:, :lmH]
+                dout = (dSP[i] if self.simple else dLC[i][:, :P]) if k == L - 1 else dEH[k + 1][i][:, :lmH]
                 ops.lstm_cell_bwd(dg("lm", k, i), cc("lm", k, i), cc("lm", k, i - 1) if i else None, dout,
                                   None if last else dEH[k][i + 1][:, in_lm[k]:], dc_lm[k],
                                   keep_prob=keep, seed=layer_seed(seed, "lm", k), step=i)
@@ -218,3 +224,8 @@ class MultiLayerPath(object):
         if T > 1:
             ops.gemm(CTX[:TB - B], dx[B:], trans_a=True, out=g["inp_w"][P:], accumulate=True)
         ops.colsum(dx, g["inp_b"])
+        if self.simple:                          # SimpleProjection: rows = the LM stack's top output, gradient = d lm_out
+            dlo = dLC.view(TB, P + D)[:, :P].contiguous()
+            LMT = torch.stack([s["lm_top"] for s in steps]).view(TB, lmH)
+            ops.gemm(LMT, dlo, trans_a=True, out=g["sp_w"], accumulate=True)
+            ops.colsum(dlo, g["sp_b"])

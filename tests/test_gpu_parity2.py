@@ -493,8 +493,8 @@ def test_training_decoder_one_launch_teacher_forced_vs_oracle_and_autograd():
 
 
 # ------------------------------------------------------------------ MultiRNNCell decoder (num_layers_dec > 1)
-@pytest.mark.parametrize("L,keep", [(2, 1.0), (3, 0.8)])
-def test_multi_layer_decoder_vs_oracle_and_autograd(L, keep):
+@pytest.mark.parametrize("L,keep,lmH", [(2, 1.0, 32), (3, 0.8, 32), (2, 0.8, 24), (3, 1.0, 40)])
+def test_multi_layer_decoder_vs_oracle_and_autograd(L, keep, lmH):
     """decoder.py:66-68, 77-78: `-num_layers_dec L` builds both decoder cells as MultiRNNCell stacks of DropoutWrapper(
     BasicLSTMCell) layers; the attention query is the TOP layer's c.  Logits and loss vs the float64 oracle and every gradient
     vs float64 autograd, ragged lengths; with dropout the per-layer masks of the counter-based generator are reproduced on
@@ -505,9 +505,11 @@ def test_multi_layer_decoder_vs_oracle_and_autograd(L, keep):
     from tests.test_gpu_model import _np_keep_scale
     nl = {"char": 2}
     m = _model(enc_update=dict(hidden_size=64), num_layers=nl, seed=43,
-               dec_update=dict(hidden_size_dec=32, lm_hidden_size=32, emb_size=24, attention_vec_size=16, num_layers_dec=L,
+               dec_update=dict(hidden_size_dec=32, lm_hidden_size=lmH, emb_size=24, attention_vec_size=16, num_layers_dec=L,
                                out_prob_dec=keep))
     assert m.decoder["char"].cell.startswith("MultiRNNCell")
+    # lmH != 32: the LM stack's top output passes through rnn/SimpleProjection (attn_decoder.py:149-151 with decoder.py:66-68)
+    assert (lmH != 32) == any("SimpleProjection" in k for k in m.variables.names())
     b = _batch(61 + L, 5, 22, 20, 9, 50)
     m.global_step = 2
     m.forward(b)
@@ -523,7 +525,7 @@ def test_multi_layer_decoder_vs_oracle_and_autograd(L, keep):
             out = []
             for k in range(nlayers):
                 # (the oracle's raw_rnn restatement also runs the LM stack once past the last step: T_out + 1 rows)
-                ii, bb, jj = np.meshgrid(np.arange(T_out + 1), np.arange(B), np.arange(32), indexing="ij")
+                ii, bb, jj = np.meshgrid(np.arange(T_out + 1), np.arange(B), np.arange(lmH if stack == "lm" else 32), indexing="ij")
                 out.append(_np_keep_scale(layer_seed(seed, stack, k), ii * B + bb, jj, keep))
             return out
         lm_masks, dec_masks = masks("lm", L), masks("dec", L - 1)
