@@ -70,7 +70,8 @@ void prof_end(int tag, hipStream_t s);
 int resident_wg_budget();
 // splitk.hip: split-K partial tiles through per-stream slabs + a fixed-order reduce instead of float atomics (opt-in deterministic mode)
 int wgrad_slabs();
-float* slab_arena(hipStream_t s, size_t bytes);
+float* slab_arena(hipStream_t s, size_t bytes, int which = 0);
+int transpose_add(hipStream_t s, float* C, int ldc, const float* T, int M, int N, int accumulate);    // C[m][n] (+)= T[n][m], T [N][M]
 struct SlabMap {
     int M, N, nsl, nsl_alloc, batch;       // slab s of batch z at ((z * nsl_alloc + s) * M) * N floats (N % 4 == 0); nsl of them hold data
     int Nvalid;                            // columns n >= Nvalid of a slab row are padding (never read)

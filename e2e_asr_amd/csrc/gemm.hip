@@ -839,18 +839,21 @@ extern "C" int asr_gemm_f32_batched(void* stream, int transA, int transB, int M,
     if (M < 0 || N < 0 || K < 0 || !C || (K > 0 && (!A || !B))) return ASR_EINVAL;
     if (M == 0 || N == 0) return ASR_OK;
     if (lda < (transA ? M : K) || ldb < (transB ? K : N) || ldc < N) return ASR_EINVAL;
-    // Weight-gradient form with a long K and a ragged N (the decoder's OutputProjection gradient h^T . dlogits, 256 x 1000 x 3840):
-    // the whole-tile split3 kernel takes N % 128 == 0 only and the product fell to the exact-fp32 MFMA kernel with bounds
-    // checks (40 TF/s, 59 us per step; rocBLAS: 76 TF/s).  Columns [0, N - N % 128) go to the split3 kernel, the ragged rest
-    // to the bounds-checked one: two launches, same arithmetic per column as before for the rest, split3 (fp32-accurate) for
-    // the whole tiles.
-    if (transA && !transB && !bias && (g_gemm_split || g_gemm_bf16 != 0) && N % 128 != 0 && N > 256 && M >= 64 && K >= 1024 && K % BKS == 0 &&
-        (batch == 1 || accumulate) && (ldb % 4 == 0) && (strideB % 4 == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0)) {
-        const int n1 = N - N % 128;
-        const int rc = asr_gemm_f32_batched(stream, transA, transB, M, n1, K, A, lda, strideA, B, ldb, strideB, C, ldc, strideC, nullptr, accumulate, batch);
-        if (rc != ASR_OK) return rc;
-        return asr_gemm_f32_batched(stream, transA, transB, M, N - n1, K, A, lda, strideA, B + n1, ldb, strideB, C + n1, ldc, strideC, nullptr,
-                                    accumulate, batch);
+    // Weight-gradient form with a long K, whole row tiles and a ragged N (the decoder's OutputProjection gradient h^T . dlogits,
+    // 256 x 1000 x 3840): the whole-tile split3 kernel takes N % 128 == 0 only and the product fell to the exact-fp32 MFMA kernel
+    // with bounds checks (40 TF/s, 50-59 us per step; rocBLAS: 76 TF/s).  The TRANSPOSED product dlogits^T . h has the ragged
+    // dimension in M, which the weight-gradient instantiation of the split3 kernel takes (partial last row of tiles): it goes to a
+    // scratch [N][M] of this stream and a tiled transpose adds it into C.  (Splitting the columns into whole tiles + a ragged
+    // rest was measured first: the 104-column rest alone -- 2 tiles x 15 K slices -- took 41 us.)
+    if (transA && !transB && !bias && batch == 1 && (g_gemm_split || g_gemm_bf16 != 0) && N % 128 != 0 && N >= 64 && M % 128 == 0 &&
+        K >= 1024 && K % BKS == 0 && lda % 4 == 0 && ldb % 4 == 0 && ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0) {
+        hipStream_t st = static_cast<hipStream_t>(stream);
+        float* T = slab_arena(st, (size_t)N * M * sizeof(float), 1);
+        if (T) {
+            const int rc = asr_gemm_f32_batched(stream, 1, 0, N, M, K, B, ldb, 0, A, lda, 0, T, M, 0, nullptr, 0, 1);
+            if (rc != ASR_OK) return rc;
+            return transpose_add(st, C, ldc, T, M, N, accumulate);
+        }
     }
     GemmArgs g;
     g.A = A; g.B = B; g.C = C; g.bias = bias;

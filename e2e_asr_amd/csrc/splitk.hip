@@ -28,15 +28,16 @@ int wgrad_slabs() {
 }
 
 struct Arena { float* p = nullptr; size_t bytes = 0; };
-static std::map<std::pair<int, hipStream_t>, Arena> g_arenas;
+static std::map<std::pair<int, std::pair<hipStream_t, int>>, Arena> g_arenas;
 static std::mutex g_arena_mu;
 
-// >= bytes of device memory owned by (current device, stream s); grow-only (growing synchronises the device: warm-up only)
-float* slab_arena(hipStream_t s, size_t bytes) {
+// >= bytes of device memory owned by (current device, stream s, slot `which`); grow-only (growing synchronises the device:
+// warm-up only).  Slot 0: K slices / column-sum partials; slot 1: the transposed product of asr_gemm_f32's ragged-N form.
+float* slab_arena(hipStream_t s, size_t bytes, int which) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     std::lock_guard<std::mutex> lk(g_arena_mu);
-    Arena& a = g_arenas[std::make_pair(dev, s)];
+    Arena& a = g_arenas[std::make_pair(dev, std::make_pair(s, which))];
     if (a.bytes < bytes) {
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) return nullptr;   // no allocation inside a capture
@@ -101,6 +102,29 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(float* __restrict__ C,
             }
         }
     }
+}
+
+// C[m][n] (+)= T[n][m]  (T [N][M] row-major, pitch M): 32 x 32 tiles through LDS, coalesced on both sides
+__global__ __launch_bounds__(256) void transpose_add_kernel(float* __restrict__ C, int ldc, const float* __restrict__ T, int M, int N, int accumulate) {
+    __shared__ float tile[32][33];
+    const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int n = n0 + r, m = m0 + tx;
+        tile[r][tx] = (n < N && m < M) ? T[(size_t)n * M + m] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int m = m0 + r, n = n0 + tx;
+        if (m < M && n < N) {
+            float* d = C + (size_t)m * ldc + n;
+            *d = accumulate ? *d + tile[tx][r] : tile[tx][r];
+        }
+    }
+}
+int transpose_add(hipStream_t s, float* C, int ldc, const float* T, int M, int N, int accumulate) {
+    hipLaunchKernelGGL(transpose_add_kernel, dim3((M + 31) / 32, (N + 31) / 32), dim3(256), 0, s, C, ldc, T, M, N, accumulate);
+    return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
 }
 
 int slab_reduce(hipStream_t s, float* C, const float* slab, const SlabMap& q) {
