@@ -412,6 +412,19 @@ def main():
         else:
             model.forward(b)
 
+    # BENCH_r04's 10.34 ms (20 x 7.78 + 51 ms): ONE generation-2 pass of CPython's cyclic garbage collector (26-40 ms over the
+    # ~172 000 container objects that torch + the model keep alive; scripts/host_stall.py, profiles/r05_host_stall.txt) landed in
+    # the 0.16-s timed window: the enqueue of one step took 40 ms and the GPU ran dry.  Whether a run meets one depends on the
+    # allocation count since the interpreter started (generation-2 threshold 10 x 10 x 700), so it came and went with unrelated
+    # edits.  The step itself makes no cyclic garbage: collect once and move the survivors to the permanent generation --
+    # exactly what Train.train does before its loop (e2e_asr_amd/train.py) -- and count what still runs in the window.
+    # BEFORE the warm-up steps, and the timed region's events are created here too: between the last warm-up step and the
+    # timed region lies nothing but the bracket the contract asks for (a 40-ms collection there let the GPU's clocks drop and
+    # the first timed step ran 8.9 instead of 7.8 ms).
+    import gc
+    gc.collect()
+    gc.freeze()
+    step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     for _ in range(args.warmup):
         one_step()
     torch.cuda.synchronize()
@@ -435,17 +448,7 @@ def main():
     # self-diagnosis of the timed region (no synchronisation inside it): an event at every step's end on the launch stream,
     # read after the loop, and the host's clock when each step's enqueue returned.  An outlier step, a host-bound loop
     # (host_enqueue_ms ~ the whole region) and lost side-stream overlap (side_stream_tail_ms) are three different pictures.
-    step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     host_marks = []
-    # BENCH_r04's 10.34 ms (20 x 7.78 + 51 ms): ONE generation-2 pass of CPython's cyclic garbage collector (26-40 ms over the
-    # ~172 000 container objects that torch + the model keep alive; scripts/host_stall.py, profiles/r05_host_stall.txt) landed in
-    # the 0.16-s timed window: the enqueue of one step took 40 ms and the GPU ran dry.  Whether a run meets one depends on the
-    # allocation count since the interpreter started (generation-2 threshold 10 x 10 x 700), so it came and went with unrelated
-    # edits.  The step itself makes no cyclic garbage: collect once and move the survivors to the permanent generation --
-    # exactly what Train.train does before its loop (e2e_asr_amd/train.py) -- and count what still runs in the window.
-    import gc
-    gc.collect()
-    gc.freeze()
     gc_log, gc_t = [], [0.0]
 
     def gc_cb(phase, info):
