@@ -673,6 +673,22 @@ def set_decoder_bf16_planes(n):
     _decoder_precision.planes = int(n)
 
 
+_const_cache = {}
+
+
+def _const(kind, dev, n, value=0):
+    """Read-only device constants the decoder entry points take (an all-zero initial state, a lengths vector of one value): built
+    once per (device, size, value) instead of by a fill kernel on the launch stream of every step (two launches + their gaps
+    between the encoder's last kernel and the decoder's first, round 5).  NEVER written by the library."""
+    key = (kind, dev, int(n), int(value))
+    t = _const_cache.get(key)
+    if t is None:
+        t = (torch.zeros(n, device=dev, dtype=torch.float32) if kind == "zeros" else
+             torch.full((n,), int(value), device=dev, dtype=torch.int32))
+        _const_cache[key] = t
+    return t
+
+
 def attn_decoder_fwd(wt, dec_inp, seq_len, enc, enc_len, mode=0, coin=None, samp_prob=0.0,
                      keep_lm=1.0, seed=0, t_out=None):
     """Whole attention decoder forward (attn_decoder.py:37-172).
@@ -696,7 +712,7 @@ def attn_decoder_fwd(wt, dec_inp, seq_len, enc, enc_len, mode=0, coin=None, samp
               sp=f(T, B, H) if wt.get("simple_w") is not None else None, x=f(T, B, E),
               dec_gates=f(T, B, 4 * H), dec_c=f(T, B, H), dec_h=f(T, B, H), alpha=f(T, B, Te),
               ctx=f(T, B, D), p=f(T, B, H),
-              zeros=torch.zeros(B * max(H, lmH, D), device=dev, dtype=torch.float32), y=f(T, B, A))
+              zeros=_const("zeros", dev, B * max(H, lmH, D)), y=f(T, B, A))
     L = _lib.lib()
     if mode != 1 and L.asr_decoder_chain_supported(B, Te, D, A, H):       # persistent decoder-chain path
         P_ = H if wt.get("simple_w") is not None else lmH
@@ -707,7 +723,7 @@ def attn_decoder_fwd(wt, dec_inp, seq_len, enc, enc_len, mode=0, coin=None, samp
             ws["lm_act"] = f(T, B, lmH, 8)
             ws["lm_hprev"] = f(T, B, lmH)
             ws["lm_state"] = f(2, 2, B, lmH)
-            ws["lm_len"] = torch.full((B,), T, device=dev, dtype=torch.int32)
+            ws["lm_len"] = _const("full_i32", dev, B, T)
             ws["lm_hx"] = _hx(dev, L.asr_lstm_ws_bytes(B, lmH, 1))
     if mode == 1 and wt.get("simple_w") is None and keep_lm >= 1.0 and L.asr_decoder_greedy_supported(B, Te, D, A, H, lmH, E, V):
         ws["w2k"] = f(lmH + D + 1, 4 * H)         # inference graph: the whole greedy loop in one persistent launch

@@ -171,7 +171,7 @@ class Seq2SeqModel(BaseParams):
             total = None
             for task in params.tasks:                               # :140-144
                 total = self.losses[task] if total is None else total + self.losses[task]
-            if params.avg:
+            if params.avg and len(params.tasks) > 1:            # (one task: x / 1.0 == x, no launch for it on the step's critical path)
                 total = total / float(len(params.tasks))
             self.total_loss = total
         return self.outputs
