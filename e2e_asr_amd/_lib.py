@@ -155,6 +155,10 @@ SIGNATURES = {
     "asr_decoder_lm_chain_supported": (C.c_int, [C.c_int] * 2),
     "asr_zero_finished_rows": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int]),
     "asr_resident_wg_budget": (C.c_int, []),
+    "asr_gru_layer_fwd": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, vp, vp, vp,
+                                    vp, C.c_int, vp, vp, vp, vp, C.c_float, C.c_uint]),
+    "asr_gru_layer_bwd": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, vp, vp, C.c_int,
+                                    vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_uint]),
     "asr_race_hunt_build": (C.c_int, []),
     "asr_set_wgrad_mode": (C.c_int, [C.c_int]),
     "asr_get_wgrad_mode": (C.c_int, []),

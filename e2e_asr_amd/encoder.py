@@ -15,7 +15,7 @@ import torch
 from . import ops
 from .base_params import BaseParams, Bunch
 from .devcache import dev_i32
-from .weights import enc_name
+from .weights import enc_gru_name, enc_name
 
 
 class Encoder(BaseParams):
@@ -37,20 +37,23 @@ class Encoder(BaseParams):
         self._require_lstm()
 
     def _require_lstm(self):
-        """The GRU branch of encoder.py:45-48 is not built: the reference CLI cannot reach it (`--use_lstm` is
-        `default=True, action="store_true"`, encoder.py:187), although `class_params()` itself says GRU (encoder.py:27).  Refused at
-        construction, with what to set, instead of somewhere inside the first call."""
-        if not self.params.use_lstm:
-            raise ValueError("Encoder: GRU cells (use_lstm=False, the class_params() default) are not built; set "
-                             "params.use_lstm = True as the reference's main.py always does (encoder.py:187)")
+        """Kept for callers of earlier rounds: both cells of encoder.py:42-53 are built now (round 5)."""
+        return None
 
     def get_cell(self):
-        """encoder.py:42-53.  The cell is realised inside csrc/lstm.hip; only LSTM exists
-        (the GRU branch is unreachable from the reference CLI, encoder.py:187)."""
-        self._require_lstm()
-        if not self.params.use_lstm:
-            raise NotImplementedError("GRUCell encoder: not on the hot path (reference CLI always sets use_lstm)")
-        return "BasicLSTMCell(%d)" % self.params.hidden_size
+        """encoder.py:42-53.  The cells are realised inside csrc/lstm.hip (BasicLSTMCell: the persistent recurrent kernels) and
+        csrc/gru.hip (GRUCell -- the `class_params()` default, encoder.py:27, which the reference CLI always overrides,
+        encoder.py:187: a plain one-workgroup-per-utterance kernel, off the measured path)."""
+        return ("BasicLSTMCell(%d)" if self.params.use_lstm else "GRUCell(%d)") % self.params.hidden_size
+
+    def _gru_cells(self, depth, grad=False):
+        """Per direction (gates kernel, gates bias, candidate kernel, candidate bias) of a GRUCell layer, or their gradients."""
+        v = self.variables
+        get = v.grad_of if grad else v.__getitem__
+        dirs = ("fw", "bw") if self.params.bi_dir else ("",)
+        return [tuple(get(enc_gru_name(depth, dr, part, leaf, self.params.bi_dir))
+                      for part, leaf in (("gates", "kernel"), ("gates", "bias"), ("candidate", "kernel"), ("candidate", "bias")))
+                for dr in dirs]
 
     def _layer_weights(self, depth):
         v = self.variables
@@ -74,7 +77,7 @@ class Encoder(BaseParams):
         num_layers {task: depth}.  Returns (attention_states{depth: [B,T_d,D]},
         time_major_states{depth}, seq_len_inps{depth: host int64 array}) -- encoder.py:122-180."""
         params = self.params
-        self.get_cell()
+        gru = not params.use_lstm
         attention_states, time_major_states, seq_len_inps = {}, {}, {}
         max_depth = 0
         for task, nl in num_layers.items():
@@ -90,7 +93,7 @@ class Encoder(BaseParams):
         save = self.isTraining
         self.saved = []
         ahead = {}                                                 # {depth: (kx_cat, bias_cat)}: one launch for all layers
-        if x.is_cuda and params.bi_dir and ops._KXCAT >= 1 and os.environ.get("ASR_KXCAT_MULTI", "1") != "0":
+        if not gru and x.is_cuda and params.bi_dir and ops._KXCAT >= 1 and os.environ.get("ASR_KXCAT_MULTI", "1") != "0":
             todo = [(d,) + tuple(self._layer_weights(d)) for d in range(1, max_depth + 1)]
             todo = [t for t in todo if t[1].shape[1] // 4 in ops.LSTM_KERNEL_H]
             for c0 in range(0, len(todo), 4):
@@ -100,7 +103,7 @@ class Encoder(BaseParams):
         # Operands as bf16 planes (csrc/gemm_p3.hip): the recurrent kernels write their outputs (h for the layer
         # above, h_prev, and in the backward dG) as planes, the weights are split once per step, and no GEMM of the encoder splits
         # fp32 operands inside its k-loop.  np_ = 0: off (ASR_P3=0, exact-fp32 mode, CPU tensors).
-        np_ = ops.p3_planes() if x.is_cuda and params.bi_dir else 0
+        np_ = ops.p3_planes() if x.is_cuda and params.bi_dir and not gru else 0
         x_p3 = None                                                 # P3 image of the current layer's input, if any
         wsplit = {}                                                 # {depth: (K_x^T image, unit-major K_x image or None)}: ONE launch
         if np_ and ahead:
@@ -118,8 +121,27 @@ class Encoder(BaseParams):
             reduce_after = params.skip_step > 1 and i != max_depth - 1 and res < params.max_scaling_down
             t_out = self._pyramid_plan(T, lens) if reduce_after else T
             lens_dev = dev_i32(lens, x.device)
-            kf, bf, kb, bb = self._layer_weights(d)
             seed = (self.dropout_seed * 1000003 + d * 7919) & 0x7FFFFFFF
+            if gru:                                                # encoder.py:47-48: tf.nn.rnn_cell.GRUCell
+                r = ops.gru_layer_fwd(x.contiguous(), lens_dev, self._gru_cells(d), t_out=t_out, save=save, keep_prob=keep, seed=seed)
+                out = r[0] if save else r
+                if save:
+                    self.saved.append(dict(x=x, lens=lens, lens_dev=lens_dev, gru=r[1:], out=out, T=T, t_out=t_out, keep=keep,
+                                           seed=seed, depth=d))
+                view = out[:, :T] if t_out != T else out
+                if d in time_major_states:
+                    time_major_states[d] = view.transpose(0, 1)
+                if d in attention_states:
+                    attention_states[d] = view
+                seq_len_inps[d] = lens
+                if reduce_after:
+                    x = out.view(B, t_out // params.skip_step, out.shape[2] * params.skip_step)
+                    lens = np.ceil(lens / float(params.skip_step)).astype(np.int64)
+                    res *= params.skip_step
+                else:
+                    x = out
+                continue
+            kf, bf, kb, bb = self._layer_weights(d)
             kx, bc = ahead.get(d, (None, None))
             p3 = None
             H = kf.shape[1] // 4
@@ -187,6 +209,13 @@ class Encoder(BaseParams):
                     pad = dout.new_zeros(dout.shape[0], sv["t_out"], dout.shape[2])
                     pad[:, :dout.shape[1]] = dout
                     dout = pad
+            if "gru" in sv:                                        # GRUCell layer (csrc/gru.hip)
+                gx, cx, hprev, rh = sv["gru"]
+                dx = ops.gru_layer_bwd(sv["x"].contiguous(), sv["lens_dev"], self._gru_cells(d), dout.contiguous(), gx, cx, hprev, rh,
+                                       self._gru_cells(d, grad=True), need_dx=d > 1, keep_prob=sv["keep"], seed=sv["seed"])
+                if on_layer_done is not None:
+                    on_layer_done(d)
+                continue
             if self.params.bi_dir:
                 names = [enc_name(d, "fw", "kernel"), enc_name(d, "fw", "bias"), enc_name(d, "bw", "kernel"), enc_name(d, "bw", "bias")]
                 kf, kb = v[names[0]], v[names[2]]

@@ -413,6 +413,53 @@ def lstm_layer_bwd(x, seq_len, kernel_fw, kernel_bw, dout, gates, act, hprev, dk
     return dx
 
 
+def _ptr_array(ts):
+    arr = (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    return arr
+
+
+def gru_layer_fwd(x, seq_len, cells, t_out=None, save=False, keep_prob=1.0, seed=0):
+    """One (Bi)GRU encoder layer (encoder.py:42-53 with use_lstm False).  cells: per direction (gates kernel [in+H, 2H], gates bias
+    [2H], candidate kernel [in+H, H], candidate bias [H]).  Returns out [B, t_out, ndir*H] and, when save, (gx, cx, hprev, rh)."""
+    _f32(x, "x"); _i32(seq_len, "seq_len")
+    B, T, IN = x.shape
+    ndir = len(cells)
+    H = cells[0][2].shape[1]
+    for wg, bg, wc, bc in cells:
+        if wg.shape != (IN + H, 2 * H) or wc.shape != (IN + H, H) or bg.numel() != 2 * H or bc.numel() != H:
+            raise ValueError("gru cell shapes do not match in=%d, H=%d" % (IN, H))
+        for t_ in (wg, bg, wc, bc):
+            _f32(t_, "gru weight")
+    t_out = T if t_out is None else t_out
+    dev = x.device
+    f = lambda *s: torch.empty(s, device=dev, dtype=torch.float32)
+    out, gx, cx = f(B, t_out, ndir * H), f(B, T, ndir, 2 * H), f(B, T, ndir, H)
+    hprev, rh = (f(B, T, ndir, H), f(B, T, ndir, H)) if save else (None, None)
+    a = [_ptr_array([c[i] for c in cells]) for i in range(4)]
+    rc = _lib.lib().asr_gru_layer_fwd(_stream(), _p(x), B, T, IN, IN, _p(seq_len), H, ndir, a[0], a[1], a[2], a[3],
+                                      _p(out), t_out, _p(gx), _p(cx), _p(hprev), _p(rh), float(keep_prob), int(seed) & 0xFFFFFFFF)
+    _check(rc, "asr_gru_layer_fwd")
+    return (out, gx, cx, hprev, rh) if save else out
+
+
+def gru_layer_bwd(x, seq_len, cells, dout, gx, cx, hprev, rh, grads, need_dx=True, keep_prob=1.0, seed=0):
+    """Backward of gru_layer_fwd.  grads: per direction (d gates kernel, d gates bias, d candidate kernel, d candidate bias) views
+    of the flat gradient buffer (accumulated into).  Returns dx [B, T, in] or None."""
+    B, T, IN = x.shape
+    ndir = len(cells)
+    H = cells[0][2].shape[1]
+    dev = x.device
+    dx = torch.empty_like(x) if need_dx else None
+    wt = torch.empty(ndir * 3 * H * H, device=dev, dtype=torch.float32)
+    w = [_ptr_array([c[i] for c in cells]) for i in (0, 2)]
+    g = [_ptr_array([c[i] for c in grads]) for i in range(4)]
+    rc = _lib.lib().asr_gru_layer_bwd(_stream(), _p(x), B, T, IN, IN, _p(seq_len), H, ndir, w[0], w[1], _p(_f32(dout, "dout")),
+                                      dout.shape[1], _p(gx), _p(cx), _p(hprev), _p(rh), _p(wt), g[0], g[1], g[2], g[3], _p(dx),
+                                      float(keep_prob), int(seed) & 0xFFFFFFFF)
+    _check(rc, "asr_gru_layer_bwd")
+    return dx
+
+
 def linear_wt(x, wt, out=None, accumulate=False, n=None, k=None, ldw=None):
     """out[M,N] (+)= x[M,K] @ wt[N,K]^T -- data-gradient products (wt = rows of a TF kernel)."""
     M = x.shape[0]

@@ -16,6 +16,11 @@ def enc_name(depth, direction, leaf, bi_dir=True):
     return "model/encoder/RNNLayer%d/%d/basic_lstm_cell/%s" % (depth, depth, leaf)
 
 
+def enc_gru_name(depth, direction, part, leaf, bi_dir=True):
+    """GRUCell encoder layer (encoder.py:45-48, use_lstm False): .../gru_cell/{gates,candidate}/{kernel,bias}."""
+    return enc_name(depth, direction, "%s/%s" % (part, leaf), bi_dir).replace("basic_lstm_cell", "gru_cell")
+
+
 def dec_name(task, leaf):
     return "model/rnn_decoder_%s/%s" % (task, leaf)
 
@@ -52,8 +57,12 @@ def multi_cell_leaf(stack, layer, leaf):
 
 def init_weights(feat=80, hidden=256, bi_dir=True, depth=4, tasks=("char",), vocab=None,
                  emb=256, hidden_dec=256, lm_hidden=256, attn_vec=128, num_layers=None,
-                 seed=10, skip_step=2, max_scaling_down=8, initial_res_fac=1, num_layers_dec=1, ind_softmax=None):
+                 seed=10, skip_step=2, max_scaling_down=8, initial_res_fac=1, num_layers_dec=1, ind_softmax=None,
+                 use_lstm=True):
     """Random-init weights of the reference architecture.
+
+    use_lstm False: GRUCell encoder layers (encoder.py:45-48) -- gates kernel [in+H, 2H] / bias [2H] = 1.0 (GRUCell's default bias
+    initializer for the gates), candidate kernel [in+H, H] / bias 0; kernels from the scope's U(-0.075, 0.075) like the LSTM's.
 
     Encoder kernels U(-0.075, 0.075) (encoder.py:74), biases 0 (BasicLSTMCell default),
     embedding U(-1,1) (decoder.py:97-99), everything else Glorot-uniform (TF default for
@@ -73,6 +82,14 @@ def init_weights(feat=80, hidden=256, bi_dir=True, depth=4, tasks=("char",), voc
     for d, in_dim in enumerate(encoder_layer_inputs(feat, hidden, bi_dir, depth, skip_step, max_scaling_down,
                                                        initial_res_fac), 1):
         for direction in (("fw", "bw") if bi_dir else ("",)):
+            if not use_lstm:
+                w[enc_gru_name(d, direction, "gates", "kernel", bi_dir)] = rng.uniform(
+                    -0.075, 0.075, (in_dim + hidden, 2 * hidden)).astype(np.float32)
+                w[enc_gru_name(d, direction, "gates", "bias", bi_dir)] = np.ones(2 * hidden, np.float32)
+                w[enc_gru_name(d, direction, "candidate", "kernel", bi_dir)] = rng.uniform(
+                    -0.075, 0.075, (in_dim + hidden, hidden)).astype(np.float32)
+                w[enc_gru_name(d, direction, "candidate", "bias", bi_dir)] = np.zeros(hidden, np.float32)
+                continue
             w[enc_name(d, direction, "kernel", bi_dir)] = rng.uniform(
                 -0.075, 0.075, (in_dim + hidden, 4 * hidden)).astype(np.float32)
             w[enc_name(d, direction, "bias", bi_dir)] = np.zeros(4 * hidden, np.float32)

@@ -445,6 +445,23 @@ int asr_resident_wg_budget(void);
 int asr_set_lstm_mfma(int on);
 int asr_get_lstm_mfma(void);
 
+/* One GRU encoder layer (tf.nn.rnn_cell.GRUCell under [bidirectional_]dynamic_rnn: /root/reference/encoder.py:42-53 with use_lstm False
+ * -- the Encoder.class_params() default, encoder.py:27; the reference CLI always sets use_lstm, encoder.py:187, so this cell is off
+ * the measured path and built for completeness, not speed).  Per direction d: wg[d] [in+H][2H] / bg[d] [2H] = gru_cell/gates/{kernel,
+ * bias}, wc[d] [in+H][H] / bc[d] [H] = gru_cell/candidate/{kernel,bias} (TF layouts; r | u gate order).  x [B][T][in] (row pitch ldx);
+ * out [B][Tout][ndir*H], zeros past each length; bw direction walks t = len-1 .. 0.  gx [B][T][ndir][2H], cx [B][T][ndir][H]:
+ * workspaces; hprev and rh [B][T][ndir][H] both non-NULL = save for the backward pass.  Output-only dropout (DropoutWrapper).
+ * Backward: gx / cx (what the forward left) are overwritten with dG; wt_ws >= ndir*3*H*H floats; weight / bias gradients are
+ * ACCUMULATED into dwg / dbg / dwc / dbc; dx [B][T][in] (or NULL) is overwritten.  H <= 1024.  Everything on `stream`. */
+int asr_gru_layer_fwd(void* stream, const float* x, int B, int T, int in_dim, int ldx, const int* len, int H, int ndir,
+                      const float* const* wg, const float* const* bg, const float* const* wc, const float* const* bc,
+                      float* out, int Tout, float* gx, float* cx, float* hprev, float* rh, float keep_prob, unsigned seed);
+int asr_gru_layer_bwd(void* stream, const float* x, int B, int T, int in_dim, int ldx, const int* len, int H, int ndir,
+                      const float* const* wg, const float* const* wc, const float* dout, int Tout,
+                      float* gx, float* cx, const float* hprev, const float* rh, float* wt_ws,
+                      float* const* dwg, float* const* dbg, float* const* dwc, float* const* dbc, float* dx,
+                      float keep_prob, unsigned seed);
+
 /* How the K slices of a split-K weight-gradient product (tf.gradients, seq2seq_model.py:148: X^T . dY with K = B*T) meet in C.
  * 0 (default): float atomics into C (order, hence the last bits, vary from run to run).  1 = DETERMINISTIC mode (environment
  * ASR_WGRAD_SLABS=1): each slice stores its partial tile into a per-stream slab arena owned by the library and a streaming

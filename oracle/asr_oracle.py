@@ -70,6 +70,49 @@ def lstm_cell(x, c, h, w, b):
 
 
 # ----------------------------------------------------------------------------
+# tf.nn.rnn_cell.GRUCell (TF 1.x) -- the cell encoder.py:45-48 / decoder.py:56-59 build when use_lstm is False.  NOT in the
+# reference's NumPy half and absent from /root/reference: restated from the published TF-1.x implementation
+# (rnn_cell_impl.GRUCell.call) -- PARITY UNPINNED, like the rest of the TF-graph half.
+#   gate_inputs = [x, h] . W_gates + b_gates (b_gates initialised to 1.0);  r, u = split(sigmoid(gate_inputs), 2)
+#   candidate   = [x, r * h] . W_cand + b_cand;  c = tanh(candidate);  h' = u * h + (1 - u) * c
+# ----------------------------------------------------------------------------
+def gru_cell(x, h, wg, bg, wc, bc):
+    """x [..., E], h [..., H], wg [E+H, 2H], bg [2H], wc [E+H, H], bc [H] -> h'."""
+    v = sigmoid(np.matmul(np.concatenate((x, h), axis=-1), wg) + bg)
+    r, u = np.split(v, 2, axis=-1)
+    c = np.tanh(np.matmul(np.concatenate((x, r * h), axis=-1), wc) + bc)
+    return u * h + (1 - u) * c
+
+
+def gru_layer(x_tm, seq_len, wg, bg, wc, bc, reverse=False, keep_mask=None):
+    """One direction of encoder.py:55-91 with GRUCell: the same dynamic_rnn semantics as lstm_layer (zero output and
+    copied-through state past each length, the bw half walks t = len-1 .. 0, output-only dropout)."""
+    T, B, _ = x_tm.shape
+    H = wc.shape[1]
+    out = np.zeros((T, B, H), x_tm.dtype)
+    h = np.zeros((B, H), x_tm.dtype)
+    seq_len = np.asarray(seq_len).astype(np.int64)
+    for s in range(T):
+        t_idx = (seq_len - 1 - s) if reverse else np.full((B,), s, np.int64)
+        live = s < seq_len
+        if not live.any():
+            break
+        t_safe = np.where(live, t_idx, 0)
+        nh = gru_cell(x_tm[t_safe, np.arange(B)], h, wg, bg, wc, bc)
+        h = np.where(live[:, None], nh, h)
+        rows = np.nonzero(live)[0]
+        out[t_idx[rows], rows] = nh[rows]
+    if keep_mask is not None:
+        out = out * keep_mask
+    return out, h
+
+
+def enc_gru_var(depth, direction, part, leaf, bi_dir=True):
+    """TF variable names of a GRUCell encoder layer: .../gru_cell/{gates,candidate}/{kernel,bias}."""
+    return enc_var(depth, direction, "%s/%s" % (part, leaf), bi_dir).replace("basic_lstm_cell", "gru_cell")
+
+
+# ----------------------------------------------------------------------------
 # encoder.py
 # ----------------------------------------------------------------------------
 def lstm_layer(x_tm, seq_len, w, b, reverse=False, keep_mask=None):
@@ -175,7 +218,15 @@ def encoder(x_bm, seq_len, weights, num_layers, bi_dir=True, skip_step=2,
         d = i + 1
         x_tm = np.transpose(enc_in, (1, 0, 2))             # encoder.py:158
         km = keep_masks.get(d) if keep_masks else None
-        if bi_dir:
+        if enc_gru_var(d, "fw" if bi_dir else "", "gates", "kernel", bi_dir) in weights:      # use_lstm False (encoder.py:45-48)
+            dirs = ("fw", "bw") if bi_dir else ("",)
+            halves = []
+            for k, dr in enumerate(dirs):
+                g = lambda part, leaf: weights[enc_gru_var(d, dr, part, leaf, bi_dir)]
+                halves.append(gru_layer(x_tm, seq_len, g("gates", "kernel"), g("gates", "bias"), g("candidate", "kernel"),
+                                        g("candidate", "bias"), dr == "bw", km[k] if km else None)[0])
+            out_tm = np.concatenate(halves, axis=2)
+        elif bi_dir:
             out_tm = bilstm_layer(
                 x_tm, seq_len,
                 weights[enc_var(d, "fw", "kernel")], weights[enc_var(d, "fw", "bias")],

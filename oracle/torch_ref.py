@@ -52,6 +52,30 @@ def lstm_layer(x_tm, seq_len, w, b, reverse=False, keep_mask=None):
     return out
 
 
+def gru_layer(x_tm, seq_len, wg, bg, wc, bc, reverse=False, keep_mask=None):
+    """encoder.py:55-91 with tf.nn.rnn_cell.GRUCell, one direction (see asr_oracle.gru_layer)."""
+    T, B, _ = x_tm.shape
+    H = wc.shape[1]
+    seq_len = torch.as_tensor(np.asarray(seq_len), dtype=torch.long)
+    h = x_tm.new_zeros(B, H)
+    ar = torch.arange(B)
+    out = x_tm.new_zeros(T, B, H)
+    for s in range(int(seq_len.max())):
+        live = (s < seq_len)
+        t_idx = (seq_len - 1 - s) if reverse else torch.full((B,), s, dtype=torch.long)
+        t_safe = torch.where(live, t_idx, torch.zeros_like(t_idx))
+        x = x_tm[t_safe, ar]
+        v = torch.sigmoid(torch.cat((x, h), -1) @ wg + bg)
+        r, u = v.chunk(2, -1)
+        c = torch.tanh(torch.cat((x, r * h), -1) @ wc + bc)
+        nh = u * h + (1 - u) * c
+        h = torch.where(live[:, None], nh, h)
+        out = out.index_put((t_safe[live], ar[live]), nh[live])
+    if keep_mask is not None:
+        out = out * keep_mask
+    return out
+
+
 def encoder(x_bm, seq_len, W, num_layers, bi_dir=True, skip_step=2, max_scaling_down=8, keep_masks=None):
     """encoder.py:122-180."""
     att, lens = {}, {}
@@ -62,7 +86,14 @@ def encoder(x_bm, seq_len, W, num_layers, bi_dir=True, skip_step=2, max_scaling_
         d = i + 1
         x_tm = enc_in.transpose(0, 1)
         km = keep_masks.get(d) if keep_masks else (None, None)
-        if bi_dir:
+        if O.enc_gru_var(d, "fw" if bi_dir else "", "gates", "kernel", bi_dir) in W:
+            halves = []
+            for k, dr in enumerate(("fw", "bw") if bi_dir else ("",)):
+                g = lambda part, leaf: W[O.enc_gru_var(d, dr, part, leaf, bi_dir)]
+                halves.append(gru_layer(x_tm, seq_len, g("gates", "kernel"), g("gates", "bias"), g("candidate", "kernel"),
+                                        g("candidate", "bias"), dr == "bw", km[k]))
+            out = torch.cat(halves, 2)
+        elif bi_dir:
             fw = lstm_layer(x_tm, seq_len, W[O.enc_var(d, "fw", "kernel")], W[O.enc_var(d, "fw", "bias")], False, km[0])
             bw = lstm_layer(x_tm, seq_len, W[O.enc_var(d, "bw", "kernel")], W[O.enc_var(d, "bw", "bias")], True, km[1])
             out = torch.cat((fw, bw), 2)

@@ -130,16 +130,16 @@ def test_shifted_targets_and_lazy_weight_mask():
     assert calls == ["char"]                                             # built once, on first access
 
 
-def test_gru_cells_are_refused_at_construction_with_what_to_set():
-    """encoder.py:45-48 / decoder.py:56-59: the GRU branches are not built; `Encoder.class_params()` defaults to GRU (encoder.py:27)
-    although the reference CLI always sets use_lstm (encoder.py:187) -- a clear ValueError when the object is made, not a
-    failure somewhere inside the first call."""
+def test_encoder_builds_both_cells_and_the_decoder_gru_is_refused_with_what_to_set():
+    """encoder.py:45-48: `Encoder.class_params()` defaults to GRUCell (encoder.py:27) although the reference CLI always sets use_lstm
+    (encoder.py:187): a default-constructed Encoder is a GRU encoder (round 5, csrc/gru.hip).  decoder.py:56-59: the decoder's GRU
+    branch (never reachable: Decoder.class_params() says LSTM and main.py has no flag for it) stays refused -- a clear ValueError
+    when the object is made, not a failure somewhere inside the first call."""
     from e2e_asr_amd.attn_decoder import AttnDecoder
     from e2e_asr_amd.encoder import Encoder
-    with pytest.raises(ValueError, match="use_lstm"):
-        Encoder()                                   # class_params(): use_lstm False
+    assert Encoder().get_cell() == "GRUCell(256)"          # class_params(): use_lstm False
     p = Encoder.class_params(); p.use_lstm = True
-    Encoder(params=p)
+    assert Encoder(params=p).get_cell() == "BasicLSTMCell(256)"
     dp = AttnDecoder.class_params(); dp.use_lstm = False
     with pytest.raises(ValueError, match="use_lstm"):
         AttnDecoder(True, dp, scope="char")

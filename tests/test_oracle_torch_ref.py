@@ -93,3 +93,48 @@ def test_adam_and_clip_tf_semantics():
     var, m, v = O.adam_step(np.array([1.0]), np.zeros(1), np.zeros(1), np.array([0.5]), 1, 1e-3)
     # step 1: m = 0.05, v = 2.5e-4, lr_t = 1e-3*sqrt(1e-3)/0.1 -> update = lr_t*m/(sqrt(v)+eps) ~= 1e-3
     np.testing.assert_allclose(var, 1.0 - 1e-3 * np.sqrt(1e-3) / 0.1 * 0.05 / (np.sqrt(2.5e-4) + 1e-8))
+
+
+def test_gru_layer_oracle_matches_the_torch_twin_and_dynamic_rnn_properties():
+    """tf.nn.rnn_cell.GRUCell under dynamic_rnn (encoder.py:45-48; restated from the published TF-1.x cell -- parity unpinned like
+    the rest of the TF-graph half): the NumPy oracle equals its autograd twin; outputs past each length are zero; the bw
+    direction equals reverse(fw(reverse(x))) per utterance; equal lengths == no masking."""
+    import torch
+    from oracle import asr_oracle as O, torch_ref as R
+    rng = np.random.default_rng(5)
+    T, B, IN, H = 11, 4, 6, 5
+    x = rng.standard_normal((T, B, IN))
+    lens = [11, 7, 2, 1]
+    wg = rng.uniform(-0.5, 0.5, (IN + H, 2 * H)); bg = np.ones(2 * H)
+    wc = rng.uniform(-0.5, 0.5, (IN + H, H)); bc = rng.uniform(-0.1, 0.1, H)
+    tt = lambda a: torch.tensor(a)
+    for rev in (False, True):
+        o, hlast = O.gru_layer(x, lens, wg, bg, wc, bc, rev)
+        t = R.gru_layer(tt(x), lens, tt(wg), tt(bg), tt(wc), tt(bc), rev).numpy()
+        np.testing.assert_allclose(o, t, atol=1e-14)
+        for b, l in enumerate(lens):
+            assert np.abs(o[l:, b]).max(initial=0.0) == 0.0
+    o_bw, _ = O.gru_layer(x, lens, wg, bg, wc, bc, True)
+    for b, l in enumerate(lens):
+        o_f, _ = O.gru_layer(x[:l, b:b + 1][::-1], [l], wg, bg, wc, bc, False)
+        np.testing.assert_allclose(o_f[::-1, 0], o_bw[:l, b], atol=1e-14)
+    # one step by hand: h' = u*h + (1-u)*tanh([x, r*h].Wc + bc), r|u = sigmoid([x,h].Wg + bg) with h = 0
+    h1 = O.gru_cell(x[0], np.zeros((B, H)), wg, bg, wc, bc)
+    u = 1.0 / (1.0 + np.exp(-(x[0] @ wg[:IN] + bg)))[:, H:]
+    np.testing.assert_allclose(h1, (1 - u) * np.tanh(x[0] @ wc[:IN] + bc), atol=1e-14)
+
+
+def test_gru_encoder_oracle_equals_twin_through_the_pyramid():
+    import torch
+    from oracle import asr_oracle as O, torch_ref as R
+    from e2e_asr_amd.weights import init_weights
+    w = {k: v.astype(np.float64) for k, v in init_weights(feat=6, hidden=5, depth=3, seed=2, use_lstm=False, vocab={"char": 20},
+                                                          emb=4, hidden_dec=5, lm_hidden=5, attn_vec=3).items()}
+    assert any("gru_cell/gates/kernel" in k for k in w) and not any("encoder" in k and "basic_lstm_cell" in k for k in w)
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((3, 13, 6)); lens = [13, 9, 4]
+    att, _, ln = O.encoder(x, lens, w, {"char": 3})
+    W = R.weights_to_torch(w)
+    att_t, _ = R.encoder(torch.tensor(x), lens, W, {"char": 3})
+    np.testing.assert_allclose(att[3], att_t[3].detach().numpy(), atol=1e-13)
+    assert att[3].shape == (3, 4, 10)
