@@ -156,9 +156,10 @@ SIGNATURES = {
     "asr_zero_finished_rows": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int]),
     "asr_resident_wg_budget": (C.c_int, []),
     "asr_gru_layer_fwd": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, vp, vp, vp,
-                                    vp, C.c_int, vp, vp, vp, vp, C.c_float, C.c_uint]),
+                                    vp, C.c_int, vp, vp, vp, vp, C.c_float, C.c_uint, vp, vp]),
     "asr_gru_layer_bwd": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, vp, vp, C.c_int,
-                                    vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_uint]),
+                                    vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_uint, vp, vp]),
+    "asr_attn_bwd": (C.c_int, [vp] * 11 + [C.c_int] + [vp] * 5 + [C.c_int] * 5),
     "asr_race_hunt_build": (C.c_int, []),
     "asr_set_wgrad_mode": (C.c_int, [C.c_int]),
     "asr_get_wgrad_mode": (C.c_int, []),

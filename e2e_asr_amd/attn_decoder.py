@@ -35,7 +35,10 @@ class AttnDecoder(Decoder):
         self.cell = self.get_cell()
         self.saved = None
         self.multi = None
-        if self.params.num_layers_dec > 1:          # MultiRNNCell stacks: host-composed per-step path
+        if not self.params.use_lstm:                # GRUCell decoder (decoder.py:56-59): host-composed per-step path
+            from .gru_decoder import GruDecoderPath
+            self.multi = GruDecoderPath(self)
+        elif self.params.num_layers_dec > 1:        # MultiRNNCell stacks: host-composed per-step path
             from .multi_decoder import MultiLayerPath
             self.multi = MultiLayerPath(self)
         # scheduled-sampling coin = f(coin_seed, task, coin_step): common to all data-parallel ranks by construction.

@@ -38,6 +38,7 @@ struct DecBwdStepArgs {
     const float* c_prev;       // [B][H] or nullptr
     const float* dh_carry; int ld_dh;        // dXH[i+1][:, E:] or nullptr
     float* dc_carry;           // [B][H] in/out
+    float* dq_out;             // attention-only form (gates == nullptr): dq_ap + dq_att [B][H] out (asr_attn_bwd)
     int B, Te, H, A, D;
 };
 
@@ -271,6 +272,7 @@ __global__ __launch_bounds__(DBW_NT) void dec_attn_cell_bwd_kernel(DecBwdStepArg
                 const float* wr = a.w_att + (size_t)kk * A;
                 for (int aa = 0; aa < A; ++aa) dq_att = fmaf(wr[aa], dys[aa], dq_att);
             }
+            if (!a.gates) { a.dq_out[(size_t)b * H + kk] = a.dqc[(size_t)b * (H + D) + kk] + dq_att; continue; }     // attention only
             const float dq = a.dqc[(size_t)b * (H + D) + kk] + dq_att + a.dc_carry[(size_t)b * H + kk];
             const float dh = a.dh_carry ? a.dh_carry[(size_t)b * a.ld_dh + kk] : 0.f;
             float* gp = a.gates + (size_t)b * 4 * H + kk;
@@ -423,7 +425,7 @@ extern "C" int asr_attn_decoder_bwd(void* stream, const asr_dec_weights* w, cons
         a.gates = ws->dec_gates + o * 4 * H;
         a.c_prev = i ? ws->dec_c + (o - B) * H : nullptr;
         a.dh_carry = last ? nullptr : bw->dXH + (o + B) * ldXH + E; a.ld_dh = ldXH;
-        a.dc_carry = bw->dc_dec;
+        a.dc_carry = bw->dc_dec; a.dq_out = nullptr;
         a.B = B; a.Te = Te; a.H = H; a.A = A; a.D = D;
         hipLaunchKernelGGL(dec_attn_cell_bwd_kernel, dim3(B), dim3(DBW_NT), lds, s, a);
         // [dx | dh_prev] = dG_dec . K_dec^T
@@ -591,7 +593,30 @@ extern "C" int asr_attn_cell_bwd(void* stream, const float* q, const float* w_at
     a.q = q; a.w_att = w_att; a.b_att = b_att; a.v = v; a.hf = hf; a.enc = enc; a.enc_len = enc_len; a.alpha = alpha;
     a.y_saved = y_saved; a.dqc = dqc; a.dctx_carry = dctx_carry; a.ld_carry = ld_carry; a.dhf = dhf; a.dctx_out = dctx_out;
     a.dy = dy; a.dv_part = dv_part; a.gates = gates; a.c_prev = c_prev; a.dh_carry = dh_carry; a.ld_dh = ld_dh;
-    a.dc_carry = dc_carry; a.B = B; a.Te = Te; a.H = H; a.A = A; a.D = D;
+    a.dc_carry = dc_carry; a.dq_out = nullptr; a.B = B; a.Te = Te; a.H = H; a.A = A; a.D = D;
+    hipLaunchKernelGGL(dec_attn_cell_bwd_kernel, dim3(B), dim3(DBW_NT), lds, static_cast<hipStream_t>(stream), a);
+    ASR_CHECK_LAUNCH();
+    return ASR_OK;
+}
+// The attention backward of asr_attn_cell_bwd ALONE: dq_out [B][H] = dqc[:, :H] + dy . W_att^T, the gradient w.r.t. the query,
+// for callers whose query is not an LSTM cell state (the GRU decoder: the query is the GRU state itself, decoder.py:79-80).
+extern "C" int asr_attn_bwd(void* stream, const float* q, const float* w_att, const float* b_att, const float* v,
+                            const float* hf, const float* enc, const int* enc_len, const float* alpha,
+                            const float* dqc, const float* dctx_carry, int ld_carry, float* dhf, float* dctx_out, float* dy,
+                            float* dv_part, float* dq_out, int B, int Te, int H, int A, int D) {
+    using namespace asr;
+    if (!q || !w_att || !b_att || !v || !hf || !enc || !enc_len || !alpha || !dqc || !dhf || !dctx_out || !dy || !dv_part ||
+        !dq_out || B <= 0 || Te <= 0) return ASR_EINVAL;
+    if ((A & 3) || (D & 3) || A > 256) return ASR_EUNSUPPORTED;
+    const size_t lds = dec_bwd_lds(Te, H, A, D);
+    if (lds > 150 * 1024) return ASR_EUNSUPPORTED;
+    if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_attn_cell_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    DecBwdStepArgs a;
+    a.q = q; a.w_att = w_att; a.b_att = b_att; a.v = v; a.hf = hf; a.enc = enc; a.enc_len = enc_len; a.alpha = alpha;
+    a.y_saved = nullptr; a.dqc = dqc; a.dctx_carry = dctx_carry; a.ld_carry = ld_carry; a.dhf = dhf; a.dctx_out = dctx_out;
+    a.dy = dy; a.dv_part = dv_part; a.gates = nullptr; a.c_prev = nullptr; a.dh_carry = nullptr; a.ld_dh = 0;
+    a.dc_carry = nullptr; a.dq_out = dq_out; a.B = B; a.Te = Te; a.H = H; a.A = A; a.D = D;
     hipLaunchKernelGGL(dec_attn_cell_bwd_kernel, dim3(B), dim3(DBW_NT), lds, static_cast<hipStream_t>(stream), a);
     ASR_CHECK_LAUNCH();
     return ASR_OK;

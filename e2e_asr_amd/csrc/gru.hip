@@ -26,6 +26,8 @@ struct GruArgs {
     float* rh;         // [B][T][ND][H]   r * h_{t-1} (saved by the forward: the A operand of dW_cand[in:])
     float* out;        // forward: [B][Tout][ND*H]
     const float* dout; // backward: [B][Tout][ND*H]
+    const float* h0;   // forward: initial state [B][ND][H] or NULL (zeros);  backward: dh of the state BEHIND the last step, or NULL
+    float* h_last;     // forward: final (plain) state [B][ND][H] or NULL;    backward: dh of the initial state [B][ND][H] or NULL
     const int* len;
     int B, T, Tout, ND, H, dir;      // dir: the direction this launch runs (arrays keep both)
     float keep; uint32_t seed;
@@ -41,7 +43,7 @@ __global__ __launch_bounds__(NT) void gru_rec_fwd_kernel(GruArgs a) {
     const int b = blockIdx.x, dir = a.dir;
     const int tid = threadIdx.x;
     const int S = min(max(a.len[b], 0), a.T);
-    for (int j = tid; j < H; j += NT) hs[j] = 0.f;
+    for (int j = tid; j < H; j += NT) hs[j] = a.h0 ? a.h0[((size_t)b * a.ND + dir) * H + j] : 0.f;
     __syncthreads();
     for (int s = 0; s < S; ++s) {
         const int t = dir ? (S - 1 - s) : s;
@@ -85,6 +87,7 @@ __global__ __launch_bounds__(NT) void gru_rec_fwd_kernel(GruArgs a) {
         for (int q = 0; q < UPT; ++q) { const int j = tid + q * NT; if (j < H) hs[j] = r_[q]; }
         __syncthreads();
     }
+    if (a.h_last) for (int j = tid; j < H; j += NT) a.h_last[((size_t)b * a.ND + dir) * H + j] = hs[j];
     // zero output past the length (dynamic_rnn zero-fill; also the pyramid pad frame), zero saved rows there
     for (int idx = tid; idx < (a.Tout - S) * H; idx += NT) {
         const int t = S + idx / H, j = idx % H;
@@ -110,7 +113,7 @@ __global__ __launch_bounds__(NT) void gru_rec_bwd_kernel(GruArgs a) {
     const int S = min(max(a.len[b], 0), a.T);
     float dhc[UPT];            // dh carried to the earlier step, per owned unit
 #pragma unroll
-    for (int q = 0; q < UPT; ++q) dhc[q] = 0.f;
+    for (int q = 0; q < UPT; ++q) { const int j = tid + q * NT; dhc[q] = (a.h0 && j < H) ? a.h0[((size_t)b * a.ND + dir) * H + j] : 0.f; }
     for (int s = 0; s < S; ++s) {
         const int t = dir ? s : (S - 1 - s);               // the forward's last step first
         const size_t row = ((size_t)b * a.T + t) * a.ND + dir;
@@ -164,6 +167,10 @@ __global__ __launch_bounds__(NT) void gru_rec_bwd_kernel(GruArgs a) {
         }
         __syncthreads();
     }
+    if (a.h_last) {
+#pragma unroll
+        for (int q = 0; q < UPT; ++q) { const int j = tid + q * NT; if (j < H) a.h_last[((size_t)b * a.ND + dir) * H + j] = dhc[q]; }
+    }
     // dG = 0 past the row's length (the weight / input GEMMs read every row)
     for (int idx = tid; idx < (a.T - S) * H; idx += NT) {
         const int t = S + idx / H, j = idx % H;
@@ -192,9 +199,12 @@ static int gru_dispatch(bool bwd, hipStream_t s, const GruArgs& a) {
 // d: wg[d] [in+H][2H], bg[d] [2H], wc[d] [in+H][H], bc[d] [H] (TF layouts).  out [B][Tout][ndir*H] (zeros past each length).
 // gx [B][T][ndir][2H], cx [B][T][ndir][H]: workspaces; hprev / rh [B][T][ndir][H] non-NULL = save for the backward pass (gx / cx
 // then hold the activated r | u and c).  Dropout: output-only, mask keep_scale(seed, b*Tout + t, dir*H + unit).
+// h0 [B][ndir][H] (NULL: zeros) = the initial state; h_last [B][ndir][H] (NULL: not wanted) = the final PLAIN state -- a caller that
+// composes its own time loop (the GRU attention decoder, e2e_asr_amd/gru_decoder.py) runs T = 1 steps with them.
 extern "C" int asr_gru_layer_fwd(void* stream, const float* x, int B, int T, int in_dim, int ldx, const int* len, int H, int ndir,
                                  const float* const* wg, const float* const* bg, const float* const* wc, const float* const* bc,
-                                 float* out, int Tout, float* gx, float* cx, float* hprev, float* rh, float keep_prob, unsigned seed) {
+                                 float* out, int Tout, float* gx, float* cx, float* hprev, float* rh, float keep_prob, unsigned seed,
+                                 const float* h0, float* h_last) {
     using namespace asr;
     if (!x || !len || !wg || !bg || !wc || !bc || !out || !gx || !cx || (hprev != nullptr) != (rh != nullptr)) return ASR_EINVAL;
     if (B <= 0 || T <= 0 || in_dim <= 0 || H <= 0 || Tout < T || ldx < in_dim || (ndir != 1 && ndir != 2)) return ASR_EINVAL;
@@ -211,6 +221,7 @@ extern "C" int asr_gru_layer_fwd(void* stream, const float* x, int B, int T, int
         GruArgs a;
         a.wgh = wg[d] + (size_t)in_dim * 2 * H; a.wch = wc[d] + (size_t)in_dim * H;
         a.gx = gx; a.cx = cx; a.hprev = hprev; a.rh = rh; a.out = out; a.dout = nullptr; a.len = len;
+        a.h0 = h0; a.h_last = h_last;
         a.B = B; a.T = T; a.Tout = Tout; a.ND = ndir; a.H = H; a.dir = d; a.keep = keep_prob; a.seed = seed;
         if ((rc = gru_dispatch(false, static_cast<hipStream_t>(stream), a))) return rc;
     }
@@ -220,12 +231,13 @@ extern "C" int asr_gru_layer_fwd(void* stream, const float* x, int B, int T, int
 // Backward of asr_gru_layer_fwd (tf.gradients through the layer, seq2seq_model.py:148).  gx / cx / hprev / rh: what the forward
 // saved; gx / cx are overwritten with dG_gates / dG_cand.  dout [B][Tout][ndir*H].  wt_ws: >= ndir * 3*H*H floats (the transposed
 // recurrent weights).  Weight / bias gradients are ACCUMULATED into dwg / dbg / dwc / dbc (same layouts as the weights); dx
-// [B][T][in] (NULL: not needed) is overwritten.  Everything on `stream`.
+// [B][T][in] (NULL: not needed) is overwritten.  dh_last [B][ndir][H] (NULL: zero) = gradient w.r.t. the final state (what the
+// forward returned in h_last); dh0 [B][ndir][H] (NULL: not wanted) = gradient w.r.t. h0.  Everything on `stream`.
 extern "C" int asr_gru_layer_bwd(void* stream, const float* x, int B, int T, int in_dim, int ldx, const int* len, int H, int ndir,
                                  const float* const* wg, const float* const* wc, const float* dout, int Tout,
                                  float* gx, float* cx, const float* hprev, const float* rh, float* wt_ws,
                                  float* const* dwg, float* const* dbg, float* const* dwc, float* const* dbc, float* dx,
-                                 float keep_prob, unsigned seed) {
+                                 float keep_prob, unsigned seed, const float* dh_last, float* dh0) {
     using namespace asr;
     if (!x || !len || !wg || !wc || !dout || !gx || !cx || !hprev || !rh || !wt_ws || !dwg || !dbg || !dwc || !dbc) return ASR_EINVAL;
     if (B <= 0 || T <= 0 || in_dim <= 0 || H <= 0 || Tout < T || ldx < in_dim || (ndir != 1 && ndir != 2)) return ASR_EINVAL;
@@ -242,6 +254,7 @@ extern "C" int asr_gru_layer_bwd(void* stream, const float* x, int B, int T, int
         GruArgs a;
         a.wgh = wgT; a.wch = wcT;
         a.gx = gx; a.cx = cx; a.hprev = const_cast<float*>(hprev); a.rh = const_cast<float*>(rh); a.out = nullptr; a.dout = dout; a.len = len;
+        a.h0 = dh_last; a.h_last = dh0;
         a.B = B; a.T = T; a.Tout = Tout; a.ND = ndir; a.H = H; a.dir = d; a.keep = keep_prob; a.seed = seed;
         if ((rc = gru_dispatch(true, s, a))) return rc;
     }

@@ -22,23 +22,25 @@ class Decoder(BaseParams):
         self.scope = scope              # task name: variables live under model/rnn_decoder_<scope>/
         self.variables = variables
         self.rng_seed = 0
-        if not self.params.use_lstm:
-            # decoder.py:56-59: the GRU branch is not built (the reference's main.py never clears use_lstm; the decoder's own
-            # default is LSTM, decoder.py:34).  Refused here, not inside the first call.
-            raise ValueError("Decoder: GRU cells (use_lstm=False) are not built; leave params.use_lstm = True (decoder.py:34)")
+        if not self.params.use_lstm and int(self.params.num_layers_dec) > 1:
+            # decoder.py:56-59 with 66-68: GRU cells in MultiRNNCell stacks are not built (no reference flag reaches either).
+            # Refused here, not inside the first call.
+            raise ValueError("Decoder: GRU cells (use_lstm=False) in stacks (num_layers_dec > 1) are not built; set "
+                             "params.use_lstm = True (decoder.py:34) or num_layers_dec = 1")
 
     def get_cell(self, hidden_size=None):
-        """decoder.py:49-72.  The cell itself is csrc/skinny.hip's fused LSTM epilogue."""
+        """decoder.py:49-72.  The LSTM cell itself is csrc/skinny.hip's fused epilogue / the persistent decoder kernels; the GRU
+        cell is csrc/gru.hip."""
         p = self.params
-        if not p.use_lstm:
-            raise NotImplementedError("GRUCell decoder: not on the hot path")
         size = p.hidden_size_dec if hidden_size is None else hidden_size
+        if not p.use_lstm:             # decoder.py:58-59 (runs through e2e_asr_amd/gru_decoder.py)
+            return "GRUCell(%d)" % size
         if p.num_layers_dec > 1:       # decoder.py:66-68 (runs through e2e_asr_amd/multi_decoder.py)
             return "MultiRNNCell([BasicLSTMCell(%d)] * %d)" % (size, p.num_layers_dec)
         return "BasicLSTMCell(%d)" % size
 
     def get_state(self, state):
-        """decoder.py:74-82: the attention query is the LSTM CELL state c (not h)."""
+        """decoder.py:74-82: the attention query is the LSTM CELL state c (not h); with GRU cells the state itself."""
         if self.params.num_layers_dec > 1:
             state = state[-1]
         return state[0] if self.params.use_lstm else state      # state = (c, h)

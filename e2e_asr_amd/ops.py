@@ -418,7 +418,7 @@ def _ptr_array(ts):
     return arr
 
 
-def gru_layer_fwd(x, seq_len, cells, t_out=None, save=False, keep_prob=1.0, seed=0):
+def gru_layer_fwd(x, seq_len, cells, t_out=None, save=False, keep_prob=1.0, seed=0, h0=None, want_last=False):
     """One (Bi)GRU encoder layer (encoder.py:42-53 with use_lstm False).  cells: per direction (gates kernel [in+H, 2H], gates bias
     [2H], candidate kernel [in+H, H], candidate bias [H]).  Returns out [B, t_out, ndir*H] and, when save, (gx, cx, hprev, rh)."""
     _f32(x, "x"); _i32(seq_len, "seq_len")
@@ -436,13 +436,19 @@ def gru_layer_fwd(x, seq_len, cells, t_out=None, save=False, keep_prob=1.0, seed
     out, gx, cx = f(B, t_out, ndir * H), f(B, T, ndir, 2 * H), f(B, T, ndir, H)
     hprev, rh = (f(B, T, ndir, H), f(B, T, ndir, H)) if save else (None, None)
     a = [_ptr_array([c[i] for c in cells]) for i in range(4)]
+    h_last = f(B, ndir, H) if want_last else None
     rc = _lib.lib().asr_gru_layer_fwd(_stream(), _p(x), B, T, IN, IN, _p(seq_len), H, ndir, a[0], a[1], a[2], a[3],
-                                      _p(out), t_out, _p(gx), _p(cx), _p(hprev), _p(rh), float(keep_prob), int(seed) & 0xFFFFFFFF)
+                                      _p(out), t_out, _p(gx), _p(cx), _p(hprev), _p(rh), float(keep_prob), int(seed) & 0xFFFFFFFF,
+                                      _p(_f32(h0, "h0")), _p(h_last))
     _check(rc, "asr_gru_layer_fwd")
-    return (out, gx, cx, hprev, rh) if save else out
+    r = (out, gx, cx, hprev, rh) if save else out
+    if want_last:
+        return (r + (h_last,)) if save else (r, h_last)
+    return r
 
 
-def gru_layer_bwd(x, seq_len, cells, dout, gx, cx, hprev, rh, grads, need_dx=True, keep_prob=1.0, seed=0):
+def gru_layer_bwd(x, seq_len, cells, dout, gx, cx, hprev, rh, grads, need_dx=True, keep_prob=1.0, seed=0, dh_last=None,
+                  want_dh0=False):
     """Backward of gru_layer_fwd.  grads: per direction (d gates kernel, d gates bias, d candidate kernel, d candidate bias) views
     of the flat gradient buffer (accumulated into).  Returns dx [B, T, in] or None."""
     B, T, IN = x.shape
@@ -451,13 +457,14 @@ def gru_layer_bwd(x, seq_len, cells, dout, gx, cx, hprev, rh, grads, need_dx=Tru
     dev = x.device
     dx = torch.empty_like(x) if need_dx else None
     wt = torch.empty(ndir * 3 * H * H, device=dev, dtype=torch.float32)
+    dh0 = torch.empty((B, ndir, H), device=dev, dtype=torch.float32) if want_dh0 else None
     w = [_ptr_array([c[i] for c in cells]) for i in (0, 2)]
     g = [_ptr_array([c[i] for c in grads]) for i in range(4)]
     rc = _lib.lib().asr_gru_layer_bwd(_stream(), _p(x), B, T, IN, IN, _p(seq_len), H, ndir, w[0], w[1], _p(_f32(dout, "dout")),
                                       dout.shape[1], _p(gx), _p(cx), _p(hprev), _p(rh), _p(wt), g[0], g[1], g[2], g[3], _p(dx),
-                                      float(keep_prob), int(seed) & 0xFFFFFFFF)
+                                      float(keep_prob), int(seed) & 0xFFFFFFFF, _p(_f32(dh_last, "dh_last")), _p(dh0))
     _check(rc, "asr_gru_layer_bwd")
-    return dx
+    return (dx, dh0) if want_dh0 else dx
 
 
 def linear_wt(x, wt, out=None, accumulate=False, n=None, k=None, ldw=None):
@@ -511,6 +518,18 @@ def attn_cell_bwd(q, w_att, b_att, v, hf, enc, enc_len, alpha, dqc, dctx_carry, 
                                       _p(dctx_out), _p(dy), _p(dv_part), _p(gates), _p(c_prev), _p(dh_carry),
                                       0 if dh_carry is None else dh_carry.stride(0), _p(dc_carry), B, Te, H, A, D)
     _check(rc, "asr_attn_cell_bwd")
+
+
+def attn_bwd(q, w_att, b_att, v, hf, enc, enc_len, alpha, dqc, dctx_carry, dhf, dctx_out, dy, dv_part):
+    """Attention backward alone (include/e2e_asr_hip.h asr_attn_bwd): returns dq [B, H], the gradient w.r.t. the query."""
+    B, Te, D = enc.shape
+    H, A = w_att.shape
+    dq = torch.empty((B, H), device=enc.device, dtype=torch.float32)
+    rc = _lib.lib().asr_attn_bwd(_stream(), _p(q), _p(w_att), _p(b_att), _p(v), _p(hf), _p(enc), _p(enc_len), _p(alpha), _p(dqc),
+                                 _p(dctx_carry), 0 if dctx_carry is None else dctx_carry.stride(0), _p(dhf), _p(dctx_out), _p(dy),
+                                 _p(dv_part), _p(dq), B, Te, H, A, D)
+    _check(rc, "asr_attn_bwd")
+    return dq
 
 
 def colsum(x, out, accumulate=True):

@@ -91,7 +91,7 @@ class Seq2SeqModel(BaseParams):
             emb=dp.emb_size, hidden_dec=dp.hidden_size_dec, lm_hidden=dp.lm_hidden_size,
             attn_vec=dp.attention_vec_size, seed=seed, skip_step=ep.skip_step,
             max_scaling_down=ep.max_scaling_down, initial_res_fac=ep.initial_res_fac,
-            num_layers_dec=getattr(dp, "num_layers_dec", 1), use_lstm=bool(ep.use_lstm),
+            num_layers_dec=getattr(dp, "num_layers_dec", 1), use_lstm=bool(ep.use_lstm), dec_use_lstm=bool(getattr(dp, "use_lstm", True)),
             ind_softmax={t: bool(getattr(params.decoder_params[t], "ind_softmax", False)) for t in tasks})
         return VariableStore.from_arrays(arrays, device)
 

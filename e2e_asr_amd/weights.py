@@ -58,7 +58,7 @@ def multi_cell_leaf(stack, layer, leaf):
 def init_weights(feat=80, hidden=256, bi_dir=True, depth=4, tasks=("char",), vocab=None,
                  emb=256, hidden_dec=256, lm_hidden=256, attn_vec=128, num_layers=None,
                  seed=10, skip_step=2, max_scaling_down=8, initial_res_fac=1, num_layers_dec=1, ind_softmax=None,
-                 use_lstm=True):
+                 use_lstm=True, dec_use_lstm=True):
     """Random-init weights of the reference architecture.
 
     use_lstm False: GRUCell encoder layers (encoder.py:45-48) -- gates kernel [in+H, 2H] / bias [2H] = 1.0 (GRUCell's default bias
@@ -109,7 +109,14 @@ def init_weights(feat=80, hidden=256, bi_dir=True, depth=4, tasks=("char",), voc
         w[dec_name(task, "rnn/OutputProjection/bias")] = np.zeros(V, np.float32)
         if ind_softmax and ind_softmax.get(task):       # drawn AFTER every default variable: other seeds' streams unchanged
             ind_tasks.append((task, H, V))
-        if num_layers_dec <= 1:
+        if not dec_use_lstm:      # GRUCell decoder (decoder.py:56-59): LM cell `gru_cell`, outer cell `gru_cell_1` (creation order as for the LSTMs)
+            for idx, (ein, hh) in enumerate(((E, lmH), (E, H))):
+                scope = "rnn/gru_cell%s/" % ("" if idx == 0 else "_1")
+                w[dec_name(task, scope + "gates/kernel")] = _glorot(rng, (ein + hh, 2 * hh))
+                w[dec_name(task, scope + "gates/bias")] = np.ones(2 * hh, np.float32)
+                w[dec_name(task, scope + "candidate/kernel")] = _glorot(rng, (ein + hh, hh))
+                w[dec_name(task, scope + "candidate/bias")] = np.zeros(hh, np.float32)
+        elif num_layers_dec <= 1:
             w[dec_name(task, "rnn/basic_lstm_cell/kernel")] = _glorot(rng, (E + lmH, 4 * lmH))
             w[dec_name(task, "rnn/basic_lstm_cell/bias")] = np.zeros(4 * lmH, np.float32)
             w[dec_name(task, "rnn/basic_lstm_cell_1/kernel")] = _glorot(rng, (E + H, 4 * H))

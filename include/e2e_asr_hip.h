@@ -329,6 +329,14 @@ int asr_attn_cell_bwd(void* stream, const float* q, const float* w_att, const fl
                       float* dv_part, float* gates, const float* c_prev, const float* dh_carry, int ld_dh,
                       float* dc_carry, int B, int Te, int H, int A, int D);
 
+/* The attention backward of asr_attn_cell_bwd alone: dq_out [B][H] = dqc[:, :H] + dy . W_att^T = the gradient w.r.t. the query,
+ * for a caller whose query is not an LSTM cell state (e2e_asr_amd/gru_decoder.py: with GRUCell the query is the state itself,
+ * /root/reference/decoder.py:79-80).  Everything else as asr_attn_cell_bwd. */
+int asr_attn_bwd(void* stream, const float* q, const float* w_att, const float* b_att, const float* v,
+                 const float* hf, const float* enc, const int* enc_len, const float* alpha,
+                 const float* dqc, const float* dctx_carry, int ld_carry, float* dhf, float* dctx_out, float* dy,
+                 float* dv_part, float* dq_out, int B, int Te, int H, int A, int D);
+
 /* One beam-search step for the k live hypotheses of one utterance: BeamSearch.get_top_k (beam_search.py:163-221) up
  * to the two logit vectors (decoder and external LM); the float64 scoring / argpartition stays on the host.
  * d->B = k rows; hf [Te,A] = enc . AttnW (asr_gemm_f32), enc [Te,D], enc_len[0] = Te.  State rows are per hypothesis
@@ -452,15 +460,18 @@ int asr_get_lstm_mfma(void);
  * out [B][Tout][ndir*H], zeros past each length; bw direction walks t = len-1 .. 0.  gx [B][T][ndir][2H], cx [B][T][ndir][H]:
  * workspaces; hprev and rh [B][T][ndir][H] both non-NULL = save for the backward pass.  Output-only dropout (DropoutWrapper).
  * Backward: gx / cx (what the forward left) are overwritten with dG; wt_ws >= ndir*3*H*H floats; weight / bias gradients are
- * ACCUMULATED into dwg / dbg / dwc / dbc; dx [B][T][in] (or NULL) is overwritten.  H <= 1024.  Everything on `stream`. */
+ * ACCUMULATED into dwg / dbg / dwc / dbc; dx [B][T][in] (or NULL) is overwritten.  H <= 1024.  Everything on `stream`.
+ * h0 / h_last [B][ndir][H] (optional): initial state in, final plain state out; dh_last / dh0: their gradients (a caller that
+ * composes its own time loop -- the GRU attention decoder of decoder.py:56-59 -- runs T = 1 steps with them). */
 int asr_gru_layer_fwd(void* stream, const float* x, int B, int T, int in_dim, int ldx, const int* len, int H, int ndir,
                       const float* const* wg, const float* const* bg, const float* const* wc, const float* const* bc,
-                      float* out, int Tout, float* gx, float* cx, float* hprev, float* rh, float keep_prob, unsigned seed);
+                      float* out, int Tout, float* gx, float* cx, float* hprev, float* rh, float keep_prob, unsigned seed,
+                      const float* h0, float* h_last);
 int asr_gru_layer_bwd(void* stream, const float* x, int B, int T, int in_dim, int ldx, const int* len, int H, int ndir,
                       const float* const* wg, const float* const* wc, const float* dout, int Tout,
                       float* gx, float* cx, const float* hprev, const float* rh, float* wt_ws,
                       float* const* dwg, float* const* dbg, float* const* dwc, float* const* dbc, float* dx,
-                      float keep_prob, unsigned seed);
+                      float keep_prob, unsigned seed, const float* dh_last, float* dh0);
 
 /* How the K slices of a split-K weight-gradient product (tf.gradients, seq2seq_model.py:148: X^T . dY with K = B*T) meet in C.
  * 0 (default): float atomics into C (order, hence the last bits, vary from run to run).  1 = DETERMINISTIC mode (environment

@@ -258,6 +258,11 @@ def dec_var(task, leaf):
     return "model/rnn_decoder_%s/%s" % (task, leaf)
 
 
+def stack_hidden(entry):
+    """Hidden size of a cell-stack entry: (kernel [in+H,4H], bias) = BasicLSTMCell, (wg [in+H,2H], bg, wc [in+H,H], bc) = GRUCell."""
+    return entry[2].shape[1] if len(entry) == 4 else entry[0].shape[1] // 4
+
+
 def decoder_weights(weights, task="char", ind_softmax=False):
     """beam_search.py:53-98 -- name -> role mapping (AttnW squeezed to [D,A]).
     ind_softmax (attn_decoder.py:119-125): the TF-graph decoder's softmax is `rnn/OutputProjection2`, not the
@@ -267,7 +272,12 @@ def decoder_weights(weights, task="char", ind_softmax=False):
     g = lambda leaf: weights[dec_var(task, leaf)]
     opt = lambda leaf: weights.get(dec_var(task, leaf))
     multi = lambda stack, k, leaf: "rnn/multi_rnn_cell%s/cell_%d/basic_lstm_cell/%s" % ("" if stack == "lm" else "_1", k, leaf)
-    if opt(multi("lm", 0, "kernel")) is not None:           # MultiRNNCell decoder (decoder.py:66-68, num_layers_dec > 1)
+    gru = lambda idx, part, leaf: "rnn/gru_cell%s/%s/%s" % ("" if idx == 0 else "_1", part, leaf)
+    if opt(gru(0, "gates", "kernel")) is not None:          # GRUCell decoder (decoder.py:56-59, use_lstm False): stack entries of 4
+        cellw = lambda idx: (g(gru(idx, "gates", "kernel")), g(gru(idx, "gates", "bias")),
+                             g(gru(idx, "candidate", "kernel")), g(gru(idx, "candidate", "bias")))
+        lm_stack, dec_stack = [cellw(0)], [cellw(1)]
+    elif opt(multi("lm", 0, "kernel")) is not None:         # MultiRNNCell decoder (decoder.py:66-68, num_layers_dec > 1)
         L = 0
         while opt(multi("lm", L, "kernel")) is not None:
             L += 1
@@ -280,6 +290,7 @@ def decoder_weights(weights, task="char", ind_softmax=False):
         lm_stack=lm_stack, dec_stack=dec_stack,
         lm_lstm_w=lm_stack[0][0], lm_lstm_b=lm_stack[0][1],
         dec_lstm_w=dec_stack[0][0], dec_lstm_b=dec_stack[0][1],
+        dec_hidden=stack_hidden(dec_stack[0]), lm_hidden=stack_hidden(lm_stack[0]),
         attn_dec_w=g("rnn/Attention/kernel"), attn_dec_b=g("rnn/Attention/bias"),
         inp_w=g("rnn/InputProjection/kernel"), inp_b=g("rnn/InputProjection/bias"),
         attn_proj_w=g("rnn/AttnProjection/kernel"), attn_proj_b=g("rnn/AttnProjection/bias"),
@@ -308,9 +319,13 @@ def cell_stack(x, states, stack, masks, step):
     DROPPED output; the state keeps the plain (c, h).  masks: None or per layer an array indexed by step (or None).
     Returns (top dropped output, new states)."""
     new, inp = [], x
-    for k, (w, b) in enumerate(stack):
-        c, h = lstm_cell(inp, states[k][0], states[k][1], w, b)
-        new.append((c, h))
+    for k, entry in enumerate(stack):
+        if len(entry) == 4:          # GRUCell (decoder.py:58-59): the state IS h -- kept as the pair (h, h) so that the
+            h = gru_cell(inp, states[k][1], *entry)     # "state selector" [0] of decoder.py:79-80 returns h for it
+            new.append((h, h))
+        else:
+            c, h = lstm_cell(inp, states[k][0], states[k][1], *entry)
+            new.append((c, h))
         inp = h if (masks is None or masks[k] is None) else h * masks[k][step]
     return inp, new
 
@@ -346,8 +361,7 @@ def attn_decoder(dec_inp, seq_len, enc, seq_len_inp, weights, task="char",
     seq_len = np.asarray(seq_len).astype(np.int64)
     seq_len_inp = np.asarray(seq_len_inp).astype(np.int64)
     B, Te, D = enc.shape
-    H = p["dec_lstm_w"].shape[1] // 4
-    lmH = p["lm_lstm_w"].shape[1] // 4
+    H, lmH = p["dec_hidden"], p["lm_hidden"]
     V = p["out_w"].shape[1]
     L = len(p["lm_stack"])
     lm_masks = None if lm_keep_masks is None else (list(lm_keep_masks) if L > 1 else [lm_keep_masks])

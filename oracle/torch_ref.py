@@ -125,7 +125,13 @@ def attn_decoder(dec_inp, seq_len, enc, seq_len_inp, W, task="char", lm_keep_mas
     g = lambda leaf: W[O.dec_var(task, leaf)]
     opt = lambda leaf: W.get(O.dec_var(task, leaf))
     multi = lambda stack, k, leaf: "rnn/multi_rnn_cell%s/cell_%d/basic_lstm_cell/%s" % ("" if stack == "lm" else "_1", k, leaf)
-    if opt(multi("lm", 0, "kernel")) is not None:
+    gru = lambda idx, part, leaf: "rnn/gru_cell%s/%s/%s" % ("" if idx == 0 else "_1", part, leaf)
+    if opt(gru(0, "gates", "kernel")) is not None:           # GRUCell decoder (decoder.py:56-59)
+        L = 1
+        cellw = lambda idx: (g(gru(idx, "gates", "kernel")), g(gru(idx, "gates", "bias")),
+                             g(gru(idx, "candidate", "kernel")), g(gru(idx, "candidate", "bias")))
+        lm_stack, dec_stack = [cellw(0)], [cellw(1)]
+    elif opt(multi("lm", 0, "kernel")) is not None:
         L = 0
         while opt(multi("lm", L, "kernel")) is not None:
             L += 1
@@ -140,16 +146,24 @@ def attn_decoder(dec_inp, seq_len, enc, seq_len_inp, W, task="char", lm_keep_mas
 
     def stack_step(x, states, stack, masks, step):
         new, inp = [], x
-        for k, (w, b) in enumerate(stack):
-            c, h = lstm_cell(inp, states[k][0], states[k][1], w, b)
-            new.append((c, h))
+        for k, entry in enumerate(stack):
+            if len(entry) == 4:          # GRUCell: state = h, kept as (h, h) (see asr_oracle.cell_stack)
+                wg, bg, wc, bc = entry
+                hp = states[k][1]
+                v = torch.sigmoid(torch.cat((inp, hp), -1) @ wg + bg)
+                r, u = v.chunk(2, -1)
+                cnd = torch.tanh(torch.cat((inp, r * hp), -1) @ wc + bc)
+                h = u * hp + (1 - u) * cnd
+                new.append((h, h))
+            else:
+                c, h = lstm_cell(inp, states[k][0], states[k][1], *entry)
+                new.append((c, h))
             inp = h if (masks is None or masks[k] is None) else h * masks[k][step]
         return inp, new
     emb = g("decoder/embedding")
     seq_len = np.asarray(seq_len).astype(np.int64)
     B, Te, D = enc.shape
-    H = dec_stack[0][0].shape[1] // 4
-    lmH = lm_stack[0][0].shape[1] // 4
+    H, lmH = O.stack_hidden(dec_stack[0]), O.stack_hidden(lm_stack[0])
     T_out = int(seq_len.max())
     mask = (torch.arange(Te)[None] < torch.as_tensor(np.asarray(seq_len_inp))[:, None]).to(enc.dtype)
     aw = g("AttnW"); aw = aw.reshape(aw.shape[-2], aw.shape[-1])

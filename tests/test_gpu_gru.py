@@ -122,3 +122,73 @@ def test_default_encoder_params_train_end_to_end_vs_oracle_and_autograd():
         losses.append(float(m.step(b)["char"]))
     ops.check_device_flag(torch.device(DEV))
     assert np.isfinite(losses).all() and losses[-1] < losses[0]
+
+
+# ------------------------------------------------------------------ the GRUCell attention decoder (decoder.py:56-59, 79-80)
+@pytest.mark.parametrize("keep,lmH", [(1.0, 32), (0.8, 32), (0.8, 24)])
+def test_gru_decoder_logits_loss_and_gradients_vs_oracle_and_autograd(keep, lmH):
+    """use_lstm False in the decoder's params: both decoder cells are GRUCells, the attention query is the GRU state itself
+    (e2e_asr_amd/gru_decoder.py: a host-composed per-step path over csrc/gru.hip with T = 1, asr_attn_bwd, the step kernels).
+    Logits and loss vs the float64 oracle, every gradient vs float64 autograd; ragged lengths; the LM cell's output dropout masks
+    are reproduced from the counter-based generator; lmH != 32: + SimpleProjection.  With the encoder's default (GRU) cell too."""
+    from tests.test_gpu_parity3 import _model, _f64
+    from tests.test_gpu_model import _np_keep_scale
+    from e2e_asr_amd import ops
+    from e2e_asr_amd.gru_decoder import step_seed
+    from e2e_asr_amd.weights import synthetic_batch
+    from oracle import torch_ref as R
+    nl = {"char": 2}
+    m = _model(enc_update=dict(use_lstm=False, hidden_size=40), num_layers=nl, seed=21,
+               dec_update=dict(use_lstm=False, hidden_size_dec=32, lm_hidden_size=lmH, emb_size=24, attention_vec_size=16,
+                               out_prob_dec=keep))
+    assert m.decoder["char"].cell == "GRUCell(32)"
+    names = m.variables.names()
+    assert any("rnn/gru_cell_1/gates/kernel" in n for n in names) and not any("basic_lstm_cell" in n for n in names)
+    B = 5
+    b = synthetic_batch(B=B, T=22, F=20, t_dec=9, vocab=50, variable_len=True, seed=61)
+    m.global_step = 3
+    m.forward(b)
+    ops.check_device_flag(torch.device(DEV))
+    T_out = m.decoder["char"].saved["t_out"]
+    seed = m.decoder["char"].saved["seed"]
+    lm_masks = None
+    if keep < 1.0:          # (the oracle's raw_rnn restatement also runs the LM cell once past the last step: T_out + 1 rows)
+        bb, jj = np.meshgrid(np.arange(B), np.arange(lmH), indexing="ij")
+        lm_masks = np.stack([_np_keep_scale(step_seed(seed, "lm", i), bb, jj, keep) for i in range(T_out + 1)])
+    w = _f64(m.variables.to_arrays())
+    b64 = dict(b); b64["logmel"] = b["logmel"].astype(np.float64)
+    att, _, lens = O.encoder(b64["logmel"], b64["logmel_len"], w, nl)
+    ref = O.attn_decoder(np.transpose(b["char"]), b["char_len"], att[2], lens[2], w, is_training=True, lm_keep_masks=lm_masks)
+    np.testing.assert_allclose(m.outputs["char"].cpu().numpy(), ref, rtol=0, atol=1e-4)
+    m.backward()
+    ops.check_device_flag(torch.device(DEV))
+    W = R.weights_to_torch(w)
+    total, _, _ = R.seq2seq_loss(b64, W, num_layers=nl, lm_keep_masks=None if lm_masks is None else {"char": torch.tensor(lm_masks)})
+    np.testing.assert_allclose(m.total_loss.item(), total.item(), rtol=2e-5)
+    total.backward()
+    for name in names:
+        ref_g = W[name].grad.numpy()
+        err = np.abs(m.variables.grad_of(name).cpu().numpy() - ref_g).max() / max(1e-3, np.abs(ref_g).max())
+        assert err < 2e-3, (name, err)
+
+
+def test_gru_decoder_inference_and_sampling_modes():
+    """The GRU decoder in the inference graph (argmax feedback every step: ids equal to the float64 oracle's) and under scheduled
+    sampling (runs, feeds drawn tokens, stays finite, the loss falls over a few steps)."""
+    from tests.test_gpu_parity3 import _model, _f64
+    from e2e_asr_amd import ops
+    from e2e_asr_amd.weights import synthetic_batch
+    dec = dict(use_lstm=False, hidden_size_dec=32, lm_hidden_size=32, emb_size=24, attention_vec_size=16)
+    m = _model(enc_update=dict(hidden_size=64), num_layers={"char": 2}, seed=47, training=False, dec_update=dec, max_output={"char": 9})
+    b = synthetic_batch(B=4, T=18, F=20, t_dec=8, vocab=50, variable_len=True, seed=71)
+    out = m.forward(b)["char"].cpu().numpy()
+    w = _f64(m.variables.to_arrays())
+    b64 = dict(b); b64["logmel"] = b["logmel"].astype(np.float64)
+    r = O.seq2seq_forward(b64, w, num_layers={"char": 2}, is_training=False, max_output={"char": 9})["outputs"]["char"]
+    np.testing.assert_allclose(out, r, rtol=0, atol=1e-4)
+    np.testing.assert_array_equal(m.greedy_ids().cpu().numpy(), O.greedy_decode_ids(r, 4))
+    m2 = _model(enc_update=dict(hidden_size=64), num_layers={"char": 2}, seed=47, dec_update=dict(dec, samp_prob=0.5))
+    m2.decoder["char"].coin_seed = 3
+    losses = [float(m2.step(b)["char"]) for _ in range(8)]
+    ops.check_device_flag(torch.device(DEV))
+    assert torch.isfinite(m2.variables.flat).all() and m2.global_step == 8 and losses[-1] < losses[0]

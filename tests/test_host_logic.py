@@ -130,16 +130,19 @@ def test_shifted_targets_and_lazy_weight_mask():
     assert calls == ["char"]                                             # built once, on first access
 
 
-def test_encoder_builds_both_cells_and_the_decoder_gru_is_refused_with_what_to_set():
+def test_both_cells_of_encoder_and_decoder_construct_and_gru_stacks_are_refused_with_what_to_set():
     """encoder.py:45-48: `Encoder.class_params()` defaults to GRUCell (encoder.py:27) although the reference CLI always sets use_lstm
     (encoder.py:187): a default-constructed Encoder is a GRU encoder (round 5, csrc/gru.hip).  decoder.py:56-59: the decoder's GRU
-    branch (never reachable: Decoder.class_params() says LSTM and main.py has no flag for it) stays refused -- a clear ValueError
-    when the object is made, not a failure somewhere inside the first call."""
+    branch (no reference flag reaches it) runs through e2e_asr_amd/gru_decoder.py; only GRU cells in MultiRNNCell STACKS stay
+    refused -- a clear ValueError when the object is made, not a failure somewhere inside the first call."""
     from e2e_asr_amd.attn_decoder import AttnDecoder
     from e2e_asr_amd.encoder import Encoder
     assert Encoder().get_cell() == "GRUCell(256)"          # class_params(): use_lstm False
     p = Encoder.class_params(); p.use_lstm = True
     assert Encoder(params=p).get_cell() == "BasicLSTMCell(256)"
     dp = AttnDecoder.class_params(); dp.use_lstm = False
+    d = AttnDecoder(True, dp, scope="char")
+    assert d.get_cell() == "GRUCell(256)" and d.get_cell(64) == "GRUCell(64)" and d.get_state("h") == "h"
+    dp2 = AttnDecoder.class_params(); dp2.use_lstm = False; dp2.num_layers_dec = 2
     with pytest.raises(ValueError, match="use_lstm"):
-        AttnDecoder(True, dp, scope="char")
+        AttnDecoder(True, dp2, scope="char")

@@ -138,3 +138,24 @@ def test_gru_encoder_oracle_equals_twin_through_the_pyramid():
     att_t, _ = R.encoder(torch.tensor(x), lens, W, {"char": 3})
     np.testing.assert_allclose(att[3], att_t[3].detach().numpy(), atol=1e-13)
     assert att[3].shape == (3, 4, 10)
+
+
+def test_gru_decoder_oracle_equals_twin_and_queries_the_state():
+    """decoder.py:56-59, 79-80 with use_lstm False: both decoder cells are GRUCells and the attention query is the GRU state itself.
+    The NumPy oracle (cell_stack with 4-entry GRU cells, state kept as (h, h)) equals its autograd twin, teacher-forced, ragged."""
+    import torch
+    from oracle import asr_oracle as O, torch_ref as R
+    from e2e_asr_amd.weights import init_weights, synthetic_batch
+    w = {k: v.astype(np.float64) for k, v in init_weights(feat=6, hidden=5, depth=2, seed=4, use_lstm=False, dec_use_lstm=False,
+                                                          vocab={"char": 17}, emb=4, hidden_dec=6, lm_hidden=5, attn_vec=3).items()}
+    assert any("rnn/gru_cell_1/candidate/kernel" in k for k in w) and not any("basic_lstm_cell" in k for k in w)
+    assert any("SimpleProjection" in k for k in w)                  # lm_hidden 5 != hidden_dec 6
+    b = synthetic_batch(B=4, T=14, F=6, t_dec=7, vocab=17, variable_len=True, seed=3)
+    b64 = dict(b); b64["logmel"] = b["logmel"].astype(np.float64)
+    r = O.seq2seq_forward(b64, w, num_layers={"char": 2}, is_training=True)
+    W = R.weights_to_torch(w)
+    total, losses, outs = R.seq2seq_loss(b64, W, num_layers={"char": 2})
+    np.testing.assert_allclose(r["outputs"]["char"], outs["char"].detach().numpy(), atol=1e-12)
+    np.testing.assert_allclose(r["losses"]["char"], float(losses["char"]), rtol=1e-12)
+    total.backward()
+    assert all(W[k].grad is not None and np.isfinite(W[k].grad.numpy()).all() for k in W if "rnn_decoder_char" in k)
