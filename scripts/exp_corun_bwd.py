@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from e2e_asr_amd import ops
 dev = torch.device("cuda:0")
-B, T, IN, H = 32, int(os.environ.get("T", 800)), 80, 256
+B, T, IN, H = int(os.environ.get("B", 32)), int(os.environ.get("T", 800)), 80, 256
 NG = int(os.environ.get("NG", 2))
 x = torch.randn(B, T, IN, device=dev) * 0.3
 ln = torch.full((B,), T, dtype=torch.int32, device=dev)
