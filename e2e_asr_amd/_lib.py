@@ -39,7 +39,7 @@ class DecWs(C.Structure):
 
 class DecBwdWs(C.Structure):
     _fields_ = [(n, vp) for n in ("dP", "dQC", "dY", "dXH", "dLC", "dlm", "dEH", "dc_dec", "dc_lm", "dhf",
-                                  "dv_part", "dctx", "emb_all", "chain_ws", "wc", "lm_hx")]
+                                  "dv_part", "dctx", "emb_all", "chain_ws", "wc", "lm_hx")] + [("lm_deferred", C.c_int)]
 
 
 class LmWeights(C.Structure):
@@ -160,6 +160,8 @@ SIGNATURES = {
     "asr_gru_layer_bwd": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, vp, vp, C.c_int,
                                     vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_uint, vp, vp]),
     "asr_attn_bwd": (C.c_int, [vp] * 11 + [C.c_int] + [vp] * 5 + [C.c_int] * 5),
+    "asr_attn_decoder_bwd_lm": (C.c_int, [vp, C.POINTER(DecWeights), C.POINTER(DecWeights), C.POINTER(DecDims), C.POINTER(DecWs),
+                                          C.POINTER(DecBwdWs), C.c_float, C.c_uint]),
     "asr_race_hunt_build": (C.c_int, []),
     "asr_set_wgrad_mode": (C.c_int, [C.c_int]),
     "asr_get_wgrad_mode": (C.c_int, []),

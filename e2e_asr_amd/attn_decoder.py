@@ -111,18 +111,28 @@ class AttnDecoder(Decoder):
             out[field] = v.grad_of(name) if name in v else None
         return out
 
-    def backward(self, dlogits, denc):
+    def backward(self, dlogits, denc, defer_lm=False):
         """Gradient of __call__: accumulates weight gradients into the flat buffer and the
-        encoder-state gradient into denc [B,Te,D]."""
+        encoder-state gradient into denc [B,Te,D].  defer_lm: the LM cell chain's backward is left to backward_lm_tail(),
+        which the caller runs behind the encoder's backward pass (Seq2SeqModel.backward)."""
         sv = self.saved
+        self._lm_tail = None
         if self.multi is not None:
             self.variables.ensure_grad()
             self.multi.backward(sv["multi"], dlogits, denc)
             self.saved = None
             return
-        ops.attn_decoder_bwd(self.weight_tensors(), self.grad_tensors(), sv["ws"], sv["enc"], sv["enc_len_dev"],
-                             dlogits, denc, keep_lm=sv["keep_lm"], seed=sv["seed"])
+        bw = ops.attn_decoder_bwd(self.weight_tensors(), self.grad_tensors(), sv["ws"], sv["enc"], sv["enc_len_dev"],
+                                  dlogits, denc, keep_lm=sv["keep_lm"], seed=sv["seed"], defer_lm=defer_lm)
+        if "_lm_tail" in bw:
+            self._lm_tail = bw
         self.saved = None
+
+    def backward_lm_tail(self):
+        """The part of backward() that defer_lm left out (no-op otherwise); before ops.side_join()."""
+        bw, self._lm_tail = getattr(self, "_lm_tail", None), None
+        if bw is not None:
+            ops.attn_decoder_bwd_lm(bw)
 
     @classmethod
     def add_parse_options(cls, parser):

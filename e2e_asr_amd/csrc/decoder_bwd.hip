@@ -338,6 +338,87 @@ static size_t dec_bwd_lds(int Te, int H, int A, int D) {
     return sizeof(float) * (r4(D) + r4(Te) + 2 * r4(A) + r4(H) + part);
 }
 
+// The LM cell chain's backward (BPTT over all steps, demb, the LM kernel / bias / embedding gradients).  `ss`: the stream it runs
+// on -- the library's side stream, already ordered behind the decoder chain by the caller (asr_attn_decoder_bwd, as in rounds
+// 1-4), or the caller's own stream later (asr_attn_decoder_bwd_lm, the deferred form).  fork: make `ss` wait for `s` first.
+// *e_lm_bptt: event behind the persistent BPTT launch (NULL if the per-step path ran).
+static int dec_lm_chain_bwd(hipStream_t s, hipStream_t ss, bool fork, const asr_dec_weights* w, const asr_dec_weights* g,
+                            const asr_dec_dims* d, const asr_dec_ws* ws, const asr_dec_bwd_ws* bw, float keep_lm, unsigned seed,
+                            hipEvent_t* e_lm_bptt_out) {
+    using namespace asr;
+    const int B = d->B, Te = d->Te, D = d->D, A = d->A, H = d->H, lmH = d->lmH, E = d->E, V = d->V, T = d->T_out;
+    const int TB = T * B;
+    const int P = w->simple_w ? H : lmH;
+    const int ldLC = P + D, ldEH = E + lmH;
+    void* side = static_cast<void*>(ss);
+    hipEvent_t e_lm_bptt = nullptr;
+    int rc;
+    (void)V;
+    // ---- LM chain backward on the side stream: it needs only dLC[i] (all produced above) and its
+    // own carries, so it runs concurrently with the data-gradient GEMMs the caller's stream does next; the caller's stream
+    // waits for its BPTT before this function returns (one persistent kernel at a time, see the end), the remaining
+    // side-stream GEMMs overlap the encoder's BPTT.  asr_side_join() orders them before the optimizer.
+    if (fork) {
+        hipEvent_t e_loop = next_event();
+        if (hipEventRecord(e_loop, s) != hipSuccess || hipStreamWaitEvent(ss, e_loop, 0) != hipSuccess) return ASR_ELAUNCH;
+    }
+    if (hipMemsetAsync(bw->dc_lm, 0, sizeof(float) * B * lmH, ss) != hipSuccess) return ASR_ELAUNCH;
+    // persistent LM chain (the forward ran csrc/lstm.hip time-major under the same predicate): one BPTT launch
+    // over all steps (dG overwrites lm_gates), then demb = dG . K_x^T for all steps as one GEMM
+    const bool lm_chain = ws->chain_ws && ws->w2k && ws->err && ws->y && asr_decoder_chain_supported(B, Te, D, A, H) &&
+                          ws->lm_act && ws->lm_hprev && ws->lm_state && ws->lm_len && ws->lm_hx && bw->lm_hx &&
+                          asr_decoder_lm_chain_supported(B, lmH);
+    if (lm_chain) {
+        const float* dlo = bw->dLC; int ld_dlo = ldLC;
+        if (w->simple_w) {
+            if ((rc = asr_gemm_f32(side, 0, 1, TB, lmH, H, bw->dLC, ldLC, w->simple_w, H, bw->dlm, lmH, nullptr, 0))) return rc;
+            dlo = bw->dlm; ld_dlo = lmH;
+        }
+        if ((rc = asr_lstm_rec_bwd_tm(ss, ws->lm_gates, ws->lm_act, dlo, ld_dlo, w->lm_kernel + (size_t)E * 4 * lmH, ws->lm_len,
+                                      bw->lm_hx, ws->err, B, T, lmH, keep_lm, seed))) return rc;
+        e_lm_bptt = next_event();
+        if (hipEventRecord(e_lm_bptt, ss) != hipSuccess) return ASR_ELAUNCH;
+        if ((rc = asr_gemm_f32(side, 0, 1, TB, E, 4 * lmH, ws->lm_gates, 4 * lmH, w->lm_kernel, 4 * lmH, bw->dEH, ldEH, nullptr, 0)))
+            return rc;
+    }
+    for (int i = T - 1; i >= 0 && !lm_chain; --i) {
+        const size_t o = (size_t)i * B;
+        const bool last = i == T - 1;
+        const float* dlo = bw->dLC + o * ldLC; int ld_dlo = ldLC;
+        if (w->simple_w) {
+            if ((rc = asr_linear_wt_fwd(side, bw->dLC + o * ldLC, ldLC, H, w->simple_w, H, bw->dlm + o * lmH, lmH, B, lmH, 0)))
+                return rc;
+            dlo = bw->dlm + o * lmH; ld_dlo = lmH;
+        }
+        LmBwdArgs l;
+        l.gates = ws->lm_gates + o * 4 * lmH; l.c = ws->lm_c + o * lmH; l.c_prev = i ? ws->lm_c + (o - B) * lmH : nullptr;
+        l.dlo = dlo; l.ld_dlo = ld_dlo;
+        l.dh_carry = last ? nullptr : bw->dEH + (o + B) * ldEH + E; l.ld_dh = ldEH;
+        l.dc_carry = bw->dc_lm; l.B = B; l.H = lmH; l.keep = keep_lm; l.seed = seed; l.step = (uint32_t)i;
+        hipLaunchKernelGGL(lm_cell_bwd_kernel, dim3((B * lmH + 255) / 256), dim3(256), 0, ss, l);
+        // [demb | dlm_h_prev] = dG_lm . K_lm^T
+        if ((rc = asr_linear_wt_fwd(side, ws->lm_gates + o * 4 * lmH, 4 * lmH, 4 * lmH, w->lm_kernel, 4 * lmH,
+                                    bw->dEH + o * ldEH, ldEH, B, E + lmH, 0))) return rc;
+    }
+    {
+        float* gwl = nullptr;
+        if ((rc = asr_gather_rows(side, w->embedding, ws->tok, bw->emb_all, TB, E))) return rc;
+        gwl = const_cast<float*>(g->lm_kernel);
+        if ((rc = asr_gemm_f32(side, 1, 0, E, 4 * lmH, TB, bw->emb_all, E, ws->lm_gates, 4 * lmH, gwl, 4 * lmH, nullptr, 1))) return rc;
+        if (lm_chain) {      // h_{t-1} of every step was saved by the recurrent kernel (row 0 = zeros)
+            if ((rc = asr_gemm_f32(side, 1, 0, lmH, 4 * lmH, TB, ws->lm_hprev, lmH, ws->lm_gates, 4 * lmH,
+                                   gwl + (size_t)E * 4 * lmH, 4 * lmH, nullptr, 1))) return rc;
+        } else if (T > 1 && (rc = asr_gemm_f32(side, 1, 0, lmH, 4 * lmH, TB - B, ws->lm_h, lmH, ws->lm_gates + (size_t)B * 4 * lmH, 4 * lmH,
+                                        gwl + (size_t)E * 4 * lmH, 4 * lmH, nullptr, 1))) return rc;
+        if ((rc = asr_colsum_f32(side, ws->lm_gates, 4 * lmH, TB, 4 * lmH, const_cast<float*>(g->lm_bias), 1))) return rc;
+        if (asr::wgrad_slabs() == 1 && E <= 1024) {      // occurrences of a token added in ascending order, no atomics (csrc/splitk.hip)
+            if ((rc = asr_scatter_add_rows_ordered(side, const_cast<float*>(g->embedding), V, ws->tok, bw->dEH, TB, E, ldEH))) return rc;
+        } else if ((rc = asr_scatter_add_rows_ld(side, const_cast<float*>(g->embedding), ws->tok, bw->dEH, TB, E, ldEH))) return rc;
+    }
+    if (e_lm_bptt_out) *e_lm_bptt_out = e_lm_bptt;
+    return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
+}
+
 // Gradients are ACCUMULATED into `g` (same field layout as the weights) and into denc
 // [B,Te,D]; dec_gates / lm_gates in `ws` are overwritten with the pre-activation gradients.
 extern "C" int asr_attn_decoder_bwd(void* stream, const asr_dec_weights* w, const asr_dec_weights* g,
@@ -435,65 +516,18 @@ extern "C" int asr_attn_decoder_bwd(void* stream, const asr_dec_weights* w, cons
         if ((rc = asr_linear_wt_fwd(stream, bw->dXH + o * ldXH, ldXH, E, w->inp_w, E, bw->dLC + o * ldLC, ldLC, B, P + D, 0)))
             return rc;
     }
-    // ---- LM chain backward on the side stream: it needs only dLC[i] (all produced above) and its
-    // own carries, so it runs concurrently with the data-gradient GEMMs the caller's stream does next; the caller's stream
-    // waits for its BPTT before this function returns (one persistent kernel at a time, see the end), the remaining
-    // side-stream GEMMs overlap the encoder's BPTT.  asr_side_join() orders them before the optimizer.
-    hipEvent_t e_loop = next_event();
-    if (hipEventRecord(e_loop, s) != hipSuccess || hipStreamWaitEvent(ss, e_loop, 0) != hipSuccess) return ASR_ELAUNCH;
-    if (hipMemsetAsync(bw->dc_lm, 0, sizeof(float) * B * lmH, ss) != hipSuccess) return ASR_ELAUNCH;
-    // persistent LM chain (the forward ran csrc/lstm.hip time-major under the same predicate): one BPTT launch
-    // over all steps (dG overwrites lm_gates), then demb = dG . K_x^T for all steps as one GEMM
-    const bool lm_chain = ws->chain_ws && ws->w2k && ws->err && ws->y && asr_decoder_chain_supported(B, Te, D, A, H) &&
-                          ws->lm_act && ws->lm_hprev && ws->lm_state && ws->lm_len && ws->lm_hx && bw->lm_hx &&
-                          asr_decoder_lm_chain_supported(B, lmH);
-    if (lm_chain) {
-        const float* dlo = bw->dLC; int ld_dlo = ldLC;
-        if (w->simple_w) {
-            if ((rc = asr_gemm_f32(side, 0, 1, TB, lmH, H, bw->dLC, ldLC, w->simple_w, H, bw->dlm, lmH, nullptr, 0))) return rc;
-            dlo = bw->dlm; ld_dlo = lmH;
-        }
-        if ((rc = asr_lstm_rec_bwd_tm(ss, ws->lm_gates, ws->lm_act, dlo, ld_dlo, w->lm_kernel + (size_t)E * 4 * lmH, ws->lm_len,
-                                      bw->lm_hx, ws->err, B, T, lmH, keep_lm, seed))) return rc;
-        e_lm_bptt = next_event();
-        if (hipEventRecord(e_lm_bptt, ss) != hipSuccess) return ASR_ELAUNCH;
-        if ((rc = asr_gemm_f32(side, 0, 1, TB, E, 4 * lmH, ws->lm_gates, 4 * lmH, w->lm_kernel, 4 * lmH, bw->dEH, ldEH, nullptr, 0)))
-            return rc;
-    }
-    for (int i = T - 1; i >= 0 && !lm_chain; --i) {
-        const size_t o = (size_t)i * B;
-        const bool last = i == T - 1;
-        const float* dlo = bw->dLC + o * ldLC; int ld_dlo = ldLC;
-        if (w->simple_w) {
-            if ((rc = asr_linear_wt_fwd(side, bw->dLC + o * ldLC, ldLC, H, w->simple_w, H, bw->dlm + o * lmH, lmH, B, lmH, 0)))
-                return rc;
-            dlo = bw->dlm + o * lmH; ld_dlo = lmH;
-        }
-        LmBwdArgs l;
-        l.gates = ws->lm_gates + o * 4 * lmH; l.c = ws->lm_c + o * lmH; l.c_prev = i ? ws->lm_c + (o - B) * lmH : nullptr;
-        l.dlo = dlo; l.ld_dlo = ld_dlo;
-        l.dh_carry = last ? nullptr : bw->dEH + (o + B) * ldEH + E; l.ld_dh = ldEH;
-        l.dc_carry = bw->dc_lm; l.B = B; l.H = lmH; l.keep = keep_lm; l.seed = seed; l.step = (uint32_t)i;
-        hipLaunchKernelGGL(lm_cell_bwd_kernel, dim3((B * lmH + 255) / 256), dim3(256), 0, ss, l);
-        // [demb | dlm_h_prev] = dG_lm . K_lm^T
-        if ((rc = asr_linear_wt_fwd(side, ws->lm_gates + o * 4 * lmH, 4 * lmH, 4 * lmH, w->lm_kernel, 4 * lmH,
-                                    bw->dEH + o * ldEH, ldEH, B, E + lmH, 0))) return rc;
-    }
+    // ---- LM chain backward: on the side stream now (the caller's stream then waits for its BPTT before this function returns:
+    // one persistent kernel at a time, see the end), or -- bw->lm_deferred -- not at all here: the caller runs it with
+    // asr_attn_decoder_bwd_lm on its own stream behind the encoder's last BPTT, where the LM chain's BPTT (128 workgroups since
+    // round 5) shares the chip with the side stream's weight-gradient backlog instead of holding up the encoder's BPTT.
+    // (the side stream waits HERE for the backward chain in either case: the weight-gradient GEMMs queued on it further down
+    // read dY, dG, dXH ...; with the LM part deferred and this wait inside it they ran on unfinished data -- found by
+    // test_decoder_chain_path_vs_oracle_and_autograd, not by the bench)
     {
-        float* gwl = nullptr;
-        if ((rc = asr_gather_rows(side, w->embedding, ws->tok, bw->emb_all, TB, E))) return rc;
-        gwl = const_cast<float*>(g->lm_kernel);
-        if ((rc = asr_gemm_f32(side, 1, 0, E, 4 * lmH, TB, bw->emb_all, E, ws->lm_gates, 4 * lmH, gwl, 4 * lmH, nullptr, 1))) return rc;
-        if (lm_chain) {      // h_{t-1} of every step was saved by the recurrent kernel (row 0 = zeros)
-            if ((rc = asr_gemm_f32(side, 1, 0, lmH, 4 * lmH, TB, ws->lm_hprev, lmH, ws->lm_gates, 4 * lmH,
-                                   gwl + (size_t)E * 4 * lmH, 4 * lmH, nullptr, 1))) return rc;
-        } else if (T > 1 && (rc = asr_gemm_f32(side, 1, 0, lmH, 4 * lmH, TB - B, ws->lm_h, lmH, ws->lm_gates + (size_t)B * 4 * lmH, 4 * lmH,
-                                        gwl + (size_t)E * 4 * lmH, 4 * lmH, nullptr, 1))) return rc;
-        if ((rc = asr_colsum_f32(side, ws->lm_gates, 4 * lmH, TB, 4 * lmH, const_cast<float*>(g->lm_bias), 1))) return rc;
-        if (asr::wgrad_slabs() == 1 && E <= 1024) {      // occurrences of a token added in ascending order, no atomics (csrc/splitk.hip)
-            if ((rc = asr_scatter_add_rows_ordered(side, const_cast<float*>(g->embedding), V, ws->tok, bw->dEH, TB, E, ldEH))) return rc;
-        } else if ((rc = asr_scatter_add_rows_ld(side, const_cast<float*>(g->embedding), ws->tok, bw->dEH, TB, E, ldEH))) return rc;
+        hipEvent_t e_loop = next_event();
+        if (hipEventRecord(e_loop, s) != hipSuccess || hipStreamWaitEvent(ss, e_loop, 0) != hipSuccess) return ASR_ELAUNCH;
     }
+    if (!bw->lm_deferred && (rc = dec_lm_chain_bwd(s, ss, false, w, g, d, ws, bw, keep_lm, seed, &e_lm_bptt))) return rc;
     if (hipGetLastError() != hipSuccess) return ASR_ELAUNCH;
     // ---- the encoder-state gradient is what the caller's stream needs next: do it first, there
     // denc[b] += sum_i alpha_i[b,:]^T . dctx_i[b,:]  -- one batched GEMM over the B utterances
@@ -550,6 +584,15 @@ extern "C" int asr_attn_decoder_bwd(void* stream, const asr_dec_weights* w, cons
     if (e_lm_bptt && !lm_overlap && hipStreamWaitEvent(s, e_lm_bptt, 0) != hipSuccess) return ASR_ELAUNCH;
     prof_end(ASR_PROF_DECODER_BWD, s);
     return ASR_OK;
+}
+
+// The deferred LM-chain part of asr_attn_decoder_bwd (bw->lm_deferred = 1 there): everything on `stream`.  Call it after the
+// encoder's backward pass was enqueued on the same stream (never next to another persistent kernel) and before asr_side_join.
+extern "C" int asr_attn_decoder_bwd_lm(void* stream, const asr_dec_weights* w, const asr_dec_weights* g, const asr_dec_dims* d,
+                                       const asr_dec_ws* ws, const asr_dec_bwd_ws* bw, float keep_lm, unsigned seed) {
+    if (!w || !g || !d || !ws || !bw) return ASR_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return dec_lm_chain_bwd(s, s, false, w, g, d, ws, bw, keep_lm, seed, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------

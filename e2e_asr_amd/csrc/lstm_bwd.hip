@@ -856,8 +856,13 @@ __global__ __launch_bounds__(2 * H + 64) void lstm_rec_bwd2_kernel(LstmBwdArgs a
 // wave itself fetches the activation record of the NEXT step and turns it into the pointwise operands in the slack after its
 // own contraction (it never polls, so its loads delay nobody's polls), one step ahead as the loader wave did.
 // ---------------------------------------------------------------------------------------------------------------
+// REC32: the saved activations are the 32-byte records {i,j,f,o | c, c_prev, -, -} of the decoder's LM cell chain (written by the
+// one-launch training decoder, csrc/decoder_greedy.hip) instead of the encoder's 20-byte split records: the time-major LM-chain
+// BPTT (asr_lstm_rec_bwd_tm) then runs on this kernel too -- 32 groups x 4 = 128 workgroups, half the chip.
+template <bool REC32 = false>
 __global__ __launch_bounds__(512) void lstm_rec_bwd4_kernel(LstmBwdArgs a) {
     constexpr int H = 256, HS = 64, G = 4, NW = 8, NT = 512, H4 = 4 * H, N = 4 * H;
+    constexpr unsigned GSTR = REC32 ? 8u : 4u, CSTR = REC32 ? 8u : 1u;     // floats per unit-step in the gates / c arrays
     __shared__ __attribute__((aligned(16))) float dgs[NW][128];
     __shared__ __attribute__((aligned(16))) float part[2][NW][HS];
     __shared__ __attribute__((aligned(16))) float opnd[2][HS][8];
@@ -917,19 +922,19 @@ __global__ __launch_bounds__(512) void lstm_rec_bwd4_kernel(LstmBwdArgs a) {
     // the cell wave, the wave all others wait for.)
     float4 ra = make_float4(0.f, 0.f, 0.f, 0.f);
     float rc_ = 0.f, rcn = 0.f, dout_v = 0.f;
-    const float* const act_g = a.act + ((((size_t)cb * a.sb) * a.ND + dir) * H + cj) * 4;
-    const float* const act_cc = a.act_c + (((size_t)cb * a.sb) * a.ND + dir) * H + cj;
+    const float* const act_g = a.act + ((((size_t)cb * a.sb) * a.ND + dir) * H + cj) * GSTR;
+    const float* const act_cc = REC32 ? act_g + 4 : a.act_c + (((size_t)cb * a.sb) * a.ND + dir) * H + cj;
     const float* const dout_b = a.dout + ((size_t)cb * a.osb) * a.ldo + dir * H + cj;
     const unsigned tstr = (unsigned)(a.st * a.ND * H), ostr = (unsigned)(a.ost * a.ldo);
     auto time_of = [&](int s) { const int t = dir ? s : (S - 1 - s); return (unsigned)min(max(t, 0), a.T - 1); };
     auto prefetch = [&](int s) {
         const unsigned ts = time_of(s), tn = time_of(min(s + 1, S - 1));
-        ra = *reinterpret_cast<const float4*>(act_g + ts * tstr * 4u);
+        ra = *reinterpret_cast<const float4*>(act_g + ts * tstr * GSTR);
         // c of this step AND of the next one (= this step's c_prev), both loaded here: carrying the second over to the next step
         // in a register made the compiler copy it at the loop's back edge, i.e. wait for the load it had just issued.  The two
         // are neighbours in time: the second load is the next step's first and hits the same lines.
-        rc_ = act_cc[ts * tstr];
-        rcn = act_cc[tn * tstr];
+        rc_ = act_cc[ts * tstr * CSTR];
+        rcn = act_cc[tn * tstr * CSTR];
         dout_v = dout_b[ts * ostr];
     };
     auto hand_over = [&](int s) {
@@ -1226,7 +1231,7 @@ extern "C" int asr_lstm_layer_bwd_p3(void* stream, const float* x, int B, int T,
             const int padded = ((groups + 7) & ~7) * 4;
             const int grid = padded <= asr_lstm_max_wgs() ? padded : groups * 4;
             prof_begin(ASR_PROF_LSTM_REC_BWD, s);
-            hipLaunchKernelGGL(asr::lstm_rec_bwd4_kernel, dim3(grid), dim3(512), 0, s, c);
+            hipLaunchKernelGGL(asr::lstm_rec_bwd4_kernel<false>, dim3(grid), dim3(512), 0, s, c);
             prof_end(ASR_PROF_LSTM_REC_BWD, s);
             if (hipGetLastError() != hipSuccess) return ASR_ELAUNCH;
         }
@@ -1347,6 +1352,15 @@ int asr_lstm_rec_bwd_tm(hipStream_t s, float* gates, const float* act, const flo
     a.sb = 1; a.st = B; a.osb = 1; a.ost = B; a.ldo = ldo; a.dsb = 1; a.dst = B;
     a.dbg = nullptr; a.db_part = nullptr;
     a.dg_p3 = nullptr; a.p3_np = 0; a.dg_f32 = 1; a.act_c = nullptr;
+    // groups of four workgroups (lstm_rec_bwd4_kernel<REC32>): 4 B workgroups instead of 8 B -- at B = 32 half the chip, and the
+    // faster step (1.15 vs 1.3 us).  ASR_LM_G4=0: the eight-workgroup kernel as before round 5.
+    static const bool lm_g4 = [] { const char* e = getenv("ASR_LM_G4"); return !(e && e[0] == '0'); }();
+    if (lm_g4 && H == 256 && asr_lstm_g4_selected(B, H, 1) && 4 * B <= asr_lstm_max_wgs()) {
+        const int padded = ((B + 7) & ~7) * 4;
+        const int grid = padded <= asr_lstm_max_wgs() ? padded : B * 4;
+        hipLaunchKernelGGL(asr::lstm_rec_bwd4_kernel<true>, dim3(grid), dim3(512), 0, s, a);
+        return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
+    }
     int R = asr_lstm_pick_rows(B, 1, H / 32);
     if (H == 512 && R > 2) R = 2;          // (asr_lstm_tm_supported has checked that the batch fits)
     switch (H) {

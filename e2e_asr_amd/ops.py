@@ -816,10 +816,11 @@ def attn_decoder_fwd(wt, dec_inp, seq_len, enc, enc_len, mode=0, coin=None, samp
     return logits, ws
 
 
-def attn_decoder_bwd(wt, gt, ws, enc, enc_len, dlogits, denc, keep_lm=1.0, seed=0):
+def attn_decoder_bwd(wt, gt, ws, enc, enc_len, dlogits, denc, keep_lm=1.0, seed=0, defer_lm=False):
     """Backward of attn_decoder_fwd.  wt/gt: weight and gradient tensors by struct field (gradients
     are accumulated into gt, which are views of the flat gradient buffer); denc [B,Te,D] is
-    accumulated into."""
+    accumulated into.  defer_lm: leave the LM cell chain's backward (its persistent BPTT, the embedding / LM-cell gradients)
+    to a later attn_decoder_bwd_lm(returned dict) -- only honoured on the persistent LM-chain path."""
     B, Te, D, A, H, lmH, E, V, T = ws["_dims"]
     dev = enc.device
     f = lambda *s: torch.empty(s, device=dev, dtype=torch.float32)
@@ -839,13 +840,30 @@ def attn_decoder_bwd(wt, gt, ws, enc, enc_len, dlogits, denc, keep_lm=1.0, seed=
     cd = _lib.DecDims(B, Te, D, A, H, lmH, E, V, T)
     cws = _dec_struct(_lib.DecWs, {k: v for k, v in ws.items() if k != "_dims"})
     cbw = _dec_struct(_lib.DecBwdWs, bw)
+    deferred = bool(defer_lm) and ws.get("lm_act") is not None and bw.get("lm_hx") is not None
+    cbw.lm_deferred = int(deferred)
     with _decoder_precision():
         rc = _lib.lib().asr_attn_decoder_bwd(_stream(), C.byref(cw), C.byref(cg), C.byref(cd), C.byref(cws),
                                              C.byref(cbw), _p(enc), _p(enc_len), _p(_f32(dlogits, "dlogits")),
                                              _p(_f32(denc, "denc")), float(keep_lm), int(seed) & 0xFFFFFFFF)
     _check(rc, "asr_attn_decoder_bwd")
     keep_until_join(bw, ws, wt, gt, enc, enc_len, dlogits)
+    if deferred:
+        bw["_lm_tail"] = (cw, cg, cd, cws, cbw, float(keep_lm), int(seed) & 0xFFFFFFFF)
     return bw
+
+
+def attn_decoder_bwd_lm(bw):
+    """The deferred LM-chain part of attn_decoder_bwd(defer_lm=True), on the current stream (asr_attn_decoder_bwd_lm): call it
+    behind the encoder's backward pass and before side_join().  No-op when nothing was deferred."""
+    t = bw.pop("_lm_tail", None)
+    if t is None:
+        return
+    cw, cg, cd, cws, cbw, keep_lm, seed = t
+    with _decoder_precision():
+        rc = _lib.lib().asr_attn_decoder_bwd_lm(_stream(), C.byref(cw), C.byref(cg), C.byref(cd), C.byref(cws), C.byref(cbw),
+                                                keep_lm, seed)
+    _check(rc, "asr_attn_decoder_bwd_lm")
 
 
 def pyramid_reduce(x, seq_len=None, skip=2):

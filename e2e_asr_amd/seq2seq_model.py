@@ -7,6 +7,8 @@ decoder -> loss on the HIP kernels and fills the same attributes (`outputs`, `lo
 one sess.run of `updates`: forward, backward, [data-parallel all-reduce], global-norm clip,
 Adam, global_step += 1.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -189,6 +191,11 @@ class Seq2SeqModel(BaseParams):
             self._gscale = torch.full((1,), 1.0 / len(params.tasks) if params.avg else 1.0, device=self.device)
         gscale = self._gscale
         d_states = {}
+        # The decoders' LM cell chains (a persistent BPTT each, 4 B workgroups) are independent of the encoder: run behind the
+        # encoder's last BPTT they share the chip with the side stream's weight-gradient backlog instead of making the
+        # encoder's first BPTT wait for them (round 5; ASR_LM_DEFER=0: right behind the decoder chain as before).  Not in the
+        # data-parallel overlap mode, whose buckets assume the decoder's gradients are complete when the encoder's begin.
+        defer_lm = os.environ.get("ASR_LM_DEFER", "1") != "0" and not (self.dist is not None and getattr(self.dist, "overlap", False))
         for task in params.tasks:
             lw = self._loss_ws[task]
             dlogits = lw.pop("dlogits", None)
@@ -197,11 +204,13 @@ class Seq2SeqModel(BaseParams):
             d = params.num_layers[task]
             if d not in d_states:
                 d_states[d] = torch.zeros_like(self.decoder[task].saved["enc"])
-            self.decoder[task].backward(dlogits, d_states[d])
+            self.decoder[task].backward(dlogits, d_states[d], defer_lm=defer_lm)
         # the decoders' LM-chain gradients are still in flight on the library's side stream and overlap the encoder BPTT;
         # data-parallel overlap mode all-reduces the finished buckets in the tail after the last BPTT (parallel.py)
         self.encoder.backward(d_states, on_layer_done=(
             (lambda depth: self.dist.grad_ready(depth, v.grad)) if self.dist is not None else None))
+        for task in params.tasks:
+            self.decoder[task].backward_lm_tail()
         ops.side_join()
         if self.dist is not None:
             self.dist.grad_ready(0, v.grad)

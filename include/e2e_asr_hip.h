@@ -302,6 +302,7 @@ typedef struct {              /* backward scratch (device), sized by the caller 
     void*  chain_ws;          /* asr_decoder_chain_bwd_ws_bytes() bytes, or NULL: per-step launches */
     float* wc;                /* [D,4H] W_inp[P:] . K_x (persistent chain only, else NULL) */
     void*  lm_hx;             /* asr_lstm_bwd_ws_bytes(B, lmH, 1) bytes (persistent LM chain only, else NULL) */
+    int    lm_deferred;       /* 1: asr_attn_decoder_bwd leaves the LM cell chain's backward to a later asr_attn_decoder_bwd_lm */
 } asr_dec_bwd_ws;
 
 /* Backward of asr_attn_decoder_fwd.  Weight gradients are ACCUMULATED into `g` (same field
@@ -311,6 +312,12 @@ int asr_attn_decoder_bwd(void* stream, const asr_dec_weights* w, const asr_dec_w
                          const asr_dec_dims* d, const asr_dec_ws* ws, const asr_dec_bwd_ws* bw,
                          const float* enc, const int* enc_len, const float* dlogits,
                          float* denc, float keep_lm, unsigned seed);
+/* The LM cell chain's part of asr_attn_decoder_bwd (BPTT over all steps, embedding / LM kernel / LM bias gradients) when that
+ * call was made with bw->lm_deferred = 1: everything on `stream`.  To be enqueued behind the encoder's backward pass on the same
+ * stream -- its persistent BPTT (4 B workgroups) then runs beside the side stream's weight-gradient GEMMs instead of holding
+ * up the encoder's BPTT (round 5) -- and before asr_side_join / the optimizer.  New: no counterpart in the reference. */
+int asr_attn_decoder_bwd_lm(void* stream, const asr_dec_weights* w, const asr_dec_weights* g, const asr_dec_dims* d,
+                            const asr_dec_ws* ws, const asr_dec_bwd_ws* bw, float keep_lm, unsigned seed);
 int asr_scatter_add_rows_ld(void* stream, float* table_grad, const int* idx, const float* g, int rows, int width, int ldg);
 
 /* Step-level backward kernels of the launch-based decoder path, for callers that compose their own decoder loop on the host
