@@ -39,7 +39,7 @@ class DecWs(C.Structure):
 
 class DecBwdWs(C.Structure):
     _fields_ = [(n, vp) for n in ("dP", "dQC", "dY", "dXH", "dLC", "dlm", "dEH", "dc_dec", "dc_lm", "dhf",
-                                  "dv_part", "dctx", "emb_all", "chain_ws", "wc", "lm_hx")] + [("lm_deferred", C.c_int)]
+                                  "dv_part", "dctx", "emb_all", "chain_ws", "wc", "lm_hx")] + [("lm_deferred", C.c_int), ("side_busy", C.c_int)]
 
 
 class LmWeights(C.Structure):

@@ -111,10 +111,11 @@ class AttnDecoder(Decoder):
             out[field] = v.grad_of(name) if name in v else None
         return out
 
-    def backward(self, dlogits, denc, defer_lm=False):
+    def backward(self, dlogits, denc, defer_lm=False, side_busy=False):
         """Gradient of __call__: accumulates weight gradients into the flat buffer and the
         encoder-state gradient into denc [B,Te,D].  defer_lm: the LM cell chain's backward is left to backward_lm_tail(),
-        which the caller runs behind the encoder's backward pass (Seq2SeqModel.backward)."""
+        which the caller runs behind the encoder's backward pass (Seq2SeqModel.backward).  side_busy: not the first decoder of
+        this step (ops.attn_decoder_bwd)."""
         sv = self.saved
         self._lm_tail = None
         if self.multi is not None:
@@ -123,7 +124,8 @@ class AttnDecoder(Decoder):
             self.saved = None
             return
         bw = ops.attn_decoder_bwd(self.weight_tensors(), self.grad_tensors(), sv["ws"], sv["enc"], sv["enc_len_dev"],
-                                  dlogits, denc, keep_lm=sv["keep_lm"], seed=sv["seed"], defer_lm=defer_lm)
+                                  dlogits, denc, keep_lm=sv["keep_lm"], seed=sv["seed"], defer_lm=defer_lm,
+                                  side_busy=side_busy)
         if "_lm_tail" in bw:
             self._lm_tail = bw
         self.saved = None

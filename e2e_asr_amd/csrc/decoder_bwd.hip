@@ -444,7 +444,10 @@ extern "C" int asr_attn_decoder_bwd(void* stream, const asr_dec_weights* w, cons
     // ---- what the chain needs besides dQC -- the composed context weight wc = W_inp[P:] . K_x (weights only) and three zeroed
     // accumulators -- goes to the side stream, next to the two data-gradient products below instead of in a row behind them
     // (ASR_DEC_SIDE_SMALL=0: on the caller's stream)
-    static const bool side_small = [] { const char* e = getenv("ASR_DEC_SIDE_SMALL"); return !(e && e[0] == '0'); }();
+    // bw->side_busy: the side stream still holds the previous decoder's weight gradients (config 4: the phone chain waited
+    // 150 us for these 30 us of work) -- then on the caller's stream too
+    static const bool side_small_env = [] { const char* e = getenv("ASR_DEC_SIDE_SMALL"); return !(e && e[0] == '0'); }();
+    const bool side_small = side_small_env && !bw->side_busy;
     const bool chain_ok = bw->chain_ws && bw->wc && ws->y && ws->err &&
                           asr_decoder_chain_supported(B, Te, D, A, H) && asr_decoder_chain_bwd_fits(Te, D, A, H);
     hipEvent_t e_small = nullptr;

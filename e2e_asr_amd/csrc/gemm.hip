@@ -969,7 +969,7 @@ extern "C" int asr_gemm_f32_batched(void* stream, int transA, int transB, int M,
         // split3 on 64x64 tiles (fp32-accurate, bf16 pipe): few 128x128 tiles, or edges the 128x128 kernel does not take
         // (V = 1000 logit columns, (T-1)*B rows)
         const int nwg64 = ((M + 63) / 64) * ((N + 63) / 64);
-        if (np == 3 && s3s && splits == 1 && ((long long)nwg * batch < small_thr || M % 128 || N % 128) && K % 4 == 0 && K >= 16 &&
+        if (np == 3 && s3s && splits == 1 && ((long long)nwg * batch < small_thr || M % 128 || N % 128 || K % BK) && (K % 4 == 0 || (transA && !transB)) && K >= 16 &&
             g.vecA && g.vecB && !(transA && transB) && nwg64 >= 8) {
             if (transA)       hipLaunchKernelGGL((gemm_split3s_kernel<true, false>), dim3(nwg64, 1, batch), dim3(256), 0, s, g);
             else if (transB)  hipLaunchKernelGGL((gemm_split3s_kernel<false, true>), dim3(nwg64, 1, batch), dim3(256), 0, s, g);

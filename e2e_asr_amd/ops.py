@@ -816,11 +816,12 @@ def attn_decoder_fwd(wt, dec_inp, seq_len, enc, enc_len, mode=0, coin=None, samp
     return logits, ws
 
 
-def attn_decoder_bwd(wt, gt, ws, enc, enc_len, dlogits, denc, keep_lm=1.0, seed=0, defer_lm=False):
+def attn_decoder_bwd(wt, gt, ws, enc, enc_len, dlogits, denc, keep_lm=1.0, seed=0, defer_lm=False, side_busy=False):
     """Backward of attn_decoder_fwd.  wt/gt: weight and gradient tensors by struct field (gradients
     are accumulated into gt, which are views of the flat gradient buffer); denc [B,Te,D] is
     accumulated into.  defer_lm: leave the LM cell chain's backward (its persistent BPTT, the embedding / LM-cell gradients)
-    to a later attn_decoder_bwd_lm(returned dict) -- only honoured on the persistent LM-chain path."""
+    to a later attn_decoder_bwd_lm(returned dict) -- only honoured on the persistent LM-chain path.  side_busy: an earlier
+    decoder's weight gradients are still queued on the side stream (second task of a multitask step)."""
     B, Te, D, A, H, lmH, E, V, T = ws["_dims"]
     dev = enc.device
     f = lambda *s: torch.empty(s, device=dev, dtype=torch.float32)
@@ -842,6 +843,7 @@ def attn_decoder_bwd(wt, gt, ws, enc, enc_len, dlogits, denc, keep_lm=1.0, seed=
     cbw = _dec_struct(_lib.DecBwdWs, bw)
     deferred = bool(defer_lm) and ws.get("lm_act") is not None and bw.get("lm_hx") is not None
     cbw.lm_deferred = int(deferred)
+    cbw.side_busy = int(bool(side_busy))
     with _decoder_precision():
         rc = _lib.lib().asr_attn_decoder_bwd(_stream(), C.byref(cw), C.byref(cg), C.byref(cd), C.byref(cws),
                                              C.byref(cbw), _p(enc), _p(enc_len), _p(_f32(dlogits, "dlogits")),

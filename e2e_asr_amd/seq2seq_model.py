@@ -196,7 +196,7 @@ class Seq2SeqModel(BaseParams):
         # encoder's first BPTT wait for them (round 5; ASR_LM_DEFER=0: right behind the decoder chain as before).  Not in the
         # data-parallel overlap mode, whose buckets assume the decoder's gradients are complete when the encoder's begin.
         defer_lm = os.environ.get("ASR_LM_DEFER", "1") != "0" and not (self.dist is not None and getattr(self.dist, "overlap", False))
-        for task in params.tasks:
+        for k, task in enumerate(params.tasks):
             lw = self._loss_ws[task]
             dlogits = lw.pop("dlogits", None)
             if dlogits is None:
@@ -204,7 +204,7 @@ class Seq2SeqModel(BaseParams):
             d = params.num_layers[task]
             if d not in d_states:
                 d_states[d] = torch.zeros_like(self.decoder[task].saved["enc"])
-            self.decoder[task].backward(dlogits, d_states[d], defer_lm=defer_lm)
+            self.decoder[task].backward(dlogits, d_states[d], defer_lm=defer_lm, side_busy=k > 0)
         # the decoders' LM-chain gradients are still in flight on the library's side stream and overlap the encoder BPTT;
         # data-parallel overlap mode all-reduces the finished buckets in the tail after the last BPTT (parallel.py)
         self.encoder.backward(d_states, on_layer_done=(

@@ -303,6 +303,9 @@ typedef struct {              /* backward scratch (device), sized by the caller 
     float* wc;                /* [D,4H] W_inp[P:] . K_x (persistent chain only, else NULL) */
     void*  lm_hx;             /* asr_lstm_bwd_ws_bytes(B, lmH, 1) bytes (persistent LM chain only, else NULL) */
     int    lm_deferred;       /* 1: asr_attn_decoder_bwd leaves the LM cell chain's backward to a later asr_attn_decoder_bwd_lm */
+    int    side_busy;         /* 1: the library's side stream still holds an earlier decoder's weight gradients (second task of a
+                               * multitask step): the chain's small preparations stay on the caller's stream instead of queueing
+                               * behind them */
 } asr_dec_bwd_ws;
 
 /* Backward of asr_attn_decoder_fwd.  Weight gradients are ACCUMULATED into `g` (same field

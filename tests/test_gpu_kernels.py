@@ -70,6 +70,28 @@ def test_gemm_weight_gradient_form_with_ragged_n(dev, M, N, K):
     assert float(big[:, N:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("M,N,K,batch", [(400, 512, 250, 3), (200, 512, 119, 2), (256, 256, 250, 1), (64, 192, 17, 4)])
+def test_gemm_contraction_over_rows_takes_any_k(dev, M, N, K, batch):
+    """alpha^T . dctx per utterance (the attention's encoder-state gradient under tf.gradients, attn_decoder.py:64-66) contracts
+    over the T_out decoder steps: any K, not only multiples of 4 (the phone task's 250 steps fell to the bounds-checked fp32
+    kernel, 123 us per step).  Both operands are stored with the contraction index as the row: the 64x64 split kernel zero-fills
+    the last k-tile value by value.  Held to the float64 product."""
+    from e2e_asr_amd import ops
+    rng = np.random.default_rng(M + N + K + batch)
+    a = rng.standard_normal((batch, K, M)).astype(np.float32)
+    b = rng.standard_normal((batch, K, N)).astype(np.float32)
+    c0 = rng.standard_normal((batch, M, N)).astype(np.float32)
+    ref = np.einsum("bkm,bkn->bmn", a.astype(np.float64), b.astype(np.float64))
+    ta, tb, out = T(a, dev), T(b, dev), T(c0, dev)
+    ops.gemm_batched(ta, tb, out, M, N, K, M, N, N, K * M, K * N, M * N, batch, trans_a=True, accumulate=True)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.cpu().numpy(), ref + c0, rtol=0, atol=2e-5 * np.sqrt(K) + 1e-5)
+    out2 = torch.empty_like(out)
+    ops.gemm_batched(ta, tb, out2, M, N, K, M, N, N, K * M, K * N, M * N, batch, trans_a=True)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out2.cpu().numpy(), ref, rtol=0, atol=2e-5 * np.sqrt(K) + 1e-5)
+
+
 @pytest.mark.parametrize("form", ["planes", "exact", "p3_rr"])
 def test_split_k_through_slabs_is_bit_stable_and_equals_the_atomic_form(dev, form):
     """Weight-gradient products with K split over workgroups (seq2seq_model.py:148): in slab mode (the opt-in deterministic mode) the same
