@@ -130,6 +130,7 @@ SIGNATURES = {
     "asr_get_lstm_mfma": (C.c_int, []),
     "asr_decoder_chain_supported": (C.c_int, [C.c_int] * 5),
     "asr_decoder_chain_rows": (C.c_int, [C.c_int]),
+    "asr_decoder_chain_bwd_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "asr_decoder_greedy_supported": (C.c_int, [C.c_int] * 8),
     "asr_decoder_greedy_ws_bytes": (C.c_size_t, [C.c_int] * 6),
     "asr_decoder_greedy_fwd": (C.c_int, [vp] * 22 + [C.c_int] * 9),

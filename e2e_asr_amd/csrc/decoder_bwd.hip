@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256) void lm_cell_bwd_kernel(LmBwdArgs a) {
 
 extern "C" int asr_colsum_f32(void*, const float*, int, int, int, float*, int);
 extern "C" int asr_decoder_chain_supported(int B, int Te, int D, int A, int H);
-extern "C" int asr_decoder_chain_rows(int Te);
+extern "C" int asr_decoder_chain_bwd_rows(int Te, int D, int A, int H);
 extern "C" int asr_decoder_lm_chain_supported(int B, int lmH);
 int asr_lstm_rec_bwd_tm(hipStream_t s, float* gates, const float* act, const float* dout, int ldo, const float* kh,
                         const int* full_len, void* hx_ws, int* err, int B, int T, int H, float keep, unsigned seed);
@@ -490,7 +490,7 @@ extern "C" int asr_attn_decoder_bwd(void* stream, const asr_dec_weights* w, cons
                                         w->dec_kernel + (size_t)E * 4 * H, bw->wc, w->attn_w, w->attn_v, ws->hf, enc, enc_len,
                                         bw->dY, bw->dctx, bw->dhf, bw->dv_part, bw->chain_ws, ws->err, B, Te, D, A, H, T)))
             return rc;
-        { const int cr = asr_decoder_chain_rows(Te); dv_rows = ((B + cr - 1) / cr) * 16; }      // one partial per workgroup
+        { const int cr = asr_decoder_chain_bwd_rows(Te, D, A, H); dv_rows = ((B + cr - 1) / cr) * 16; }      // one partial per workgroup
         // dx = dG . K_x^T for all steps, then dlm_out = dx . W_inp[:P]^T (the dh / dctx carries stayed on chip)
         if ((rc = asr_gemm_f32(stream, 0, 1, TB, E, 4 * H, ws->dec_gates, 4 * H, w->dec_kernel, 4 * H, bw->dXH, ldXH, nullptr, 0)))
             return rc;

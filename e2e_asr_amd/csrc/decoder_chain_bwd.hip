@@ -94,9 +94,13 @@ __device__ __forceinline__ void pubg(u64* dst, uint32_t epoch, float v, bool fas
 
 // STAMP: diagnostic instantiation (ASR_CHAIN_STAMP=1 + asr_debug_set_buffer): per-phase s_memtime totals of wave 0 of
 // workgroup 0 (phase = code between two consecutive barriers of a step); never used for timing claims.
-// R: utterances per group (2: up to 16 encoder positions per workgroup, Te <= 256; 1: 32 positions, Te <= 512) -- the same
-// decomposition the forward chain used for this Te (asr_decoder_chain_rows).
-template <int H, int D, int A, int R = 2, bool STAMP = false>
+// R: utterances per group (2: up to 16 encoder positions per workgroup, Te <= 256; 1: 32 positions, Te <= 512).
+// PASSES = 2 (round 5, R = 2 only): two utterances per group with up to 32 positions each -- the 64 (utterance, position) slots
+// of a workgroup take the 32 DPP rows of the position phases in two passes (pass p = utterance p); the hf slice and the dhf
+// accumulator of a slot live in the REGISTERS of the 16 lanes that own it in both phases (8 + 8 values per pass) instead of
+// 2 x 32 KB of LDS, which leaves room for both utterances' enc rows up to 400 positions (config 4's phone task: one launch of
+// 16 groups instead of two launches of one utterance per group).
+template <int H, int D, int A, int R = 2, bool STAMP = false, int PASSES = 1>
 __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) {
     unsigned int stamp[16] = {0};
     unsigned long long tlast = 0;
@@ -104,6 +108,8 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
 #define CHAIN_STAMP() if (STAMP) { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); stamp[sph & 15] += (unsigned int)(t__ - tlast); tlast = t__; ++sph; }
     constexpr int G = 16, NT = 512;
     static_assert(R == 1 || R == 2, "rows per group");
+    static_assert(PASSES == 1 || (PASSES == 2 && R == 2), "two passes: two utterances of up to 32 positions");
+    constexpr bool WIDE = PASSES == 2;
     constexpr int HS = H / G, AS = A / G, DS = D / G;
     constexpr int NGT = 192;                          // gathering threads of the all-gathers: waves 1-3
     constexpr int N4 = 4 * H;                         // dG positions per row: p = 4*unit + gate
@@ -116,7 +122,8 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
     constexpr int NQUAD4 = R * N4 / 4;                // quads gathered per step
     constexpr int NPP4 = (NQUAD4 + NGT - 1) / NGT;    // ... per gathering thread
     static_assert(NPP4 >= 1 && NPP4 <= 3, "quads per gathering thread");
-    constexpr int MAXTS = 32 / R;
+    constexpr int MAXTS = 32 * PASSES / R;            // position slots per utterance and workgroup
+    constexpr int DYR = WIDE ? 8 : MAXTS;             // partial-dy rows per utterance in dyrow (WIDE: one per wave)
     constexpr int AL = A / 16;                        // a values per lane in the tanh phase
     constexpr int H4 = 4 * H;
     // slots per (dst, src): even counts so that pairs never straddle
@@ -148,11 +155,11 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
     float* dys = dyp + R * A;                         // dy for my a-slice [R][AS2]
     float* dyall = dys + R * AS2;                     // dy of both rows over ALL attention columns [R][A] (all-gather)
     float* dql = dyall + R * A;                       // dq_att for my units [R][HS2]
-    float* hfl = dql + R * HS2;                       // hf slice [R][MAXTS][A]
-    float* dhfl = hfl + R * MAXTS * A;                // dhf accumulator [R][MAXTS][A]
+    float* hfl = dql + R * HS2;                       // hf slice [R][MAXTS][A]          (registers when WIDE)
+    float* dhfl = hfl + (WIDE ? 0 : R * MAXTS * A);   // dhf accumulator [R][MAXTS][A]   (registers when WIDE)
     const int Te = a.Te;
     const int TS = (Te + G - 1) / G;
-    float* wal = dhfl + R * MAXTS * A;                // W_att rows of my units [HS][A]
+    float* wal = dhfl + (WIDE ? 0 : R * MAXTS * A);   // W_att rows of my units [HS][A]
     float* vl = wal + H * AS;                         // v [A]
     float* encl = vl + A;                             // enc rows of my positions, all context columns [R][TS][D]
     // operands of the CURRENT step that depend on no exchange: fetched one step ahead by the prefetch waves
@@ -205,18 +212,36 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
     for (int idx = tid; idx < A; idx += NT) vl[idx] = a.v[idx];
     // hf / enc slices -> LDS, dhf accumulator = 0
     const int tau0 = mem * TS;
-    for (int idx = tid; idx < R * MAXTS * A; idx += NT) {
-        const int r = idx / (MAXTS * A), rem = idx % (MAXTS * A), tl = rem / A, aa = rem % A;
-        const int tau = tau0 + tl;
-        hfl[idx] = (tl < TS && tau < Te) ? a.hf[((size_t)browf(r) * Te + tau) * A + aa] : 0.f;
-        dhfl[idx] = 0.f;
+    if constexpr (!WIDE) {
+        for (int idx = tid; idx < R * MAXTS * A; idx += NT) {
+            const int r = idx / (MAXTS * A), rem = idx % (MAXTS * A), tl = rem / A, aa = rem % A;
+            const int tau = tau0 + tl;
+            hfl[idx] = (tl < TS && tau < Te) ? a.hf[((size_t)browf(r) * Te + tau) * A + aa] : 0.f;
+            dhfl[idx] = 0.f;
+        }
     }
     for (int idx = tid; idx < R * TS * D; idx += NT) {
         const int r = idx / (TS * D), tl = (idx / D) % TS, dcol = idx % D, tau = mem * TS + tl;
         encl[idx] = tau < Te ? a.enc[((size_t)browf(r) * Te + tau) * D + dcol] : 0.f;
     }
-    // tanh-phase mapping: DPP row -> (tl = row % MAXTS, r = row / MAXTS), lane kq -> AL consecutive a
-    const int trow_tl = row % MAXTS, trow_r = row / MAXTS;
+    // position-phase mapping: slot = pass * 32 + DPP row -> (tl = slot % MAXTS, r = slot / MAXTS), lane kq -> AL columns a
+    // WIDE: hf / dhf of my slots in registers (element q of lane kq = column (q / 4) * 64 + kq * 4 + (q & 3), as the LDS form)
+    static_assert(!WIDE || AL % 4 == 0, "register-resident hf: float4 chunks");
+    float hreg[WIDE ? PASSES : 1][AL], greg[WIDE ? PASSES : 1][AL];
+    if constexpr (WIDE) {
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+            const int slot = p * 32 + row, r = slot / MAXTS, tl = slot % MAXTS, tau = tau0 + tl;
+            const bool ok = tl < TS && tau < Te;
+#pragma unroll
+            for (int c = 0; c < AL / 4; ++c) {
+                float4 h4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ok) h4 = *reinterpret_cast<const float4*>(a.hf + ((size_t)browf(r) * Te + tau) * A + c * 64 + kq * 4);
+                hreg[p][4 * c] = h4.x; hreg[p][4 * c + 1] = h4.y; hreg[p][4 * c + 2] = h4.z; hreg[p][4 * c + 3] = h4.w;
+                greg[p][4 * c] = 0.f; greg[p][4 * c + 1] = 0.f; greg[p][4 * c + 2] = 0.f; greg[p][4 * c + 3] = 0.f;
+            }
+        }
+    }
     float dvacc[AL];
 #pragma unroll
     for (int q = 0; q < AL; ++q) dvacc[q] = 0.f;
@@ -227,7 +252,7 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
     const int cb = r0 + cr;
     const bool cb_ok = cell && cb < a.B;
     float dc = 0.f;
-    constexpr int NPF = 5, PF0 = 256, PFN = NT - PF0;      // waves 4-7 prefetch
+    constexpr int NPF = WIDE ? 6 : 5, PF0 = 256, PFN = NT - PF0;      // waves 4-7 prefetch (the host checks nitems <= NPF * PFN)
     const bool pfw = __builtin_amdgcn_readfirstlane(tid) >= PF0;
     // Per (thread, slot) descriptors of the prefetched items, built once: address of the item at time index 0 and its
     // stride per time step (low bit: "the item of step t lives at t-1 and is zero at t = 0", the c_{t-1} rows).  The
@@ -475,8 +500,9 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
         CHAIN_STAMP()
         // ---- dalpha for my positions over ALL context columns (DPP row = one (row r, position tl), 16 lanes over D) and the
         // softmax scalar S = sum of the G partials (fixed order): del = dalpha, sp[2 + r] = S
-        {
-            const int r = trow_r, tl = trow_tl, tau = tau0 + tl;
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+            const int slot = p * 32 + row, r = slot / MAXTS, tl = slot % MAXTS, tau = tau0 + tl;
             float x = 0.f;
             if (tl < TS && tau < blenf(r)) {
                 const float* dr = dctall + r * D1;
@@ -508,8 +534,9 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
         __syncthreads();
         CHAIN_STAMP()
         // ---- (d) tanh backward on my positions
-        {
-            const int r = trow_r, tl = trow_tl, tau = tau0 + tl;
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+            const int slot = p * 32 + row, r = slot / MAXTS, tl = slot % MAXTS, tau = tau0 + tl;
             float de = 0.f;
             if (tl < TS && tau < blenf(r)) de = alf[r * TeP + tau] * (del[r * MAXTS + tl] - sp[2 + r]);
             // element q of lane kq is column acol(q): float4 chunks 64 columns apart, so that the 16 lanes of a DPP row
@@ -521,17 +548,32 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
 #pragma unroll
                 for (int c = 0; c < AL / 4; ++c) {
                     const int a0 = c * 64 + kq * 4;
-                    const float4 h4 = *reinterpret_cast<const float4*>(hrow + a0);
+                    float4 h4, g4;
+                    if constexpr (WIDE) {
+                        h4 = make_float4(hreg[p][4 * c], hreg[p][4 * c + 1], hreg[p][4 * c + 2], hreg[p][4 * c + 3]);
+                        g4 = make_float4(greg[p][4 * c], greg[p][4 * c + 1], greg[p][4 * c + 2], greg[p][4 * c + 3]);
+                    } else {
+                        h4 = *reinterpret_cast<const float4*>(hrow + a0);
+                        g4 = *reinterpret_cast<float4*>(grow + a0);
+                    }
                     const float4 y4 = *reinterpret_cast<const float4*>(yrow + a0);
                     const float4 v4 = *reinterpret_cast<const float4*>(vl + a0);
-                    float4 g4 = *reinterpret_cast<float4*>(grow + a0);
                     float4 d4;
                     float th;
 #define ASR_TBW(f, j) th = fast_tanh(h4.f + y4.f); d4.f = de * v4.f * (1.f - th * th); g4.f += d4.f; dvacc[4 * c + j] = fmaf(de, th, dvacc[4 * c + j]);
                     ASR_TBW(x, 0) ASR_TBW(y, 1) ASR_TBW(z, 2) ASR_TBW(w, 3)
 #undef ASR_TBW
-                    *reinterpret_cast<float4*>(grow + a0) = g4;
-                    *reinterpret_cast<float4*>(dyrow + row * A + a0) = d4;
+                    if constexpr (WIDE) {
+                        greg[p][4 * c] = g4.x; greg[p][4 * c + 1] = g4.y; greg[p][4 * c + 2] = g4.z; greg[p][4 * c + 3] = g4.w;
+                        // the four DPP rows of a wave hold four positions of the SAME utterance (r = p): summed here in a
+                        // fixed order, one partial-dy row per wave
+                        d4.x += lane_xor16(d4.x); d4.y += lane_xor16(d4.y); d4.z += lane_xor16(d4.z); d4.w += lane_xor16(d4.w);
+                        d4.x += lane_xor32(d4.x); d4.y += lane_xor32(d4.y); d4.z += lane_xor32(d4.z); d4.w += lane_xor32(d4.w);
+                        if (lane < 16) *reinterpret_cast<float4*>(dyrow + (p * DYR + wave) * A + a0) = d4;
+                    } else {
+                        *reinterpret_cast<float4*>(grow + a0) = g4;
+                        *reinterpret_cast<float4*>(dyrow + row * A + a0) = d4;
+                    }
                 }
             } else {
 #pragma unroll
@@ -547,11 +589,11 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
         }
         __syncthreads();
         CHAIN_STAMP()
-        for (int idx = tid; idx < R * A; idx += NT) {        // partial dy[r][a] = sum over my positions (MAXTS DPP rows)
+        for (int idx = tid; idx < R * A; idx += NT) {        // partial dy[r][a] = sum over my positions (MAXTS DPP rows; WIDE: 8 waves)
             const int r = idx / A, aa = idx % A;
             float x = 0.f;
 #pragma unroll
-            for (int t = 0; t < MAXTS; ++t) x += dyrow[(r * MAXTS + t) * A + aa];
+            for (int t = 0; t < DYR; ++t) x += dyrow[(r * DYR + t) * A + aa];
             dyp[idx] = x;
         }
         __syncthreads();
@@ -682,10 +724,23 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
 #undef CHAIN_STAMP
     // ---- epilogue: dhf slice and dv partial
     __syncthreads();
-    for (int idx = tid; idx < R * MAXTS * A; idx += NT) {
-        const int r = idx / (MAXTS * A), rem = idx % (MAXTS * A), tl = rem / A, aa = rem % A;
-        const int tau = tau0 + tl;
-        if (rok(r) && tl < TS && tau < Te) a.dhf[((size_t)(r0 + r) * Te + tau) * A + aa] = dhfl[idx];
+    if constexpr (WIDE) {
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+            const int slot = p * 32 + row, r = slot / MAXTS, tl = slot % MAXTS, tau = tau0 + tl;
+            if (rok(r) && tl < TS && tau < Te) {
+#pragma unroll
+                for (int c = 0; c < AL / 4; ++c)
+                    *reinterpret_cast<float4*>(a.dhf + ((size_t)(r0 + r) * Te + tau) * A + c * 64 + kq * 4) =
+                        make_float4(greg[p][4 * c], greg[p][4 * c + 1], greg[p][4 * c + 2], greg[p][4 * c + 3]);
+            }
+        }
+    } else {
+        for (int idx = tid; idx < R * MAXTS * A; idx += NT) {
+            const int r = idx / (MAXTS * A), rem = idx % (MAXTS * A), tl = rem / A, aa = rem % A;
+            const int tau = tau0 + tl;
+            if (rok(r) && tl < TS && tau < Te) a.dhf[((size_t)(r0 + r) * Te + tau) * A + aa] = dhfl[idx];
+        }
     }
 #pragma unroll
     for (int q = 0; q < AL; ++q) dyrow[row * A + (AL % 4 == 0 ? (q / 4) * 64 + kq * 4 + (q & 3) : kq * AL + q)] = dvacc[q];
@@ -710,38 +765,69 @@ extern "C" size_t asr_decoder_chain_bwd_ws_bytes(int B, int D, int A, int H) {  
     return std::max(chain_bwd_ws_bytes_r(B, D, A, H, 1), chain_bwd_ws_bytes_r(B, D, A, H, 2));
 }
 
-// Dynamic LDS of the backward chain kernel (floats, in carve order); the hardware limit is 160 KB per workgroup.
-size_t asr_decoder_chain_bwd_lds_bytes(int Te, int D, int A, int H) {
-    const size_t R = asr_decoder_chain_rows(Te);
+// Dynamic LDS of the backward chain kernel (floats, in carve order) for R utterances per group in `passes` passes over the
+// position slots; the hardware limit is 160 KB per workgroup.  *npf_ok: the prefetched items fit the kernel's descriptor slots.
+static size_t chain_bwd_lds_bytes_r(int Te, int D, int A, int H, int Rr, int passes, bool* npf_ok) {
+    const size_t R = Rr;
+    const bool wide = passes == 2;
     const size_t G = 16, HS = H / G, AS = A / G, DS = D / G, HS2 = (HS + 1) & ~(size_t)1, AS2 = (AS + 1) & ~(size_t)1;
     const size_t D1 = D + G, CSB = (size_t)4 * H / 64 + 4, NOUT = HS + DS, TS = ((size_t)Te + G - 1) / G, TeP = ((size_t)Te + 1) & ~(size_t)1;
+    const size_t MAXTS = 32 * (size_t)passes / R, NPF = wide ? 6 : 5;
     const size_t uni_a = ((R * D1 + 3) & ~(size_t)3) + R * 64 * CSB + ((NOUT * R * 4 + 3) & ~(size_t)3);
     const size_t uni = uni_a > 32 * (size_t)A ? uni_a : 32 * (size_t)A;
     const size_t nitems = R * A + R * TeP + 2 * R * DS + R * HS * 4 + 3 * R * HS, nitemsP = (nitems + 3) & ~(size_t)3;
-    const size_t floats = 4 + R * HS2 + 4 + 32 + uni + R * A + R * AS2 + R * A + R * HS2 + 2 * 32 * A + HS * A + A +
-                          R * TS * D + 2 * nitemsP + 3 * 5 * 256;
+    if (npf_ok) *npf_ok = nitems <= NPF * 256 && TS <= MAXTS;
+    const size_t floats = 4 + R * HS2 + 4 + R * MAXTS + uni + R * A + R * AS2 + R * A + R * HS2 + (wide ? 0 : 2 * R * MAXTS * A) + HS * A + A +
+                          R * TS * D + 2 * nitemsP + 3 * NPF * 256;
     return floats * sizeof(float) + 64;
 }
+static const size_t kChainBwdLdsMax = 160 * 1024 - 64;
+// The backward chain's decomposition for this shape: two utterances per group up to 256 encoder positions (16 per workgroup and
+// utterance); beyond, two utterances in two passes with hf / dhf in registers while both utterances' enc rows fit the LDS
+// (400 positions at config-2 widths; ASR_CHAIN_BWD_WIDE=0: never), else one utterance per group (up to 512).
+static void chain_bwd_mode(int Te, int D, int A, int H, int* R, int* passes) {
+    *passes = 1;
+    if (Te <= 256) { *R = 2; return; }
+    const char* e = getenv("ASR_CHAIN_BWD_WIDE");
+    bool ok = false;
+    if (!(e && e[0] == '0') && (A / 16) % 4 == 0 && chain_bwd_lds_bytes_r(Te, D, A, H, 2, 2, &ok) <= kChainBwdLdsMax && ok) { *R = 2; *passes = 2; return; }
+    *R = 1;
+}
+// utterances per 16-workgroup group of the backward chain (dv_part holds one partial per workgroup: ceil(B / rows) * 16 rows)
+extern "C" int asr_decoder_chain_bwd_rows(int Te, int D, int A, int H) {
+    int R, passes;
+    chain_bwd_mode(Te, D, A, H, &R, &passes);
+    return R;
+}
+size_t asr_decoder_chain_bwd_lds_bytes(int Te, int D, int A, int H) {
+    int R, passes;
+    chain_bwd_mode(Te, D, A, H, &R, &passes);
+    return chain_bwd_lds_bytes_r(Te, D, A, H, R, passes, nullptr);
+}
 bool asr_decoder_chain_bwd_fits(int Te, int D, int A, int H) {
-    return Te <= 512 && asr_decoder_chain_bwd_lds_bytes(Te, D, A, H) <= 160 * 1024 - 64;
+    int R, passes;
+    chain_bwd_mode(Te, D, A, H, &R, &passes);
+    bool ok = false;
+    return Te <= 512 && chain_bwd_lds_bytes_r(Te, D, A, H, R, passes, &ok) <= kChainBwdLdsMax && ok;
 }
 
-template <int H, int D, int A, int R>
+template <int H, int D, int A, int R, int PASSES = 1>
 static int chain_bwd_launch(hipStream_t s, asr::ChainBwdArgs& a) {
     constexpr int G = 16;
     const int groups = a.ng;
     const int grid_groups = (((groups + 7) & ~7) * G <= asr::resident_wg_budget()) ? ((groups + 7) & ~7) : groups;
-    const size_t lds = asr_decoder_chain_bwd_lds_bytes(a.Te, D, A, H);
-    if (lds > 160 * 1024 - 64) return ASR_EUNSUPPORTED;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asr::decoder_chain_bwd_kernel<H, D, A, R>),
+    bool ok = false;
+    const size_t lds = chain_bwd_lds_bytes_r(a.Te, D, A, H, R, PASSES, &ok);
+    if (lds > kChainBwdLdsMax || !ok) return ASR_EUNSUPPORTED;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asr::decoder_chain_bwd_kernel<H, D, A, R, false, PASSES>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (H == 256 && R == 2 && a.dbg) {
+    if (H == 256 && R == 2 && PASSES == 1 && a.dbg) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asr::decoder_chain_bwd_kernel<256, 512, 128, 2, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((asr::decoder_chain_bwd_kernel<256, 512, 128, 2, true>), dim3(grid_groups * G), dim3(512), lds, s, a);
         return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
     }
-    hipLaunchKernelGGL((asr::decoder_chain_bwd_kernel<H, D, A, R>), dim3(grid_groups * G), dim3(512), lds, s, a);
+    hipLaunchKernelGGL((asr::decoder_chain_bwd_kernel<H, D, A, R, false, PASSES>), dim3(grid_groups * G), dim3(512), lds, s, a);
     return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
 }
 
@@ -759,7 +845,8 @@ int asr_decoder_chain_bwd(void* stream, float* gates, const float* dec_c, const 
     a.gates = gates; a.dec_c = dec_c; a.alpha = alpha; a.y = y; a.ctx = ctx; a.dqc = dqc; a.wh = wh; a.wc = wc;
     a.w_att = w_att; a.v = v; a.hf = hf; a.enc = enc; a.enc_len = enc_len; a.dY = dY; a.dctx = dctx; a.dhf = dhf;
     a.dv_part = dv_part; a.gx = static_cast<u64*>(ws);
-    const int R = asr_decoder_chain_rows(Te);
+    int R, passes;
+    chain_bwd_mode(Te, D, A, H, &R, &passes);
     const int groups = (B + R - 1) / R;
     a.xcc_slots = reinterpret_cast<u64*>(static_cast<char*>(ws) + chain_bwd_ws_bytes_r(B, D, A, H, R)) - ((size_t)groups * 16);
     a.err = err; a.B = B; a.Te = Te; a.T = T;
@@ -768,8 +855,10 @@ int asr_decoder_chain_bwd(void* stream, float* gates, const float* dec_c, const 
     for (int g0 = 0; g0 < groups; g0 += gpl) {
         a.g0 = g0; a.ng = groups - g0 < gpl ? groups - g0 : gpl;
         int rc;
-        if (H == 256) rc = R == 2 ? chain_bwd_launch<256, 512, 128, 2>(s, a) : chain_bwd_launch<256, 512, 128, 1>(s, a);
-        else rc = R == 2 ? chain_bwd_launch<64, 128, 16, 2>(s, a) : chain_bwd_launch<64, 128, 16, 1>(s, a);
+        if (H == 256) rc = passes == 2 ? chain_bwd_launch<256, 512, 128, 2, 2>(s, a)
+                              : (R == 2 ? chain_bwd_launch<256, 512, 128, 2>(s, a) : chain_bwd_launch<256, 512, 128, 1>(s, a));
+        else rc = passes == 2 ? ASR_EUNSUPPORTED       // (chain_bwd_mode never picks two passes at these widths: A / 16 = 1 column per lane)
+                              : (R == 2 ? chain_bwd_launch<64, 128, 16, 2>(s, a) : chain_bwd_launch<64, 128, 16, 1>(s, a));
         if (rc) return rc;
     }
     return ASR_OK;

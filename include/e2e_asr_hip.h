@@ -427,10 +427,13 @@ int asr_side_join(void* stream);
  * everything.  New (the reference is single-device): used by e2e_asr_amd/parallel.py's tail overlap. */
 int asr_side_wait(void* stream);
 /* Persistent decoder chain (csrc/decoder_chain.hip): used inside asr_attn_decoder_fwd when supported (Te <= 512).
- * asr_decoder_chain_rows: utterances per 16-workgroup group of the BACKWARD chain for this Te (2 up to 256 encoder positions,
- * else 1; the forward chain keeps 2 wherever both utterances' slices fit the LDS, up to 432 positions at config-2 widths). */
+ * asr_decoder_chain_bwd_rows: utterances per 16-workgroup group of the BACKWARD chain for this shape: 2 up to 256 encoder
+ * positions; beyond, 2 (two passes over the position slots, hf / dhf in registers) while both utterances' enc rows fit the LDS
+ * -- 400 positions at config-2 widths -- else 1 (up to 512).  asr_decoder_chain_rows(Te): the rule of rounds 2-4 (2 up to 256
+ * positions, else 1), kept for callers that size by it.  The forward chain keeps 2 wherever both utterances' slices fit. */
 int asr_decoder_chain_supported(int B, int Te, int D, int A, int H);
 int asr_decoder_chain_rows(int Te);
+int asr_decoder_chain_bwd_rows(int Te, int D, int A, int H);
 /* Inference graph (mode 1) as one persistent launch (csrc/decoder_greedy.hip): argmax feedback, LM cell, attention,
  * projections of all steps on chip.  Used inside asr_attn_decoder_fwd when supported and ws->greedy_ws is set; only the
  * logits and tok are produced (no saved activations).  The same kernel's training instantiation runs the training graph

@@ -81,20 +81,25 @@ def _grad_check(m, b, tol=2e-3, outs=None, **kw):
 
 # ------------------------------------------------------------------ config 4 at its stated shape
 @pytest.mark.parametrize("Te", [260, 400])
-@pytest.mark.parametrize("fwd_path", ["one_launch", "segment_chains"])
-def test_config4_phone_decoder_on_layer2_states_real_widths(monkeypatch, Te, fwd_path):
+@pytest.mark.parametrize("fwd_path,bwd_wide", [("one_launch", "1"), ("segment_chains", "1"), ("one_launch", "0")])
+def test_config4_phone_decoder_on_layer2_states_real_widths(monkeypatch, Te, fwd_path, bwd_wide):
     """BASELINE config 4: char decoder on depth 4 + phone decoder (V=50) on LAYER-2 states, real widths (BiLSTM(256),
     decoder 256, A=128).  Te = T/2 > 256 encoder positions: the phone decoder's forward is the one-launch training kernel
     with 16 positions per workgroup (decoder_greedy_kernel<..., TRAIN, 16>, round 4), or -- ASR_DEC_GREEDY_TEMAX=256, the
     path of rounds 1-3 -- decoder_chain_fwd_kernel<256,512,128,R=1> per scheduled-sampling segment; the backward is
-    decoder_chain_bwd_kernel<256,512,128,R=1> either way.  Te = 400 is the 800-frame batch of the config.  Logits and
+    decoder_chain_bwd_kernel<256,512,128,R=2,PASSES=2> (round 5: two utterances per group, their 2 x 25 positions per
+    workgroup in two passes, hf / dhf in registers) or -- ASR_CHAIN_BWD_WIDE=0, rounds 2-4 -- <R=1>, one utterance per
+    group.  Te = 400 is the 800-frame batch of the config.  Logits and
     losses vs the float64 oracle (seq2seq_model.py:88-144, losses averaged), every gradient vs float64 autograd."""
     from e2e_asr_amd import _lib, ops
     L = _lib.lib()
     T = 2 * Te
     if fwd_path == "segment_chains":
         monkeypatch.setenv("ASR_DEC_GREEDY_TEMAX", "256")
+    monkeypatch.setenv("ASR_CHAIN_BWD_WIDE", bwd_wide)
     assert L.asr_decoder_chain_rows(Te) == 1 and L.asr_decoder_chain_supported(3, Te, 512, 128, 256) == 1
+    assert L.asr_decoder_chain_bwd_rows(Te, 512, 128, 256) == (2 if bwd_wide == "1" else 1)
+    assert L.asr_decoder_chain_bwd_rows(401, 512, 128, 256) == 1 and L.asr_decoder_chain_bwd_rows(256, 512, 128, 256) == 2
     assert L.asr_decoder_greedy_supported(3, Te, 512, 128, 256, 256, 256, 50) == (1 if fwd_path == "one_launch" else 0)
     tasks = ("char", "phone")
     nl = {"char": 4, "phone": 2}

@@ -30,6 +30,7 @@ CASES = {
                                                          "test_decoder_chain_equals_launch_path_under_scheduled_sampling or "
                                                          "test_decoder_chain_long_encoder_one_row_groups or "
                                                          "test_persistent_lm_chain_equals_per_step_lm_cells"),
+    "decoder_chain_bwd_two_passes": ("tests/test_gpu_parity2.py", "test_config4_phone_decoder_on_layer2_states_real_widths"),
     "config2_all_chains": ("tests/test_gpu_model.py", "test_config2_full_batch_persistent_paths_equal_launch_paths"),
 }
 
