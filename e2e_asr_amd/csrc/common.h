@@ -154,6 +154,13 @@ __device__ __forceinline__ void pk_fma_alo(f32x2& acc, f32x2 a, f32x2 b) {
 __device__ __forceinline__ void pk_fma_ahi(f32x2& acc, f32x2 a, f32x2 b) {
     asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(a), "v"(b));
 }
+// the same with `a` a wave-uniform pair in scalar registers (e.g. an input row fetched with s_load)
+__device__ __forceinline__ void pk_fma_alo_s(f32x2& acc, f32x2 a, f32x2 b) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "s"(a), "v"(b));
+}
+__device__ __forceinline__ void pk_fma_ahi_s(f32x2& acc, f32x2 a, f32x2 b) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "s"(a), "v"(b));
+}
 // lanes 32-63 of x <-> lanes 0-31 of y (v_permlane32_swap), then x + y: the lower half-wave ends with x summed over the two
 // halves, the upper half-wave with y summed over the two halves
 __device__ __forceinline__ float swap32_add(float x, float y) {

@@ -623,8 +623,18 @@ static int g_lstm_mfma = -1;
 // for the whole workgroup and is fetched one step ahead with scalar loads.  The product costs a wave 2 * IK packed FMAs in
 // front of its poll, where it would only wait; what it saves is the 25 600 x 2 048 projection GEMM (K = 80: 89 us, bound by
 // writing 210 MB of gates) and the recurrence's own reading them back -- the streaming operand that costs the exchange most.
-template <int IK = 0>
+// XPRE (round 5, with IK > 0; ASR_LSTM_XPRE=0 keeps the kernel of rounds 3-4): (i) the x part of a step's product does not
+// depend on the exchange, so the polling waves form it BEFORE they poll (xpa) and its 20 packed FMAs leave the chain; (ii) the x row
+// is fetched with real scalar loads (constant address space: s_load_dwordx8 + x2) into 10 SGPRs -- the "scalar" loads above were
+// global_load into 10 VGPRs, counted by the vmcnt they shared with the step's record stores; (iii) the loads of the prologue
+// (bias, initial state) are waited for once, in the prologue: left in flight at the loop's entry they made the compiler's merged
+// wait in front of the cell a vmcnt(0) on EVERY step, i.e. a wait for the previous step's stores.  Layer 1 of config 2:
+// 1.10 -> 1.02 us per step (scripts/bench_lstm.py, same box).  The same treatment of the instantiation with gate rows (rows
+// requested two steps ahead in front of the stores, the cell free of vmcnt waits) was measured SLOWER (1.007 -> 1.09 us per step
+// at T = 400) and is not in the code.
+template <int IK = 0, bool XPRE = false>
 __global__ __launch_bounds__(512) void lstm_rec_fwd4_kernel(LstmRecArgs a) {
+    static_assert(!XPRE || IK > 0, "XPRE belongs to the instantiation with the input projection inside");
     constexpr int H = 256, HS = 64, G = 4, NW = 8, NT = 512, H4 = 4 * H;
     constexpr bool XIN = IK > 0;
     __shared__ __attribute__((aligned(16))) float hs[NW][32];
@@ -671,8 +681,15 @@ __global__ __launch_bounds__(512) void lstm_rec_fwd4_kernel(LstmRecArgs a) {
             const int t = dir ? (S - 1 - s) : s;
             const int ts = min(max(t, 0), a.T - 1);
             const float* xp = a.x + ((size_t)cb * a.T + ts) * a.ldx + wave * IK;
+            if constexpr (XPRE) {        // (x is not written during the launch)
+                typedef const float __attribute__((address_space(4))) cfloat;
+                const cfloat* xc = (const cfloat*)xp;
 #pragma unroll
-            for (int k = 0; k < IK; ++k) xb[k] = xp[k];
+                for (int k = 0; k < IK; ++k) xb[k] = xc[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < IK; ++k) xb[k] = xp[k];
+            }
         }
     };
     // x part of a step's pre-activations (two chains per gate pair, as the h part)
@@ -683,8 +700,13 @@ __global__ __launch_bounds__(512) void lstm_rec_fwd4_kernel(LstmRecArgs a) {
                 const f32x2 x2 = f32x2{xb[k], k + 1 < IK ? xb[k + 1] : 0.f};
 #pragma unroll
                 for (int p2 = 0; p2 < 2; ++p2) {
-                    pk_fma_alo(pa[p2][0], x2, wx[k][p2]);
-                    if (k + 1 < IK) pk_fma_ahi(pa[p2][1], x2, wx[k + 1][p2]);
+                    if constexpr (XPRE) {
+                        pk_fma_alo_s(pa[p2][0], x2, wx[k][p2]);
+                        if (k + 1 < IK) pk_fma_ahi_s(pa[p2][1], x2, wx[k + 1][p2]);
+                    } else {
+                        pk_fma_alo(pa[p2][0], x2, wx[k][p2]);
+                        if (k + 1 < IK) pk_fma_ahi(pa[p2][1], x2, wx[k + 1][p2]);
+                    }
                 }
             }
         }
@@ -692,6 +714,7 @@ __global__ __launch_bounds__(512) void lstm_rec_fwd4_kernel(LstmRecArgs a) {
     float c = 0.f, h = 0.f;
     const bool has_init = a.h0 != nullptr;
     if (has_init && cell_wave) { h = a.h0[(size_t)cb * H + cj]; c = a.c0[(size_t)cb * H + cj]; }
+    if constexpr (XPRE) asm volatile("" : "+v"(c), "+v"(h));       // (iii): waited for here, by every wave
     u64* hxg = a.hx + (size_t)grp * 2 * H;             // [2 parities][H] granules
     const bool fast = group_shares_xcd(a.xcc_slots + (size_t)grp * 16, G, mem, tid, a.err, nullptr, (uint32_t)a.ep0, 4);
     float gx0 = 0.f, gx1 = 0.f, gx2 = 0.f, gx3 = 0.f;
@@ -714,17 +737,21 @@ __global__ __launch_bounds__(512) void lstm_rec_fwd4_kernel(LstmRecArgs a) {
         gx0 = gp_[0]; gx1 = gp_[H]; gx2 = gp_[2 * H]; gx3 = gp_[3 * H];
     };
     if (cell_wave) {
-        if constexpr (XIN) { const float* bp = a.bias[dir] + cj; gx0 = bp[0]; gx1 = bp[H]; gx2 = bp[2 * H]; gx3 = bp[3 * H]; }
-        else prefetch(0);
+        if constexpr (XIN) {
+            const float* bp = a.bias[dir] + cj; gx0 = bp[0]; gx1 = bp[H]; gx2 = bp[2 * H]; gx3 = bp[3 * H];
+            if constexpr (XPRE) asm volatile("" : "+v"(gx0), "+v"(gx1), "+v"(gx2), "+v"(gx3));      // (iii)
+        } else prefetch(0);
     }
 
-    auto slice_partial = [&](int par) {
+    f32x2 xpa[2][2] = {{f32x2{0.f, 0.f}, f32x2{0.f, 0.f}}, {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}}};   // XPRE: x part of the NEXT product
+    auto slice_partial = [&](int par, bool xpre = false) {
         const f32x4* hq = reinterpret_cast<const f32x4*>(&hs[wave][0]);
         f32x4 hall[8];
 #pragma unroll
         for (int k4 = 0; k4 < 8; ++k4) hall[k4] = hq[k4];
         f32x2 pa[2][2] = {{f32x2{0.f, 0.f}, f32x2{0.f, 0.f}}, {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}}};   // [gate pair][chain]
-        x_partial(pa);
+        if (xpre) { pa[0][0] = xpa[0][0]; pa[0][1] = xpa[0][1]; pa[1][0] = xpa[1][0]; pa[1][1] = xpa[1][1]; }
+        else x_partial(pa);
 #pragma unroll
         for (int k4 = 0; k4 < 8; ++k4) {
             const f32x4 hv = hall[k4];
@@ -759,14 +786,19 @@ __global__ __launch_bounds__(512) void lstm_rec_fwd4_kernel(LstmRecArgs a) {
         const int par = s & 1;
         if (s > 0 || has_init || XIN) {
             if (!cell_wave && s > 0) {
+                if constexpr (XPRE) {        // (i): x_s . K_x in front of the poll; then the request for the next row
+                    xpa[0][0] = xpa[0][1] = xpa[1][0] = xpa[1][1] = f32x2{0.f, 0.f};
+                    x_partial(xpa);
+                    if (s + 1 < S) load_x(s + 1);
+                }
                 if (lane < 32) {
                     float v = 0.f;
                     poll_granule1(hxg + (size_t)((s - 1) & 1) * H + kbase + lane, (uint32_t)(a.ep0 + s), v, a.err);
                     hs[wave][lane] = v;
                 }
                 __builtin_amdgcn_wave_barrier();
-                slice_partial(par);
-                if (XIN && s + 1 < S) load_x(s + 1);
+                slice_partial(par, XPRE);
+                if (XIN && !XPRE && s + 1 < S) load_x(s + 1);
             }
             __syncthreads();
         }
@@ -794,6 +826,14 @@ __global__ __launch_bounds__(512) void lstm_rec_fwd4_kernel(LstmRecArgs a) {
                 if (fast) asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(dst), "v"(gv) : "memory");
                 else __hip_atomic_store(dst, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+            if constexpr (XPRE) {        // the own slice's product in front of the record stores
+                if (more) {
+                    if (lane < 32) hs[0][lane] = h;
+                    __builtin_amdgcn_wave_barrier();
+                    slice_partial(par ^ 1);
+                    if (s + 2 < S) load_x(s + 2);
+                }
+            }
             {
                 const unsigned roff = (unsigned)t * rstr;
                 float o = h;
@@ -819,7 +859,7 @@ __global__ __launch_bounds__(512) void lstm_rec_fwd4_kernel(LstmRecArgs a) {
                 if (a.out_p3) p3_store1(a.out_p3, p3_elem_off((size_t)cb * a.osb + (size_t)t * a.ost, dir * H + cj, a.ldo >> 3, a.p3_np), o, a.p3_np, false);
                 if (a.hprev_p3) p3_store1(a.hprev_p3, p3_elem_off((size_t)cb * a.sb + (size_t)t * a.st, dir * H + cj, (a.ND * H) >> 3, a.p3_np), h_old, a.p3_np, true);
             }
-            if (more) {
+            if (!XPRE && more) {
                 prefetch(s + 1);
                 if (lane < 32) hs[0][lane] = h;          // the first half of the own slice, for the next step
                 __builtin_amdgcn_wave_barrier();
@@ -1058,7 +1098,9 @@ extern "C" int asr_lstm_layer_fwd_p3(void* stream, const float* x, int B, int T,
             const int padded = ((groups + 7) & ~7) * 4;
             const int grid = padded <= asr_lstm_max_wgs() ? padded : groups * 4;
             prof_begin(ASR_PROF_LSTM_REC_FWD, s);
-            if (xin) hipLaunchKernelGGL(asr::lstm_rec_fwd4_kernel<10>, dim3(grid), dim3(512), 0, s, c);
+            static const bool xpre = [] { const char* e = getenv("ASR_LSTM_XPRE"); return !(e && e[0] == '0'); }();
+            if (xin && xpre) hipLaunchKernelGGL((asr::lstm_rec_fwd4_kernel<10, true>), dim3(grid), dim3(512), 0, s, c);
+            else if (xin) hipLaunchKernelGGL(asr::lstm_rec_fwd4_kernel<10>, dim3(grid), dim3(512), 0, s, c);
             else hipLaunchKernelGGL(asr::lstm_rec_fwd4_kernel<0>, dim3(grid), dim3(512), 0, s, c);
             prof_end(ASR_PROF_LSTM_REC_FWD, s);
             ASR_CHECK_LAUNCH();

@@ -859,11 +859,20 @@ __global__ __launch_bounds__(2 * H + 64) void lstm_rec_bwd2_kernel(LstmBwdArgs a
 // REC32: the saved activations are the 32-byte records {i,j,f,o | c, c_prev, -, -} of the decoder's LM cell chain (written by the
 // one-launch training decoder, csrc/decoder_greedy.hip) instead of the encoder's 20-byte split records: the time-major LM-chain
 // BPTT (asr_lstm_rec_bwd_tm) then runs on this kernel too -- 32 groups x 4 = 128 workgroups, half the chip.
-template <bool REC32 = false>
+// QUAD (round 5; ASR_BPTT_QUAD=0 keeps the mapping of rounds 3-4): the broadcast of the dG slice through LDS was ON the chain.
+// With lane = own unit every lane of a wave needs all 128 values of the wave's half slice: 32 ds_read_b128 per lane, 1 KB of
+// return data each, 7 polling waves at once -- ~900 cycles of the LDS return path per step (a timing-only build that read 8 of
+// the 32 quads ran 1.02 instead of 1.17 us per step; the forward, whose lanes need 32 values, is at 1.0).  QUAD: the four lanes
+// of a quad share four own units and split the 128 values: lane (u4, r) contracts the 32 values of source units 8r .. 8r+7 with
+// the rows of own units 4 u4 .. 4 u4 + 3 (still 128 weights in registers, 64 packed FMAs), 8 ds_read_b128 per lane, and the
+// quad's four partial sums of each own unit meet in three DPP adds (reduce-scatter over quad_perm; fixed order).
+template <bool REC32 = false, bool QUAD = false>
 __global__ __launch_bounds__(512) void lstm_rec_bwd4_kernel(LstmBwdArgs a) {
     constexpr int H = 256, HS = 64, G = 4, NW = 8, NT = 512, H4 = 4 * H, N = 4 * H;
     constexpr unsigned GSTR = REC32 ? 8u : 4u, CSTR = REC32 ? 8u : 1u;     // floats per unit-step in the gates / c arrays
-    __shared__ __attribute__((aligned(16))) float dgs[NW][128];
+    // QUAD: the quad of source unit su sits at float 4 * (su + su / 8): the four 8-unit ranges a quad's lanes read start 36
+    // floats apart, i.e. in different banks (128 floats apart they would be a 4-way conflict)
+    __shared__ __attribute__((aligned(16))) float dgs[NW][QUAD ? 144 : 128];
     __shared__ __attribute__((aligned(16))) float part[2][NW][HS];
     __shared__ __attribute__((aligned(16))) float opnd[2][HS][8];
 
@@ -901,10 +910,21 @@ __global__ __launch_bounds__(512) void lstm_rec_bwd4_kernel(LstmBwdArgs a) {
 #pragma unroll
             for (int i = 0; i < 32; ++i) tile[(2 * i + rh) * 33 + (lane & 31)] = v[i];
             __builtin_amdgcn_wave_barrier();
+            if constexpr (QUAD) {       // wq[2 * (8 i + m) + pair]: own unit 4 (lane / 4) + i, source unit 8 (lane % 4) + m
 #pragma unroll
-            for (int su = 0; su < 32; ++su) {
-                const float x = tile[lane * 33 + su];
-                if (g == 0) wq[2 * su].x = x; else if (g == 1) wq[2 * su].y = x; else if (g == 2) wq[2 * su + 1].x = x; else wq[2 * su + 1].y = x;
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) {
+                        const float x = tile[(4 * (lane >> 2) + i) * 33 + 8 * (lane & 3) + m];
+                        const int su = 8 * i + m;
+                        if (g == 0) wq[2 * su].x = x; else if (g == 1) wq[2 * su].y = x; else if (g == 2) wq[2 * su + 1].x = x; else wq[2 * su + 1].y = x;
+                    }
+            } else {
+#pragma unroll
+                for (int su = 0; su < 32; ++su) {
+                    const float x = tile[lane * 33 + su];
+                    if (g == 0) wq[2 * su].x = x; else if (g == 1) wq[2 * su].y = x; else if (g == 2) wq[2 * su + 1].x = x; else wq[2 * su + 1].y = x;
+                }
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -954,6 +974,32 @@ __global__ __launch_bounds__(512) void lstm_rec_bwd4_kernel(LstmBwdArgs a) {
 
     // this wave's half slice (staged in dgs[wave]) against its weights -> the partial of dh of the own unit
     auto slice_partial = [&](int par) {
+        if constexpr (QUAD) {
+            const f32x4* dq = reinterpret_cast<const f32x4*>(&dgs[wave][36 * (lane & 3)]);
+            f32x4 dv[8];
+#pragma unroll
+            for (int m = 0; m < 8; ++m) dv[m] = dq[m];
+            f32x2 acc[4] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};      // one per own unit of the quad
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const f32x2 d01 = __builtin_shufflevector(dv[m], dv[m], 0, 1), d23 = __builtin_shufflevector(dv[m], dv[m], 2, 3);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(d01), "v"(wq[2 * (8 * i + m)]));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(d23), "v"(wq[2 * (8 * i + m) + 1]));
+            }
+            const float p0 = acc[0].x + acc[0].y, p1 = acc[1].x + acc[1].y, p2 = acc[2].x + acc[2].y, p3 = acc[3].x + acc[3].y;
+            // reduce-scatter over the quad: lane r ends with own unit 4 u4 + r summed over the four lanes
+            const bool odd = lane & 1, hi = lane & 2;
+            float ka = odd ? p1 : p0, kb = odd ? p3 : p2;                     // kept: indices with bit 0 = r & 1
+            const float sa = odd ? p0 : p1, sb = odd ? p2 : p3;               // sent to lane r ^ 1
+            ka += dpp_mov<0xB1>(sa); kb += dpp_mov<0xB1>(sb);                 // quad_perm [1,0,3,2]
+            float k = hi ? kb : ka;                                           // kept: index (r & 1) + 2 * (r >> 1) = r
+            const float sx = hi ? ka : kb;                                    // sent to lane r ^ 2
+            k += dpp_mov<0x4E>(sx);                                           // quad_perm [2,3,0,1]
+            part[par][wave][lane] = k;
+            return;
+        }
         const f32x4* dq = reinterpret_cast<const f32x4*>(&dgs[wave][0]);
         f32x2 acc[4] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
 #pragma unroll
@@ -980,7 +1026,7 @@ __global__ __launch_bounds__(512) void lstm_rec_bwd4_kernel(LstmBwdArgs a) {
                 if (lane < 32) {
                     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                     tagged_poll4(hxg + (size_t)((s - 1) & 1) * N + 4 * (sbase + lane), tag_bit(s - 1), v, a.err);
-                    *reinterpret_cast<float4*>(&dgs[wave][4 * lane]) = v;
+                    *reinterpret_cast<float4*>(&dgs[wave][QUAD ? 4 * (lane + (lane >> 3)) : 4 * lane]) = v;
                 }
                 __builtin_amdgcn_wave_barrier();
                 slice_partial(par);
@@ -1029,7 +1075,7 @@ __global__ __launch_bounds__(512) void lstm_rec_bwd4_kernel(LstmBwdArgs a) {
             if (more) {
                 // first half of the own slice for the next step: the truncated values the peers will read
                 if (lane < 32)
-                    *reinterpret_cast<float4*>(&dgs[0][4 * lane]) = make_float4(__uint_as_float(g0.x & ~1u), __uint_as_float(g0.y & ~1u),
+                    *reinterpret_cast<float4*>(&dgs[0][QUAD ? 4 * (lane + (lane >> 3)) : 4 * lane]) = make_float4(__uint_as_float(g0.x & ~1u), __uint_as_float(g0.y & ~1u),
                                                                                 __uint_as_float(g0.z & ~1u), __uint_as_float(g0.w & ~1u));
                 __builtin_amdgcn_wave_barrier();
                 slice_partial(par ^ 1);
@@ -1231,7 +1277,9 @@ extern "C" int asr_lstm_layer_bwd_p3(void* stream, const float* x, int B, int T,
             const int padded = ((groups + 7) & ~7) * 4;
             const int grid = padded <= asr_lstm_max_wgs() ? padded : groups * 4;
             prof_begin(ASR_PROF_LSTM_REC_BWD, s);
-            hipLaunchKernelGGL(asr::lstm_rec_bwd4_kernel<false>, dim3(grid), dim3(512), 0, s, c);
+            static const bool quad = [] { const char* e = getenv("ASR_BPTT_QUAD"); return !(e && e[0] == '0'); }();
+            if (quad) hipLaunchKernelGGL((asr::lstm_rec_bwd4_kernel<false, true>), dim3(grid), dim3(512), 0, s, c);
+            else hipLaunchKernelGGL((asr::lstm_rec_bwd4_kernel<false, false>), dim3(grid), dim3(512), 0, s, c);
             prof_end(ASR_PROF_LSTM_REC_BWD, s);
             if (hipGetLastError() != hipSuccess) return ASR_ELAUNCH;
         }
@@ -1358,7 +1406,9 @@ int asr_lstm_rec_bwd_tm(hipStream_t s, float* gates, const float* act, const flo
     if (lm_g4 && H == 256 && asr_lstm_g4_selected(B, H, 1) && 4 * B <= asr_lstm_max_wgs()) {
         const int padded = ((B + 7) & ~7) * 4;
         const int grid = padded <= asr_lstm_max_wgs() ? padded : B * 4;
-        hipLaunchKernelGGL(asr::lstm_rec_bwd4_kernel<true>, dim3(grid), dim3(512), 0, s, a);
+        static const bool quad = [] { const char* e = getenv("ASR_BPTT_QUAD"); return !(e && e[0] == '0'); }();
+        if (quad) hipLaunchKernelGGL((asr::lstm_rec_bwd4_kernel<true, true>), dim3(grid), dim3(512), 0, s, a);
+        else hipLaunchKernelGGL((asr::lstm_rec_bwd4_kernel<true, false>), dim3(grid), dim3(512), 0, s, a);
         return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
     }
     int R = asr_lstm_pick_rows(B, 1, H / 32);
