@@ -196,16 +196,20 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
     // ---- resident operands
     // [dh|dctx] of the EARLIER step = dG . [K_h ; WK_c]^T for my own outputs: wave w owns outputs w*OPW .. +OPW-1 (unit
     // rows of K_h, then context rows of WK_c), lane l the positions [l*PC, l*PC + PC) of all 4H gate columns
-    float wo[OPW][PC];
+    // (outputs in PAIRS: the contraction runs on v_pk_fma_f32 with the dG value broadcast to both halves -- half the issue slots
+    //  of the 2 x OPW x PC scalar FMAs per thread, same order of summation, same bits; round 5)
+    constexpr int OPW2 = (OPW + 1) / 2;
+    f32x2 wo[OPW2][PC];
 #pragma unroll
-    for (int i = 0; i < OPW; ++i) {
+    for (int i = 0; i < 2 * OPW2; ++i) {
         const int o = wave * OPW + i;
-        const bool ook = o < NOUT;
+        const bool ook = i < OPW && o < NOUT;
         const float* wr = (o < HS) ? a.wh + (size_t)(mem * HS + (ook ? o : 0)) * H4 : a.wc + (size_t)(mem * DS + (ook ? o - HS : 0)) * H4;
 #pragma unroll
         for (int q = 0; q < PC; ++q) {
             const int pos = lane * PC + q;
-            wo[i][q] = ook ? wr[(pos & 3) * H + (pos >> 2)] : 0.f;
+            const float w = ook ? wr[(pos & 3) * H + (pos >> 2)] : 0.f;
+            if (i & 1) wo[i >> 1][q].y = w; else wo[i >> 1][q].x = w;
         }
     }
     for (int idx = tid; idx < HS * A; idx += NT) wal[idx] = a.w_att[(size_t)(mem * HS + idx / A) * A + idx % A];
@@ -399,23 +403,27 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
         // ---- [dh_i | dctx_carry_i] for my outputs = dG_{i+1} . [K_h ; WK_c]^T: 64 position chunks per wave, DPP-row
         // butterflies, the 4 rows of the wave meet in LDS (summed in fixed order by the consumers below)
         if (s > 0) {
-            float acc[R][OPW];
+            float acc[R][2 * OPW2];
 #pragma unroll
             for (int r = 0; r < R; ++r) {
+                f32x2 ap[OPW2];
 #pragma unroll
-                for (int i = 0; i < OPW; ++i) acc[r][i] = 0.f;
-                const float4* dp = reinterpret_cast<const float4*>(dga + (r * 64 + lane) * CSB);
+                for (int i = 0; i < OPW2; ++i) ap[i] = f32x2{0.f, 0.f};
+                const f32x4* dp = reinterpret_cast<const f32x4*>(dga + (r * 64 + lane) * CSB);
 #pragma unroll
                 for (int q4 = 0; q4 < PC / 4; ++q4) {
-                    const float4 dv = dp[q4];
+                    const f32x4 dv = dp[q4];
+                    const f32x2 lo = __builtin_shufflevector(dv, dv, 0, 1), hi = __builtin_shufflevector(dv, dv, 2, 3);
 #pragma unroll
-                    for (int i = 0; i < OPW; ++i) {
-                        acc[r][i] = fmaf(dv.x, wo[i][4 * q4 + 0], acc[r][i]);
-                        acc[r][i] = fmaf(dv.y, wo[i][4 * q4 + 1], acc[r][i]);
-                        acc[r][i] = fmaf(dv.z, wo[i][4 * q4 + 2], acc[r][i]);
-                        acc[r][i] = fmaf(dv.w, wo[i][4 * q4 + 3], acc[r][i]);
+                    for (int i = 0; i < OPW2; ++i) {
+                        pk_fma_alo(ap[i], lo, wo[i][4 * q4 + 0]);
+                        pk_fma_ahi(ap[i], lo, wo[i][4 * q4 + 1]);
+                        pk_fma_alo(ap[i], hi, wo[i][4 * q4 + 2]);
+                        pk_fma_ahi(ap[i], hi, wo[i][4 * q4 + 3]);
                     }
                 }
+#pragma unroll
+                for (int i = 0; i < OPW2; ++i) { acc[r][2 * i] = ap[i].x; acc[r][2 * i + 1] = ap[i].y; }
             }
 #pragma unroll
             for (int r = 0; r < R; ++r)
