@@ -229,6 +229,20 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
 
     if (STAMP) tlast = __builtin_amdgcn_s_memtime();
     bool lm_ready = false;      // uniform: this step's LM output is already in LDS (gathered during the previous step)
+    // MAXTS = 16: the hf rows of this thread's two positions (scores phase: DPP row -> (utterance, position % 8), lane kq -> two
+    // float4 chunks) do not change from step to step: 16 registers, loaded once (rounds 4 - 5 re-read them from L2 in every step,
+    // 26 KB per workgroup and an L2 round trip in front of the tanh)
+    float4 hreg[2][2];
+    if constexpr (!HFL) {
+        const int r = row / 8;
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            const int tl = (row % 8) + 8 * ps, tau = min(tau0 + min(tl, TS - 1), Te - 1);
+            const float* hrow = a.hf + ((size_t)browf(r) * Te + tau) * A;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) hreg[ps][c] = *reinterpret_cast<const float4*>(hrow + c * 64 + kq * 4);
+        }
+    }
     const int tid_outer = tid;
     int nfb = 0;                // feedback steps so far (uniform): numbers the exchange of p, which only those steps make
     for (int i = 0; i < a.T; ++i) {
@@ -508,19 +522,10 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
             sc = row16_allreduce_sum(sc);
             if (kq == 0) eout[row] = sc;
         } else {
-            // two passes of 8 positions per utterance (DPP row -> (utterance, position % 8)); the hf rows come from L2, all loads
-            // of both passes first
+            // two passes of 8 positions per utterance (DPP row -> (utterance, position % 8)); the hf rows are in registers (hreg)
             static_assert(MAXTS == 8 || AL / 4 == 2, "two 64-column chunks per row");
             const int r = row / 8;
             const float* yrow = yl + r * A;
-            float4 h4[2][2];
-#pragma unroll
-            for (int ps = 0; ps < 2; ++ps) {
-                const int tl = (row % 8) + 8 * ps, tau = min(tau0 + min(tl, TS - 1), Te - 1);
-                const float* hrow = a.hf + ((size_t)browf(r) * Te + tau) * A;
-#pragma unroll
-                for (int c = 0; c < 2; ++c) h4[ps][c] = *reinterpret_cast<const float4*>(hrow + c * 64 + kq * 4);
-            }
 #pragma unroll
             for (int ps = 0; ps < 2; ++ps) {
                 const int tl = (row % 8) + 8 * ps;
@@ -530,7 +535,7 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
                     const int a0 = c * 64 + kq * 4;
                     const float4 y4 = *reinterpret_cast<const float4*>(yrow + a0);
                     const float4 v4 = *reinterpret_cast<const float4*>(vl + a0);
-                    const float4 x4 = h4[ps][c];
+                    const float4 x4 = hreg[ps][c];
                     sc = fmaf(v4.x, fast_tanh(x4.x + y4.x), sc); sc = fmaf(v4.y, fast_tanh(x4.y + y4.y), sc);
                     sc = fmaf(v4.z, fast_tanh(x4.z + y4.z), sc); sc = fmaf(v4.w, fast_tanh(x4.w + y4.w), sc);
                 }
