@@ -12,4 +12,5 @@ bash scripts/prof_tl_env.sh c4 --config 4 && cp gpurun_out/timeline_c4.txt $O/ti
 python scripts/host_time.py > $O/host_time.txt 2>&1
 python scripts/bench_lstm.py > $O/bench_lstm.txt 2>&1
 python scripts/bench_gemm.py > $O/gemm_bench.log 2>&1
+bash scripts/prof_stats.sh && cp $(find gpurun_out/stats_final -name "*kernel_stats.csv" | head -1) $O/train_kernel_stats.csv
 cat $O/bench_modes.log

@@ -108,7 +108,11 @@ unit_steps = [t * B * 2 * H for t in T_layers]
 alg_fwd = unit_steps[0] * 7 * 4 + B * T_layers[0] * F * 4 + sum(u * 11 * 4 for u in unit_steps[1:])
 alg_bwd = sum(u * 10 * 4 for u in unit_steps)
 fb, fn, frows = family("lstm_rec_fwd4_kernel")
-bb, bn, brows = family("lstm_rec_bwd4_kernel")
+# (the encoder's four launches only: <true, ..> = REC32 is the decoder's LM-chain BPTT on the same kernel since round 5 -- one more
+#  launch per step over 120 steps of 32 rows, reported under per_instantiation but not part of the family bench.py times)
+bb, bn, brows = family("lstm_rec_bwd4_kernel<false")
+_, _, lmrows = family("lstm_rec_bwd4_kernel<true")
+brows = dict(brows, **lmrows)
 traffic = {
     "note": "HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KiB * 1024 from separate rocprofv3 --pmc FETCH_SIZE / --pmc "
             "WRITE_SIZE passes (--kernel-trace only) over `bench.py --steps 3 --warmup 2 --no-cpu-baseline`; FETCH_SIZE doubled per "
