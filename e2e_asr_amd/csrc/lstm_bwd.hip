@@ -897,7 +897,30 @@ __global__ __launch_bounds__(512) void lstm_rec_bwd4_kernel(LstmBwdArgs a) {
     // of two rows, the 64 x 32 tile of one gate goes through a wave-private LDS tile (pitch 33: conflict-free both ways) and
     // each lane picks up its own row.
     f32x2 wq[64];
-    {
+    if constexpr (QUAD) {
+        // wq[2 * (8 i + m) + pair]: own unit 4 (lane / 4) + i, source unit 8 (lane % 4) + m.  Straight from memory: a lane's 8
+        // source units are 32 contiguous bytes of a K_h row, so one float4 wave instruction touches 16 rows x one 128-byte line --
+        // 32 loads per lane, all in flight, no LDS (the lane = own unit layout needed the tile below: four rounds of 32 loads +
+        // transpose, ~14 us of prologue more than the forward's at every launch)
+        const float* kr = a.kh[dir] + (size_t)(j0 + 4 * (lane >> 2)) * H4 + sbase + 8 * (lane & 3);
+        float4 v[4][4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int mq = 0; mq < 2; ++mq) v[i][g][mq] = *reinterpret_cast<const float4*>(kr + (size_t)i * H4 + g * H + 4 * mq);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int mq = 0; mq < 2; ++mq) {
+                const int su = 8 * i + 4 * mq;
+                wq[2 * su + 0] = f32x2{v[i][0][mq].x, v[i][1][mq].x}; wq[2 * su + 1] = f32x2{v[i][2][mq].x, v[i][3][mq].x};
+                wq[2 * su + 2] = f32x2{v[i][0][mq].y, v[i][1][mq].y}; wq[2 * su + 3] = f32x2{v[i][2][mq].y, v[i][3][mq].y};
+                wq[2 * su + 4] = f32x2{v[i][0][mq].z, v[i][1][mq].z}; wq[2 * su + 5] = f32x2{v[i][2][mq].z, v[i][3][mq].z};
+                wq[2 * su + 6] = f32x2{v[i][0][mq].w, v[i][1][mq].w}; wq[2 * su + 7] = f32x2{v[i][2][mq].w, v[i][3][mq].w};
+            }
+    } else {
         __shared__ float wt[NW][64 * 33];
         float* tile = &wt[wave][0];
         const float* kr = a.kh[dir] + (size_t)j0 * H4 + sbase + (lane & 31);
@@ -910,21 +933,10 @@ __global__ __launch_bounds__(512) void lstm_rec_bwd4_kernel(LstmBwdArgs a) {
 #pragma unroll
             for (int i = 0; i < 32; ++i) tile[(2 * i + rh) * 33 + (lane & 31)] = v[i];
             __builtin_amdgcn_wave_barrier();
-            if constexpr (QUAD) {       // wq[2 * (8 i + m) + pair]: own unit 4 (lane / 4) + i, source unit 8 (lane % 4) + m
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int m = 0; m < 8; ++m) {
-                        const float x = tile[(4 * (lane >> 2) + i) * 33 + 8 * (lane & 3) + m];
-                        const int su = 8 * i + m;
-                        if (g == 0) wq[2 * su].x = x; else if (g == 1) wq[2 * su].y = x; else if (g == 2) wq[2 * su + 1].x = x; else wq[2 * su + 1].y = x;
-                    }
-            } else {
-#pragma unroll
-                for (int su = 0; su < 32; ++su) {
-                    const float x = tile[lane * 33 + su];
-                    if (g == 0) wq[2 * su].x = x; else if (g == 1) wq[2 * su].y = x; else if (g == 2) wq[2 * su + 1].x = x; else wq[2 * su + 1].y = x;
-                }
+            for (int su = 0; su < 32; ++su) {
+                const float x = tile[lane * 33 + su];
+                if (g == 0) wq[2 * su].x = x; else if (g == 1) wq[2 * su].y = x; else if (g == 2) wq[2 * su + 1].x = x; else wq[2 * su + 1].y = x;
             }
             __builtin_amdgcn_wave_barrier();
         }
