@@ -629,16 +629,24 @@ static int g_lstm_mfma = -1;
 // global_load into 10 VGPRs, counted by the vmcnt they shared with the step's record stores; (iii) the loads of the prologue
 // (bias, initial state) are waited for once, in the prologue: left in flight at the loop's entry they made the compiler's merged
 // wait in front of the cell a vmcnt(0) on EVERY step, i.e. a wait for the previous step's stores.  Layer 1 of config 2:
-// 1.10 -> 1.02 us per step (scripts/bench_lstm.py, same box).  The same treatment of the instantiation with gate rows (rows
-// requested two steps ahead in front of the stores, the cell free of vmcnt waits) was measured SLOWER (1.007 -> 1.09 us per step
-// at T = 400) and is not in the code.
-template <int IK = 0, bool XPRE = false>
+// 1.10 -> 1.02 us per step (scripts/bench_lstm.py, same box).  The instantiation with gate rows: GXL below.
+// GXL (round 5, the instantiation with gate rows; ASR_LSTM_GXL=0 keeps rounds 2-4): the gate rows x_t.K_x + b of a step were
+// requested one step ahead, behind that step's record stores, and waited for in front of the cell: a knock-out build that read
+// the same (cached) row every step ran 0.89 instead of 1.01 us per step at T = 400 (105 MB of rows from HBM), no difference at
+// T = 100 (rows still in the Infinity Cache).  Now as in the BPTT: the rows are requested TWO steps ahead and handed to the next
+// cell through LDS (gxs) at the END of a step, behind the own slice's product -- the cell reads LDS and never waits on vmcnt (the
+// prologue's loads are pinned as for XPRE).  1.00 -> 0.95 us per step at T = 400.  (Two other forms were measured slower: the rows
+// copied between register sets right behind the publishing store, 1.007 -> 1.07-1.09; that plus the own slice's product in front
+// of the record stores, the same.)
+template <int IK = 0, bool XPRE = false, bool GXL = false>
 __global__ __launch_bounds__(512) void lstm_rec_fwd4_kernel(LstmRecArgs a) {
     static_assert(!XPRE || IK > 0, "XPRE belongs to the instantiation with the input projection inside");
+    static_assert(!GXL || IK == 0, "GXL belongs to the instantiation with gate rows");
     constexpr int H = 256, HS = 64, G = 4, NW = 8, NT = 512, H4 = 4 * H;
     constexpr bool XIN = IK > 0;
     __shared__ __attribute__((aligned(16))) float hs[NW][32];
     __shared__ __attribute__((aligned(16))) float4 part[2][NW][HS];
+    __shared__ __attribute__((aligned(16))) float4 gxs[GXL ? 2 : 1][GXL ? HS : 1];      // GXL: gate rows of the next step
 
     __builtin_amdgcn_s_setprio(3);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -714,7 +722,7 @@ __global__ __launch_bounds__(512) void lstm_rec_fwd4_kernel(LstmRecArgs a) {
     float c = 0.f, h = 0.f;
     const bool has_init = a.h0 != nullptr;
     if (has_init && cell_wave) { h = a.h0[(size_t)cb * H + cj]; c = a.c0[(size_t)cb * H + cj]; }
-    if constexpr (XPRE) asm volatile("" : "+v"(c), "+v"(h));       // (iii): waited for here, by every wave
+    if constexpr (XPRE || GXL) asm volatile("" : "+v"(c), "+v"(h));       // (iii): waited for here, by every wave
     u64* hxg = a.hx + (size_t)grp * 2 * H;             // [2 parities][H] granules
     const bool fast = group_shares_xcd(a.xcc_slots + (size_t)grp * 16, G, mem, tid, a.err, nullptr, (uint32_t)a.ep0, 4);
     float gx0 = 0.f, gx1 = 0.f, gx2 = 0.f, gx3 = 0.f;
@@ -740,7 +748,14 @@ __global__ __launch_bounds__(512) void lstm_rec_fwd4_kernel(LstmRecArgs a) {
         if constexpr (XIN) {
             const float* bp = a.bias[dir] + cj; gx0 = bp[0]; gx1 = bp[H]; gx2 = bp[2 * H]; gx3 = bp[3 * H];
             if constexpr (XPRE) asm volatile("" : "+v"(gx0), "+v"(gx1), "+v"(gx2), "+v"(gx3));      // (iii)
-        } else prefetch(0);
+        } else {
+            prefetch(0);
+            if constexpr (GXL) {
+                gxs[0][lane] = make_float4(gx0, gx1, gx2, gx3);
+                if (S > 1) prefetch(1);
+                asm volatile("" : "+v"(gx0), "+v"(gx1), "+v"(gx2), "+v"(gx3));
+            }
+        }
     }
 
     f32x2 xpa[2][2] = {{f32x2{0.f, 0.f}, f32x2{0.f, 0.f}}, {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}}};   // XPRE: x part of the NEXT product
@@ -812,10 +827,12 @@ __global__ __launch_bounds__(512) void lstm_rec_fwd4_kernel(LstmRecArgs a) {
                 }
             }
             const float h_old = h, c_old = c;
-            const float gi = fast_sigmoid(pre.x + gx0);
-            const float gj = fast_tanh(pre.y + gx1);
-            const float gf = fast_sigmoid(pre.z + gx2 + 1.0f);
-            const float go = fast_sigmoid(pre.w + gx3);
+            float4 gxv = make_float4(gx0, gx1, gx2, gx3);
+            if constexpr (GXL) gxv = gxs[par][lane];
+            const float gi = fast_sigmoid(pre.x + gxv.x);
+            const float gj = fast_tanh(pre.y + gxv.y);
+            const float gf = fast_sigmoid(pre.z + gxv.z + 1.0f);
+            const float go = fast_sigmoid(pre.w + gxv.w);
             c = c * gf + gi * gj;
             h = go * fast_tanh(c);
             const bool more = s + 1 < S;
@@ -860,10 +877,14 @@ __global__ __launch_bounds__(512) void lstm_rec_fwd4_kernel(LstmRecArgs a) {
                 if (a.hprev_p3) p3_store1(a.hprev_p3, p3_elem_off((size_t)cb * a.sb + (size_t)t * a.st, dir * H + cj, (a.ND * H) >> 3, a.p3_np), h_old, a.p3_np, true);
             }
             if (!XPRE && more) {
-                prefetch(s + 1);
+                if constexpr (!GXL) prefetch(s + 1);
                 if (lane < 32) hs[0][lane] = h;          // the first half of the own slice, for the next step
                 __builtin_amdgcn_wave_barrier();
                 slice_partial(par ^ 1);
+                if constexpr (GXL) {       // the rows requested a step ago -> LDS for the next cell; then the request for the step after it
+                    gxs[par ^ 1][lane] = make_float4(gx0, gx1, gx2, gx3);
+                    if (s + 2 < S) prefetch(s + 2);
+                }
                 if (XIN && s + 2 < S) load_x(s + 2);
             }
         }
@@ -1101,7 +1122,11 @@ extern "C" int asr_lstm_layer_fwd_p3(void* stream, const float* x, int B, int T,
             static const bool xpre = [] { const char* e = getenv("ASR_LSTM_XPRE"); return !(e && e[0] == '0'); }();
             if (xin && xpre) hipLaunchKernelGGL((asr::lstm_rec_fwd4_kernel<10, true>), dim3(grid), dim3(512), 0, s, c);
             else if (xin) hipLaunchKernelGGL(asr::lstm_rec_fwd4_kernel<10>, dim3(grid), dim3(512), 0, s, c);
-            else hipLaunchKernelGGL(asr::lstm_rec_fwd4_kernel<0>, dim3(grid), dim3(512), 0, s, c);
+            else {
+                static const bool gxl = [] { const char* e = getenv("ASR_LSTM_GXL"); return !(e && e[0] == '0'); }();
+                if (gxl) hipLaunchKernelGGL((asr::lstm_rec_fwd4_kernel<0, false, true>), dim3(grid), dim3(512), 0, s, c);
+                else hipLaunchKernelGGL(asr::lstm_rec_fwd4_kernel<0>, dim3(grid), dim3(512), 0, s, c);
+            }
             prof_end(ASR_PROF_LSTM_REC_FWD, s);
             ASR_CHECK_LAUNCH();
             if (b0 + rpl < B && hipMemsetAsync(hx_ws, 0, asr_lstm_ws_bytes(B, H, ndir), s) != hipSuccess) return ASR_ELAUNCH;
