@@ -109,6 +109,21 @@ __device__ __forceinline__ float row16_allreduce_sum(float v) {
     v += dpp_mov<0x140>(v);   // row_mirror           (joins the two halves of the 16)
     return v;
 }
+// Four values at once through fused v_add_f32_dpp (round 5): the compiler turns four row16_allreduce_sum calls into 16 v_mov_b32_dpp
+// + 8 v_pk_add_f32 per butterfly step... per 16 values, i.e. 1.5 instructions per value and step; fused it is 1 (the matvec
+// phases of the decoder kernels reduce 32 values per thread and step: a knock-out build without three of the four steps ran the
+// decoder forward 5 % faster).  A DPP read of a VGPR needs 2 wait states behind the VALU write, which the hardware does not
+// interlock and the compiler cannot see into inline asm: inside the block every instruction reads a register written four
+// instructions earlier, and an s_nop 1 stands at either end.  Same operands meet in the same order: bit-identical sums.
+__device__ __forceinline__ void row16_allreduce_sum4(float& a, float& b, float& c, float& d) {
+#define ASR_DPP4(ctrl) "v_add_f32_dpp %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+                       "v_add_f32_dpp %1, %1, %1 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+                       "v_add_f32_dpp %2, %2, %2 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+                       "v_add_f32_dpp %3, %3, %3 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+    asm("s_nop 1\n\t" ASR_DPP4("quad_perm:[1,0,3,2]") ASR_DPP4("quad_perm:[2,3,0,1]") ASR_DPP4("row_half_mirror") ASR_DPP4("row_mirror") "s_nop 1"
+        : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+#undef ASR_DPP4
+}
 // The value the lane 16 (32) away holds -- what `__shfl_xor(v, 16)` / `(v, 32)` return -- by v_permlane16_swap / v_permlane32_swap
 // (gfx950) instead of ds_bpermute: two VALU instructions, no trip through the LDS crossbar (round 3: the cross-row steps of the
 // wave-wide reductions below were two dependent ds_bpermute round trips each; the softmax phases of the decoder kernels pay

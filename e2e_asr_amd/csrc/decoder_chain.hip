@@ -273,8 +273,7 @@ __global__ __launch_bounds__(512) void decoder_chain_fwd_kernel(ChainArgs a) {
                         acc[r][g] = fmaf(sv.w, wb[4 * i4 + 3][g], acc[r][g]);
                     }
                 }
-#pragma unroll
-                for (int g = 0; g < 4; ++g) acc[r][g] = row16_allreduce_sum(acc[r][g]);
+                row16_allreduce_sum4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
             }
             if (kq == 0 && cact) {
 #pragma unroll

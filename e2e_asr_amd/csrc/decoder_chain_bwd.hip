@@ -425,10 +425,14 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
 #pragma unroll
                 for (int i = 0; i < OPW2; ++i) { acc[r][2 * i] = ap[i].x; acc[r][2 * i + 1] = ap[i].y; }
             }
+            {   // butterflies over the 16 lanes of a DPP row, four values per fused block (common.h)
+                constexpr int NV = R * 2 * OPW2;
+                float* f = &acc[0][0];
 #pragma unroll
-            for (int r = 0; r < R; ++r)
+                for (int g = 0; g + 4 <= NV; g += 4) row16_allreduce_sum4(f[g], f[g + 1], f[g + 2], f[g + 3]);
 #pragma unroll
-                for (int i = 0; i < OPW; ++i) acc[r][i] = row16_allreduce_sum(acc[r][i]);
+                for (int g = NV & ~3; g < NV; ++g) f[g] = row16_allreduce_sum(f[g]);
+            }
             if ((lane & 15) == 0) {
 #pragma unroll
                 for (int r = 0; r < R; ++r)

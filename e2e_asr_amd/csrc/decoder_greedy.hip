@@ -392,8 +392,8 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
             }
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                acc[r][0] = row16_allreduce_sum(ap2[r][0].x); acc[r][1] = row16_allreduce_sum(ap2[r][0].y);
-                acc[r][2] = row16_allreduce_sum(ap2[r][1].x); acc[r][3] = row16_allreduce_sum(ap2[r][1].y);
+                acc[r][0] = ap2[r][0].x; acc[r][1] = ap2[r][0].y; acc[r][2] = ap2[r][1].x; acc[r][3] = ap2[r][1].y;
+                row16_allreduce_sum4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
             }
             if (kq == 0) {
 #pragma unroll
@@ -414,8 +414,8 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
                     pk_fma_ahi(t0, xlo, wlm[1][0]); pk_fma_ahi(t1, xlo, wlm[1][1]);
                     pk_fma_alo(t0, xhi, wlm[2][0]); pk_fma_alo(t1, xhi, wlm[2][1]);
                     pk_fma_ahi(t0, xhi, wlm[3][0]); pk_fma_ahi(t1, xhi, wlm[3][1]);
-                    al[r][0] = row16_allreduce_sum(t0.x); al[r][1] = row16_allreduce_sum(t0.y);
-                    al[r][2] = row16_allreduce_sum(t1.x); al[r][3] = row16_allreduce_sum(t1.y);
+                    al[r][0] = t0.x; al[r][1] = t0.y; al[r][2] = t1.x; al[r][3] = t1.y;
+                    row16_allreduce_sum4(al[r][0], al[r][1], al[r][2], al[r][3]);
                 }
                 if (kq == 0) {
 #pragma unroll
@@ -474,8 +474,9 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
             for (int r = 0; r < R; ++r) {
                 const float4 x = *reinterpret_cast<const float4*>(v_ap + r * KA + ypart * 64 + kq * 4);
                 acc[r] = fmaf(x.x, wy[0], fmaf(x.y, wy[1], fmaf(x.z, wy[2], x.w * wy[3])));
-                acc[r] = row16_allreduce_sum(acc[r]);
             }
+            static_assert(R == 4, "row16_allreduce_sum4");
+            row16_allreduce_sum4(acc[0], acc[1], acc[2], acc[3]);
             if (kq == 0 && yact) {
 #pragma unroll
                 for (int r = 0; r < R; ++r) ysum[(ypart * AS + ycol) * R + r] = acc[r];
@@ -696,8 +697,8 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
                     acc[r] = fmaf(x.x, wap[j * 4 + 0], acc[r]); acc[r] = fmaf(x.y, wap[j * 4 + 1], acc[r]);
                     acc[r] = fmaf(x.z, wap[j * 4 + 2], acc[r]); acc[r] = fmaf(x.w, wap[j * 4 + 3], acc[r]);
                 }
-                acc[r] = row16_allreduce_sum(acc[r]);
             }
+            row16_allreduce_sum4(acc[0], acc[1], acc[2], acc[3]);
             if (kq == 0) {
 #pragma unroll
                 for (int r = 0; r < R; ++r) psum[(part * PS + u8) * R + r] = acc[r];
@@ -736,8 +737,8 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
                     acc[r] = fmaf(x.x, wout[j * 4 + 0], acc[r]); acc[r] = fmaf(x.y, wout[j * 4 + 1], acc[r]);
                     acc[r] = fmaf(x.z, wout[j * 4 + 2], acc[r]); acc[r] = fmaf(x.w, wout[j * 4 + 3], acc[r]);
                 }
-                acc[r] = row16_allreduce_sum(acc[r]);
             }
+            row16_allreduce_sum4(acc[0], acc[1], acc[2], acc[3]);
             if (kq == 0) {
 #pragma unroll
                 for (int r = 0; r < R; ++r) lg[r * VS + row] = acc[r] + outb;
@@ -754,8 +755,8 @@ __global__ __launch_bounds__(512) void decoder_greedy_kernel(GreedyArgs a) {
                     pk_fma_ahi(t0, xlo, wlm[1][0]); pk_fma_ahi(t1, xlo, wlm[1][1]);
                     pk_fma_alo(t0, xhi, wlm[2][0]); pk_fma_alo(t1, xhi, wlm[2][1]);
                     pk_fma_ahi(t0, xhi, wlm[3][0]); pk_fma_ahi(t1, xhi, wlm[3][1]);
-                    al[r][0] = row16_allreduce_sum(t0.x); al[r][1] = row16_allreduce_sum(t0.y);
-                    al[r][2] = row16_allreduce_sum(t1.x); al[r][3] = row16_allreduce_sum(t1.y);
+                    al[r][0] = t0.x; al[r][1] = t0.y; al[r][2] = t1.x; al[r][3] = t1.y;
+                    row16_allreduce_sum4(al[r][0], al[r][1], al[r][2], al[r][3]);
                 }
                 if (kq == 0) {
 #pragma unroll
