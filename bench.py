@@ -441,7 +441,33 @@ def main():
         eager_step = one_step
         one_step = g.replay
         one_step(); torch.cuda.synchronize()
-    ops.prof_enable(not args.graph)
+    # Which kernel family the `roofline` object reports is decided BEFORE the timed region, from two profiled steps: inside the
+    # region only that family's launches carry events (every event pair costs the launch stream a few microseconds -- with all
+    # families on, +0.10 ms per 7.2-ms step, profiles/r05_bench_prof_overhead.txt); the other families' times
+    # (`phases_ms_per_step`, `side_stream_tail_ms`) come from PHASE_STEPS extra steps behind the region.
+    FAMILIES = ("lstm_rec_fwd", "lstm_rec_bwd", "decoder_fwd", "decoder_bwd", "optim")
+
+    def read_families(nsteps):
+        r = {}
+        for f in FAMILIES:
+            ms, n = ops.prof_read(f)
+            r[f] = (ms / nsteps, n / float(nsteps))
+        return r
+
+    dom_family = None
+    if not args.graph:
+        ops.prof_enable(True)
+        for _ in range(2):
+            one_step()
+        torch.cuda.synchronize()
+        pre = read_families(2)
+        ops.prof_enable(False)
+        dom_family = "lstm_rec_bwd" if (mode == "train" and pre["lstm_rec_bwd"][0] > pre["lstm_rec_fwd"][0]) else "lstm_rec_fwd"
+        if mt is not None and mode == "train" and max(pre["decoder_fwd"][0], pre["decoder_bwd"][0]) > pre[dom_family][0]:
+            dom_family = "decoder_bwd" if pre["decoder_bwd"][0] > pre["decoder_fwd"][0] else "decoder_fwd"
+        # (ASR_BENCH_PROF=all / none: every family's events / no events inside the timed region -- the overhead measurement)
+        prof_env = os.environ.get("ASR_BENCH_PROF", "")
+        ops.prof_enable(prof_env != "none", only=None if prof_env == "all" else (dom_family,))
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -510,13 +536,26 @@ def main():
             del buf
         except Exception as e:      # never lose the bench line to the side measurement
             comm = {"error": repr(e)}
-    rec_ms, rec_n = ops.prof_read("lstm_rec_fwd")
-    recb_ms, recb_n = ops.prof_read("lstm_rec_bwd")
-    decf_ms, decf_n = ops.prof_read("decoder_fwd")
-    decb_ms, decb_n = ops.prof_read("decoder_bwd")
-    opt_ms, opt_n = ops.prof_read("optim")
-    tails = ops.prof_read_each("side_tail")
+    dom_timed_ms, dom_timed_n = ops.prof_read(dom_family) if dom_family else (0.0, 0)      # the roofline family: events of the timed region
     ops.prof_enable(False)
+    PHASE_STEPS = min(5, args.steps)
+    tails = []
+    fam = {f: (0.0, 0.0) for f in FAMILIES}
+    if not args.graph and PHASE_STEPS > 0:
+        ops.prof_enable(True)
+        for _ in range(PHASE_STEPS):
+            one_step()
+        torch.cuda.synchronize()
+        fam = read_families(PHASE_STEPS)
+        tails = ops.prof_read_each("side_tail")
+        ops.prof_enable(False)
+        ops.check_device_flag(dev)
+    if dom_family and dom_timed_n:
+        fam[dom_family] = (dom_timed_ms / args.steps, dom_timed_n / float(args.steps))
+    # (per-step family times scaled to the timed region's step count: the expressions below divide by args.steps)
+    rec_ms, rec_n = fam["lstm_rec_fwd"][0] * args.steps, int(round(fam["lstm_rec_fwd"][1] * args.steps))
+    recb_ms, recb_n = fam["lstm_rec_bwd"][0] * args.steps, int(round(fam["lstm_rec_bwd"][1] * args.steps))
+    decf_ms, decb_ms, opt_ms = fam["decoder_fwd"][0] * args.steps, fam["decoder_bwd"][0] * args.steps, fam["optim"][0] * args.steps
     if tails:
         # per step: from the launch stream reaching asr_side_join (everything of the backward pass enqueued in front of it done)
         # to the end of the side stream's work.  ~0.6-0.8 ms = the layer-1 weight gradients that follow the last BPTT; a
@@ -536,7 +575,7 @@ def main():
     # T=800/400/200/100); report the slower of the two.  Same algorithmic FLOPs (h.K_h resp. dG.K_h^T).
     rec_per_step_ms = rec_ms / args.steps
     recb_per_step_ms = recb_ms / args.steps
-    use_bwd = mode == "train" and recb_per_step_ms > rec_per_step_ms
+    use_bwd = (dom_family == "lstm_rec_bwd") if dom_family in ("lstm_rec_fwd", "lstm_rec_bwd") else (mode == "train" and recb_per_step_ms > rec_per_step_ms)
     dom_ms = recb_per_step_ms if use_bwd else rec_per_step_ms
     v2 = os.environ.get("ASR_LSTM_V2", "1") != "0"
     g4 = v2 and os.environ.get("ASR_LSTM_G4", "1") != "0" and 2 * B * 4 <= 256       # csrc/lstm.hip: groups of four workgroups when the batch fits
@@ -550,12 +589,12 @@ def main():
         # config 4: the two decoders' persistent chains outweigh each recurrent kernel -- report the larger decoder family
         # (decoder_fwd = both training-graph decoders; decoder_bwd = both backward chains incl. their GEMMs)
         dec_fwd_step, dec_bwd_step = decf_ms / args.steps, decb_ms / args.steps
-        if max(dec_fwd_step, dec_bwd_step) > dom_ms:
-            use_dec_bwd = dec_bwd_step > dec_fwd_step
+        if dom_family in ("decoder_fwd", "decoder_bwd") or (dom_family is None and max(dec_fwd_step, dec_bwd_step) > dom_ms):
+            use_dec_bwd = (dom_family == "decoder_bwd") if dom_family else dec_bwd_step > dec_fwd_step
             dom_ms = dec_bwd_step if use_dec_bwd else dec_fwd_step
             dom_flop = dec_flop * (2 if use_dec_bwd else 1)
             dom_name = ("asr_attn_decoder_bwd (persistent backward chains of the char and phone decoders + their GEMMs)" if use_dec_bwd else
-                        "asr_attn_decoder_fwd (char: one-launch training decoder; phone: persistent segment chains, Te = %d)" % (T >> (mt - 1)))
+                        "asr_attn_decoder_fwd (char and phone: one-launch training decoders; phone memory Te = %d, 16 positions per workgroup)" % (T >> (mt - 1)))
             achieved = dom_flop / (dom_ms * 1e-3) / 1e12
             dom_launches, chain_steps = 2.0, (TDEC - 1) + (TDEC_PHONE - 1)
     # HBM traffic per launch cannot be read by the process that is being timed (the PMC passes are separate rocprofv3
@@ -602,6 +641,8 @@ def main():
                                "decoder_fwd": decf_ms / args.steps, "decoder_bwd": decb_ms / args.steps},
     }
     out["phases_ms_per_step"]["optimizer"] = opt_ms / args.steps
+    out["phases_source"] = ("`%s` (the roofline family): HIP events around its launches inside the timed region; the other families and "
+                            "side_stream_tail_ms: %d extra steps behind the timed region with every family's events on (not timed)" % (dom_family, PHASE_STEPS))
     out.update(diag)
     sum_len = int(np.sum(batch["logmel_len"])) * world
     out["frames_true_sum_len_per_s"] = sum_len / (dt / args.steps)      # rate on the true sum of lengths next to padded B*T

@@ -168,6 +168,7 @@ SIGNATURES = {
     "asr_get_wgrad_mode": (C.c_int, []),
     "asr_scatter_add_rows_ordered": (C.c_int, [vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int]),
     "asr_prof_enable": (C.c_int, [C.c_int]),
+    "asr_prof_enable_mask": (C.c_int, [C.c_uint]),
     "asr_debug_set_buffer": (C.c_int, [vp]),
     "asr_prof_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "asr_prof_read_each": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int)]),

@@ -927,8 +927,16 @@ def get_wgrad_mode():
 PROF_TAGS = {"lstm_rec_fwd": 0, "lstm_rec_bwd": 1, "gemm": 2, "decoder_fwd": 3, "decoder_bwd": 4, "optim": 5, "side_tail": 6}
 
 
-def prof_enable(on=True):
-    _lib.lib().asr_prof_enable(int(on))
+def prof_enable(on=True, only=None):
+    """HIP-event timing of the persistent kernel families (PROF_TAGS).  only: names of the families to record (each event pair
+    costs the stream a few microseconds: a timed run records the family it reports, bench.py)."""
+    if on and only is not None:
+        mask = 0
+        for name in only:
+            mask |= 1 << PROF_TAGS[name]
+        _lib.lib().asr_prof_enable_mask(mask)
+    else:
+        _lib.lib().asr_prof_enable(int(bool(on)))
 
 
 def prof_read(tag):

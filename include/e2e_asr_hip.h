@@ -506,6 +506,9 @@ int asr_race_hunt_build(void);
  * tag: 0 lstm recurrent fwd, 1 lstm recurrent bwd, 2 gemm, 3 decoder fwd, 4 decoder bwd, 5 optimizer.
  * asr_prof_read is a HOST call that synchronises on the recorded events. */
 int asr_prof_enable(int on);
+/* As asr_prof_enable(1) for the families whose bit (1 << tag) is set in `mask` only: each event pair costs the stream a few
+ * microseconds, so a timed run records the one family it reports a roofline for.  New: measurement tooling. */
+int asr_prof_enable_mask(unsigned mask);
 /* Diagnostic: device buffer (>= 8 u64) for in-kernel phase stamps of the stamped LSTM build (ASR_LSTM_STAMP=1). */
 int asr_debug_set_buffer(void* dev_buf);
 int asr_prof_read(int tag, double* total_ms, int* launches);
