@@ -468,8 +468,14 @@ extern "C" int asr_attn_decoder_bwd(void* stream, const asr_dec_weights* w, cons
     if ((rc = asr_gemm_f32(stream, 0, 1, TB, H, V, dlogits, V, w->out_w, V, bw->dP, H, nullptr, 0))) return rc;
     if ((rc = asr_gemm_f32(stream, 0, 1, TB, H + D, H, bw->dP, H, w->ap_w, H, bw->dQC, H + D, nullptr, 0))) return rc;
     {   // the weight gradients that need only dLogits / dP run on the side stream UNDER the (latency-bound) chain below
-        hipEvent_t e_pre = next_event();
-        if (hipEventRecord(e_pre, s) != hipSuccess || hipStreamWaitEvent(ss, e_pre, 0) != hipSuccess) return ASR_ELAUNCH;
+        // (dLogits and p are complete when this call starts: the fork at its top orders the side stream behind them.  A second
+        //  fork here only delayed the product behind dP / dQC -- and every fork costs the recording stream 10-20 us,
+        //  scripts/micro/event_cost.py; ASR_DEC_FORK_PRE=1 restores it)
+        static const bool fork_pre = [] { const char* e = getenv("ASR_DEC_FORK_PRE"); return e && e[0] == '1'; }();
+        if (fork_pre) {
+            hipEvent_t e_pre = next_event();
+            if (hipEventRecord(e_pre, s) != hipSuccess || hipStreamWaitEvent(ss, e_pre, 0) != hipSuccess) return ASR_ELAUNCH;
+        }
         auto wg0 = [&](int M, int N, int K, const float* Ap, int lda, const float* Bp, int ldb, float* C) {
             return asr_gemm_f32(side, 1, 0, M, N, K, Ap, lda, Bp, ldb, C, N, nullptr, 1);
         };
