@@ -63,6 +63,10 @@ namespace asr {
 
 void prof_begin(int tag, hipStream_t s);   // prof.hip
 void prof_end(int tag, hipStream_t s);
+// For a family that is ONE kernel launch: the events to hand to hipExtLaunchKernelGGL as its start / stop events (the dispatch's
+// own signals: no marker packets in front of and behind the kernel, which cost the stream ~3 us each and more when another
+// stream waits on them -- scripts/micro/fork_cost.hip), or nullptrs when the family is not being recorded.
+void prof_launch_events(int tag, hipEvent_t* start, hipEvent_t* stop);
 // Workgroups of ONE persistent launch that are certainly co-resident: the compute units of the current device (each of
 // the persistent kernels is one 512-thread workgroup per CU), optionally lowered by ASR_LSTM_MAXWG.  Every persistent
 // launch sizes its grid by this; a group that does not fit returns ASR_EUNSUPPORTED instead of spinning into the

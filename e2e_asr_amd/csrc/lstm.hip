@@ -27,6 +27,7 @@
 // lanes of a DPP row hold the 16 K-chunks of one unit, so the K reduction is 4 DPP
 // butterflies with no LDS, and lanes kq < R of each row run the cell for batch row kq.
 #include "common.h"
+#include <hip/hip_ext.h>
 #include "p3.h"
 
 namespace asr {
@@ -1118,16 +1119,20 @@ extern "C" int asr_lstm_layer_fwd_p3(void* stream, const float* x, int B, int T,
             const int groups = ndir * c.B;
             const int padded = ((groups + 7) & ~7) * 4;
             const int grid = padded <= asr_lstm_max_wgs() ? padded : groups * 4;
-            prof_begin(ASR_PROF_LSTM_REC_FWD, s);
+            // (timing events = the dispatch's own start / stop signals, as in csrc/lstm_bwd.hip)
+            static const bool ext_ev = [] { const char* e = getenv("ASR_EXT_EVENTS"); return !(e && e[0] == '0'); }();
+            hipEvent_t ev_a = nullptr, ev_b = nullptr;
+            if (ext_ev) prof_launch_events(ASR_PROF_LSTM_REC_FWD, &ev_a, &ev_b);
+            else prof_begin(ASR_PROF_LSTM_REC_FWD, s);
             static const bool xpre = [] { const char* e = getenv("ASR_LSTM_XPRE"); return !(e && e[0] == '0'); }();
-            if (xin && xpre) hipLaunchKernelGGL((asr::lstm_rec_fwd4_kernel<10, true>), dim3(grid), dim3(512), 0, s, c);
-            else if (xin) hipLaunchKernelGGL(asr::lstm_rec_fwd4_kernel<10>, dim3(grid), dim3(512), 0, s, c);
+            if (xin && xpre) hipExtLaunchKernelGGL((asr::lstm_rec_fwd4_kernel<10, true>), dim3(grid), dim3(512), 0, s, ev_a, ev_b, 0, c);
+            else if (xin) hipExtLaunchKernelGGL(asr::lstm_rec_fwd4_kernel<10>, dim3(grid), dim3(512), 0, s, ev_a, ev_b, 0, c);
             else {
                 static const bool gxl = [] { const char* e = getenv("ASR_LSTM_GXL"); return !(e && e[0] == '0'); }();
-                if (gxl) hipLaunchKernelGGL((asr::lstm_rec_fwd4_kernel<0, false, true>), dim3(grid), dim3(512), 0, s, c);
-                else hipLaunchKernelGGL(asr::lstm_rec_fwd4_kernel<0>, dim3(grid), dim3(512), 0, s, c);
+                if (gxl) hipExtLaunchKernelGGL((asr::lstm_rec_fwd4_kernel<0, false, true>), dim3(grid), dim3(512), 0, s, ev_a, ev_b, 0, c);
+                else hipExtLaunchKernelGGL(asr::lstm_rec_fwd4_kernel<0>, dim3(grid), dim3(512), 0, s, ev_a, ev_b, 0, c);
             }
-            prof_end(ASR_PROF_LSTM_REC_FWD, s);
+            if (!ext_ev) prof_end(ASR_PROF_LSTM_REC_FWD, s);
             ASR_CHECK_LAUNCH();
             if (b0 + rpl < B && hipMemsetAsync(hx_ws, 0, asr_lstm_ws_bytes(B, H, ndir), s) != hipSuccess) return ASR_ELAUNCH;
         }

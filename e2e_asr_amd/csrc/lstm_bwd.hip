@@ -21,6 +21,7 @@
 // columns = 2 units x 4 gates) and each lane KG = H/32 output rows k, so the reduction over
 // columns is again 4 DPP butterflies.
 #include "common.h"
+#include <hip/hip_ext.h>
 #include "p3.h"
 #include "granule.h"
 #include <cstdlib>
@@ -1270,6 +1271,7 @@ extern "C" int asr_lstm_layer_bwd_p3(void* stream, const float* x, int B, int T,
     // the pair shares the 20-byte split record format
     const bool g4 = asr_lstm_g4_selected(B, H, ndir);
     if (p3_dg && !g4) return ASR_EUNSUPPORTED;            // only the groups-of-four BPTT writes planes
+    hipEvent_t e_bptt_done = nullptr;                     // stop event of the (single) BPTT launch, or nullptr
     if (g4) {
         const int rpl4 = asr_lstm_max_wgs() / (4 * ndir);
         if (!a.db_part) a.db_part = reinterpret_cast<float*>(static_cast<char*>(hx_ws) + lstm_bwd_sync_bytes(B, H, ndir));
@@ -1288,12 +1290,20 @@ extern "C" int asr_lstm_layer_bwd_p3(void* stream, const float* x, int B, int T,
             const int groups = ndir * c.B;
             const int padded = ((groups + 7) & ~7) * 4;
             const int grid = padded <= asr_lstm_max_wgs() ? padded : groups * 4;
-            prof_begin(ASR_PROF_LSTM_REC_BWD, s);
+            // start / stop events of the dispatch itself (hipExtLaunchKernelGGL): the timing events of bench.py's roofline leg, and
+            // -- single launch -- the event the side stream's weight gradients wait on, without marker packets on this stream
+            // (a recorded event costs the stream ~3 us, ~6 with a waiter: scripts/micro/fork_cost.hip; ASR_EXT_EVENTS=0: records)
+            static const bool ext_ev = [] { const char* e = getenv("ASR_EXT_EVENTS"); return !(e && e[0] == '0'); }();
+            hipEvent_t ev_a = nullptr, ev_b = nullptr;
+            if (ext_ev) prof_launch_events(ASR_PROF_LSTM_REC_BWD, &ev_a, &ev_b);
+            else prof_begin(ASR_PROF_LSTM_REC_BWD, s);
+            if (ext_ev && !ev_b && B <= rpl4) ev_b = next_event();
             static const bool quad = [] { const char* e = getenv("ASR_BPTT_QUAD"); return !(e && e[0] == '0'); }();
-            if (quad) hipLaunchKernelGGL((asr::lstm_rec_bwd4_kernel<false, true>), dim3(grid), dim3(512), 0, s, c);
-            else hipLaunchKernelGGL((asr::lstm_rec_bwd4_kernel<false, false>), dim3(grid), dim3(512), 0, s, c);
-            prof_end(ASR_PROF_LSTM_REC_BWD, s);
+            if (quad) hipExtLaunchKernelGGL((asr::lstm_rec_bwd4_kernel<false, true>), dim3(grid), dim3(512), 0, s, ev_a, ev_b, 0, c);
+            else hipExtLaunchKernelGGL((asr::lstm_rec_bwd4_kernel<false, false>), dim3(grid), dim3(512), 0, s, ev_a, ev_b, 0, c);
+            if (!ext_ev) prof_end(ASR_PROF_LSTM_REC_BWD, s);
             if (hipGetLastError() != hipSuccess) return ASR_ELAUNCH;
+            if (ext_ev && B <= rpl4) e_bptt_done = ev_b;
         }
     } else
     for (int b0 = 0; b0 < B; b0 += rows_per_launch) {
@@ -1338,8 +1348,12 @@ extern "C" int asr_lstm_layer_bwd_p3(void* stream, const float* x, int B, int T,
                                        dx, in_dim, nullptr, 0, 1))) return rc;
         static const bool wg_inline_p = [] { const char* e = getenv("ASR_WGRAD_INLINE"); return e && e[0] == '1'; }();
         hipStream_t ssp = wg_inline_p ? s : side_stream();
-        hipEvent_t e_dgp = next_event();
-        if (!wg_inline_p && (hipEventRecord(e_dgp, s) != hipSuccess || hipStreamWaitEvent(ssp, e_dgp, 0) != hipSuccess)) return ASR_ELAUNCH;
+        // the weight gradients read dG (and x, h_prev of the forward): they wait for the BPTT, not for the dX product above
+        if (!wg_inline_p && e_bptt_done) { if (hipStreamWaitEvent(ssp, e_bptt_done, 0) != hipSuccess) return ASR_ELAUNCH; }
+        else {
+            hipEvent_t e_dgp = next_event();
+            if (!wg_inline_p && (hipEventRecord(e_dgp, s) != hipSuccess || hipStreamWaitEvent(ssp, e_dgp, 0) != hipSuccess)) return ASR_ELAUNCH;
+        }
         if ((rc = p3_lstm_wgrad(ssp, M, p3->x_cols, in_dim, H, ndir, p3->x_p3, p3->x_cols / 8, p3->hprev_p3, p3->dg_p3, p3->np,
                                 dkernel_fw, (long long)(dkernel_bw - dkernel_fw), p3->colmap))) return rc;
         hipEvent_t e_donep = next_event();
@@ -1362,8 +1376,11 @@ extern "C" int asr_lstm_layer_bwd_p3(void* stream, const float* x, int B, int T,
     static const bool wg_inline = [] { const char* e = getenv("ASR_WGRAD_INLINE"); return e && e[0] == '1'; }();
     hipStream_t ss = wg_inline ? s : side_stream();
     void* side = static_cast<void*>(ss);
-    hipEvent_t e_dg = next_event();
-    if (!wg_inline && (hipEventRecord(e_dg, s) != hipSuccess || hipStreamWaitEvent(ss, e_dg, 0) != hipSuccess)) return ASR_ELAUNCH;
+    if (!wg_inline && e_bptt_done) { if (hipStreamWaitEvent(ss, e_bptt_done, 0) != hipSuccess) return ASR_ELAUNCH; }
+    else {
+        hipEvent_t e_dg = next_event();
+        if (!wg_inline && (hipEventRecord(e_dg, s) != hipSuccess || hipStreamWaitEvent(ss, e_dg, 0) != hipSuccess)) return ASR_ELAUNCH;
+    }
     // both directions of a product as ONE batched launch when the two gradient buffers sit a vector-aligned stride apart
     // (they do in the flat gradient buffer): X is then streamed once for the two dK_x instead of twice, and a launch has
     // twice the tiles (less split-K, fewer atomics)

@@ -20,6 +20,18 @@ void prof_begin(int tag, hipStream_t s) {
     }
     (void)hipEventRecord(p.a[p.used], s);
 }
+void prof_launch_events(int tag, hipEvent_t* start, hipEvent_t* stop) {
+    *start = *stop = nullptr;
+    if (!((g_prof_on >> tag) & 1)) return;
+    ProfPool& p = g_pool[tag];
+    if (p.used == p.a.size()) {
+        hipEvent_t e0, e1;
+        (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+        p.a.push_back(e0); p.b.push_back(e1);
+    }
+    *start = p.a[p.used]; *stop = p.b[p.used];
+    p.used++;
+}
 void prof_end(int tag, hipStream_t s) {
     if (!((g_prof_on >> tag) & 1)) return;
     ProfPool& p = g_pool[tag];
