@@ -100,7 +100,12 @@ __device__ __forceinline__ void pubg(u64* dst, uint32_t epoch, float v, bool fas
 // accumulator of a slot live in the REGISTERS of the 16 lanes that own it in both phases (8 + 8 values per pass) instead of
 // 2 x 32 KB of LDS, which leaves room for both utterances' enc rows up to 400 positions (config 4's phone task: one launch of
 // 16 groups instead of two launches of one utterance per group).
-template <int H, int D, int A, int R = 2, bool STAMP = false, int PASSES = 1>
+// ARED (round 5; ASR_CHAIN_BWD_ARED=0 keeps the two hops): the reduce-scatter of the partial dy to the owners of the A-slices and the
+// all-gather of the reduced dy that followed it -- two store -> L2 -> poll hops and two barriers -- as ONE all-reduce: every
+// workgroup publishes its partial dy of the group's rows ([R][A] floats = one wave instruction of tagged quads, summed over its
+// DPP rows by the publishing lane itself) and gathers all 16 partials (four lanes per quad, four sources each, summed in a fixed
+// order and joined by two DPP adds).  16 KB polled per workgroup and step instead of 2 x 2 KB, one hop (~1 us) less.
+template <int H, int D, int A, int R = 2, bool STAMP = false, int PASSES = 1, bool ARED = false>
 __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) {
     unsigned int stamp[16] = {0};
     unsigned long long tlast = 0;
@@ -601,6 +606,75 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
         }
         __syncthreads();
         CHAIN_STAMP()
+        if constexpr (ARED) {
+            constexpr int NQ = R * A / 4;                 // quads of the partial dy of the group's rows
+            static_assert(A % 4 == 0 && NQ <= 64 && 4 * NQ <= NT - 64, "one publishing wave instruction, four polling lanes per quad");
+            uint32_t* const ar = reinterpret_cast<uint32_t*>(g2);          // [source workgroup][R * A] tagged floats
+            const uint32_t tb = ((((uint32_t)s) >> 1) & 1u) ^ 1u;
+            typedef unsigned int u32x4a __attribute__((ext_vector_type(4)));
+            if (wave0 && lane < NQ) {      // my partial: quad `lane` summed over the DPP rows (fixed order), published at once
+                const int idx = 4 * lane, r = idx / A, aa = idx % A;
+                float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int t = 0; t < DYR; ++t) {
+                    const float4 v = *reinterpret_cast<const float4*>(dyrow + (r * DYR + t) * A + aa);
+                    x.x += v.x; x.y += v.y; x.z += v.z; x.w += v.w;
+                }
+                const u32x4a q0 = {(__float_as_uint(x.x) & ~1u) | tb, (__float_as_uint(x.y) & ~1u) | tb,
+                                   (__float_as_uint(x.z) & ~1u) | tb, (__float_as_uint(x.w) & ~1u) | tb};
+                uint32_t* dst = ar + (size_t)mem * (R * A) + idx;
+                ASR_RACE_HUNT_DELAY();
+                if (fast) asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(dst), "v"(q0) : "memory");
+                else {
+                    __hip_atomic_store(dst + 0, q0.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(dst + 1, q0.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(dst + 2, q0.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(dst + 3, q0.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            if (tid >= 64 && tid < 64 + 4 * NQ) {      // gather: lane (quad q, part p) takes sources 4 p .. 4 p + 3
+                const int q = (tid - 64) >> 2, part = (tid - 64) & 3;
+                const u32x4a* qp[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) qp[j] = reinterpret_cast<const u32x4a*>(ar + (size_t)(4 * part + j) * (R * A) + 4 * q);
+                u32x4a xq[4];
+                long long t0w = 0;
+                ASR_RACE_HUNT_DELAY();
+                for (uint32_t spins = 0;; ++spins) {
+                    asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\t"
+                                 "global_load_dwordx4 %2, %6, off sc1\n\tglobal_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
+                                 : "=&v"(xq[0]), "=&v"(xq[1]), "=&v"(xq[2]), "=&v"(xq[3])
+                                 : "v"(qp[0]), "v"(qp[1]), "v"(qp[2]), "v"(qp[3]) : "memory");
+                    uint32_t bits = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) bits += (xq[j].x & 1u) + (xq[j].y & 1u) + (xq[j].z & 1u) + (xq[j].w & 1u);
+                    if (bits == 16u * tb) break;
+                    ASR_POLL_BACKOFF();
+                    if ((spins & 1023) == 1023) {
+                        const long long now = wall_clock64();
+                        if (t0w == 0) t0w = now;
+                        else if (now - t0w > 200000000LL) { *a.err = 55; break; }
+                        if (__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                    }
+                }
+                float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    x.x += __uint_as_float(xq[j].x & ~1u); x.y += __uint_as_float(xq[j].y & ~1u);
+                    x.z += __uint_as_float(xq[j].z & ~1u); x.w += __uint_as_float(xq[j].w & ~1u);
+                }
+                // the four parts of a quad sit in four adjacent lanes: (p0 + p1) + (p2 + p3)
+                x.x += dpp_mov<0xB1>(x.x); x.y += dpp_mov<0xB1>(x.y); x.z += dpp_mov<0xB1>(x.z); x.w += dpp_mov<0xB1>(x.w);
+                x.x += dpp_mov<0x4E>(x.x); x.y += dpp_mov<0x4E>(x.y); x.z += dpp_mov<0x4E>(x.z); x.w += dpp_mov<0x4E>(x.w);
+                if (part == 0) *reinterpret_cast<float4*>(dyall + 4 * q) = x;
+            }
+            __syncthreads();
+            CHAIN_STAMP()
+            if (wave0 && tid < R * AS) {      // my A-slice of dy, saved for dW_att = q^T . dy after the loop
+                const int r = tid / AS, al = tid % AS;
+                if (rok(r)) a.dY[((size_t)i * a.B + r0 + r) * A + mem * AS + al] = dyall[r * A + mem * AS + al];
+            }
+        } else {
         for (int idx = tid; idx < R * A; idx += NT) {        // partial dy[r][a] = sum over my positions (MAXTS DPP rows; WIDE: 8 waves)
             const int r = idx / A, aa = idx % A;
             float x = 0.f;
@@ -665,6 +739,7 @@ __global__ __launch_bounds__(512) void decoder_chain_bwd_kernel(ChainBwdArgs a) 
         }
         __syncthreads();
         CHAIN_STAMP()
+        }
         // ---- dq_att for my units: dq[r][u] = dy[r][:] . W_att[unit u][:]  (DPP row = one (r, u), 16 lanes over the columns)
         {
             const int o = row;                       // 0 .. 31
@@ -831,7 +906,10 @@ static int chain_bwd_launch(hipStream_t s, asr::ChainBwdArgs& a) {
     bool ok = false;
     const size_t lds = chain_bwd_lds_bytes_r(a.Te, D, A, H, R, PASSES, &ok);
     if (lds > kChainBwdLdsMax || !ok) return ASR_EUNSUPPORTED;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asr::decoder_chain_bwd_kernel<H, D, A, R, false, PASSES>),
+    static const bool ared = [] { const char* e = getenv("ASR_CHAIN_BWD_ARED"); return !(e && e[0] == '0'); }();
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asr::decoder_chain_bwd_kernel<H, D, A, R, false, PASSES, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asr::decoder_chain_bwd_kernel<H, D, A, R, false, PASSES, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (H == 256 && R == 2 && PASSES == 1 && a.dbg) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asr::decoder_chain_bwd_kernel<256, 512, 128, 2, true>),
@@ -839,7 +917,8 @@ static int chain_bwd_launch(hipStream_t s, asr::ChainBwdArgs& a) {
         hipLaunchKernelGGL((asr::decoder_chain_bwd_kernel<256, 512, 128, 2, true>), dim3(grid_groups * G), dim3(512), lds, s, a);
         return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
     }
-    hipLaunchKernelGGL((asr::decoder_chain_bwd_kernel<H, D, A, R, false, PASSES>), dim3(grid_groups * G), dim3(512), lds, s, a);
+    if (ared) hipLaunchKernelGGL((asr::decoder_chain_bwd_kernel<H, D, A, R, false, PASSES, true>), dim3(grid_groups * G), dim3(512), lds, s, a);
+    else hipLaunchKernelGGL((asr::decoder_chain_bwd_kernel<H, D, A, R, false, PASSES, false>), dim3(grid_groups * G), dim3(512), lds, s, a);
     return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
 }
 
