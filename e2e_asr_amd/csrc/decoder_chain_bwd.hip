@@ -13,13 +13,14 @@
 //       dalpha for MY positions over all D (enc rows of my positions in LDS); de = alpha (dalpha - S)
 //   (d) tanh backward on my positions: ds = de v (1 - th^2); dhf slice += ds (LDS, written once at the
 //       end); dv += de th (registers); partial dy[a] over my positions               -> X2 publish
-//   X2  gather dy for my A-slice (reduce-scatter over the position slices; saved: dW_att = q^T.dy after the loop)
-//   AG  gather dy over all A columns; dq_att for MY units = dy . W_att[unit, :]
+//   AR  all-reduce of dy over the group's 16 position slices (round 5, ARED: one hop; every workgroup publishes its partial
+//       [R][A] and gathers all 16 -- rounds 2-4: X2 reduce-scatter to the owners of the A-slices, then an all-gather);
+//       my A-slice is saved (dW_att = q^T.dy after the loop); dq_att for MY units = dy . W_att[unit, :]
 //       cell pointwise backward -> dG (in place over the saved gates), dc carry; the 4 dG values of each unit are
 //       published first (AG of the next step)
 // Three of the four exchanges are all-gathers of the SMALL vector a workgroup owns (64 / 64+1 / 16 publishing stores) with
 // the contraction done by the consumer; the first version reduce-scattered partial sums of everything (2848 publishing
-// stores per workgroup and step by one wave, 12.6 us per step; now 6.3).  Granules are tagged 8-byte {step, value} words;
+// stores per workgroup and step by one wave, 12.6 us per step; 6.3 with the four exchanges of rounds 2-4, 5.7 with three).  Granules are tagged 8-byte {step, value} words;
 // gathering threads keep all their loads in flight and sum in fixed order (reproducible).  Wave 0 owns every global store.
 // dx = dG.K_x^T and dlm_out = dx.W_inp[:P]^T are GEMMs after the loop.
 #include "common.h"
